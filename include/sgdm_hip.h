@@ -1,0 +1,167 @@
+/* sgdm_hip.h -- C-ABI of libsgdm_hip.so: the MI355X (gfx950) kernels behind the
+ * self-guided-diffusion drop-in (UNet denoiser evaluation, CFG sampling step, train step).
+ *
+ * The reference has no FFI of its own: it is pure Python on ATen, and its
+ * operator boundary is the pair of nn.Module classes instantiated through the Hydra
+ * `target:` strings.  This header is the boundary a maintainer binds
+ * *below* those classes (ctypes stub in INTEGRATION.md): every entry point replaces the
+ * ATen op sequence of the cited reference lines.
+ *
+ * Conventions
+ *   - plain pointers are DEVICE pointers unless stated; sizes are in elements;
+ *   - activations are fp32 NHWC: [N, H, W, C] == rows of C channels;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); launchers are
+ *     asynchronous, allocate nothing, keep no global state, and are graph-capturable;
+ *   - return value: 0 ok, 1 invalid argument (nothing launched), 2 launch failure.
+ */
+#ifndef SGDM_HIP_H
+#define SGDM_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SGD_ABI_VERSION 1
+int sgd_abi_version(void);
+
+/* --------------------------------------------------------------------------------------
+ * Fused implicit-GEMM convolution / linear layer.
+ *   y[row, :Cout] = epilogue( W * prologue(x)[row-neighbourhood] )
+ * replaces nn.Conv2d 3x3 s1/s2 p1, nn.Conv2d/Conv1d 1x1, nn.Linear together with the
+ * element-wise ops the reference runs around them:
+ *   ResBlock            openaimodel.py:300-320  (GN+SiLU -> conv, FiLM GN -> SiLU -> conv, +skip)
+ *   Up/Downsample       openaimodel.py:151,200 ; openaimodel_ca.py:128,167-174
+ *   skip concat         openaimodel.py:950 (two input pointers, no materialised cat)
+ *   qkv / proj_out      openaimodel.py:349,357,368-371
+ *   Attention_LR linears  crossattetion_lr.py:71-79,86-88,103,140
+ *   time/cond MLPs, emb_layers  openaimodel.py:570-574,603-607,262-268
+ * -------------------------------------------------------------------------------------- */
+enum { SGD_MODE_FLAT = 0, SGD_MODE_CONV3 = 1 };
+enum { SGD_RS_NONE = 0, SGD_RS_AVGPOOL2 = 1, SGD_RS_UP2 = 2 };
+enum { SGD_PRO_NONE = 0, SGD_PRO_AFFINE_NC = 1, SGD_PRO_LN_ROW = 2 };
+enum { SGD_PREC_F32 = 0, SGD_PREC_F16X3 = 1, SGD_PREC_BF16X3 = 2 };
+
+typedef struct sgd_igemm_args {
+    /* input: channels [0,c0) from x0, [c0,c0+c1) from x1 (x1 may be NULL with c1 = 0) */
+    const float* x0;
+    const float* x1;
+    int32_t c0, c1;
+    int32_t mode;          /* SGD_MODE_* */
+    int32_t n, hi, wi;     /* CONV3: input dims of x0/x1 (before resample).  FLAT: unused */
+    int32_t ho, wo;        /* CONV3: output spatial dims */
+    int32_t m;             /* FLAT: number of rows.  CONV3: ignored (n*ho*wo) */
+    int32_t rows_per_n;    /* FLAT + PRO_AFFINE_NC: rows per batch element (n = row / rows_per_n) */
+    int32_t stride;        /* CONV3: 1 or 2 */
+    int32_t resample;      /* CONV3: SGD_RS_* applied to the (activated) input before the conv */
+    /* prologue on every input element */
+    int32_t pro;           /* SGD_PRO_* */
+    int32_t pro_silu;      /* 1: SiLU after the prologue affine (or alone) */
+    const float* pa;       /* AFFINE_NC: a[n, C]      LN_ROW: stats[row, 2] = (mean, rstd) */
+    const float* pb;       /* AFFINE_NC: b[n, C]      LN_ROW: gamma[C] */
+    const float* pc;       /*                         LN_ROW: beta[C] or NULL */
+    /* weights packed by sgd_pack_weight: [taps][cout_p][cin_p] (precision-specific element) */
+    const void* w;
+    int32_t cin_p, cout_p;
+    const float* bias;     /* [cout] or NULL */
+    /* epilogue */
+    const float* res;      /* residual tensor (cout channels) or NULL */
+    int32_t res_mode;      /* SGD_RS_NONE: same rows; AVGPOOL2: res is at 2x resolution; UP2: at 1/2 */
+    float* y;
+    int32_t cout;
+    int32_t y_ld;          /* row stride of y in floats (>= cout) */
+    /* output row remap: out_row = (row / orows_in) * orows_out + orow_off + row % orows_in
+       (orows_in == 0: identity).  Lets to_kv / to_context write into the shared K/V buffer. */
+    int32_t orows_in, orows_out, orow_off;
+    int32_t prec;          /* SGD_PREC_* */
+} sgd_igemm_args;
+
+int sgd_igemm(const sgd_igemm_args* args /* HOST pointer */, void* stream);
+
+/* bytes of the packed weight buffer for given dims; w_src is [cout, cin, k, k] (OIHW) or [cout, cin] */
+int64_t sgd_packed_weight_bytes(int32_t cout, int32_t cin, int32_t ksize, int32_t prec);
+int sgd_pack_weight(const float* w_src, void* w_dst, int32_t cout, int32_t cin, int32_t ksize,
+                    int32_t prec, int32_t* cin_p, int32_t* cout_p /* HOST out */, void* stream);
+
+/* --------------------------------------------------------------------------------------
+ * GroupNorm(32) as statistics + per-(n,c) affine coefficients consumed by sgd_igemm's
+ * prologue (util.py:199-216; openaimodel.py:246-247,270-271,312-316,348,831-832).
+ *   sums[n, c, 2] = (sum, sum of squares) over the HW rows of x[n]   (chan offset for concat)
+ *   a, b such that GN(x)*(1+scale)+shift == x*a + b
+ * -------------------------------------------------------------------------------------- */
+int sgd_chan_stats(const float* x, int32_t n, int32_t hw, int32_t c,
+                   float* sums /* [n, c_total, 2] */, int32_t c_total, int32_t c_off, void* stream);
+int sgd_gn_coef(const float* sums, const float* gamma, const float* beta,
+                const float* film /* [n, film_ld] scale at +0, shift at +c; or NULL */, int32_t film_ld,
+                int32_t n, int32_t c, int32_t groups, int32_t hw, float eps,
+                float* a, float* b, void* stream);
+
+/* LayerNorm over the channel dim of rows (crossattetion_lr.py:36-43; openaimodel_ca.py:583,1017) */
+int sgd_ln_stats(const float* x, int32_t rows, int32_t c, float eps, float* stats /* [rows,2] */, void* stream);
+/* out = (res ? res : 0) + LN(x) * gamma + (beta ? beta : 0) */
+int sgd_ln_apply(const float* x, const float* gamma, const float* beta, const float* res,
+                 int32_t rows, int32_t c, float eps, float* out, void* stream);
+
+/* --------------------------------------------------------------------------------------
+ * Attention cores.
+ *  legacy QKV self-attention  (QKVAttentionLegacy, openaimodel.py:403-420)
+ *  multi-query attention over [context | null | self] keys (crossattetion_lr.py:90-139)
+ * q rows: [b, tq, *] with row stride q_ld, head h at +h*q_hs; k/v rows: [b, tk, *] with row
+ * stride kv_ld, head h at +h*kv_hs (0 for multi-query).  out[b, tq, heads*d] head-major.
+ * softmax(scale * q.k) ; d in {16, 32, 64}.
+ * -------------------------------------------------------------------------------------- */
+int sgd_attention(const float* q, int32_t q_ld, int32_t q_hs,
+                  const float* k, const float* v, int32_t kv_ld, int32_t kv_hs,
+                  int32_t batch, int32_t heads, int32_t tq, int32_t tk, int32_t d, float scale,
+                  float* out, int32_t out_ld, void* stream);
+
+/* --------------------------------------------------------------------------------------
+ * Small glue kernels on the UNet boundary.
+ * -------------------------------------------------------------------------------------- */
+/* timestep_embedding (util.py:151-171): t int64 [n_src], row r uses t[r % n_src] -> out[n, dim];
+ * freqs[dim/2] = exp(-ln(1e4) * arange(dim/2) / (dim/2)) as fp32 (host-built table, util.py:162-164) */
+int sgd_timestep_embedding(const int64_t* t, const float* freqs, int32_t n_src, int32_t n, int32_t dim,
+                           float* out, void* stream);
+/* cond select (openaimodel.py:929-931): out[r,:] = mask[r] ? null_row : cond[r % n_src,:]; cond is
+ * float32 (is_i64 = 0) or int64 one-hot (is_i64 = 1, cast as openaimodel.py:911) */
+int sgd_cond_select(const void* cond, int32_t is_i64, const uint8_t* mask, const float* null_row,
+                    int32_t n_src, int32_t n, int32_t k, float* out, void* stream);
+/* x NCHW [n_src,cx,h,w] (+ layout NCHW [n_src,cl,h,w] masked by mask -> null_layout[h*w]) -> NHWC
+ * [n, h, w, cx+cl]  (openaimodel.py:933-939, 944; batch doubling of :886-891 via r % n_src) */
+int sgd_pack_input(const float* x, const float* layout, const uint8_t* mask, const float* null_layout,
+                   int32_t n_src, int32_t n, int32_t cx, int32_t cl, int32_t h, int32_t w,
+                   float* out, void* stream);
+/* NHWC [n,h,w,c] -> NCHW [n,c,h,w] */
+int sgd_nhwc_to_nchw(const float* x, int32_t n, int32_t h, int32_t w, int32_t c, float* out, void* stream);
+/* broadcast null_kv rows into the shared K/V buffer (crossattetion_lr.py:95-97):
+ * kv[b, row, 0:d] = null_kv[0], kv[b, row, d:2d] = null_kv[1] */
+int sgd_fill_null_kv(const float* null_kv, int32_t batch, int32_t rows_per_b, int32_t row, int32_t d,
+                     float* kv, void* stream);
+
+/* --------------------------------------------------------------------------------------
+ * Sampler step kernels (one launch per step).  eps_nhwc is the UNet output at 2B
+ * ([cond ; uncond] halves, NHWC) when cfg_mode != 0, else at B.
+ *   guided = cfg_mode 1 (imagen): (1-w)*eps_u + w*eps_c     (openaimodel.py:855)
+ *            cfg_mode 2 (cfg)   : (1+w)*eps_c - w*eps_u     (openaimodel.py:857)
+ * x, z, x_out, x0_out are NCHW [b,c,h,w].
+ * DDPM ancestral step: ddpm_sampler.py:132-137,154-192.  coef = {sqrt_recip_ac, sqrt_recipm1_ac,
+ * post_mean_coef1, post_mean_coef2, exp(0.5*post_log_var)*nonzero*temperature} for this t.
+ * DDIM step: ddim_plms_sampler.py:346-391. coef = {sqrt_one_minus_at, 1/sqrt(a_t) is NOT used
+ * (the reference divides by a_t.sqrt()), a_t, a_prev, sigma_t*temperature, 0}.
+ * -------------------------------------------------------------------------------------- */
+int sgd_ddpm_step(const float* x, const float* eps_nhwc, const float* z, int32_t cfg_mode, float w,
+                  const float* coef /* HOST [5] */, int32_t clip, int32_t b, int32_t c, int32_t hw,
+                  float* x_out, float* x0_out, void* stream);
+int sgd_ddim_step(const float* x, const float* eps_nhwc, const float* z, int32_t cfg_mode, float w,
+                  const float* coef /* HOST [4]: sqrt_one_minus_at, a_t, a_prev, sigma_t */, float temperature,
+                  int32_t clip, int32_t b, int32_t c, int32_t hw, float* x_out, float* x0_out, void* stream);
+/* ((x+1)*127.5).clamp(0,255).to(uint8)  (diffusion_utils/util.py:99-100) */
+int sgd_to_uint8(const float* x, int64_t count, uint8_t* out, void* stream);
+/* guided eps only (forward_with_cond_scale return value): eps_nhwc [2b,h,w,c] -> NCHW [b,c,h,w] */
+int sgd_cfg_combine(const float* eps_nhwc, int32_t cfg_mode, float w, int32_t b, int32_t c, int32_t hw,
+                    float* out_nchw, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SGDM_HIP_H */

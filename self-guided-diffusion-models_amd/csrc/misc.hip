@@ -1,0 +1,230 @@
+// Small boundary / sampler kernels (gfx950).  All element-wise, HBM- or launch-bound.
+#include "sgdm_common.h"
+#include "../../include/sgdm_hip.h"
+
+namespace {
+
+// timestep_embedding (util.py:151-171): cat(cos(t*f), sin(t*f)); the frequency table f_j =
+// exp(-ln(1e4) * j / half) is deterministic host math (built once with the reference's own fp32 op
+// order) so that t*f is bit-identical to the reference -- a 1-ulp change of f moves cos(999 f) by 1e-5.
+__global__ void temb_kernel(const int64_t* __restrict__ t, const float* __restrict__ freqs, int n_src, int n,
+                            int dim, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * dim) return;
+    const int r = i / dim, j = i % dim;
+    const int half = dim / 2;
+    float val = 0.f;                       // odd dim: last column is zero (util.py:167-168)
+    if (j < 2 * half) {
+        const int jj = j < half ? j : j - half;
+        const float arg = (float)t[r % n_src] * freqs[jj];
+        val = j < half ? cosf(arg) : sinf(arg);
+    }
+    out[i] = val;
+}
+
+__global__ void cond_select_kernel(const void* __restrict__ cond, int is_i64, const uint8_t* __restrict__ mask,
+                                   const float* __restrict__ null_row, int n_src, int n, int k,
+                                   float* __restrict__ out) {
+    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (i >= (long)n * k) return;
+    const int r = i / k, j = i % k;
+    float v;
+    if (mask && mask[r]) v = null_row[j];
+    else if (is_i64) v = (float)reinterpret_cast<const int64_t*>(cond)[(long)(r % n_src) * k + j];
+    else v = reinterpret_cast<const float*>(cond)[(long)(r % n_src) * k + j];
+    out[i] = v;
+}
+
+// NCHW x (+ masked layout) -> NHWC; thread per output pixel-channel, output-coalesced
+__global__ void pack_input_kernel(const float* __restrict__ x, const float* __restrict__ layout,
+                                  const uint8_t* __restrict__ mask, const float* __restrict__ null_layout,
+                                  int n_src, int n, int cx, int cl, int hw, float* __restrict__ out) {
+    const int ct = cx + cl;
+    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (i >= (long)n * hw * ct) return;
+    const int c = i % ct;
+    const long t = i / ct;
+    const int p = t % hw, r = t / hw;
+    const int rs = r % n_src;
+    float v;
+    if (c < cx) v = x[((long)rs * cx + c) * hw + p];
+    else if (mask && mask[r]) v = null_layout[p];          // null_layout_emb is [1,1,H,W]: broadcast over channels
+    else v = layout[((long)rs * cl + (c - cx)) * hw + p];
+    out[i] = v;
+}
+
+__global__ void nhwc_to_nchw_kernel(const float* __restrict__ x, int n, int hw, int c, float* __restrict__ out) {
+    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (i >= (long)n * hw * c) return;
+    const int p = i % hw;
+    const long t = i / hw;
+    const int cc = t % c, r = t / c;
+    out[i] = x[((long)r * hw + p) * c + cc];
+}
+
+__global__ void fill_null_kv_kernel(const float* __restrict__ null_kv, int batch, int rows_per_b, int row, int d,
+                                    float* __restrict__ kv) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= batch * 2 * d) return;
+    const int b = i / (2 * d), j = i % (2 * d);
+    kv[((long)b * rows_per_b + row) * 2 * d + j] = null_kv[j];      // [k(0:d) | v(d:2d)] == null_kv[0], null_kv[1]
+}
+
+__device__ __forceinline__ float guided(const float* __restrict__ eps, int cfg_mode, float w, int b, int n, int c,
+                                        int hw, int cc, int p) {
+    const float ec = eps[((long)n * hw + p) * c + cc];
+    if (cfg_mode == 0) return ec;
+    const float eu = eps[((long)(n + b) * hw + p) * c + cc];
+    if (cfg_mode == 1) return (1.f - w) * eu + w * ec;        // imagen  (openaimodel.py:855)
+    return (1.f + w) * ec - w * eu;                           // cfg     (openaimodel.py:857)
+}
+
+struct Coef5 { float v[5]; };
+
+__global__ void ddpm_step_kernel(const float* __restrict__ x, const float* __restrict__ eps,
+                                 const float* __restrict__ z, int cfg_mode, float w, Coef5 k, int clip, int b, int c,
+                                 int hw, float* __restrict__ x_out, float* __restrict__ x0_out) {
+    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (i >= (long)b * c * hw) return;
+    const int p = i % hw;
+    const long t = i / hw;
+    const int cc = t % c, n = t / c;
+    const float e = guided(eps, cfg_mode, w, b, n, c, hw, cc, p);
+    const float xv = x[i];
+    float x0 = k.v[0] * xv - k.v[1] * e;                      // predict_start_from_noise (ddpm_sampler.py:132-137)
+    if (clip) x0 = fminf(fmaxf(x0, -1.f), 1.f);               // clip_x0_minus_one_to_one, dtp == 1
+    const float mean = k.v[2] * x0 + k.v[3] * xv;             // q_posterior (ddpm_sampler.py:121-125)
+    x_out[i] = mean + k.v[4] * z[i];                          // :190-191, k4 = nonzero*exp(.5 logvar)*temperature
+    if (x0_out) x0_out[i] = x0;
+}
+
+__global__ void ddim_step_kernel(const float* __restrict__ x, const float* __restrict__ eps,
+                                 const float* __restrict__ z, int cfg_mode, float w, Coef5 k, float temperature,
+                                 int clip, int b, int c, int hw, float* __restrict__ x_out,
+                                 float* __restrict__ x0_out) {
+    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (i >= (long)b * c * hw) return;
+    const int p = i % hw;
+    const long t = i / hw;
+    const int cc = t % c, n = t / c;
+    const float e = guided(eps, cfg_mode, w, b, n, c, hw, cc, p);
+    const float s1m = k.v[0], a_t = k.v[1], a_prev = k.v[2], sigma = k.v[3];
+    float x0 = (x[i] - s1m * e) / sqrtf(a_t);                 // ddim_plms_sampler.py:369-370
+    if (clip) x0 = fminf(fmaxf(x0, -1.f), 1.f);
+    const float dir = sqrtf(1.0f - a_prev - sigma * sigma) * e;   // :381-382
+    const float noise = sigma * z[i] * temperature;              // :383-387
+    x_out[i] = sqrtf(a_prev) * x0 + dir + noise;                 // :390
+    if (x0_out) x0_out[i] = x0;
+}
+
+__global__ void to_uint8_kernel(const float* __restrict__ x, long count, uint8_t* __restrict__ out) {
+    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    float v = (x[i] + 1.f) * 127.5f;
+    v = fminf(fmaxf(v, 0.f), 255.f);
+    out[i] = (uint8_t)v;                                       // truncation like .to(torch.uint8)
+}
+
+__global__ void cfg_combine_kernel(const float* __restrict__ eps, int cfg_mode, float w, int b, int c, int hw,
+                                   float* __restrict__ out) {
+    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (i >= (long)b * c * hw) return;
+    const int p = i % hw;
+    const long t = i / hw;
+    const int cc = t % c, n = t / c;
+    out[i] = guided(eps, cfg_mode, w, b, n, c, hw, cc, p);
+}
+
+inline unsigned nblk(long total) { return (unsigned)((total + 255) / 256); }
+
+}  // namespace
+
+extern "C" int sgd_timestep_embedding(const int64_t* t, const float* freqs, int32_t n_src, int32_t n, int32_t dim,
+                                      float* out, void* stream) {
+    SGD_CLEAR_ERR();
+    if (!t || !freqs || !out || n_src <= 0 || n <= 0 || dim <= 0) return SGD_ERR_ARG;
+    hipLaunchKernelGGL(temb_kernel, dim3(nblk((long)n * dim)), dim3(256), 0, (hipStream_t)stream, t, freqs, n_src, n,
+                       dim, out);
+    return sgd_check_launch();
+}
+
+extern "C" int sgd_cond_select(const void* cond, int32_t is_i64, const uint8_t* mask, const float* null_row,
+                               int32_t n_src, int32_t n, int32_t k, float* out, void* stream) {
+    SGD_CLEAR_ERR();
+    if (!cond || !out || n_src <= 0 || n <= 0 || k <= 0 || (mask && !null_row)) return SGD_ERR_ARG;
+    hipLaunchKernelGGL(cond_select_kernel, dim3(nblk((long)n * k)), dim3(256), 0, (hipStream_t)stream, cond, is_i64,
+                       mask, null_row, n_src, n, k, out);
+    return sgd_check_launch();
+}
+
+extern "C" int sgd_pack_input(const float* x, const float* layout, const uint8_t* mask, const float* null_layout,
+                              int32_t n_src, int32_t n, int32_t cx, int32_t cl, int32_t h, int32_t w, float* out,
+                              void* stream) {
+    SGD_CLEAR_ERR();
+    if (!x || !out || n_src <= 0 || n <= 0 || cx <= 0 || cl < 0 || h <= 0 || w <= 0) return SGD_ERR_ARG;
+    if (cl > 0 && (!layout || (mask && !null_layout))) return SGD_ERR_ARG;
+    hipLaunchKernelGGL(pack_input_kernel, dim3(nblk((long)n * h * w * (cx + cl))), dim3(256), 0, (hipStream_t)stream,
+                       x, layout, mask, null_layout, n_src, n, cx, cl, h * w, out);
+    return sgd_check_launch();
+}
+
+extern "C" int sgd_nhwc_to_nchw(const float* x, int32_t n, int32_t h, int32_t w, int32_t c, float* out,
+                                void* stream) {
+    SGD_CLEAR_ERR();
+    if (!x || !out || n <= 0 || h <= 0 || w <= 0 || c <= 0) return SGD_ERR_ARG;
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(nblk((long)n * h * w * c)), dim3(256), 0, (hipStream_t)stream, x, n,
+                       h * w, c, out);
+    return sgd_check_launch();
+}
+
+extern "C" int sgd_fill_null_kv(const float* null_kv, int32_t batch, int32_t rows_per_b, int32_t row, int32_t d,
+                                float* kv, void* stream) {
+    SGD_CLEAR_ERR();
+    if (!null_kv || !kv || batch <= 0 || rows_per_b <= 0 || row < 0 || row >= rows_per_b || d <= 0) return SGD_ERR_ARG;
+    hipLaunchKernelGGL(fill_null_kv_kernel, dim3(nblk((long)batch * 2 * d)), dim3(256), 0, (hipStream_t)stream,
+                       null_kv, batch, rows_per_b, row, d, kv);
+    return sgd_check_launch();
+}
+
+extern "C" int sgd_ddpm_step(const float* x, const float* eps_nhwc, const float* z, int32_t cfg_mode, float w,
+                             const float* coef, int32_t clip, int32_t b, int32_t c, int32_t hw, float* x_out,
+                             float* x0_out, void* stream) {
+    SGD_CLEAR_ERR();
+    if (!x || !eps_nhwc || !z || !coef || !x_out || b <= 0 || c <= 0 || hw <= 0 || cfg_mode < 0 || cfg_mode > 2)
+        return SGD_ERR_ARG;
+    Coef5 k;
+    for (int i = 0; i < 5; ++i) k.v[i] = coef[i];
+    hipLaunchKernelGGL(ddpm_step_kernel, dim3(nblk((long)b * c * hw)), dim3(256), 0, (hipStream_t)stream, x, eps_nhwc,
+                       z, cfg_mode, w, k, clip, b, c, hw, x_out, x0_out);
+    return sgd_check_launch();
+}
+
+extern "C" int sgd_ddim_step(const float* x, const float* eps_nhwc, const float* z, int32_t cfg_mode, float w,
+                             const float* coef, float temperature, int32_t clip, int32_t b, int32_t c, int32_t hw,
+                             float* x_out, float* x0_out, void* stream) {
+    SGD_CLEAR_ERR();
+    if (!x || !eps_nhwc || !z || !coef || !x_out || b <= 0 || c <= 0 || hw <= 0 || cfg_mode < 0 || cfg_mode > 2)
+        return SGD_ERR_ARG;
+    Coef5 k;
+    for (int i = 0; i < 4; ++i) k.v[i] = coef[i];
+    k.v[4] = 0.f;
+    hipLaunchKernelGGL(ddim_step_kernel, dim3(nblk((long)b * c * hw)), dim3(256), 0, (hipStream_t)stream, x, eps_nhwc,
+                       z, cfg_mode, w, k, temperature, clip, b, c, hw, x_out, x0_out);
+    return sgd_check_launch();
+}
+
+extern "C" int sgd_to_uint8(const float* x, int64_t count, uint8_t* out, void* stream) {
+    SGD_CLEAR_ERR();
+    if (!x || !out || count <= 0) return SGD_ERR_ARG;
+    hipLaunchKernelGGL(to_uint8_kernel, dim3(nblk(count)), dim3(256), 0, (hipStream_t)stream, x, (long)count, out);
+    return sgd_check_launch();
+}
+
+extern "C" int sgd_cfg_combine(const float* eps_nhwc, int32_t cfg_mode, float w, int32_t b, int32_t c, int32_t hw,
+                               float* out_nchw, void* stream) {
+    SGD_CLEAR_ERR();
+    if (!eps_nhwc || !out_nchw || b <= 0 || c <= 0 || hw <= 0 || cfg_mode < 0 || cfg_mode > 2) return SGD_ERR_ARG;
+    hipLaunchKernelGGL(cfg_combine_kernel, dim3(nblk((long)b * c * hw)), dim3(256), 0, (hipStream_t)stream, eps_nhwc,
+                       cfg_mode, w, b, c, hw, out_nchw);
+    return sgd_check_launch();
+}

@@ -1,0 +1,160 @@
+// GroupNorm / LayerNorm statistics kernels (gfx950).  HBM-bound: each reads its input once with
+// 16-byte lane loads; reductions are wave-shuffle + LDS, deterministic (no atomics).
+//
+// GroupNorm(32, C) (util.py:199-216) is split into
+//   sgd_chan_stats : per-(n, channel) sum / sum-of-squares over the HW rows (NHWC => coalesced),
+//   sgd_gn_coef    : folds group statistics, gamma/beta and the ResBlock FiLM scale/shift
+//                    (openaimodel.py:312-316) into per-(n, c) coefficients a, b with
+//                    GN(x)*(1+scale)+shift == a*x + b, consumed by sgd_igemm's prologue.
+// Per-channel sums make the grouping independent of where the channels live, so a GroupNorm over a
+// virtual concat (openaimodel.py:950 -> :246) is two sgd_chan_stats calls into one sums buffer.
+#include "sgdm_common.h"
+#include "../../include/sgdm_hip.h"
+
+namespace {
+
+// block: 256 threads = 8 channel-quads x 32 row lanes; one block per (n, 32-channel slab)
+__global__ __launch_bounds__(256) void chan_stats_kernel(const float* __restrict__ x, int hw, int c,
+                                                         float* __restrict__ sums, int c_total, int c_off) {
+    const int slabs = (c + 31) / 32;
+    const int n = blockIdx.x / slabs, slab = blockIdx.x % slabs;
+    const int q = threadIdx.x & 7, rl = threadIdx.x >> 3;
+    const int ch = slab * 32 + q * 4;
+    float s[4] = {0, 0, 0, 0}, ss[4] = {0, 0, 0, 0};
+    const float* base = x + (long)n * hw * c;
+    if (ch < c) {
+        if ((c & 3) == 0) {
+            for (int r = rl; r < hw; r += 32) {
+                f32x4 v = *reinterpret_cast<const f32x4*>(base + (long)r * c + ch);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { s[j] += v[j]; ss[j] += v[j] * v[j]; }
+            }
+        } else {
+            for (int r = rl; r < hw; r += 32)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (ch + j < c) { float v = base[(long)r * c + ch + j]; s[j] += v; ss[j] += v * v; }
+        }
+    }
+    __shared__ double red[32][8][8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { red[rl][q][j] = s[j]; red[rl][q][4 + j] = ss[j]; }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int qq = threadIdx.x >> 3, jj = threadIdx.x & 7;
+        double t = 0;
+        for (int r = 0; r < 32; ++r) t += red[r][qq][jj];
+        const int cc = slab * 32 + qq * 4 + (jj & 3);
+        if (cc < c) sums[((long)n * c_total + c_off + cc) * 2 + (jj >> 2)] = (float)t;
+    }
+}
+
+__global__ void gn_coef_kernel(const float* __restrict__ sums, const float* __restrict__ gamma,
+                               const float* __restrict__ beta, const float* __restrict__ film, int film_ld,
+                               int n, int c, int groups, int hw, float eps, float* __restrict__ a,
+                               float* __restrict__ b) {
+    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (i >= (long)n * c) return;
+    const int nn = i / c, cc = i % c;
+    const int cpg = c / groups, g0 = (cc / cpg) * cpg;
+    double s = 0, ss = 0;
+    for (int k = 0; k < cpg; ++k) {
+        s += sums[((long)nn * c + g0 + k) * 2];
+        ss += sums[((long)nn * c + g0 + k) * 2 + 1];
+    }
+    const double cnt = (double)cpg * hw;
+    const double mean = s / cnt;
+    double var = ss / cnt - mean * mean;
+    if (var < 0) var = 0;
+    const double rstd = 1.0 / sqrt(var + (double)eps);
+    double ga = gamma[cc] * rstd, be = beta[cc] - mean * ga;
+    if (film) {
+        const double sc = 1.0 + film[(long)nn * film_ld + cc], sh = film[(long)nn * film_ld + c + cc];
+        ga *= sc;
+        be = be * sc + sh;
+    }
+    a[i] = (float)ga;
+    b[i] = (float)be;
+}
+
+// one wave per row, row held in registers (c <= 1024)
+template <bool APPLY>
+__global__ __launch_bounds__(256) void ln_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                 const float* __restrict__ beta, const float* __restrict__ res,
+                                                 int rows, int c, float eps, float* __restrict__ out) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float* xp = x + (long)row * c;
+    float v[16];
+    float s = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        int cc = lane + k * 64;
+        v[k] = cc < c ? xp[cc] : 0.f;
+        s += v[k];
+    }
+    const float mean = wave_sum(s) / c;
+    float q = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        int cc = lane + k * 64;
+        float d = cc < c ? v[k] - mean : 0.f;
+        q += d * d;
+    }
+    const float rstd = rsqrtf(wave_sum(q) / c + eps);
+    if (!APPLY) {
+        if (lane == 0) { out[(long)row * 2] = mean; out[(long)row * 2 + 1] = rstd; }
+        return;
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        int cc = lane + k * 64;
+        if (cc < c) {
+            float y = (v[k] - mean) * rstd * gamma[cc] + (beta ? beta[cc] : 0.f);
+            if (res) y += res[(long)row * c + cc];
+            out[(long)row * c + cc] = y;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int sgd_chan_stats(const float* x, int32_t n, int32_t hw, int32_t c, float* sums, int32_t c_total,
+                              int32_t c_off, void* stream) {
+    SGD_CLEAR_ERR();
+    if (!x || !sums || n <= 0 || hw <= 0 || c <= 0 || c_off < 0 || c_off + c > c_total) return SGD_ERR_ARG;
+    const int slabs = (c + 31) / 32;
+    hipLaunchKernelGGL(chan_stats_kernel, dim3(n * slabs), dim3(256), 0, (hipStream_t)stream, x, hw, c, sums,
+                       c_total, c_off);
+    return sgd_check_launch();
+}
+
+extern "C" int sgd_gn_coef(const float* sums, const float* gamma, const float* beta, const float* film,
+                           int32_t film_ld, int32_t n, int32_t c, int32_t groups, int32_t hw, float eps, float* a,
+                           float* b, void* stream) {
+    SGD_CLEAR_ERR();
+    if (!sums || !gamma || !beta || !a || !b || n <= 0 || c <= 0 || groups <= 0 || c % groups != 0 || hw <= 0)
+        return SGD_ERR_ARG;
+    if (film && film_ld < 2 * c) return SGD_ERR_ARG;
+    const long total = (long)n * c;
+    hipLaunchKernelGGL(gn_coef_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       sums, gamma, beta, film, film_ld, n, c, groups, hw, eps, a, b);
+    return sgd_check_launch();
+}
+
+extern "C" int sgd_ln_stats(const float* x, int32_t rows, int32_t c, float eps, float* stats, void* stream) {
+    SGD_CLEAR_ERR();
+    if (!x || !stats || rows <= 0 || c <= 0 || c > 1024) return SGD_ERR_ARG;
+    hipLaunchKernelGGL((ln_kernel<false>), dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x,
+                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, rows, c, eps, stats);
+    return sgd_check_launch();
+}
+
+extern "C" int sgd_ln_apply(const float* x, const float* gamma, const float* beta, const float* res, int32_t rows,
+                            int32_t c, float eps, float* out, void* stream) {
+    SGD_CLEAR_ERR();
+    if (!x || !gamma || !out || rows <= 0 || c <= 0 || c > 1024) return SGD_ERR_ARG;
+    hipLaunchKernelGGL((ln_kernel<true>), dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, gamma, beta,
+                       res, rows, c, eps, out);
+    return sgd_check_launch();
+}

@@ -1,0 +1,51 @@
+// Shared device helpers for the sgdm HIP kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+#define SGD_WAVE 64
+
+__device__ __forceinline__ float sgd_silu(float v) {
+    // x * sigmoid(x); __expf -> v_exp_f32 path, 1 ulp-ish; the reference uses aten silu (fp32)
+    return v / (1.0f + __expf(-v));
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// error codes returned by every extern "C" launcher
+#define SGD_OK 0
+#define SGD_ERR_ARG 1
+#define SGD_ERR_LAUNCH 2
+
+// torch (or anyone) may leave a non-sticky error (e.g. hipErrorNotReady from an event query) in the
+// thread's last-error slot: clear it before launching so sgd_check_launch reports OUR launch only.
+#define SGD_CLEAR_ERR() (void)hipGetLastError()
+
+static inline int sgd_check_launch() {
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) return SGD_OK;
+    fprintf(stderr, "sgdm_hip: kernel launch failed: %s (%d)\n", hipGetErrorString(e), (int)e);
+    return SGD_ERR_LAUNCH;
+}

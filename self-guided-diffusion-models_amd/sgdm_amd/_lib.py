@@ -1,0 +1,95 @@
+"""ctypes binding of libsgdm_hip.so (include/sgdm_hip.h).
+
+The product path has NO fallback: if the library is missing or does not export a symbol the
+header declares, importing/using the HIP path raises.  (Build: ``python
+self-guided-diffusion-models_amd/build.py`` or ``__graft_entry__.build()``.)
+"""
+import ctypes as C
+import os
+
+# torch MUST be imported before the library is dlopen'ed: libsgdm_hip.so shares device pointers and
+# streams with torch, so both have to run on the ONE HIP runtime (libamdhip64) torch brings into the
+# process.  Loading ours first binds /opt/rocm's copy and the launches then see no device.
+import torch  # noqa: F401
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libsgdm_hip.so")
+
+MODE_FLAT, MODE_CONV3 = 0, 1
+RS_NONE, RS_AVGPOOL2, RS_UP2 = 0, 1, 2
+PRO_NONE, PRO_AFFINE_NC, PRO_LN_ROW = 0, 1, 2
+PREC_F32, PREC_F16X3, PREC_BF16X3 = 0, 1, 2
+PREC_BY_NAME = {"f32": PREC_F32, "f16x3": PREC_F16X3, "bf16x3": PREC_BF16X3}
+ABI_VERSION = 1
+
+vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+
+
+class IgemmArgs(C.Structure):
+    """mirror of ``struct sgd_igemm_args`` (include/sgdm_hip.h)"""
+    _fields_ = [
+        ("x0", vp), ("x1", vp), ("c0", i32), ("c1", i32), ("mode", i32),
+        ("n", i32), ("hi", i32), ("wi", i32), ("ho", i32), ("wo", i32), ("m", i32),
+        ("rows_per_n", i32), ("stride", i32), ("resample", i32), ("pro", i32), ("pro_silu", i32),
+        ("pa", vp), ("pb", vp), ("pc", vp), ("w", vp), ("cin_p", i32), ("cout_p", i32),
+        ("bias", vp), ("res", vp), ("res_mode", i32), ("y", vp), ("cout", i32), ("y_ld", i32),
+        ("orows_in", i32), ("orows_out", i32), ("orow_off", i32), ("prec", i32),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/sgdm_hip.h declares
+SIGNATURES = {
+    "sgd_abi_version": (i32, []),
+    "sgd_igemm": (i32, [C.POINTER(IgemmArgs), vp]),
+    "sgd_packed_weight_bytes": (i64, [i32, i32, i32, i32]),
+    "sgd_pack_weight": (i32, [vp, vp, i32, i32, i32, i32, C.POINTER(i32), C.POINTER(i32), vp]),
+    "sgd_chan_stats": (i32, [vp, i32, i32, i32, vp, i32, i32, vp]),
+    "sgd_gn_coef": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, vp, vp, vp]),
+    "sgd_ln_stats": (i32, [vp, i32, i32, f32, vp, vp]),
+    "sgd_ln_apply": (i32, [vp, vp, vp, vp, i32, i32, f32, vp, vp]),
+    "sgd_attention": (i32, [vp, i32, i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, vp, i32, vp]),
+    "sgd_timestep_embedding": (i32, [vp, vp, i32, i32, i32, vp, vp]),
+    "sgd_cond_select": (i32, [vp, i32, vp, vp, i32, i32, i32, vp, vp]),
+    "sgd_pack_input": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp]),
+    "sgd_nhwc_to_nchw": (i32, [vp, i32, i32, i32, i32, vp, vp]),
+    "sgd_fill_null_kv": (i32, [vp, i32, i32, i32, i32, vp, vp]),
+    "sgd_ddpm_step": (i32, [vp, vp, vp, i32, f32, C.POINTER(f32), i32, i32, i32, i32, vp, vp, vp]),
+    "sgd_ddim_step": (i32, [vp, vp, vp, i32, f32, C.POINTER(f32), f32, i32, i32, i32, i32, vp, vp, vp]),
+    "sgd_to_uint8": (i32, [vp, i64, vp, vp]),
+    "sgd_cfg_combine": (i32, [vp, i32, f32, i32, i32, i32, vp, vp]),
+}
+
+_lib = None
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the library (once) and bind every declared symbol; raises HipLibraryError loudly."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipLibraryError(
+            f"{LIB_PATH} not found: the HIP extension is not built "
+            "(run `python self-guided-diffusion-models_amd/build.py`). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise HipLibraryError(f"{LIB_PATH} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    if lib.sgd_abi_version() != ABI_VERSION:
+        raise HipLibraryError(f"ABI mismatch: library {lib.sgd_abi_version()} != binding {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f"{what} failed with code {rc} "
+                           f"({'invalid argument' if rc == 1 else 'launch failure'})")

@@ -1,0 +1,899 @@
+"""Drop-in UNet denoisers (``dynamic=unet_fast`` / ``dynamic=unetca_fast``) on hand-written HIP kernels.
+
+Host side of the operator boundary of SURVEY.md 8(b): same constructor keywords, method signatures,
+``state_dict`` names/shapes/order and return values as
+
+    dynamic.diffusionmodules.openaimodel.UNetModel      (reference openaimodel.py:466-956)
+    dynamic.diffusionmodules.openaimodel_ca.UNetModel   (reference openaimodel_ca.py:449-1033)
+
+but ``forward`` is a static program of launches into libsgdm_hip.so (include/sgdm_hip.h): NHWC fp32
+activations, GroupNorm/SiLU/FiLM, resampling, skip-concat, bias and residual fused into the
+implicit-GEMM convolution's loader/epilogue; attention cores as fused MFMA kernels.  PyTorch is used
+for parameter storage, device memory and streams only.  There is no CPU / eager fallback: without the
+HIP library or a GPU the forward raises.
+"""
+import ctypes as C
+import math
+import os
+
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+
+GN_GROUPS, GN_EPS, LN_EPS = 32, 1e-5, 1e-5
+NUM_TIME_TOKENS = NUM_COND_TOKENS = 8
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def timestep_freqs(dim, max_period=10000):
+    """frequency table of timestep_embedding, same fp32 op order as the reference (util.py:161-164)"""
+    half = dim // 2
+    return torch.exp(-math.log(max_period) * torch.arange(start=0, end=half, dtype=torch.float32) / half)
+
+
+def default_precision():
+    return os.environ.get("SGDM_PREC", "f32")
+
+
+# ------------------------------------------------------------------------------------------------
+# parameter containers: a generic nn.Module tree so that state_dict() keys equal the reference's
+# ------------------------------------------------------------------------------------------------
+class _Node(nn.Module):
+    pass
+
+
+def _register(root, name, shape, kind, init):
+    parts = name.split(".")
+    node = root
+    for p in parts[:-1]:
+        if p not in node._modules:
+            node.add_module(p, _Node())
+        node = node._modules[p]
+    t = init(shape)
+    if kind == "buffer":
+        node.register_buffer(parts[-1], t)
+    else:
+        node.register_parameter(parts[-1], nn.Parameter(t, requires_grad=(kind == "param")))
+
+
+def _get(root, name):
+    obj = root
+    for p in name.split("."):
+        obj = getattr(obj, p) if not p.isdigit() else obj._modules[p]
+    return obj
+
+
+# initialisers following the reference modules' defaults
+def _init_weight(shape):
+    w = torch.empty(shape)
+    nn.init.kaiming_uniform_(w, a=math.sqrt(5))          # nn.Linear / nn.Conv default
+    return w
+
+
+def _init_bias_for(fan_in):
+    def f(shape):
+        b = torch.empty(shape)
+        bound = 1 / math.sqrt(fan_in) if fan_in > 0 else 0
+        nn.init.uniform_(b, -bound, bound)
+        return b
+    return f
+
+
+_zeros = lambda s: torch.zeros(s)
+_ones = lambda s: torch.ones(s)
+_randn = lambda s: torch.randn(s)
+
+
+class _Spec:
+    """ordered parameter list builder"""
+
+    def __init__(self):
+        self.items = []
+
+    def linear(self, p, i, o, bias=True, zero=False):
+        self.items.append((p + ".weight", (o, i), "param", _zeros if zero else _init_weight))
+        if bias:
+            self.items.append((p + ".bias", (o,), "param", _zeros if zero else _init_bias_for(i)))
+
+    def conv(self, p, i, o, k, dims=2, zero=False):
+        self.items.append((p + ".weight", (o, i) + (k,) * dims, "param", _zeros if zero else _init_weight))
+        self.items.append((p + ".bias", (o,), "param", _zeros if zero else _init_bias_for(i * k ** dims)))
+
+    def norm(self, p, c):
+        self.items.append((p + ".weight", (c,), "param", _ones))
+        self.items.append((p + ".bias", (c,), "param", _zeros))
+
+
+# ------------------------------------------------------------------------------------------------
+# packed weights
+# ------------------------------------------------------------------------------------------------
+class _Packed:
+    """device buffer holding one conv/linear weight in the igemm layout, refreshed when the source
+    parameter(s) change (optimizer step / load_state_dict bump ``_version``)."""
+
+    def __init__(self, srcs, ksize, prec):
+        self.srcs = srcs                     # list of parameters concatenated along dim 0
+        self.ksize = ksize
+        self.prec = prec
+        self.cout = sum(s.shape[0] for s in srcs)
+        self.cin = srcs[0].shape[1]
+        lib = L.load()
+        nbytes = lib.sgd_packed_weight_bytes(self.cout, self.cin, ksize, prec)
+        self.buf = torch.empty(nbytes // 4, dtype=torch.float32, device=srcs[0].device)
+        self.cin_p = self.cout_p = 0
+        self.sig = None
+
+    def refresh(self, stream):
+        sig = tuple((s.data_ptr(), s._version) for s in self.srcs)
+        if sig == self.sig:
+            return
+        lib = L.load()
+        src = self.srcs[0].detach() if len(self.srcs) == 1 else torch.cat([s.detach() for s in self.srcs], 0)
+        src = src.contiguous().float()
+        cin_p, cout_p = C.c_int32(0), C.c_int32(0)
+        L.check(lib.sgd_pack_weight(_ptr(src), _ptr(self.buf), self.cout, self.cin, self.ksize, self.prec,
+                                    C.byref(cin_p), C.byref(cout_p), stream), "sgd_pack_weight")
+        self.cin_p, self.cout_p = cin_p.value, cout_p.value
+        self._keep = src
+        self.sig = sig
+
+
+class _Program:
+    def __init__(self):
+        self.ops = []
+        self.keep = []
+
+    def add(self, name, fn, *args):
+        self.ops.append((name, fn, args))
+
+    def run(self, stream):
+        for name, fn, args in self.ops:
+            rc = fn(*args, stream)
+            if rc:
+                L.check(rc, name)
+
+
+# ------------------------------------------------------------------------------------------------
+# the model
+# ------------------------------------------------------------------------------------------------
+class UNetModelBase(nn.Module):
+    KIND = None
+
+    # -------------------------------------------------------------- construction (reference ctor logic)
+    def _setup(self, image_size, in_channels, model_channels, out_channels, num_res_blocks,
+               attention_resolutions, dropout, channel_mult, conv_resample, dims, use_checkpoint, use_fp16,
+               num_heads, num_head_channels, num_heads_upsample, use_scale_shift_norm, resblock_updown,
+               cond_dim, condition, condition_method):
+        if dims != 2:
+            raise NotImplementedError("HIP path implements dims=2 only")
+        if use_fp16:
+            raise NotImplementedError("use_fp16=True is not supported (reference configs use fp32)")
+        if num_heads == -1 and num_head_channels == -1:
+            raise AssertionError("Either num_heads or num_head_channels has to be set")
+        if not use_scale_shift_norm:
+            raise NotImplementedError("HIP path implements use_scale_shift_norm=True (all shipped configs)")
+        if not conv_resample:
+            raise NotImplementedError("HIP path implements conv_resample=True (ctor default)")
+        self.image_size = image_size
+        self.in_channels = in_channels
+        self.model_channels = model_channels
+        self.out_channels = out_channels
+        self.num_res_blocks = num_res_blocks
+        self.attention_resolutions = tuple(attention_resolutions)
+        self.dropout = dropout
+        self.channel_mult = tuple(channel_mult)
+        self.conv_resample = conv_resample
+        self.use_checkpoint = use_checkpoint
+        self.dtype = torch.float32
+        self.num_heads = num_heads
+        self.num_head_channels = num_head_channels
+        self.num_heads_upsample = num_heads if num_heads_upsample == -1 else num_heads_upsample
+        self.use_scale_shift_norm = use_scale_shift_norm
+        self.resblock_updown = resblock_updown
+        self.cond_dim = 0 if cond_dim is None else cond_dim
+        self.condition = condition
+        self.condition_method = condition_method
+        self.hip_precision = default_precision()
+        self._engines = {}
+
+    def _heads_for(self, ch):
+        return self.num_heads if self.num_head_channels == -1 else ch // self.num_head_channels
+
+    def _walk(self):
+        """block plan; mirrors openaimodel.py:634-835 / openaimodel_ca.py:645-836"""
+        mc, cm, nrb = self.model_channels, self.channel_mult, self.num_res_blocks
+        inp = [[("conv", self._in_ch_total, mc)]]
+        chans = [mc]
+        ch, ds = mc, 1
+        for level, mult in enumerate(cm):
+            for _ in range(nrb):
+                layers = [("res", ch, mult * mc, None)]
+                ch = mult * mc
+                if ds in self.attention_resolutions:
+                    layers.append(("attn", ch, self._heads_for(ch)))
+                inp.append(layers)
+                chans.append(ch)
+            if level != len(cm) - 1:
+                inp.append([("res", ch, ch, "down")] if self.resblock_updown else [("down", ch)])
+                chans.append(ch)
+                ds *= 2
+        mid = [("res", ch, ch, None), ("attn", ch, self._heads_for(ch)), ("res", ch, ch, None)]
+        out = []
+        for level, mult in list(enumerate(cm))[::-1]:
+            for i in range(nrb + 1):
+                ich = chans.pop()
+                layers = [("res", ch + ich, mc * mult, None)]
+                ch = mc * mult
+                if ds in self.attention_resolutions:
+                    layers.append(("attn", ch, self._heads_for(ch)))
+                if level and i == nrb:
+                    layers.append(("res", ch, ch, "up") if self.resblock_updown else ("up", ch))
+                    ds //= 2
+                out.append(layers)
+        return inp, mid, out
+
+    def _layer_spec(self, sp, p, layer):
+        kind = layer[0]
+        if kind == "conv":
+            sp.conv(p, layer[1], layer[2], 3)
+        elif kind == "res":
+            _, cin, cout, _ud = layer
+            sp.norm(p + ".in_layers.0", cin)
+            sp.conv(p + ".in_layers.2", cin, cout, 3)
+            sp.linear(p + ".emb_layers.1", self._emb_ch, 2 * cout)
+            sp.norm(p + ".out_layers.0", cout)
+            sp.conv(p + ".out_layers.3", cout, cout, 3, zero=True)        # zero_module, openaimodel.py:273-276
+            if cin != cout:
+                sp.conv(p + ".skip_connection", cin, cout, 1)
+        elif kind == "attn":
+            self._attn_spec(sp, p, layer[1], layer[2])
+        elif kind == "down":
+            sp.conv(p + ".op", layer[1], layer[1], 3)
+        elif kind == "up":
+            sp.conv(p + ".conv", layer[1], layer[1], 3)
+
+    def _register_all(self, sp_head):
+        sp = sp_head
+        inp, mid, out = self._walk()
+        self._plan = (inp, mid, out)
+        for i, blk in enumerate(inp):
+            for j, layer in enumerate(blk):
+                self._layer_spec(sp, f"input_blocks.{i}.{j}", layer)
+        for j, layer in enumerate(mid):
+            self._layer_spec(sp, f"middle_block.{j}", layer)
+        for i, blk in enumerate(out):
+            for j, layer in enumerate(blk):
+                self._layer_spec(sp, f"output_blocks.{i}.{j}", layer)
+        sp.norm("out.0", self.model_channels)
+        sp.conv("out.2", self.model_channels, self.out_channels, 3, zero=True)   # openaimodel.py:833-834
+        for name, shape, kind, init in sp.items:
+            _register(self, name, shape, kind, init)
+        self._manifest = [(n, tuple(s), k) for n, s, k, _ in sp.items]
+
+    def P(self, name):
+        return _get(self, name)
+
+    # -------------------------------------------------------------- reference API
+    def get_guided_score(self, z, zc, w):
+        st = self.condition["scale_type"] if isinstance(self.condition, dict) else self.condition.scale_type
+        if st == "imagen":
+            return (1 - w) * z + w * zc
+        elif st == "cfg":
+            return (1 + w) * zc - w * z
+        raise ValueError(st)
+
+    def _scale_mode(self):
+        st = self.condition["scale_type"] if isinstance(self.condition, dict) else self.condition.scale_type
+        if st == "imagen":
+            return 1
+        if st == "cfg":
+            return 2
+        raise ValueError(st)
+
+    def convert_to_fp16(self):
+        pass
+
+    def convert_to_fp32(self):
+        pass
+
+    # -------------------------------------------------------------- engine
+    def _engine(self, n, h, w, prec):
+        dev = self._device()
+        sig = tuple(p.data_ptr() for p in self._all_tensors())
+        key = (n, h, w, prec)
+        eng = self._engines.get(key)
+        if eng is None or eng.sig != sig:
+            eng = _Engine(self, n, h, w, prec, dev)
+            eng.sig = sig
+            self._engines[key] = eng
+        return eng
+
+    def _all_tensors(self):
+        if not hasattr(self, "_tensor_list") or self._tensor_list_n != len(self._manifest):
+            self._tensor_list = [self.P(n) for n, _, _ in self._manifest]
+            self._tensor_list_n = len(self._manifest)
+        return self._tensor_list
+
+    def _device(self):
+        return self.P(self._manifest[-1][0]).device
+
+    def _check_runnable(self, x):
+        if x.device.type != "cuda":
+            raise RuntimeError("sgdm_amd UNet runs on the MI355X HIP path only (inputs must be on a cuda "
+                               "device); there is no CPU fallback")
+        L.load()
+
+    def _draw_mask(self, n, cond_drop_prob, device):
+        """prob_mask_like (openaimodel.py:462-463): same RNG consumption as the reference"""
+        return torch.zeros((n,), device=device).float().uniform_(0, 1) < cond_drop_prob
+
+    def _run(self, x, t, cond, layout, mask, n):
+        """one UNet evaluation at UNet batch n (inputs have n_src = len(x) rows, n % n_src == 0).
+        Returns the engine (eps in eng.eps_nhwc [n, H, W, out_channels])."""
+        self._check_runnable(x)
+        if torch.is_grad_enabled() and self.training and any(p.requires_grad for p in self.parameters()):
+            from .train import forward_train      # autograd-capable path
+            return forward_train(self, x, t, cond, layout, mask, n)
+        B, cx, H, W = x.shape
+        assert cx == self.in_channels
+        prec = L.PREC_BY_NAME[self.hip_precision]
+        eng = self._engine(n, H, W, prec)
+        eng.run(x, t, cond, layout, mask)
+        return eng
+
+    def _to_nchw(self, eng):
+        lib = L.load()
+        n, H, W = eng.n, eng.h, eng.w
+        out = torch.empty(n, self.out_channels, H, W, device=eng.dev, dtype=torch.float32)
+        L.check(lib.sgd_nhwc_to_nchw(_ptr(eng.eps_nhwc), n, H, W, self.out_channels, _ptr(out),
+                                     torch.cuda.current_stream().cuda_stream), "sgd_nhwc_to_nchw")
+        return out
+
+    def _cfg_combine(self, eng, w, B):
+        lib = L.load()
+        out = torch.empty(B, self.out_channels, eng.h, eng.w, device=eng.dev, dtype=torch.float32)
+        L.check(lib.sgd_cfg_combine(_ptr(eng.eps_nhwc), self._scale_mode(), float(w), B, self.out_channels,
+                                    eng.h * eng.w, _ptr(out), torch.cuda.current_stream().cuda_stream),
+                "sgd_cfg_combine")
+        return out
+
+
+# ------------------------------------------------------------------------------------------------
+class _Engine:
+    """static launch program + workspace for one (UNet batch, H, W, precision)"""
+
+    def __init__(self, model, n, h, w, prec, dev):
+        self.m, self.n, self.h, self.w, self.prec, self.dev = model, n, h, w, prec, dev
+        self.lib = L.load()
+        self.prog = _Program()
+        self.packed = []
+        self.bufs = []
+        self._build()
+
+    # ---- helpers
+    def buf(self, *shape, dtype=torch.float32):
+        t = torch.empty(*shape, dtype=dtype, device=self.dev)
+        self.bufs.append(t)
+        return t
+
+    def pack(self, names, ksize):
+        pk = _Packed([self.m.P(nm) for nm in names], ksize, self.prec)
+        self.packed.append(pk)
+        return pk
+
+    def igemm(self, tag, x0, c0, y, cout, pk, *, x1=None, c1=0, conv=None, m=0, rows_per_n=0,
+              pro=L.PRO_NONE, silu=0, pa=None, pb=None, pc=None, bias=None, res=None, res_mode=L.RS_NONE,
+              y_ld=None, y_off=0, orows=(0, 0, 0)):
+        a = L.IgemmArgs()
+        a.x0, a.x1, a.c0, a.c1 = x0.data_ptr(), (x1.data_ptr() if x1 is not None else 0), c0, c1
+        if conv is not None:
+            nimg, hi, wi, ho, wo, stride, resample = conv
+            a.mode, a.n, a.hi, a.wi, a.ho, a.wo, a.stride, a.resample = L.MODE_CONV3, nimg, hi, wi, ho, wo, stride, resample
+        else:
+            a.mode, a.m, a.rows_per_n, a.stride = L.MODE_FLAT, m, rows_per_n, 1
+        a.pro, a.pro_silu = pro, silu
+        a.pa = pa.data_ptr() if pa is not None else 0
+        a.pb = pb.data_ptr() if pb is not None else 0
+        a.pc = pc.data_ptr() if pc is not None else 0
+        a.w = pk.buf.data_ptr()
+        a.bias = bias.data_ptr() if bias is not None else 0
+        a.res = res.data_ptr() if res is not None else 0
+        a.res_mode = res_mode
+        a.y = y.data_ptr() + 4 * y_off
+        a.cout = cout
+        a.y_ld = y_ld if y_ld is not None else cout
+        a.orows_in, a.orows_out, a.orow_off = orows
+        a.prec = self.prec
+        self.prog.keep.append((a, pk))
+        self._late.append((a, pk))                # cin_p / cout_p are known after the first pack
+        self.prog.add(tag, self.lib.sgd_igemm, C.byref(a))
+
+    def gn(self, tag, srcs, hw, gname, film=None, film_ld=0):
+        """srcs: list of (tensor, channels) forming a virtual concat -> (a, b) coefficient buffers"""
+        n = self.n
+        ct = sum(c for _, c in srcs)
+        sums = self.buf(n, ct, 2)
+        off = 0
+        for t, c in srcs:
+            self.prog.add(tag + ".stats", self.lib.sgd_chan_stats, _ptr(t), n, hw, c, _ptr(sums), ct, off)
+            off += c
+        a, b = self.buf(n, ct), self.buf(n, ct)
+        self.prog.add(tag + ".coef", self.lib.sgd_gn_coef, _ptr(sums), _ptr(self.m.P(gname + ".weight")),
+                      _ptr(self.m.P(gname + ".bias")), C.c_void_p(film or 0), film_ld, n, ct, GN_GROUPS, hw,
+                      GN_EPS, _ptr(a), _ptr(b))
+        return a, b
+
+    # ---- program construction
+    def _build(self):
+        m, n, H, W = self.m, self.n, self.h, self.w
+        self._late = []
+        mc = m.model_channels
+        ted = 4 * mc
+        P = m.P
+        lib = self.lib
+        # ---------------- boundary buffers (filled by run())
+        self.temb = self.buf(n, mc)
+        self.freqs = timestep_freqs(mc).to(self.dev)
+        cin_tot = m._in_ch_total
+        self.x_in = self.buf(n, H, W, cin_tot)
+        self.cond_m = self.buf(n, max(1, m._cond_width)) if m._cond_width else None
+        # ---------------- embedding path
+        emb = self.buf(n, m._emb_ch)
+        e1 = self.buf(n, ted)
+        self.igemm("time_embed.0", self.temb, mc, e1, ted, self.pack(["time_embed.0.weight"], 1), m=n,
+                   bias=P("time_embed.0.bias"))
+        self.igemm("time_embed.2", e1, ted, emb, ted, self.pack(["time_embed.2.weight"], 1), m=n, silu=1,
+                   bias=P("time_embed.2.bias"), y_ld=m._emb_ch)
+        self.context = None
+        m._build_cond_path(self, emb)
+        # all ResBlocks' emb_layers in one GEMM (they share SiLU(emb))
+        res_names = m._res_prefixes()
+        film_w = sum(2 * co for _, co in res_names)
+        film = self.buf(n, film_w)
+        fbias = self.buf(film_w)
+        self._film_bias_src = [P(p + ".emb_layers.1.bias") for p, _ in res_names]
+        self._film_bias = fbias
+        self.igemm("emb_layers", emb, m._emb_ch, film, film_w,
+                   self.pack([p + ".emb_layers.1.weight" for p, _ in res_names], 1), m=n, silu=1, bias=fbias)
+        self.film, self.film_ld = film, film_w
+        self.film_off = {}
+        off = 0
+        for p, co in res_names:
+            self.film_off[p] = off
+            off += 2 * co
+        # ---------------- trunk
+        inp, mid, out = m._plan
+        hs = []
+        cur = (self.x_in, cin_tot, H, W)
+        for i, blk in enumerate(inp):
+            cur = self._block(f"input_blocks.{i}", blk, [cur])
+            hs.append(cur)
+        cur = self._block("middle_block", mid, [cur])
+        for i, blk in enumerate(out):
+            cur = self._block(f"output_blocks.{i}", blk, [cur, hs.pop()])
+        t, c, hh, ww = cur
+        a, b = self.gn("out.0", [(t, c)], hh * ww, "out.0")
+        self.eps_nhwc = self.buf(n, hh, ww, m.out_channels)
+        self.igemm("out.2", t, c, self.eps_nhwc, m.out_channels, self.pack(["out.2.weight"], 3),
+                   conv=(n, hh, ww, hh, ww, 1, L.RS_NONE), pro=L.PRO_AFFINE_NC, silu=1, pa=a, pb=b,
+                   bias=P("out.2.bias"))
+
+    def _block(self, prefix, blk, srcs):
+        """srcs: list of (tensor, C, H, W) (two entries = virtual concat [h, skip])"""
+        for j, layer in enumerate(blk):
+            p = f"{prefix}.{j}"
+            kind = layer[0]
+            if kind == "conv":
+                (t, c, hh, ww), = srcs
+                y = self.buf(self.n, hh, ww, layer[2])
+                self.igemm(p, t, c, y, layer[2], self.pack([p + ".weight"], 3),
+                           conv=(self.n, hh, ww, hh, ww, 1, L.RS_NONE), bias=self.m.P(p + ".bias"))
+                srcs = [(y, layer[2], hh, ww)]
+            elif kind == "res":
+                srcs = [self._res(p, layer, srcs)]
+            elif kind == "attn":
+                srcs = [self.m._build_attn(self, p, layer, srcs[0])]
+            elif kind == "down":
+                (t, c, hh, ww), = srcs
+                y = self.buf(self.n, hh // 2, ww // 2, c)
+                self.igemm(p + ".op", t, c, y, c, self.pack([p + ".op.weight"], 3),
+                           conv=(self.n, hh, ww, hh // 2, ww // 2, 2, L.RS_NONE), bias=self.m.P(p + ".op.bias"))
+                srcs = [(y, c, hh // 2, ww // 2)]
+            elif kind == "up":
+                (t, c, hh, ww), = srcs
+                y = self.buf(self.n, hh * 2, ww * 2, c)
+                self.igemm(p + ".conv", t, c, y, c, self.pack([p + ".conv.weight"], 3),
+                           conv=(self.n, hh, ww, hh * 2, ww * 2, 1, L.RS_UP2), bias=self.m.P(p + ".conv.bias"))
+                srcs = [(y, c, hh * 2, ww * 2)]
+        return srcs[0]
+
+    def _res(self, p, layer, srcs):
+        """ResBlock._forward (openaimodel.py:300-320), use_scale_shift_norm=True"""
+        _, cin, cout, ud = layer
+        n, P = self.n, self.m.P
+        t0, c0, hh, ww = srcs[0]
+        t1, c1 = (srcs[1][0], srcs[1][1]) if len(srcs) == 2 else (None, 0)
+        assert c0 + c1 == cin
+        rs = {None: L.RS_NONE, "down": L.RS_AVGPOOL2, "up": L.RS_UP2}[ud]
+        ho, wo = (hh // 2, ww // 2) if ud == "down" else ((hh * 2, ww * 2) if ud == "up" else (hh, ww))
+        a1, b1 = self.gn(p + ".in_layers.0", [(t0, c0)] + ([(t1, c1)] if t1 is not None else []), hh * ww,
+                         p + ".in_layers.0")
+        h1 = self.buf(n, ho, wo, cout)
+        self.igemm(p + ".in_layers.2", t0, c0, h1, cout, self.pack([p + ".in_layers.2.weight"], 3), x1=t1, c1=c1,
+                   conv=(n, hh, ww, ho, wo, 1, rs), pro=L.PRO_AFFINE_NC, silu=1, pa=a1, pb=b1,
+                   bias=P(p + ".in_layers.2.bias"))
+        film_ptr = self.film.data_ptr() + 4 * self.film_off[p]
+        a2, b2 = self.gn(p + ".out_layers.0", [(h1, cout)], ho * wo, p + ".out_layers.0", film=film_ptr,
+                         film_ld=self.film_ld)
+        if cin != cout:
+            assert ud is None
+            skip = self.buf(n, hh, ww, cout)
+            self.igemm(p + ".skip_connection", t0, c0, skip, cout, self.pack([p + ".skip_connection.weight"], 1),
+                       x1=t1, c1=c1, m=n * hh * ww, bias=P(p + ".skip_connection.bias"))
+            res, res_mode = skip, L.RS_NONE
+        else:
+            assert t1 is None
+            res, res_mode = t0, rs
+        y = self.buf(n, ho, wo, cout)
+        self.igemm(p + ".out_layers.3", h1, cout, y, cout, self.pack([p + ".out_layers.3.weight"], 3),
+                   conv=(n, ho, wo, ho, wo, 1, L.RS_NONE), pro=L.PRO_AFFINE_NC, silu=1, pa=a2, pb=b2,
+                   bias=P(p + ".out_layers.3.bias"), res=res, res_mode=res_mode)
+        return (y, cout, ho, wo)
+
+    # ---- execution
+    def refresh(self, stream):
+        for pk in self.packed:
+            pk.refresh(stream)
+        for a, pk in self._late:
+            a.cin_p, a.cout_p = pk.cin_p, pk.cout_p
+        sig = tuple((b.data_ptr(), b._version) for b in self._film_bias_src)
+        if sig != getattr(self, "_film_sig", None):
+            self._film_bias.copy_(torch.cat([b.detach().reshape(-1) for b in self._film_bias_src]))
+            self._film_sig = sig
+
+    def run(self, x, t, cond, layout, mask):
+        m, n, lib = self.m, self.n, self.lib
+        stream = torch.cuda.current_stream().cuda_stream
+        self.refresh(stream)
+        B = x.shape[0]
+        assert n % B == 0
+        x = x.contiguous().float()
+        t = t.contiguous().to(torch.int64)
+        mask_u8 = mask.contiguous().view(torch.uint8) if mask is not None else None
+        L.check(lib.sgd_timestep_embedding(_ptr(t), _ptr(self.freqs), B, n, m.model_channels, _ptr(self.temb),
+                                           stream), "temb")
+        cl = m._in_ch_total - m.in_channels
+        if cl:
+            if layout is None:
+                raise ValueError(f"condition_method={m.condition_method} needs `layout`")
+            layout = layout.contiguous().float()
+            assert layout.shape == (B, cl, self.h, self.w), (layout.shape, (B, cl, self.h, self.w))
+        L.check(lib.sgd_pack_input(_ptr(x), _ptr(layout) if cl else C.c_void_p(0), _ptr(mask_u8),
+                                   _ptr(m.null_layout_emb) if cl else C.c_void_p(0), B, n, m.in_channels, cl,
+                                   self.h, self.w, _ptr(self.x_in), stream), "pack_input")
+        if m._cond_width:
+            if cond is None:
+                raise ValueError(f"condition_method={m.condition_method} needs `cond`")
+            cond = cond.contiguous()
+            is_i64 = cond.dtype == torch.int64
+            if not is_i64:
+                cond = cond.float()
+            assert cond.numel() == B * m._cond_width, (cond.shape, m._cond_width)
+            L.check(lib.sgd_cond_select(_ptr(cond), int(is_i64), _ptr(mask_u8), _ptr(m.null_cond_emb), B, n,
+                                        m._cond_width, _ptr(self.cond_m), stream), "cond_select")
+        self._keep_inputs = (x, t, cond, layout, mask_u8)
+        self.prog.run(stream)
+
+
+# ------------------------------------------------------------------------------------------------
+# unet_fast
+# ------------------------------------------------------------------------------------------------
+class UNetModel(UNetModelBase):
+    """``dynamic.diffusionmodules.openaimodel.UNetModel`` (config/dynamic/unet_fast.yaml)."""
+    KIND = "unet_fast"
+
+    def __init__(self, image_size, in_channels, model_channels, out_channels, num_res_blocks,
+                 attention_resolutions, dropout=0, channel_mult=(1, 2, 4, 8), conv_resample=True, dims=2,
+                 use_checkpoint=False, use_fp16=False, num_heads=-1, num_head_channels=-1,
+                 num_heads_upsample=-1, use_scale_shift_norm=False, resblock_updown=False,
+                 use_new_attention_order=False, use_spatial_transformer=False, transformer_depth=1,
+                 context_dim=None, legacy=True, cond_dim=None, condition=None, condition_method=None):
+        super().__init__()
+        if use_spatial_transformer or context_dim is not None:
+            raise NotImplementedError("SpatialTransformer path (SURVEY 8(a) A22) is not built yet")
+        if use_new_attention_order:
+            raise NotImplementedError("use_new_attention_order=True is not used by any shipped config")
+        if condition_method == "cluster_lookup":
+            raise NotImplementedError("cluster_lookup (nn.Embedding(888888888, .)) is not supported")
+        self._setup(image_size, in_channels, model_channels, out_channels, num_res_blocks, attention_resolutions,
+                    dropout, channel_mult, conv_resample, dims, use_checkpoint, use_fp16, num_heads,
+                    num_head_channels, num_heads_upsample, use_scale_shift_norm, resblock_updown, cond_dim,
+                    condition, condition_method)
+        ted = 4 * model_channels
+        cd = self.cond_dim
+        self.mlp_cond_out = ted // 2 if cd > 0 else 0
+        self._emb_ch = ted + self.mlp_cond_out
+        self._cond_width = cd
+        ld = 0
+        sp = _Spec()
+        if cd > 0:
+            sp.items.append(("null_cond_emb", (1, cd), "frozen", _zeros))
+        if condition_method == "clusterlayout":
+            sp.items.append(("null_layout_emb", (1, 1, image_size, image_size), "frozen", _zeros))
+            ld = _layout_dim(condition, "clusterlayout")
+        self._in_ch_total = in_channels + ld
+        sp.linear("time_embed.0", model_channels, ted)
+        sp.linear("time_embed.2", ted, ted)
+        if cd > 0:
+            sp.linear("mlp_cond.0", cd, ted // 2)
+            sp.linear("mlp_cond.2", ted // 2, ted // 2)
+        self._register_all(sp)
+
+    def _attn_spec(self, sp, p, ch, heads):
+        sp.norm(p + ".norm", ch)
+        sp.conv(p + ".qkv", ch, 3 * ch, 1, dims=1)
+        sp.conv(p + ".proj_out", ch, ch, 1, dims=1, zero=True)                  # openaimodel.py:357
+
+    def _res_prefixes(self):
+        return _res_prefixes(self._plan)
+
+    def _build_cond_path(self, eng, emb):
+        if self.cond_dim <= 0:
+            return
+        ted = 4 * self.model_channels
+        P = self.P
+        c1 = eng.buf(eng.n, ted // 2)
+        eng.igemm("mlp_cond.0", eng.cond_m, self.cond_dim, c1, ted // 2, eng.pack(["mlp_cond.0.weight"], 1),
+                  m=eng.n, bias=P("mlp_cond.0.bias"))
+        eng.igemm("mlp_cond.2", c1, ted // 2, emb, ted // 2, eng.pack(["mlp_cond.2.weight"], 1), m=eng.n, silu=1,
+                  bias=P("mlp_cond.2.bias"), y_ld=self._emb_ch, y_off=ted)       # emb = cat(time, cond), :942
+
+    def _build_attn(self, eng, p, layer, src):
+        """AttentionBlock + QKVAttentionLegacy (openaimodel.py:365-371, 403-420)"""
+        _, ch, heads = layer
+        t, c, hh, ww = src
+        n, T, P = eng.n, hh * ww, self.P
+        d = ch // heads
+        a, b = eng.gn(p + ".norm", [(t, c)], T, p + ".norm")
+        qkv = eng.buf(n, T, 3 * ch)
+        eng.igemm(p + ".qkv", t, c, qkv, 3 * ch, eng.pack([p + ".qkv.weight"], 1), m=n * T, rows_per_n=T,
+                  pro=L.PRO_AFFINE_NC, pa=a, pb=b, bias=P(p + ".qkv.bias"))
+        att = eng.buf(n, T, ch)
+        # legacy layout: channel = head*3d + {q: 0, k: d, v: 2d}; scale = (d^-1/4)^2 applied to q.k
+        eng.prog.add(p + ".attn", eng.lib.sgd_attention, _ptr(qkv), 3 * ch, 3 * d,
+                     C.c_void_p(qkv.data_ptr() + 4 * d), C.c_void_p(qkv.data_ptr() + 8 * d), 3 * ch, 3 * d,
+                     n, heads, T, T, d, 1.0 / math.sqrt(d), _ptr(att), ch)
+        y = eng.buf(n, hh, ww, ch)
+        eng.igemm(p + ".proj_out", att, ch, y, ch, eng.pack([p + ".proj_out.weight"], 1), m=n * T,
+                  bias=P(p + ".proj_out.bias"), res=t)
+        return (y, ch, hh, ww)
+
+    # ---- reference entry points (openaimodel.py:861-956)
+    def forward(self, x, timesteps=None, cond=None, layout=None, cond_drop_prob=0.0, image_batch_ids=None,
+                cond_drop_mask=None):
+        n = len(x)
+        if isinstance(cond_drop_prob, (float, int)):
+            cond_drop_prob = torch.full((n,), cond_drop_prob, dtype=torch.float, device=x.device)
+        assert isinstance(cond_drop_prob, torch.Tensor)
+        mask = None
+        if self.cond_dim > 0:
+            mask = cond_drop_mask if cond_drop_mask is not None else self._draw_mask(n, cond_drop_prob, x.device)
+        eng = self._run(x, timesteps, cond, layout, mask, n)
+        if isinstance(eng, tuple):          # training path returns tensors directly
+            return eng
+        return self._to_nchw(eng), 0.0, dict()
+
+    def forward_with_cond_scale(self, x, t, cond_scale, cond, layout=None, p0=None, image_batch_ids=None):
+        B = x.shape[0]
+        if p0 is None:
+            p0 = torch.full((B,), 0.0, dtype=torch.float, device=x.device)
+        p1 = torch.full((B,), 1.0, dtype=torch.float, device=x.device)
+        is_num = isinstance(cond_scale, (int, float))
+        if is_num and cond_scale == 1:
+            return self.forward(x=x, timesteps=t, cond_drop_prob=p0, cond=cond, layout=layout)[0]
+        if is_num and cond_scale == 0:
+            return self.forward(x=x, timesteps=t, cond_drop_prob=p1, cond=cond, layout=layout)[0]
+        return _cfg_eval(self, x, t, cond_scale, cond, layout, torch.cat((p0, p1), 0))
+
+
+# ------------------------------------------------------------------------------------------------
+# unetca_fast
+# ------------------------------------------------------------------------------------------------
+class UNetModelCA(UNetModelBase):
+    """``dynamic.diffusionmodules.openaimodel_ca.UNetModel`` (config/dynamic/unetca_fast.yaml)."""
+    KIND = "unetca_fast"
+
+    def __init__(self, image_size, in_channels, model_channels, out_channels, num_res_blocks,
+                 attention_resolutions, dropout=0, channel_mult=(1, 2, 4, 8), conv_resample=True, dims=2,
+                 num_classes=None, use_checkpoint=False, use_fp16=False, num_heads=-1, num_head_channels=-1,
+                 num_heads_upsample=-1, use_scale_shift_norm=False, resblock_updown=False,
+                 use_new_attention_order=False, use_ca_block=False, transformer_depth=1, context_dim=None,
+                 n_embed=None, legacy=True, cond_token_num=0, cond_dim=None, use_cls_token_as_pooled=None,
+                 condition=None, condition_method=None):
+        super().__init__()
+        if not use_ca_block:
+            raise NotImplementedError("openaimodel_ca without use_ca_block is not a shipped configuration")
+        if cond_token_num > 1:
+            raise NotImplementedError("cond_token_num > 1 (token guidance) is not built yet")
+        assert isinstance(cond_dim, int) and cond_token_num >= 0                 # openaimodel_ca.py:559-560
+        if cond_token_num == 0:
+            assert cond_dim == 0                                                 # :563
+        self._setup(image_size, in_channels, model_channels, out_channels, num_res_blocks, attention_resolutions,
+                    dropout, channel_mult, conv_resample, dims, use_checkpoint, use_fp16, num_heads,
+                    num_head_channels, num_heads_upsample, use_scale_shift_norm, resblock_updown, cond_dim,
+                    condition, condition_method)
+        self.num_classes = num_classes
+        self.cond_token_num = cond_token_num
+        self.context_dim = context_dim
+        self.use_cls_token_as_pooled = use_cls_token_as_pooled
+        mc = model_channels
+        ted = 4 * mc
+        cd = self.cond_dim
+        self._emb_ch = ted
+        self._cond_width = cd if cond_token_num == 1 else 0
+        sp = _Spec()
+        if cond_token_num == 1:
+            sp.items.append(("null_cond_emb", (1, cd), "frozen", _zeros))
+        ld = 0
+        if condition_method in ("clusterlayout", "stegoclusterlayout", "layout"):
+            sp.items.append(("null_layout_emb", (1, 1, image_size, image_size), "frozen", _zeros))
+            ld = _layout_dim(condition, condition_method)
+        self._in_ch_total = in_channels + ld
+        sp.linear("time_embed.0", mc, ted)
+        sp.linear("time_embed.2", ted, ted)
+        sp.norm("norm_cond", context_dim)
+        sp.linear("to_time_tokens.0", mc, mc)
+        sp.linear("to_time_tokens.2", mc, context_dim * NUM_TIME_TOKENS)
+        if cond_token_num > 0:
+            sp.linear("cond_mlp.0", cd, ted)
+            sp.linear("cond_mlp.2", ted, ted)
+            sp.linear("to_cond_tokens.0", cd, context_dim * NUM_COND_TOKENS)
+            mid = int(math.sqrt(context_dim * cd))
+            sp.linear("to_cond_tokens_2d.0", cd, mid)
+            sp.linear("to_cond_tokens_2d.2", mid, mid)
+            sp.linear("to_cond_tokens_2d.4", mid, mid)
+            sp.linear("to_cond_tokens_2d.6", mid, context_dim)
+        self._register_all(sp)
+
+    def _attn_spec(self, sp, p, ch, heads):
+        dh = ch // heads
+        cd = self.context_dim
+        sp.items.append((p + ".null_kv", (2, dh), "param", _randn))
+        sp.items.append((p + ".norm.gamma", (ch,), "param", _ones))
+        sp.items.append((p + ".norm.beta", (ch,), "buffer", _zeros))
+        sp.linear(p + ".to_q", ch, dh * heads, bias=False)
+        sp.linear(p + ".to_kv", ch, 2 * dh, bias=False)
+        sp.norm(p + ".to_context.0", cd)
+        sp.linear(p + ".to_context.1", cd, 2 * dh)
+        sp.linear(p + ".to_out.0", dh * heads, ch, bias=False)
+        sp.items.append((p + ".to_out.1.gamma", (ch,), "param", _ones))
+        sp.items.append((p + ".to_out.1.beta", (ch,), "buffer", _zeros))
+
+    def _res_prefixes(self):
+        return _res_prefixes(self._plan)
+
+    def _build_cond_path(self, eng, emb):
+        """openaimodel_ca.py:942-1017: time tokens, cond tokens, emb += cond_mlp(cond), context LayerNorm"""
+        n, P = eng.n, self.P
+        mc, ctx = self.model_channels, self.context_dim
+        ted = 4 * mc
+        ntok = NUM_TIME_TOKENS + (NUM_COND_TOKENS if self.cond_token_num == 1 else 0)
+        raw = eng.buf(n, ntok, ctx)
+        t1 = eng.buf(n, mc)
+        eng.igemm("to_time_tokens.0", eng.temb, mc, t1, mc, eng.pack(["to_time_tokens.0.weight"], 1), m=n,
+                  bias=P("to_time_tokens.0.bias"))
+        eng.igemm("to_time_tokens.2", t1, mc, raw, ctx * NUM_TIME_TOKENS, eng.pack(["to_time_tokens.2.weight"], 1),
+                  m=n, silu=1, bias=P("to_time_tokens.2.bias"), y_ld=ntok * ctx)
+        if self.cond_token_num == 1:
+            eng.igemm("to_cond_tokens.0", eng.cond_m, self.cond_dim, raw, ctx * NUM_COND_TOKENS,
+                      eng.pack(["to_cond_tokens.0.weight"], 1), m=n, bias=P("to_cond_tokens.0.bias"),
+                      y_ld=ntok * ctx, y_off=ctx * NUM_TIME_TOKENS)
+            c1 = eng.buf(n, ted)
+            eng.igemm("cond_mlp.0", eng.cond_m, self.cond_dim, c1, ted, eng.pack(["cond_mlp.0.weight"], 1), m=n,
+                      bias=P("cond_mlp.0.bias"))
+            eng.igemm("cond_mlp.2", c1, ted, emb, ted, eng.pack(["cond_mlp.2.weight"], 1), m=n, silu=1,
+                      bias=P("cond_mlp.2.bias"), res=emb)                         # emb = emb + cond_condensed, :977
+        context = eng.buf(n, ntok, ctx)
+        eng.prog.add("norm_cond", eng.lib.sgd_ln_apply, _ptr(raw), _ptr(P("norm_cond.weight")),
+                     _ptr(P("norm_cond.bias")), C.c_void_p(0), n * ntok, ctx, LN_EPS, _ptr(context))
+        eng.context, eng.ntok = context, ntok
+
+    def _build_attn(self, eng, p, layer, src):
+        """Attention_LR.forward (crossattetion_lr.py:81-142)"""
+        _, ch, heads = layer
+        t, c, hh, ww = src
+        n, T, P, lib = eng.n, hh * ww, self.P, eng.lib
+        d = ch // heads
+        ntok = eng.ntok
+        J = ntok + 1 + T                                   # [context | null | self]
+        st = eng.buf(n * T, 2)
+        eng.prog.add(p + ".norm", lib.sgd_ln_stats, _ptr(t), n * T, c, LN_EPS, _ptr(st))
+        q = eng.buf(n, T, heads * d)
+        gamma, beta = P(p + ".norm.gamma"), P(p + ".norm.beta")
+        eng.igemm(p + ".to_q", t, c, q, heads * d, eng.pack([p + ".to_q.weight"], 1), m=n * T, pro=L.PRO_LN_ROW,
+                  pa=st, pb=gamma, pc=beta)
+        kv = eng.buf(n, J, 2 * d)
+        eng.igemm(p + ".to_kv", t, c, kv, 2 * d, eng.pack([p + ".to_kv.weight"], 1), m=n * T, pro=L.PRO_LN_ROW,
+                  pa=st, pb=gamma, pc=beta, orows=(T, J, ntok + 1))
+        cst = eng.buf(n * ntok, 2)
+        eng.prog.add(p + ".to_context.0", lib.sgd_ln_stats, _ptr(eng.context), n * ntok, self.context_dim, LN_EPS,
+                     _ptr(cst))
+        eng.igemm(p + ".to_context.1", eng.context, self.context_dim, kv, 2 * d,
+                  eng.pack([p + ".to_context.1.weight"], 1), m=n * ntok, pro=L.PRO_LN_ROW, pa=cst,
+                  pb=P(p + ".to_context.0.weight"), pc=P(p + ".to_context.0.bias"),
+                  bias=P(p + ".to_context.1.bias"), orows=(ntok, J, 0))
+        eng.prog.add(p + ".null_kv", lib.sgd_fill_null_kv, _ptr(P(p + ".null_kv")), n, J, ntok, d, _ptr(kv))
+        att = eng.buf(n, T, heads * d)
+        eng.prog.add(p + ".attn", lib.sgd_attention, _ptr(q), heads * d, d, _ptr(kv),
+                     C.c_void_p(kv.data_ptr() + 4 * d), 2 * d, 0, n, heads, T, J, d, d ** -0.5, _ptr(att),
+                     heads * d)
+        o = eng.buf(n, T, ch)
+        eng.igemm(p + ".to_out.0", att, heads * d, o, ch, eng.pack([p + ".to_out.0.weight"], 1), m=n * T)
+        y = eng.buf(n, hh, ww, ch)
+        eng.prog.add(p + ".to_out.1", lib.sgd_ln_apply, _ptr(o), _ptr(P(p + ".to_out.1.gamma")),
+                     _ptr(P(p + ".to_out.1.beta")), _ptr(t), n * T, ch, LN_EPS, _ptr(y))
+        return (y, ch, hh, ww)
+
+    # ---- reference entry points (openaimodel_ca.py:879-1033)
+    def forward(self, x, timesteps=None, cond_drop_prob=0.0, cond=None, layout=None, cond_drop_mask=None):
+        n = len(x)
+        if isinstance(cond_drop_prob, (float, int)):
+            cond_drop_prob = torch.full((n,), cond_drop_prob, dtype=torch.float, device=x.device)
+        else:
+            assert isinstance(cond_drop_prob, torch.Tensor)
+        mask = None
+        if self.cond_token_num == 0:
+            if self.condition_method == "clusterlayout":
+                raise NotImplementedError                                         # openaimodel_ca.py:947-948
+            if self.condition_method == "layout":
+                mask = cond_drop_mask if cond_drop_mask is not None else self._draw_mask(n, cond_drop_prob, x.device)
+        else:
+            assert cond is not None and len(cond.shape) == 2                      # :961
+            mask = cond_drop_mask if cond_drop_mask is not None else self._draw_mask(n, cond_drop_prob, x.device)
+        eng = self._run(x, timesteps, cond, layout, mask, n)
+        if isinstance(eng, tuple):
+            return eng
+        return self._to_nchw(eng), 0.0, dict()
+
+    def forward_with_cond_scale(self, x, t, cond_scale, cond=None, layout=None):
+        B = x.shape[0]
+        p0 = torch.full((B,), 0.0, dtype=torch.float, device=x.device)
+        p1 = torch.full((B,), 1.0, dtype=torch.float, device=x.device)
+        if isinstance(cond_scale, int) and cond_scale == 1:                       # int only, as the reference (:882)
+            return self.forward(x=x, timesteps=t, cond_drop_prob=p0, cond=cond, layout=layout)[0]
+        if isinstance(cond_scale, int) and cond_scale == 0:
+            return self.forward(x=x, timesteps=t, cond_drop_prob=p1, cond=cond, layout=layout)[0]
+        return _cfg_eval(self, x, t, cond_scale, cond, layout, torch.cat((p0, p1), 0))
+
+
+# ------------------------------------------------------------------------------------------------
+def _cfg_eval(model, x, t, cond_scale, cond, layout, probs):
+    """batch-doubled CFG evaluation (openaimodel.py:885-902): rows [0,B) conditional, [B,2B) dropped;
+    the doubling is done inside the boundary kernels (row % B), not by torch.cat."""
+    B = x.shape[0]
+    has_mask = (model._cond_width > 0) or (model._in_ch_total > model.in_channels)
+    mask = model._draw_mask(2 * B, probs, x.device) if has_mask else None
+    if not isinstance(cond_scale, (int, float)):
+        raise NotImplementedError("tensor cond_scale (vis sweeps, ddim_plms_sampler.py:117-142) is a 'next' row")
+    eng = model._run(x, t, cond, layout, mask, 2 * B)
+    return model._cfg_combine(eng, cond_scale, B)
+
+
+def _layout_dim(condition, method):
+    node = condition[method] if isinstance(condition, dict) else getattr(condition, method)
+    return node["layout_dim"] if isinstance(node, dict) else node.layout_dim
+
+
+def _res_prefixes(plan):
+    inp, mid, out = plan
+    names = []
+    for i, blk in enumerate(inp):
+        names += [(f"input_blocks.{i}.{j}", l[2]) for j, l in enumerate(blk) if l[0] == "res"]
+    names += [(f"middle_block.{j}", l[2]) for j, l in enumerate(mid) if l[0] == "res"]
+    for i, blk in enumerate(out):
+        names += [(f"output_blocks.{i}.{j}", l[2]) for j, l in enumerate(blk) if l[0] == "res"]
+    return names

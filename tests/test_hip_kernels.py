@@ -1,0 +1,293 @@
+"""Kernel-level parity of the C-ABI entry points (through ctypes) against plain fp32 torch-CPU
+restatements of the same op.  GPU only."""
+import ctypes as C
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import max_rel
+
+pytestmark = pytest.mark.gpu
+
+PRECS = [("f32", 2e-6), ("f16x3", 2e-5), ("bf16x3", 1e-4)]
+
+
+def _lib():
+    from sgdm_amd import _lib as L
+    return L, L.load()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _pack(w, ks, prec):
+    L, lib = _lib()
+    cout, cin = w.shape[0], w.shape[1]
+    nbytes = lib.sgd_packed_weight_bytes(cout, cin, ks, prec)
+    buf = torch.empty(nbytes // 4, device="cuda")
+    cin_p, cout_p = C.c_int32(), C.c_int32()
+    L.check(lib.sgd_pack_weight(_p(w.contiguous()), _p(buf), cout, cin, ks, prec, C.byref(cin_p), C.byref(cout_p),
+                                _stream()), "pack")
+    return buf, cin_p.value, cout_p.value
+
+
+def _nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def _run_conv(x, w, bias, prec_name, stride=1, resample=0, x1=None, pa=None, pb=None, silu=0, res=None, res_mode=0):
+    """x, x1: NCHW cpu tensors. returns NCHW cpu result of the HIP kernel."""
+    L, lib = _lib()
+    prec = L.PREC_BY_NAME[prec_name]
+    n, c0, hi, wi = x.shape
+    c1 = x1.shape[1] if x1 is not None else 0
+    hc, wc = (hi // 2, wi // 2) if resample == 1 else ((hi * 2, wi * 2) if resample == 2 else (hi, wi))
+    ho, wo = (hc // 2, wc // 2) if stride == 2 else (hc, wc)
+    cout = w.shape[0]
+    wd = w.cuda()
+    buf, cin_p, cout_p = _pack(wd, 3, prec)
+    xd = _nhwc(x).cuda()
+    x1d = _nhwc(x1).cuda() if x1 is not None else None
+    y = torch.full((n, ho, wo, cout), float("nan"), device="cuda")
+    a = L.IgemmArgs()
+    a.x0, a.x1, a.c0, a.c1 = xd.data_ptr(), (x1d.data_ptr() if x1d is not None else 0), c0, c1
+    a.mode, a.n, a.hi, a.wi, a.ho, a.wo, a.stride, a.resample = L.MODE_CONV3, n, hi, wi, ho, wo, stride, resample
+    keep = []
+    if pa is not None:
+        pad, pbd = pa.cuda(), pb.cuda()
+        keep += [pad, pbd]
+        a.pro, a.pa, a.pb = L.PRO_AFFINE_NC, pad.data_ptr(), pbd.data_ptr()
+    a.pro_silu = silu
+    a.w, a.cin_p, a.cout_p = buf.data_ptr(), cin_p, cout_p
+    bd = bias.cuda() if bias is not None else None
+    a.bias = bd.data_ptr() if bd is not None else 0
+    rd = _nhwc(res).cuda() if res is not None else None
+    a.res, a.res_mode = (rd.data_ptr() if rd is not None else 0), res_mode
+    a.y, a.cout, a.y_ld, a.prec = y.data_ptr(), cout, cout, prec
+    L.check(lib.sgd_igemm(C.byref(a), _stream()), "igemm")
+    torch.cuda.synchronize()
+    return y.cpu().permute(0, 3, 1, 2).contiguous()
+
+
+@pytest.mark.parametrize("prec,tol", PRECS)
+@pytest.mark.parametrize("shape", [(2, 32, 16, 16, 128), (3, 64, 8, 8, 64), (1, 3, 16, 16, 32), (2, 96, 4, 4, 3),
+                                   (1, 128, 32, 32, 128), (5, 30, 8, 8, 128)])
+def test_conv3x3_plain(shape, prec, tol):
+    n, cin, h, w_, cout = shape
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(n, cin, h, w_, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(cin * 9)
+    b = torch.randn(cout, generator=g)
+    ref = F.conv2d(x, w, b, padding=1)
+    got = _run_conv(x, w, b, prec)
+    assert max_rel(got, ref) < tol
+
+
+@pytest.mark.parametrize("prec,tol", PRECS)
+def test_conv3x3_fused_prologue_epilogue(prec, tol):
+    """GN-apply(+FiLM)+SiLU prologue, virtual concat, residual epilogue (ResBlock conv, openaimodel.py:300-320)"""
+    g = torch.Generator().manual_seed(2)
+    n, c0, c1, h, cout = 3, 64, 32, 16, 128
+    x0, x1 = torch.randn(n, c0, h, h, generator=g), torch.randn(n, c1, h, h, generator=g)
+    pa, pb = torch.randn(n, c0 + c1, generator=g), torch.randn(n, c0 + c1, generator=g)
+    w = torch.randn(cout, c0 + c1, 3, 3, generator=g) / math.sqrt((c0 + c1) * 9)
+    b = torch.randn(cout, generator=g)
+    res = torch.randn(n, cout, h, h, generator=g)
+    xin = torch.cat([x0, x1], 1)
+    act = F.silu(xin * pa[:, :, None, None] + pb[:, :, None, None])
+    ref = F.conv2d(act, w, b, padding=1) + res
+    got = _run_conv(x0, w, b, prec, x1=x1, pa=pa, pb=pb, silu=1, res=res)
+    assert max_rel(got, ref) < tol
+
+
+@pytest.mark.parametrize("prec,tol", PRECS[:2])
+@pytest.mark.parametrize("mode", ["down", "up", "stride2", "upconv"])
+def test_conv3x3_resample(mode, prec, tol):
+    g = torch.Generator().manual_seed(3)
+    n, c, h = 2, 64, 16
+    x = torch.randn(n, c, h, h, generator=g)
+    pa, pb = torch.randn(n, c, generator=g), torch.randn(n, c, generator=g)
+    w = torch.randn(c, c, 3, 3, generator=g) / math.sqrt(c * 9)
+    b = torch.randn(c, generator=g)
+    act = F.silu(x * pa[:, :, None, None] + pb[:, :, None, None])
+    if mode == "down":       # ResBlock(down=True): conv(avgpool(act)) + avgpool(x)
+        ref = F.conv2d(F.avg_pool2d(act, 2), w, b, padding=1) + F.avg_pool2d(x, 2)
+        got = _run_conv(x, w, b, prec, resample=1, pa=pa, pb=pb, silu=1, res=x, res_mode=1)
+    elif mode == "up":       # ResBlock(up=True)
+        ref = F.conv2d(F.interpolate(act, scale_factor=2, mode="nearest"), w, b, padding=1) \
+            + F.interpolate(x, scale_factor=2, mode="nearest")
+        got = _run_conv(x, w, b, prec, resample=2, pa=pa, pb=pb, silu=1, res=x, res_mode=2)
+    elif mode == "stride2":  # Downsample conv (openaimodel_ca.py:167-174)
+        ref = F.conv2d(x, w, b, stride=2, padding=1)
+        got = _run_conv(x, w, b, prec, stride=2)
+    else:                    # Upsample nearest + conv (openaimodel_ca.py:128-131)
+        ref = F.conv2d(F.interpolate(x, scale_factor=2, mode="nearest"), w, b, padding=1)
+        got = _run_conv(x, w, b, prec, resample=2)
+    assert got.shape == ref.shape
+    assert max_rel(got, ref) < tol
+
+
+@pytest.mark.parametrize("prec,tol", PRECS)
+@pytest.mark.parametrize("m,k,nout", [(160, 128, 512), (7, 5000, 256), (300, 96, 96), (1024, 512, 1536)])
+def test_linear_flat(m, k, nout, prec, tol):
+    L, lib = _lib()
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(m, k, generator=g)
+    w = torch.randn(nout, k, generator=g) / math.sqrt(k)
+    b = torch.randn(nout, generator=g)
+    ref = F.linear(F.silu(x), w, b)
+    p = L.PREC_BY_NAME[prec]
+    buf, cin_p, cout_p = _pack(w.cuda(), 1, p)
+    xd, bd = x.cuda(), b.cuda()
+    y = torch.full((m, nout), float("nan"), device="cuda")
+    a = L.IgemmArgs()
+    a.x0, a.c0, a.mode, a.m, a.stride, a.pro_silu = xd.data_ptr(), k, L.MODE_FLAT, m, 1, 1
+    a.w, a.cin_p, a.cout_p, a.bias = buf.data_ptr(), cin_p, cout_p, bd.data_ptr()
+    a.y, a.cout, a.y_ld, a.prec = y.data_ptr(), nout, nout, p
+    L.check(lib.sgd_igemm(C.byref(a), _stream()), "igemm")
+    assert max_rel(y.cpu(), ref) < tol
+
+
+def test_igemm_rejects_bad_args():
+    L, lib = _lib()
+    a = L.IgemmArgs()
+    assert lib.sgd_igemm(C.byref(a), _stream()) == 1
+    assert lib.sgd_igemm(None, _stream()) == 1
+
+
+@pytest.mark.parametrize("n,c,hw", [(3, 128, 256), (2, 96, 64), (1, 1024, 16), (2, 32, 4096)])
+def test_groupnorm_coefficients(n, c, hw):
+    L, lib = _lib()
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(n, c, hw, generator=g) * 2 + 0.5
+    gamma, beta = torch.randn(c, generator=g), torch.randn(c, generator=g)
+    film = torch.randn(n, 2 * c + 8, generator=g)
+    ref = F.group_norm(x, 32, gamma, beta, 1e-5) * (1 + film[:, :c, None]) + film[:, c:2 * c, None]
+    xd = x.permute(0, 2, 1).contiguous().cuda()
+    c_half = c // 2
+    sums = torch.zeros(n, c, 2, device="cuda")
+    # two calls emulate a virtual concat of channel halves: strided view is not allowed, so copy halves
+    xa, xb = xd[:, :, :c_half].contiguous(), xd[:, :, c_half:].contiguous()
+    L.check(lib.sgd_chan_stats(_p(xa), n, hw, c_half, _p(sums), c, 0, _stream()), "stats")
+    L.check(lib.sgd_chan_stats(_p(xb), n, hw, c - c_half, _p(sums), c, c_half, _stream()), "stats")
+    a, b = torch.empty(n, c, device="cuda"), torch.empty(n, c, device="cuda")
+    fd, gd, bd = film.cuda(), gamma.cuda(), beta.cuda()      # keep the device tensors alive across the launch
+    L.check(lib.sgd_gn_coef(_p(sums), _p(gd), _p(bd), _p(fd), 2 * c + 8, n, c, 32, hw, 1e-5,
+                            _p(a), _p(b), _stream()), "coef")
+    got = x * a.cpu()[:, :, None] + b.cpu()[:, :, None]
+    assert max_rel(got, ref) < 5e-6
+
+
+@pytest.mark.parametrize("rows,c", [(512, 512), (37, 32), (100, 128)])
+def test_layernorm(rows, c):
+    L, lib = _lib()
+    g = torch.Generator().manual_seed(6)
+    x, res = torch.randn(rows, c, generator=g) * 3 + 1, torch.randn(rows, c, generator=g)
+    gamma, beta = torch.randn(c, generator=g), torch.randn(c, generator=g)
+    ref = res + F.layer_norm(x, (c,), gamma, beta, 1e-5)
+    out = torch.empty(rows, c, device="cuda")
+    xd, gd, bd, rd = x.cuda(), gamma.cuda(), beta.cuda(), res.cuda()
+    L.check(lib.sgd_ln_apply(_p(xd), _p(gd), _p(bd), _p(rd), rows, c, 1e-5, _p(out), _stream()), "ln")
+    assert max_rel(out.cpu(), ref) < 2e-6
+    st = torch.empty(rows, 2, device="cuda")
+    L.check(lib.sgd_ln_stats(_p(xd), rows, c, 1e-5, _p(st), _stream()), "lnstats")
+    assert max_rel(st.cpu()[:, 0], x.mean(1)) < 2e-6
+    assert max_rel(st.cpu()[:, 1], 1 / torch.sqrt(x.var(1, unbiased=False) + 1e-5)) < 2e-6
+
+
+@pytest.mark.parametrize("b,heads,t,d", [(2, 8, 256, 64), (3, 4, 64, 32), (2, 8, 16, 16), (1, 2, 200, 64)])
+def test_attention_legacy(b, heads, t, d):
+    """QKVAttentionLegacy (openaimodel.py:403-420) on the channel-last qkv layout"""
+    L, lib = _lib()
+    g = torch.Generator().manual_seed(7)
+    ch = heads * d
+    qkv = torch.randn(b, 3 * ch, t, generator=g)
+    q, k, v = qkv.reshape(b * heads, 3 * d, t).split(d, dim=1)
+    s = 1 / math.sqrt(math.sqrt(d))
+    w = torch.softmax(torch.einsum("bct,bcs->bts", q * s, k * s), -1)
+    ref = torch.einsum("bts,bcs->bct", w, v).reshape(b, ch, t)
+    qd = qkv.permute(0, 2, 1).contiguous().cuda()                       # [b, t, 3ch]
+    out = torch.full((b, t, ch), float("nan"), device="cuda")
+    L.check(lib.sgd_attention(_p(qd), 3 * ch, 3 * d, C.c_void_p(qd.data_ptr() + 4 * d),
+                              C.c_void_p(qd.data_ptr() + 8 * d), 3 * ch, 3 * d, b, heads, t, t, d,
+                              1 / math.sqrt(d), _p(out), ch, _stream()), "attn")
+    assert max_rel(out.cpu().permute(0, 2, 1), ref) < 3e-6
+
+
+def test_attention_multiquery_273_keys():
+    """Attention_LR core (crossattetion_lr.py:115-137): 8 heads share one K/V of 16+1+256 rows"""
+    L, lib = _lib()
+    g = torch.Generator().manual_seed(8)
+    b, heads, t, j, d = 2, 8, 256, 273, 64
+    q = torch.randn(b, t, heads * d, generator=g)
+    kv = torch.randn(b, j, 2 * d, generator=g)
+    qh = q.reshape(b, t, heads, d).permute(0, 2, 1, 3) * d ** -0.5
+    attn = torch.einsum("bhid,bjd->bhij", qh, kv[..., :d]).softmax(-1)
+    ref = torch.einsum("bhij,bjd->bhid", attn, kv[..., d:]).permute(0, 2, 1, 3).reshape(b, t, heads * d)
+    qd, kvd = q.cuda(), kv.cuda()
+    out = torch.full((b, t, heads * d), float("nan"), device="cuda")
+    L.check(lib.sgd_attention(_p(qd), heads * d, d, _p(kvd), C.c_void_p(kvd.data_ptr() + 4 * d), 2 * d, 0, b, heads,
+                              t, j, d, d ** -0.5, _p(out), heads * d, _stream()), "attn")
+    assert max_rel(out.cpu(), ref) < 3e-6
+
+
+def test_attention_softmax_large_logits():
+    """force the online-softmax rescale branch: one key dominates late in the sequence"""
+    L, lib = _lib()
+    g = torch.Generator().manual_seed(9)
+    b, heads, t, d = 1, 1, 128, 32
+    q = torch.randn(b, t, d, generator=g)
+    k = torch.randn(b, t, d, generator=g)
+    v = torch.randn(b, t, d, generator=g)
+    k[0, 100] = q[0, 5] * 8          # spike for query 5 in the last key tile
+    k[0, 3] = q[0, 70] * 8           # spike in the first key tile
+    ref = torch.softmax(q @ k.transpose(1, 2) * d ** -0.5, -1) @ v
+    kv = torch.cat([k, v], -1).contiguous().cuda()
+    qd = q.cuda()
+    out = torch.empty(b, t, d, device="cuda")
+    L.check(lib.sgd_attention(_p(qd), d, d, _p(kv), C.c_void_p(kv.data_ptr() + 4 * d), 2 * d, 0, b, heads, t, t, d,
+                              d ** -0.5, _p(out), d, _stream()), "attn")
+    assert max_rel(out.cpu(), ref) < 3e-6
+
+
+def test_boundary_kernels():
+    L, lib = _lib()
+    from oracle.unet_ref import timestep_embedding
+    g = torch.Generator().manual_seed(10)
+    t = torch.tensor([0, 1, 500, 999], dtype=torch.int64)
+    for dim in (32, 128):
+        out = torch.empty(8, dim, device="cuda")
+        from sgdm_amd.unet import timestep_freqs
+        td, fd = t.cuda(), timestep_freqs(dim).cuda()
+        L.check(lib.sgd_timestep_embedding(_p(td), _p(fd), 4, 8, dim, _p(out), _stream()), "temb")
+        ref = timestep_embedding(torch.cat([t, t]), dim)
+        assert (out.cpu() - ref).abs().max() < 2e-6            # |cos|,|sin| <= 1: absolute tolerance
+    # cond select with int64 one-hot + batch doubling
+    cond = F.one_hot(torch.tensor([3, 1]), 5)
+    mask = torch.tensor([False, False, True, True])
+    null = torch.full((5,), 0.25)
+    out = torch.empty(4, 5, device="cuda")
+    cd, md, nd = cond.cuda(), mask.cuda().view(torch.uint8), null.cuda()
+    L.check(lib.sgd_cond_select(_p(cd), 1, _p(md), _p(nd), 2, 4, 5, _p(out), _stream()), "cond")
+    ref = torch.cat([cond.float(), null.expand(2, 5)])
+    assert torch.equal(out.cpu(), ref)
+    # pack input: x + masked layout, NCHW -> NHWC, doubled
+    x = torch.randn(2, 3, 8, 8, generator=g)
+    lay = torch.randn(2, 4, 8, 8, generator=g)
+    nl = torch.randn(1, 1, 8, 8, generator=g)
+    out = torch.empty(4, 8, 8, 7, device="cuda")
+    xd, ld, nld = x.cuda(), lay.cuda(), nl.cuda()
+    L.check(lib.sgd_pack_input(_p(xd), _p(ld), _p(md), _p(nld), 2, 4, 3, 4, 8, 8, _p(out), _stream()), "pack_input")
+    xx, ll = torch.cat([x, x]), torch.cat([lay, lay])
+    ref = torch.cat([xx, torch.where(mask[:, None, None, None], nl, ll)], 1).permute(0, 2, 3, 1)
+    assert torch.equal(out.cpu(), ref)
+    back = torch.empty(4, 7, 8, 8, device="cuda")
+    L.check(lib.sgd_nhwc_to_nchw(_p(out), 4, 8, 8, 7, _p(back), _stream()), "nchw")
+    assert torch.equal(back.cpu(), ref.permute(0, 3, 1, 2))
