@@ -1,0 +1,222 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: classifier-free-guided 1000-step DDPM sampling of 64x64 images.
+
+    python bench.py --gpus N --steps K --warmup W [--prec f32|f16x3|bf16x3] [--workload c2|c5]
+
+A "step" is one CFG sampling step of the reference's native sampler on one batch of synthetic input:
+one UNet evaluation at 2B (cond + uncond) + the fused x0/posterior update (ddpm_sampler.py:154-192).
+Workload (BASELINE.json configs[1]): ImageNet-64 `unet_fast` ch=128, self-labeled cluster k=5000,
+cond_scale=2, bs=40 per GPU (UNet batch 80); random-init weights, synthetic inputs (no datasets offline).
+Sampling shards by images with no collective: N ranks sample N independent batches (weak scaling).
+
+metric value = images/s of a full 1000-step trajectory = (N * B) / (1000 * t_step).
+
+One JSON line on rank 0 with `roofline` (dominant kernel: the fused implicit-GEMM conv, timed with HIP
+events around every launch in an instrumented pass) and `cpu_baseline` (the CPU oracle -- the
+restatement of the reference's UNet -- timed on this box's host cores on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "self-guided-diffusion-models_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+
+
+class AD(dict):
+    __getattr__ = dict.__getitem__
+
+
+WORKLOADS = {
+    # BASELINE.json configs[1] (C2): IN64 unet_fast ch128 cluster k=5000 w=2 bs=40
+    "c2": dict(kind="unet_fast", batch=40, image=64, cond_dim=5000, method="cluster", layout_dim=0,
+               desc="IN64 unet_fast ch128 cluster-k5000 cond_scale=2 bs=40/GPU (UNet batch 80), 1000-step native DDPM",
+               gflop_per_eval_img=79.27, mb_per_eval_img=192.2, weights_mb=301.1),
+    # BASELINE.json configs[4] (C5): COCO-Stuff-64 unetca_fast stegoclusterlayout L=27 bs=80
+    "c5": dict(kind="unetca_fast", batch=80, image=64, cond_dim=27, method="stegoclusterlayout", layout_dim=27,
+               desc="COCO-Stuff64 unetca_fast stegoclusterlayout L=27 cond_scale=2 bs=80/GPU (UNet batch 160), 1000-step native DDPM",
+               gflop_per_eval_img=67.89, mb_per_eval_img=165.8, weights_mb=253.1),
+}
+MODEL_PARAMS = dict(given_betas=None, beta_schedule="linear", linear_start=0.0001, linear_end=0.02, cosine_s=8e-3,
+                    v_posterior=0.0, logvar_init=0.0, learn_logvar=False, clip_denoised=True,
+                    parameterization="eps", log_num_per_prog=10, loss_type="l2", sampling="native",
+                    num_timesteps=1000)
+PEAK_TFLOPS = {"f32": 157.3, "f16x3": 2500.0 / 3, "bf16x3": 2500.0 / 3}     # MI355X_MICROARCH.md chip table
+
+
+def build_model(wl, device, prec, batch=None):
+    from sgdm_amd.synth import synth_batch, weights_from_seed
+    from sgdm_amd.unet import UNetModel, UNetModelCA
+    common = dict(image_size=wl["image"], in_channels=3, out_channels=3, model_channels=128, num_res_blocks=2,
+                  channel_mult=[1, 2, 4], attention_resolutions=[4], num_heads=8, use_scale_shift_norm=True,
+                  cond_dim=wl["cond_dim"], condition_method=wl["method"])
+    cond = AD(scale_type="imagen")
+    if wl["layout_dim"]:
+        cond[wl["method"]] = AD(layout_dim=wl["layout_dim"])
+    if wl["kind"] == "unet_fast":
+        m = UNetModel(dropout=0.1, resblock_updown=True, condition=cond, **common)
+    else:
+        m = UNetModelCA(dropout=0.0, use_ca_block=True, legacy=False, cond_token_num=1, context_dim=32,
+                        use_cls_token_as_pooled=True, condition=cond, **common)
+    manifest = [(k, tuple(v.shape)) for k, v in m.state_dict().items()]
+    sd = weights_from_seed(manifest, 23)
+    m.load_state_dict(sd)
+    m = m.to(device).eval()
+    m.hip_precision = prec
+    B = batch or wl["batch"]
+    data = synth_batch(wl["method"], B, wl["image"], wl["cond_dim"], wl["layout_dim"], seed=23)
+    return m, sd, data
+
+
+def cpu_baseline(wl, sd, seconds_budget=25.0):
+    """the oracle (CPU restatement of the reference UNet, pinned to the reference by tests/golden) timed
+    on the host cores: CFG steps at bs=8, extrapolated linearly to the workload's 1000-step images/s."""
+    from oracle import unet_ref as U
+    from sgdm_amd.synth import synth_batch
+    torch.set_num_threads(os.cpu_count())
+    cfg = U.make_cfg(wl["kind"], wl["image"], model_channels=128, cond_dim=wl["cond_dim"],
+                     condition_method=wl["method"], layout_dim=wl["layout_dim"],
+                     cond_token_num=1 if wl["kind"] == "unetca_fast" else 0,
+                     context_dim=32 if wl["kind"] == "unetca_fast" else None)
+    B = 8
+    data = synth_batch(wl["method"], B, wl["image"], wl["cond_dim"], wl["layout_dim"], seed=23)
+    cond = data.get("cond")
+    if cond is not None and wl["kind"] == "unetca_fast":
+        cond = cond.float()
+    x = torch.randn(B, 3, wl["image"], wl["image"], generator=torch.Generator().manual_seed(1))
+    t = torch.full((B,), 500, dtype=torch.long)
+    times = []
+    with torch.no_grad():
+        t_start = time.time()
+        while len(times) < 3 and (time.time() - t_start) < seconds_budget:
+            t0 = time.time()
+            U.forward_with_cond_scale(cfg, sd, x, t, 2.0, cond, data.get("layout"))
+            times.append(time.time() - t0)
+    per_step = min(times)
+    return dict(value=B / (1000.0 * per_step), unit="images/s", cores=os.cpu_count(), kind="port",
+                sample=f"{len(times)} CFG UNet steps at bs={B} (UNet batch {2 * B}) of the same model on the host "
+                       f"cores, best {per_step:.2f} s/step, extrapolated linearly to 1000 steps",
+                s_per_step_bs8=per_step)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--prec", default=os.environ.get("SGDM_PREC", "f16x3"))
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"launched with WORLD_SIZE={world} but --gpus {args.gpus}"
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from sgdm_amd.diffusion import LatentDiffusion
+    wl = WORKLOADS[args.workload]
+    B = args.batch or wl["batch"]
+    model, sd, data = build_model(wl, dev, args.prec, B)
+    diff = LatentDiffusion(device=str(dev), **MODEL_PARAMS)
+    diff.set_denoise_fn(model.forward, model.forward_with_cond_scale)
+    S = wl["image"]
+    cond = data.get("cond")
+    if cond is not None:
+        cond = cond.to(dev) if wl["kind"] == "unet_fast" else cond.float().to(dev)
+    layout = data["layout"].to(dev) if "layout" in data else None
+    dkw = dict(cond=cond, layout=layout, cond_scale=2.0)
+    skw = dict(sampling_method="native", num_timesteps=1000, ddim_eta=0.0, log_num_per_prog=10, clip_denoised=True,
+               dtp=1, temperature=1.0, noise_dropout=0, random_sample_condition=False, return_inter_dict=True)
+    torch.manual_seed(23 + rank)
+    x = torch.randn(B, 3, S, S, device=dev)
+
+    def run_steps(x, idx):
+        img, _ = diff.sampler.sample((B, 3, S, S), sampling_kwargs=skw, denoise_sample_fn=diff.denoise_sample_fn,
+                                     denoise_sample_fn_kwargs=dkw, x_T=x, step_indices=idx)
+        return img
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        x = run_steps(x, list(range(999, 999 - args.warmup, -1)))            # W untimed warm-up steps
+        barrier()
+        t0 = time.perf_counter()
+        x = run_steps(x, list(range(999 - args.warmup, 999 - args.warmup - args.steps, -1)))   # EXACTLY K steps
+        barrier()
+        elapsed = time.perf_counter() - t0
+    tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    elapsed = float(tt.item())
+    ms_per_step = 1000.0 * elapsed / args.steps
+    value = world * B / (1000.0 * (elapsed / args.steps))
+    assert torch.isfinite(x).all()
+
+    out = None
+    if rank == 0:
+        # ---- instrumented pass: HIP events around every launch of the UNet program (same stream)
+        roof = None
+        if not args.no_profile:
+            eng = model._engines[(2 * B, S, S, __import__("sgdm_amd._lib", fromlist=["x"]).PREC_BY_NAME[args.prec])]
+            stream = torch.cuda.current_stream().cuda_stream
+            agg = {}
+            reps = 3
+            for _ in range(reps):
+                for tag, sym, ms, fl, nb in eng.prog.run_profiled(stream):
+                    a = agg.setdefault(sym, [0.0, 0.0, 0.0, 0])
+                    a[0] += ms; a[1] += fl; a[2] += nb; a[3] += 1
+            tot_ms = sum(a[0] for a in agg.values()) / reps
+            ig = agg["sgd_igemm"]
+            ig_ms, ig_fl, ig_nb, ig_n = ig[0] / reps, ig[1] / reps, ig[2] / reps, ig[3] // reps
+            peak = PEAK_TFLOPS[args.prec]
+            ach = ig_fl / (ig_ms * 1e-3) / 1e12
+            roof = dict(bound="mfma", kernel="igemm_kernel (fused implicit-GEMM conv/linear, all launches of one UNet eval)",
+                        achieved=round(ach, 2), peak=round(peak, 1), unit="TFLOP/s", frac=round(ach / peak, 4),
+                        traffic=None, launches_per_step=ig_n, avg_launch_ms=round(ig_ms / ig_n, 4),
+                        igemm_ms_per_step=round(ig_ms, 3), all_kernels_ms_per_step=round(tot_ms, 3),
+                        algorithmic_gflop_per_step=round(ig_fl / 1e9, 1),
+                        hbm_algorithmic_frac=round((ig_nb / (ig_ms * 1e-3)) / 8.0e12, 4),
+                        peak_note=("exact fp32 MFMA peak" if args.prec == "f32" else
+                                   "2.5 PF dense 16-bit MFMA / 3 products per fp32-equivalent product"),
+                        per_kernel_ms={k: round(v[0] / reps, 3) for k, v in sorted(agg.items())})
+        cpu = None
+        if not args.no_cpu_baseline:
+            cpu = cpu_baseline(wl, sd)
+        out = {
+            "metric": "cfg_sampled_images_per_sec_64x64_1000step_ddpm", "value": round(value, 4), "unit": "images/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": {"f32": "f32", "f16x3": "f32 as 3xf16 split MFMA products, f32 accumulate",
+                      "bf16x3": "f32 as 3xbf16 split MFMA products, f32 accumulate"}[args.prec],
+            "data": "synthetic",
+            "config": {"workload": wl["desc"], "batch_per_gpu": B, "unet_batch": 2 * B, "precision_mode": args.prec,
+                       "algorithmic_tflop_per_step": round(2 * B * wl["gflop_per_eval_img"] / 1e3, 3)},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,372 @@
+"""Drop-in diffusion process: ``diffusion.ddpm.LatentDiffusion`` and its samplers on the HIP path.
+
+Mirrors (reference, /root/reference):
+    diffusion/ddpm.py:24-126                      LatentDiffusion
+    diffusion/sampler/ddpm_sampler.py:16-238      Schedule_DDPM   ('native' 1000-step ancestral sampler)
+    diffusion/sampler/ddim_plms_sampler.py:25-391 DDIMSampler     ('ddim')
+    dynamic/diffusionmodules/util.py:23-74        schedules / DDIM tables (deterministic host math)
+
+Per sampling step the host issues: one UNet evaluation at 2B (cond | uncond halves, doubled inside
+the boundary kernels) and ONE fused kernel doing CFG combine + x0 prediction + clip + posterior /
+DDIM update + noise (include/sgdm_hip.h: sgd_ddpm_step / sgd_ddim_step).  RNG draws (x_T, the
+per-step mask uniform_ and z) are kept in the reference's order so seeded runs line up.
+"""
+import copy
+import ctypes as C
+from functools import partial
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import _lib as L
+from .unet import UNetModelBase, _cfg_eval, _ptr
+
+
+class _Obj:
+    """dict2obj (diffusion_utils/util.py:85-92)"""
+
+    def __init__(self, d):
+        for a, b in d.items():
+            if isinstance(b, (list, tuple)):
+                setattr(self, a, [_Obj(x) if isinstance(x, dict) else x for x in b])
+            else:
+                setattr(self, a, _Obj(b) if isinstance(b, dict) else b)
+
+
+def make_beta_schedule(schedule, n_timestep, linear_start=1e-4, linear_end=2e-2, cosine_s=8e-3):
+    """util.py:23-43 (float64 host math, returned as numpy)"""
+    if schedule == "linear":
+        betas = torch.linspace(linear_start ** 0.5, linear_end ** 0.5, n_timestep, dtype=torch.float64) ** 2
+    elif schedule == "cosine":
+        timesteps = torch.arange(n_timestep + 1, dtype=torch.float64) / n_timestep + cosine_s
+        alphas = torch.cos(timesteps / (1 + cosine_s) * np.pi / 2).pow(2)
+        alphas = alphas / alphas[0]
+        betas = np.clip(1 - alphas[1:] / alphas[:-1], a_min=0, a_max=0.999)
+    elif schedule == "sqrt_linear":
+        betas = torch.linspace(linear_start, linear_end, n_timestep, dtype=torch.float64)
+    elif schedule == "sqrt":
+        betas = torch.linspace(linear_start, linear_end, n_timestep, dtype=torch.float64) ** 0.5
+    else:
+        raise ValueError(f"schedule '{schedule}' unknown.")
+    return betas.numpy()
+
+
+def make_ddim_timesteps(ddim_discr_method, num_ddim_timesteps, num_ddpm_timesteps, verbose=False):
+    """util.py:46-60"""
+    if ddim_discr_method == "uniform":
+        c = num_ddpm_timesteps // num_ddim_timesteps
+        ddim_timesteps = np.asarray(list(range(0, num_ddpm_timesteps, c)))
+    elif ddim_discr_method == "quad":
+        ddim_timesteps = ((np.linspace(0, np.sqrt(num_ddpm_timesteps * .8), num_ddim_timesteps)) ** 2).astype(int)
+    else:
+        raise NotImplementedError(f'There is no ddim discretization method called "{ddim_discr_method}"')
+    return ddim_timesteps + 1
+
+
+def make_ddim_sampling_parameters(alphacums, ddim_timesteps, eta, verbose=False):
+    """util.py:63-74 (alphacums: float32 CPU tensor, as the reference passes it)"""
+    alphas = alphacums[ddim_timesteps]
+    alphas_prev = np.asarray([alphacums[0]] + alphacums[ddim_timesteps[:-1]].tolist())
+    sigmas = eta * np.sqrt((1 - alphas_prev) / (1 - alphas) * (1 - alphas / alphas_prev))
+    return sigmas, alphas, alphas_prev
+
+
+def _unet_of(fn):
+    """the drop-in UNet behind a bound ``forward_with_cond_scale`` (fast fused-CFG path), else None"""
+    owner = getattr(fn, "__self__", None)
+    if isinstance(owner, UNetModelBase) and getattr(fn, "__name__", "") == "forward_with_cond_scale":
+        return owner
+    return None
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+class _StepRunner:
+    """one sampling step = UNet(2B) + one fused update kernel"""
+
+    def __init__(self, denoise_sample_fn, kwargs):
+        self.fn = denoise_sample_fn
+        self.kwargs = dict(kwargs)
+        self.model = _unet_of(getattr(denoise_sample_fn, "_sgdm_inner", denoise_sample_fn))
+        self.lib = L.load()
+
+    def eps(self, x, t):
+        """returns (eps tensor/engine buffer, cfg_mode, w, b, c) describing how the step kernel reads it"""
+        B, Cc = x.shape[0], x.shape[1]
+        m = self.model
+        if m is not None:
+            w = self.kwargs.get("cond_scale")
+            cond, layout = self.kwargs.get("cond"), self.kwargs.get("layout")
+            fast_int = isinstance(w, int) if m.KIND == "unetca_fast" else isinstance(w, (int, float))
+            if isinstance(w, (int, float)) and not (fast_int and w in (0, 1)):
+                # batch-doubled evaluation, guided score formed inside the step kernel
+                has_mask = (m._cond_width > 0) or (m._in_ch_total > m.in_channels)
+                p = torch.cat((torch.full((B,), 0.0, device=x.device), torch.full((B,), 1.0, device=x.device)))
+                mask = m._draw_mask(2 * B, p, x.device) if has_mask else None
+                eng = m._run(x, t, cond, layout, mask, 2 * B)
+                return eng.eps_nhwc, m._scale_mode(), float(w), B, Cc
+        e = self.fn(x, t, **self.kwargs)            # generic path: guided eps, NCHW
+        return e.contiguous(), 0, 0.0, B * Cc, 1
+
+
+class Schedule_DDPM(nn.Module):
+    """ddpm_sampler.py:16-238"""
+
+    def __init__(self, **kwargs):
+        super().__init__()
+        self.hparams = _Obj(kwargs)
+        h = self.hparams
+        self.register_schedule(given_betas=h.given_betas, beta_schedule=h.beta_schedule, timesteps=h.num_timesteps,
+                               linear_start=h.linear_start, linear_end=h.linear_end, cosine_s=h.cosine_s)
+
+    def register_schedule(self, given_betas=None, beta_schedule="linear", timesteps=1000, linear_start=1e-4,
+                          linear_end=2e-2, cosine_s=8e-3):
+        h = self.hparams
+        key = (id(given_betas) if given_betas is not None else None, beta_schedule, timesteps, linear_start,
+               linear_end, cosine_s)
+        if getattr(self, "_sched_key", None) == key:
+            return                       # the reference rebuilds identical buffers on every sample() call
+        betas = given_betas if given_betas is not None else make_beta_schedule(
+            beta_schedule, h.num_timesteps, linear_start=linear_start, linear_end=linear_end, cosine_s=cosine_s)
+        alphas = 1. - betas
+        alphas_cumprod = np.cumprod(alphas, axis=0)
+        alphas_cumprod_prev = np.append(1., alphas_cumprod[:-1])
+        if timesteps < h.num_timesteps:
+            raise NotImplementedError                      # ddpm_sampler.py:38-39
+        self.linear_start, self.linear_end = linear_start, linear_end
+        assert alphas_cumprod.shape[0] == timesteps, "alphas have to be defined for each timestep"
+        dev = h.device
+        to_torch = lambda a: torch.tensor(a, dtype=torch.float32).to(dev)
+        reg = self.register_buffer
+        reg("betas", to_torch(betas))
+        reg("alphas_cumprod", to_torch(alphas_cumprod))
+        reg("alphas_cumprod_prev", to_torch(alphas_cumprod_prev))
+        reg("sqrt_alphas_cumprod", to_torch(np.sqrt(alphas_cumprod)))
+        reg("sqrt_one_minus_alphas_cumprod", to_torch(np.sqrt(1. - alphas_cumprod)))
+        reg("log_one_minus_alphas_cumprod", to_torch(np.log(1. - alphas_cumprod)))
+        reg("sqrt_recip_alphas_cumprod", to_torch(np.sqrt(1. / alphas_cumprod)))
+        reg("sqrt_recipm1_alphas_cumprod", to_torch(np.sqrt(1. / alphas_cumprod - 1)))
+        vp = h.v_posterior
+        posterior_variance = (1 - vp) * betas * (1. - alphas_cumprod_prev) / (1. - alphas_cumprod) + vp * betas
+        reg("posterior_variance", to_torch(posterior_variance))
+        reg("posterior_log_variance_clipped", to_torch(np.log(np.maximum(posterior_variance, 1e-20))))
+        reg("posterior_mean_coef1", to_torch(betas * np.sqrt(alphas_cumprod_prev) / (1. - alphas_cumprod)))
+        reg("posterior_mean_coef2", to_torch((1. - alphas_cumprod_prev) * np.sqrt(alphas) / (1. - alphas_cumprod)))
+        if h.parameterization == "eps":
+            lvlb = self.betas ** 2 / (2 * self.posterior_variance * to_torch(alphas) * (1 - self.alphas_cumprod))
+        elif h.parameterization == "x0":
+            lvlb = (0.5 * np.sqrt(torch.Tensor(alphas_cumprod)) / (2. * 1 - torch.Tensor(alphas_cumprod))).to(dev)
+        else:
+            raise NotImplementedError("mu not supported")
+        lvlb[0] = lvlb[1]
+        reg("lvlb_weights", lvlb, persistent=False)
+        assert not torch.isnan(self.lvlb_weights).all()
+        reg("snr_derivative", torch.zeros(1000, dtype=torch.float32).to(dev))
+        reg("SNR", torch.zeros(1000, dtype=torch.float32).to(dev))
+        # host copies of the per-step scalars of the fused step kernel (fp32 math as on the device)
+        f = lambda name: getattr(self, name).detach().cpu()
+        self._step_tab = torch.stack([f("sqrt_recip_alphas_cumprod"), f("sqrt_recipm1_alphas_cumprod"),
+                                      f("posterior_mean_coef1"), f("posterior_mean_coef2"),
+                                      (0.5 * f("posterior_log_variance_clipped")).exp()], 1).contiguous()
+        self._sched_key = key
+
+    @staticmethod
+    def _ext(a, t, x_shape):
+        return a.gather(-1, t).reshape(t.shape[0], *((1,) * (len(x_shape) - 1)))
+
+    def q_sample(self, original_sample, noise, t):
+        noise = torch.randn_like(original_sample) if noise is None else noise
+        return (self._ext(self.sqrt_alphas_cumprod, t, original_sample.shape) * original_sample
+                + self._ext(self.sqrt_one_minus_alphas_cumprod, t, original_sample.shape) * noise)
+
+    def predict_start_from_noise(self, x_t, t, noise):
+        return (self._ext(self.sqrt_recip_alphas_cumprod, t, x_t.shape) * x_t
+                - self._ext(self.sqrt_recipm1_alphas_cumprod, t, x_t.shape) * noise)
+
+    def q_posterior(self, original_sample, x_t, t):
+        mean = (self._ext(self.posterior_mean_coef1, t, x_t.shape) * original_sample
+                + self._ext(self.posterior_mean_coef2, t, x_t.shape) * x_t)
+        return (mean, self._ext(self.posterior_variance, t, x_t.shape),
+                self._ext(self.posterior_log_variance_clipped, t, x_t.shape))
+
+    @torch.no_grad()
+    def sample(self, shape, sampling_kwargs=None, denoise_sample_fn=None, denoise_sample_fn_kwargs=None, **kwargs):
+        """ancestral DDPM loop (ddpm_sampler.py:194-238); ``x_T`` / ``noise_fn(i)`` may be injected for tests"""
+        sk = sampling_kwargs
+        temperature, noise_dropout = sk["temperature"], sk["noise_dropout"]
+        timesteps = sk["num_timesteps"]
+        h = self.hparams
+        self.register_schedule(timesteps=timesteps, given_betas=h.given_betas, beta_schedule=h.beta_schedule,
+                               linear_start=h.linear_start, linear_end=h.linear_end, cosine_s=h.cosine_s)
+        if sk.get("dtp", 1) < 1.0:
+            raise NotImplementedError("dynamic thresholding (dtp < 1) is not on the fused step path yet")
+        dev = self.betas.device
+        B, Cc = shape[0], shape[1]
+        hw = int(np.prod(shape[2:]))
+        x_T = kwargs.get("x_T")
+        img = torch.randn(shape, device=dev) if x_T is None else x_T.to(dev).float().contiguous()
+        noise_fn = kwargs.get("noise_fn")
+        if type(temperature) == float or isinstance(temperature, int):
+            temperature = [float(temperature)] * timesteps
+        snaps = torch.linspace(0, timesteps, sk["log_num_per_prog"], dtype=torch.int).cpu().numpy().tolist()
+        runner = _StepRunner(denoise_sample_fn, denoise_sample_fn_kwargs or {})
+        lib = runner.lib
+        ts_tab = torch.arange(timesteps, device=dev, dtype=torch.long).view(-1, 1).expand(timesteps, B).contiguous()
+        pred, inter = [], []
+        clip = 1 if sk["clip_denoised"] else 0
+        coef = (C.c_float * 5)()
+        nxt = torch.empty_like(img)
+        order = kwargs.get("step_indices")          # bench / teacher-forced tests: visit only these steps
+        order = reversed(range(0, timesteps)) if order is None else list(order)
+        for i in order:
+            ts = ts_tab[i]
+            eps, mode, w, bb, cc = runner.eps(img, ts)
+            z = torch.randn(shape, device=dev) if noise_fn is None else noise_fn(i).to(dev)
+            if noise_dropout > 0.:
+                z = torch.nn.functional.dropout(z, p=noise_dropout)
+            row = self._step_tab[i]
+            coef[0], coef[1], coef[2], coef[3] = row[0], row[1], row[2], row[3]
+            coef[4] = (float(row[4]) * float(temperature[i])) if i != 0 else 0.0      # no noise when t == 0
+            want = i in snaps
+            x0 = torch.empty_like(img) if want else None
+            L.check(lib.sgd_ddpm_step(_ptr(img), _ptr(eps), _ptr(z), mode, w, coef, clip, bb, cc, hw,
+                                      _ptr(nxt), _ptr(x0), _stream()), "sgd_ddpm_step")
+            img, nxt = nxt, img
+            if want:
+                pred.append(x0.unsqueeze(0))
+                inter.append(img.clone().unsqueeze(0))
+        if not pred:
+            return img, dict(pred_x0=img.new_zeros((0,) + tuple(shape)), x_inter=img.new_zeros((0,) + tuple(shape)))
+        return img, dict(pred_x0=torch.cat(pred, 0), x_inter=torch.cat(inter, 0))
+
+
+class DDIMSampler(object):
+    """ddim_plms_sampler.py:25-391 (sampler_type='ddim'; 'plms' is a 'next' row)"""
+
+    def __init__(self, ddpm_num_timesteps, device, sampler_type):
+        self.ddpm_num_timesteps = ddpm_num_timesteps
+        self.device = device
+        self.sampler_type = sampler_type
+
+    def make_schedule(self, sampling_kwargs, ddim_discretize="uniform", **kwargs):
+        S, eta = sampling_kwargs["num_timesteps"], sampling_kwargs["ddim_eta"]
+        ac = sampling_kwargs["alphas_cumprod"]
+        self.ddim_timesteps = make_ddim_timesteps(ddim_discretize, S, self.ddpm_num_timesteps)
+        assert ac.shape[0] == self.ddpm_num_timesteps, "alphas have to be defined for each timestep"
+        sig, a, ap = make_ddim_sampling_parameters(ac.detach().float().cpu(), self.ddim_timesteps, eta)
+        self.ddim_sigmas, self.ddim_alphas, self.ddim_alphas_prev = sig, a, ap
+        self.ddim_sqrt_one_minus_alphas = np.sqrt(1.0 - a)
+
+    @torch.no_grad()
+    def sample(self, shape, sampling_kwargs=None, **kwargs):
+        if self.sampler_type != "ddim":
+            raise NotImplementedError("PLMS is a 'next' row (SURVEY 8(f) rank 2)")
+        self.make_schedule(sampling_kwargs=sampling_kwargs)
+        return self.ddim_sampling(shape, sampling_kwargs=sampling_kwargs, **kwargs)
+
+    @torch.no_grad()
+    def ddim_sampling(self, shape, sampling_kwargs, denoise_sample_fn_kwargs=None, denoise_sample_fn=None, **kwargs):
+        sk = sampling_kwargs
+        if sk.get("vis") is not None and any(getattr(sk["vis"], k, None) for k in ("condscale_c", "chainvis", "interp")):
+            raise NotImplementedError("vis/exp sampling variants are a 'next' row (SURVEY 8(f) rank 2)")
+        if sk.get("dtp", 1) < 1.0:
+            raise NotImplementedError("dynamic thresholding (dtp < 1) is not on the fused step path yet")
+        dev = torch.device(self.device)
+        B, Cc = shape[0], shape[1]
+        hw = int(np.prod(shape[2:]))
+        x_T = kwargs.get("x_T")
+        img = torch.randn(shape, device=dev) if x_T is None else x_T.to(dev).float().contiguous()
+        noise_fn = kwargs.get("noise_fn")
+        timesteps = self.ddim_timesteps
+        total = timesteps.shape[0]
+        snaps = torch.linspace(0, total, sk["log_num_per_prog"], dtype=torch.int).cpu().numpy().tolist()
+        runner = _StepRunner(denoise_sample_fn, denoise_sample_fn_kwargs or {})
+        lib = runner.lib
+        pred, inter = [], []
+        clip = 1 if sk["clip_denoised"] else 0
+        coef = (C.c_float * 4)()
+        nxt = torch.empty_like(img)
+        for i, step in enumerate(np.flip(timesteps)):
+            index = total - i - 1
+            ts = torch.full((B,), int(step), device=dev, dtype=torch.long)
+            eps, mode, w, bb, cc = runner.eps(img, ts)
+            z = torch.randn(shape, device=dev) if noise_fn is None else noise_fn(i).to(dev)    # drawn even at eta=0
+            if sk["noise_dropout"] > 0.0:
+                z = torch.nn.functional.dropout(z, p=sk["noise_dropout"])
+            # torch.full_like(x, table[index]) casts the table entry to fp32 (ddim_plms_sampler.py:360-366)
+            coef[0] = float(self.ddim_sqrt_one_minus_alphas[index])
+            coef[1] = float(self.ddim_alphas[index])
+            coef[2] = float(self.ddim_alphas_prev[index])
+            coef[3] = float(self.ddim_sigmas[index])
+            want = index in snaps
+            x0 = torch.empty_like(img) if want else None
+            L.check(lib.sgd_ddim_step(_ptr(img), _ptr(eps), _ptr(z), mode, w, coef, float(sk["temperature"]), clip,
+                                      bb, cc, hw, _ptr(nxt), _ptr(x0), _stream()), "sgd_ddim_step")
+            img, nxt = nxt, img
+            if want:
+                inter.append(img.detach().cpu().unsqueeze(0))
+                pred.append(x0.detach().cpu().unsqueeze(0))
+        return img, dict(x_inter=torch.cat(inter, 0), pred_x0=torch.cat(pred, 0))
+
+
+def to_uint8(x):
+    """clip_unnormalize_to_zero_to_255 (diffusion_utils/util.py:99-100)"""
+    if x.device.type != "cuda":
+        return ((x + 1) * 127.5).clamp(0, 255).to(torch.uint8)         # snapshots the DDIM path moved to host
+    x = x.contiguous().float()
+    out = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+    L.check(L.load().sgd_to_uint8(_ptr(x), x.numel(), _ptr(out), _stream()), "sgd_to_uint8")
+    return out
+
+
+class LatentDiffusion(nn.Module):
+    """diffusion/ddpm.py:24-126 (parameterization eps|x0, loss l1|l2|huber; samplers native + ddim)"""
+
+    def __init__(self, **kwargs):
+        super().__init__()
+        self.hparams = _Obj(kwargs)
+        self.sampler = Schedule_DDPM(**kwargs)
+        h = self.hparams
+        self.sampler_list = {
+            "native": self.sampler,
+            "ddim": DDIMSampler(ddpm_num_timesteps=h.num_timesteps, device=h.device, sampler_type="ddim"),
+            "plms": DDIMSampler(ddpm_num_timesteps=h.num_timesteps, device=h.device, sampler_type="plms"),
+        }
+
+    def set_denoise_fn(self, denoise_fn, denoise_sample_fn):
+        self.denoise_fn = denoise_fn
+
+        def _denoise_sample_fn(*args, **kwargs):
+            return denoise_sample_fn(*args, **kwargs)
+
+        _denoise_sample_fn._sgdm_inner = denoise_sample_fn
+        self.denoise_sample_fn = _denoise_sample_fn
+
+    def forward_tao(self, x, **kwargs):
+        return self.forward(x, **kwargs)
+
+    def forward(self, x, *args, **kwargs):
+        t = torch.randint(0, self.hparams.num_timesteps, (len(x),), device=x.device).long()
+        return self.p_losses(x, t, *args, **kwargs)
+
+    def p_losses(self, x_start, t, noise=None, *args, **kwargs):
+        from .train import p_losses_hip
+        return p_losses_hip(self, x_start, t, noise, *args, **kwargs)
+
+    @torch.no_grad()
+    def p_sample_loop(self, sampling_method, shape, sampling_kwargs, **kwargs):
+        sk = copy.deepcopy({k: v for k, v in sampling_kwargs.items()})
+        sk.update(dict(alphas_cumprod=self.sampler.alphas_cumprod,
+                       alphas_cumprod_prev=self.sampler.alphas_cumprod_prev, betas=self.sampler.betas))
+        kwargs.pop("condition_kwargs", None)
+        samples, inter = self.sampler_list[sampling_method].sample(
+            shape=shape, denoise_sample_fn=self.denoise_sample_fn, sampling_kwargs=sk, **kwargs)
+        samples = to_uint8(samples)
+        inter["pred_x0"] = to_uint8(inter["pred_x0"])
+        return samples, inter
+
+    def vis_schedule(self):
+        raise NotImplementedError("wandb schedule plots are out of scope (SURVEY 2 row 22)")

@@ -145,16 +145,34 @@ class _Packed:
 class _Program:
     def __init__(self):
         self.ops = []
+        self.meta = []
         self.keep = []
 
-    def add(self, name, fn, *args):
+    def add(self, name, fn, *args, flops=0.0, nbytes=0.0):
         self.ops.append((name, fn, args))
+        self.meta.append((fn.__name__, flops, nbytes))
 
     def run(self, stream):
         for name, fn, args in self.ops:
             rc = fn(*args, stream)
             if rc:
                 L.check(rc, name)
+
+    def run_profiled(self, stream):
+        """same launches with a HIP event pair around each (events on the launch stream).
+        Returns [(tag, symbol, ms, algorithmic flops, algorithmic bytes)]."""
+        evs = []
+        for name, fn, args in self.ops:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            rc = fn(*args, stream)
+            e1.record()
+            if rc:
+                L.check(rc, name)
+            evs.append((e0, e1))
+        torch.cuda.synchronize()
+        return [(op[0], mt[0], e0.elapsed_time(e1), mt[1], mt[2])
+                for op, mt, (e0, e1) in zip(self.ops, self.meta, evs)]
 
 
 # ------------------------------------------------------------------------------------------------
@@ -410,7 +428,14 @@ class _Engine:
         a.prec = self.prec
         self.prog.keep.append((a, pk))
         self._late.append((a, pk))                # cin_p / cout_p are known after the first pack
-        self.prog.add(tag, self.lib.sgd_igemm, C.byref(a))
+        # algorithmic work of this launch: 2*M*N*K flops; every input/output element moved once + weights
+        rows = conv[0] * conv[3] * conv[4] if conv is not None else m
+        rows_in = conv[0] * conv[1] * conv[2] if conv is not None else m
+        taps = 9 if conv is not None else 1
+        cin = c0 + c1
+        flops = 2.0 * rows * cout * taps * cin
+        nbytes = 4.0 * (rows_in * cin + rows * cout * (2 if res is not None else 1) + taps * cin * cout)
+        self.prog.add(tag, self.lib.sgd_igemm, C.byref(a), flops=flops, nbytes=nbytes)
 
     def gn(self, tag, srcs, hw, gname, film=None, film_ld=0):
         """srcs: list of (tensor, channels) forming a virtual concat -> (a, b) coefficient buffers"""
