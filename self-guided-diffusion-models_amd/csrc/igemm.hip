@@ -1,19 +1,29 @@
 // Fused implicit-GEMM convolution / linear kernel for gfx950 (MI355X).
 //
 //   M = output rows (pixels of NHWC maps, or flat rows), N = Cout, K = taps * Cin.
-//   Block: 256 threads = 4 waves, tile 128 rows x BN cols, K chunk = 32 input channels.
-//   CONV3: the (activated) input halo tile of the 128 output pixels is staged ONCE per channel
-//          chunk in LDS and re-read by the 9 taps; the tap's weight slice [BN x 32] is staged per
-//          tap, register-prefetched one tap ahead (double-buffered LDS).
-//   Prologue (GroupNorm apply + SiLU, LayerNorm, avg-pool / nearest-upsample, channel concat)
-//   is applied in the global->LDS loader; epilogue adds bias and the residual.
+//   Tile 128 rows x BN cols, K step = one tap x 32 input channels.
 //
-//   Arithmetic: PREC_F32 uses v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32 accumulate).
-//               PREC_F16X3 / BF16X3 split every operand x = hi + lo into two 16-bit floats and
-//               accumulate hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_{f16,bf16} in fp32
-//               (BASELINE.md section 2 "precision headroom": 4.3e-6 / 2.6e-5 rel. error per UNet eval).
+// Wave-specialised block (512 threads = 8 waves, 1 block per CU, 2 waves per SIMD):
+//   waves 0-3  "compute": only ds_read_b128 fragment reads + MFMA (+ the epilogue).  Each owns a
+//              64x64 (BN=128) or 32x32 (BN=32) output sub-tile; fragments of the next K step are
+//              read BEFORE the step barrier so the matrix pipe never waits on LDS latency.
+//   waves 4-7  "loader": global -> registers -> LDS.  The activated input tile (GroupNorm apply +
+//              SiLU / LayerNorm, avg-pool / nearest-upsample, channel concat, 16-bit hi/lo split) is
+//              staged ONCE per 32-channel chunk as a halo tile and re-read by the 9 taps; the per-tap
+//              weight slice [BN x 32] runs two steps ahead in a 3-deep LDS ring.  The loaders' VALU
+//              work (exp, rcp, cvt) executes on the SIMDs' vector pipe while the compute wave of the
+//              same SIMD keeps the matrix pipe busy.
+//   One s_barrier per K step; A tile double-buffered (triple for 1x1) so no extra barrier at chunk seams.
+//
+// Arithmetic: PREC_F32 uses v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32 accumulate).
+//             PREC_F16X3 / BF16X3 split every operand x = hi + lo into two 16-bit floats and
+//             accumulate lo*hi + hi*lo + hi*hi on v_mfma_f32_32x32x16_{f16,bf16} in fp32
+//             (BASELINE.md section 2 "precision headroom": 4.3e-6 / 2.6e-5 rel. error per UNet eval).
 //
 // Replaces (reference): nn.Conv2d/Conv1d/Linear call sites listed in include/sgdm_hip.h.
+#include <stdlib.h>
+#include <type_traits>
+
 #include "sgdm_common.h"
 #include "../../include/sgdm_hip.h"
 
@@ -22,6 +32,11 @@ namespace {
 constexpr int KC = 32;        // input channels per K chunk
 constexpr int LDA = KC + 4;   // LDS row stride in floats (144 B): conflict-free b128 fragment reads
 constexpr int BM = 128;
+constexpr int NB_RING = 3;    // weight-slice ring depth
+constexpr int NTHREADS = 768;  // 4 compute waves + 6 input-tile loader waves + 2 weight loader waves
+constexpr int A_THREADS = 384;
+constexpr int B_THREADS = 128;
+constexpr int FAST_PIX = 256;  // halo tiles up to this many pixels use the split-phase A loader
 
 struct Geo {
     int tw_l2, th_l2;         // log2 of the spatial tile (CONV3)
@@ -31,6 +46,8 @@ struct Geo {
     int pix;                  // nb*hh*hw (CONV3) or 128 (FLAT)
     int mt, nt;               // number of M / N tiles
     int hc, wc;               // conv-input dims (after resample)
+    int fast_a;               // 1: split-phase A loader (stride 1, no avg-pool, pix*8 <= JMAX*256)
+    int dbg;                  // SGDM_DBG bits: 1 skip A staging, 2 skip B staging, 4 skip MFMA, 8 skip stores (timing experiments only)
 };
 
 struct KArgs {
@@ -40,47 +57,61 @@ struct KArgs {
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 
-// one activated input vector (4 consecutive channels starting at c) of conv-input pixel (n, y, x)
-// or flat row `row`; all masking (bounds / padding) is done by the caller.
+// raw input vector: 4 consecutive channels starting at c of source row `row` (virtual concat x0|x1)
 template <bool VEC>
-__device__ __forceinline__ f32x4 load_raw(const sgd_igemm_args& a, long row_idx, int c) {
-    // row_idx indexes rows of the source tensors (both have the same row count)
+__device__ __forceinline__ f32x4 load_raw(const sgd_igemm_args& a, long row, int c) {
     f32x4 v;
     if (VEC) {
-        if (c < a.c0) v = ld4(a.x0 + row_idx * a.c0 + c);
-        else v = ld4(a.x1 + row_idx * a.c1 + (c - a.c0));
+        if (c < a.c0) v = ld4(a.x0 + row * a.c0 + c);
+        else v = ld4(a.x1 + row * a.c1 + (c - a.c0));
     } else {
         const int ct = a.c0 + a.c1;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             int cc = c + j;
             float s = 0.f;
-            if (cc < ct) s = (cc < a.c0) ? a.x0[row_idx * a.c0 + cc] : a.x1[row_idx * a.c1 + (cc - a.c0)];
+            if (cc < ct) s = (cc < a.c0) ? a.x0[row * a.c0 + cc] : a.x1[row * a.c1 + (cc - a.c0)];
             v[j] = s;
         }
     }
     return v;
 }
 
+// prologue coefficients of one item
+struct Coef {
+    f32x4 p, q;       // AFFINE_NC: a, b       LN_ROW: p[0] = mean, p[1] = rstd
+};
+
 template <bool VEC>
-__device__ __forceinline__ f32x4 prologue(const sgd_igemm_args& a, f32x4 v, int n, long row, int c) {
+__device__ __forceinline__ Coef load_coef(const sgd_igemm_args& a, int n, long row, int c) {
+    Coef k;
+    k.p = f32x4{0.f, 0.f, 0.f, 0.f};
+    k.q = k.p;
     const int ct = a.c0 + a.c1;
     if (a.pro == SGD_PRO_AFFINE_NC) {
-        f32x4 pa, pb;
         if (VEC) {
-            pa = ld4(a.pa + (long)n * ct + c);
-            pb = ld4(a.pb + (long)n * ct + c);
+            k.p = ld4(a.pa + (long)n * ct + c);
+            k.q = ld4(a.pb + (long)n * ct + c);
         } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 bool ok = c + j < ct;
-                pa[j] = ok ? a.pa[(long)n * ct + c + j] : 0.f;
-                pb[j] = ok ? a.pb[(long)n * ct + c + j] : 0.f;
+                k.p[j] = ok ? a.pa[(long)n * ct + c + j] : 0.f;
+                k.q[j] = ok ? a.pb[(long)n * ct + c + j] : 0.f;
             }
         }
-        v = v * pa + pb;
     } else if (a.pro == SGD_PRO_LN_ROW) {
-        const float mean = a.pa[row * 2], rstd = a.pa[row * 2 + 1];
+        k.p[0] = a.pa[row * 2];
+        k.p[1] = a.pa[row * 2 + 1];
+    }
+    return k;
+}
+
+__device__ __forceinline__ f32x4 apply_pro(const sgd_igemm_args& a, f32x4 v, const Coef& k, int c) {
+    if (a.pro == SGD_PRO_AFFINE_NC) {
+        v = v * k.p + k.q;
+    } else if (a.pro == SGD_PRO_LN_ROW) {
+        const int ct = a.c0 + a.c1;
         f32x4 g, b;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -88,33 +119,13 @@ __device__ __forceinline__ f32x4 prologue(const sgd_igemm_args& a, f32x4 v, int 
             g[j] = ok ? a.pb[c + j] : 0.f;
             b[j] = (ok && a.pc) ? a.pc[c + j] : 0.f;
         }
-        v = (v - mean) * rstd * g + b;
+        v = (v - k.p[0]) * k.p[1] * g + b;
     }
     if (a.pro_silu) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = sgd_silu(v[j]);
     }
     return v;
-}
-
-// activated conv-input value at (n, y, x) [conv-input resolution], channels c..c+3
-template <bool VEC>
-__device__ __forceinline__ f32x4 load_act_conv(const sgd_igemm_args& a, int n, int y, int x, int c) {
-    if (a.resample == SGD_RS_AVGPOOL2) {
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int dy = 0; dy < 2; ++dy)
-#pragma unroll
-            for (int dx = 0; dx < 2; ++dx) {
-                long r = ((long)n * a.hi + (2 * y + dy)) * a.wi + (2 * x + dx);
-                acc += prologue<VEC>(a, load_raw<VEC>(a, r, c), n, r, c);
-            }
-        return acc * 0.25f;
-    }
-    long r;
-    if (a.resample == SGD_RS_UP2) r = ((long)n * a.hi + (y >> 1)) * a.wi + (x >> 1);
-    else r = ((long)n * a.hi + y) * a.wi + x;
-    return prologue<VEC>(a, load_raw<VEC>(a, r, c), n, r, c);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -154,244 +165,565 @@ __device__ __forceinline__ void lds_store_act(float* rowp, int c4, f32x4 v) {
     }
 }
 
+// MFMA operand fragments of one K sub-step of one wave tile
+template <int PREC, int MT, int NT> struct Frag {
+    typedef typename Split<PREC>::T T;
+    typedef T T8 __attribute__((ext_vector_type(8)));
+    static constexpr int NKS = KC / 16;           // 16 channels per sub-step
+    T8 ah[MT], al[MT], bh[NT], bl[NT];
+    __device__ __forceinline__ void load(const float* const* ap, const float* bp, int ks, int lh) {
+        const int goff = (ks * 2 + lh) * 8;       // float offset of this lane-half's 8-channel group
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            ah[mt] = *reinterpret_cast<const T8*>(ap[mt] + goff);
+            al[mt] = *reinterpret_cast<const T8*>(ap[mt] + goff + 4);
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            bh[nt] = *reinterpret_cast<const T8*>(bp + nt * 32 * LDA + goff);
+            bl[nt] = *reinterpret_cast<const T8*>(bp + nt * 32 * LDA + goff + 4);
+        }
+    }
+    __device__ __forceinline__ void mma(f32x16 (&acc)[MT][NT]) const {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                if constexpr (PREC == SGD_PREC_F16X3) {
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[nt], al[mt], acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[nt], ah[mt], acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[nt], ah[mt], acc[mt][nt], 0, 0, 0);
+                } else {
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[nt], al[mt], acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl[nt], ah[mt], acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[nt], ah[mt], acc[mt][nt], 0, 0, 0);
+                }
+            }
+    }
+};
+template <int MT, int NT> struct Frag<SGD_PREC_F32, MT, NT> {
+    static constexpr int NKS = KC / 8;            // 8 channels per sub-step (4 MFMA k-pairs)
+    f32x4 a[MT], b[NT];
+    __device__ __forceinline__ void load(const float* const* ap, const float* bp, int ks, int lh) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) a[mt] = *reinterpret_cast<const f32x4*>(ap[mt] + ks * 8 + lh * 4);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) b[nt] = *reinterpret_cast<const f32x4*>(bp + nt * 32 * LDA + ks * 8 + lh * 4);
+    }
+    __device__ __forceinline__ void mma(f32x16 (&acc)[MT][NT]) const {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[nt][j], a[mt][j], acc[mt][nt], 0, 0, 0);
+    }
+};
+
 // ---------------------------------------------------------------------------------------------
-// the kernel
-//   BN = 128: waves 2(M) x 2(N), each 64 x 64 (2 x 2 MFMA tiles of 32x32)
-//   BN = 32 : waves 4(M) x 1(N), each 32 x 32
+// the kernel.  TAPS = 9 (CONV3) or 1 (FLAT).  Persistent: a block walks its tiles as ONE continuous
+// stream of K steps, so the loaders are already staging tile t+1 while the compute waves finish and
+// store tile t (no per-tile prologue / epilogue bubble on the matrix pipe).
 // ---------------------------------------------------------------------------------------------
-template <int BN, int PREC, bool VEC>
-__global__ __launch_bounds__(256) void igemm_kernel(const KArgs ka) {
+struct Tile {
+    int n0c;                 // first output column
+    int img0, ty0, tx0;      // CONV3 origin
+    long m0;                 // FLAT origin
+};
+
+__device__ __forceinline__ Tile tile_at(const Geo& g, int lin, int bn, int tw, int th) {
+    Tile t;
+    const int mtile = lin / g.nt, ntile = lin - mtile * g.nt;
+    t.n0c = ntile * bn;
+    const int per_img = g.tiles_x * g.tiles_y;
+    const int it = mtile / per_img, rem = mtile - it * per_img;
+    t.img0 = it * g.nb;
+    t.ty0 = (rem / g.tiles_x) * th;
+    t.tx0 = (rem % g.tiles_x) * tw;
+    t.m0 = (long)mtile * BM;
+    return t;
+}
+
+
+template <int BN, int PREC, bool VEC, int TAPS>
+__global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
     const sgd_igemm_args& a = ka.a;
     const Geo& g = ka.g;
+    constexpr bool CONV = TAPS == 9;
+    constexpr int NA = CONV ? 2 : 3;              // A tile ring depth
     constexpr int WM = (BN == 128) ? 64 : 32;     // wave tile rows
     constexpr int WN = (BN == 128) ? 64 : 32;     // wave tile cols
     constexpr int MT = WM / 32, NT = WN / 32;
     constexpr int WAVES_N = BN / WN;
+    typedef Frag<PREC, MT, NT> FragT;
+    constexpr int NKS = FragT::NKS;
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* As = smem;                              // [pix][LDA]
-    float* Bs = smem + (size_t)g.pix * LDA;        // [2][BN][LDA]
+    const int a_floats = g.pix * LDA;
+    float* As = smem;                                       // [NA][pix][LDA]
+    float* Bs = smem + (size_t)NA * a_floats;               // [NB_RING][BN][LDA]
+    int2* pixtab = reinterpret_cast<int2*>(Bs + NB_RING * BN * LDA);   // [2][pix] (source row or -1, image n)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    // XCD-aware persistent schedule: blocks b, b+8, .. share an XCD (and its L2).  XCD x owns the tile
+    // range [x*xchunk, (x+1)*xchunk); its blocks stride through it together, so tiles in flight on one
+    // XCD are neighbours (the N tiles of one M tile share the input tile, neighbours share halos).
+    const int total = g.mt * g.nt;
+    const int xchunk = (total + 7) >> 3;
+    const int nloc = gridDim.x >> 3;              // blocks per XCD
+    const int xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
+    const int xbeg = xcd * xchunk, xend = (xbeg + xchunk < total) ? xbeg + xchunk : total;
+    const int ntiles = (xbeg + loc < xend) ? (xend - xbeg - loc + nloc - 1) / nloc : 0;
+    if (ntiles == 0) return;
+    auto lin_of = [&](int k) { return xbeg + loc + k * nloc; };
+
+    const int cin = a.c0 + a.c1;
+    const int nchunks = (cin + KC - 1) / KC;
+    const int G = nchunks * TAPS;                 // K steps per tile
+    const int S = ntiles * G;                     // K steps of this block
+    const int Q = ntiles * nchunks;               // channel chunks of this block
+    const int s = CONV ? a.stride : 1;
+    const int TW = 1 << g.tw_l2, TH = 1 << g.th_l2;
+    const int M = CONV ? a.n * a.ho * a.wo : a.m;
+
+    // source-row table of tile k's A rows (index math once per tile, not per chunk)
+    auto build_pixtab = [&](int k, int t0, int nthr) {
+        if (k >= ntiles) return;
+        const Tile T = tile_at(g, lin_of(k), BN, TW, TH);
+        int2* tab = pixtab + (size_t)(k & 1) * g.pix;
+        for (int pix = t0; pix < g.pix; pix += nthr) {
+            int2 e;
+            e.x = -1;
+            e.y = 0;
+            if (CONV) {
+                int hx = pix % g.hw, t = pix / g.hw;
+                int hy = t % g.hh, nb = t / g.hh;
+                int n = T.img0 + nb, y = T.ty0 * s - 1 + hy, x = T.tx0 * s - 1 + hx;
+                if (n < a.n && y >= 0 && y < g.hc && x >= 0 && x < g.wc) {
+                    if (a.resample == SGD_RS_UP2) e.x = (n * a.hi + (y >> 1)) * a.wi + (x >> 1);
+                    else if (a.resample == SGD_RS_AVGPOOL2) e.x = (n * a.hi + 2 * y) * a.wi + 2 * x;
+                    else e.x = (n * a.hi + y) * a.wi + x;
+                    e.y = n;
+                }
+            } else {
+                long row = T.m0 + pix;
+                if (row < M) {
+                    e.x = (int)row;
+                    e.y = (a.pro == SGD_PRO_AFFINE_NC) ? (int)(row / a.rows_per_n) : 0;
+                }
+            }
+            tab[pix] = e;
+        }
+    };
+    build_pixtab(0, tid, NTHREADS);
+    build_pixtab(1, tid, NTHREADS);
+    __syncthreads();
+
+    if (tid >= 256) {
+        // =====================================================================================
+        // loader roles.  Each wave runs ONE kind of global load in a branch-free steady state so the
+        // compiler's in-order vmcnt bookkeeping stays exact (a conditional load anywhere degrades every
+        // later wait to vmcnt(0) == full memory latency per K step):
+        //   waves 10-11  weight slices: B(step+2) registers -> LDS, then issue B(step+5)
+        //   waves 4-9    input tile:    raw loads of chunk q+1 at tap 0, transform + LDS write at taps 1..7
+        // Out-of-range prefetches are clamped to the last valid step/chunk (harmless duplicates written
+        // to ring slots nobody reads any more) instead of being branched around.
+        // =====================================================================================
+        if (tid >= 256 + A_THREADS) {
+            // ---------------------------------------------------------------- B loader
+            const int lt = tid - 256 - A_THREADS;
+            constexpr int BITEMS = BN * 8 / B_THREADS;    // float4 per thread per weight slice (8 or 2)
+            f32x4 breg[NB_RING][BITEMS];                  // B(step) lives in breg[step % 3]
+            typedef std::integral_constant<int, 0> R0;
+            typedef std::integral_constant<int, 1> R1;
+            typedef std::integral_constant<int, 2> R2;
+            const float* wthr = reinterpret_cast<const float*>(a.w) + (size_t)(lt >> 3) * a.cin_p + (lt & 7) * 4;
+            const size_t tap_stride = (size_t)a.cout_p * a.cin_p;
+            // prefetch cursor (walks the stream in order)
+            int ck = 0, ctap = 0, cchunk = 0;
+            const float* wtile = wthr + (size_t)tile_at(g, lin_of(0), BN, TW, TH).n0c * a.cin_p;
+            auto load_next = [&](auto rc) {
+                constexpr int R = decltype(rc)::value;
+                const float* wp = wtile + (size_t)ctap * tap_stride + cchunk * KC;
+                if (!(g.dbg & 2)) {
+#pragma unroll
+                for (int it = 0; it < BITEMS; ++it) breg[R][it] = ld4(wp + (size_t)(it * 16) * a.cin_p);
+                }
+                // advance, clamping at the last step of the stream
+                if (++ctap == TAPS) {
+                    ctap = 0;
+                    if (++cchunk == nchunks) {
+                        cchunk = 0;
+                        if (++ck == ntiles) { ck = ntiles - 1; cchunk = nchunks - 1; ctap = TAPS - 1; }
+                        else wtile = wthr + (size_t)tile_at(g, lin_of(ck), BN, TW, TH).n0c * a.cin_p;
+                    }
+                }
+            };
+            auto store_B = [&](int step, auto rc) {
+                constexpr int R = decltype(rc)::value;
+                float* bp = Bs + (size_t)(step % NB_RING) * BN * LDA + (lt >> 3) * LDA + (lt & 7) * 4;
+                if (!(g.dbg & 2)) {
+#pragma unroll
+                for (int it = 0; it < BITEMS; ++it) *reinterpret_cast<f32x4*>(bp + it * 16 * LDA) = breg[R][it];
+                }
+            };
+            load_next(R0());
+            load_next(R1());
+            store_B(0, R0());
+            store_B(1, R1());
+            load_next(R2());
+            load_next(R0());
+            load_next(R1());
+            __syncthreads();
+            for (int step = 0; step < S; step += 3) {
+                store_B(step + 2, R2());
+                load_next(R2());
+                __syncthreads();
+                if (step + 1 < S) {
+                    store_B(step + 3, R0());
+                    load_next(R0());
+                    __syncthreads();
+                }
+                if (step + 2 < S) {
+                    store_B(step + 4, R1());
+                    load_next(R1());
+                    __syncthreads();
+                }
+            }
+            return;
+        }
+        // -------------------------------------------------------------------- A loader
+        const int lt = tid - 256;
+        const int c4 = lt & 7;                        // this thread's channel quad inside every chunk
+        const int items = g.pix * 8;                  // float4 items of one A tile
+        // row entry of tile-row `pix`: CONV reads the tile table; FLAT rows are m0 + pix (tab carries m0)
+        struct TabRef { const int2* tab; long m0; };
+        auto tabref = [&](int k) {
+            TabRef t;
+            t.tab = pixtab + (size_t)(k & 1) * g.pix;
+            t.m0 = CONV ? 0 : tile_at(g, lin_of(k), BN, TW, TH).m0;
+            return t;
+        };
+        auto entry = [&](const TabRef& t, int pix) -> int2 {
+            if (CONV) return t.tab[pix];
+            int2 e;
+            const long row = t.m0 + pix;
+            e.x = row < M ? (int)row : -1;
+            e.y = (a.pro == SGD_PRO_AFFINE_NC) ? (int)(row / a.rows_per_n) : 0;
+            return e;
+        };
+        auto item_sync = [&](float* abuf, const TabRef& tab, int idx, int kc0) {
+            const int pix = idx >> 3;
+            const int c = kc0 + c4 * 4;
+            const int2 e = entry(tab, pix);
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (e.x >= 0 && c < cin) {
+                if (CONV && a.resample == SGD_RS_AVGPOOL2) {
+#pragma unroll
+                    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                        for (int dx = 0; dx < 2; ++dx) {
+                            long r = (long)e.x + dy * a.wi + dx;
+                            v += apply_pro(a, load_raw<VEC>(a, r, c), load_coef<VEC>(a, e.y, r, c), c);
+                        }
+                    v = v * 0.25f;
+                } else {
+                    v = apply_pro(a, load_raw<VEC>(a, e.x, c), load_coef<VEC>(a, e.y, e.x, c), c);
+                }
+            }
+            lds_store_act<PREC>(abuf + (size_t)pix * LDA, c4, v);
+        };
+        // everything at once: first chunk of the stream, avg-pool, big halo tiles
+        auto stage_A_sync = [&](int slot, int q) {
+            q = q < Q ? q : Q - 1;
+            const int k = q / nchunks, chunk = q - k * nchunks;
+            float* abuf = As + (size_t)(slot % NA) * a_floats;
+            const TabRef tab = tabref(k);
+            for (int idx = lt; idx < items; idx += A_THREADS) item_sync(abuf, tab, idx, chunk * KC);
+        };
+        auto finish_item = [&](int slot, const TabRef& tab, int chunk, int idx, f32x4 raw, const Coef* kuni) {
+            float* abuf = As + (size_t)(slot % NA) * a_floats;
+            const int c = chunk * KC + c4 * 4;
+            if (idx < items) {
+                const int pix = idx >> 3;
+                const int2 e = entry(tab, pix);
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (c < cin && e.x >= 0) v = apply_pro(a, raw, kuni ? *kuni : load_coef<VEC>(a, e.y, e.x, c), c);
+                lds_store_act<PREC>(abuf + (size_t)pix * LDA, c4, v);
+            }
+        };
+        auto raw_item = [&](const TabRef& tab, int idx, int c) -> f32x4 {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (idx < items && c < cin) {
+                const int2 e = entry(tab, idx >> 3);
+                if (e.x >= 0) v = load_raw<VEC>(a, e.x, c);
+            }
+            return v;
+        };
+
+        if (CONV) {
+            constexpr int AJ = (FAST_PIX * 8 + A_THREADS - 1) / A_THREADS;   // item slots per thread (6)
+            stage_A_sync(0, 0);
+            __syncthreads();
+            const bool uni = g.nb == 1 && a.pro == SGD_PRO_AFFINE_NC;
+            f32x4 araw[AJ];
+            for (int q = 0; q < Q; ++q) {
+                // stream chunk q is being computed; stage chunk q+1 (clamped) into ring slot q+1
+                const int nq = q + 1 < Q ? q + 1 : q;
+                const int nk = nq / nchunks, nchunk = nq - nk * nchunks;
+                const TabRef tab = tabref(nk);
+                if (g.dbg & 1) {
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) __syncthreads();
+                } else if (g.fast_a) {
+                    const int c = nchunk * KC + c4 * 4;
+#pragma unroll
+                    for (int j = 0; j < AJ; ++j) araw[j] = raw_item(tab, lt + j * A_THREADS, c);   // tap 0
+                    Coef kuni;
+                    kuni.p = f32x4{0.f, 0.f, 0.f, 0.f};
+                    kuni.q = kuni.p;
+                    if (uni && c < cin) kuni = load_coef<VEC>(a, tile_at(g, lin_of(nk), BN, TW, TH).img0, 0, c);
+                    __syncthreads();
+#pragma unroll
+                    for (int t = 1; t < 8; ++t) {                                                  // taps 1..7
+#pragma unroll
+                        for (int j = 0; j < AJ; ++j)
+                            if (1 + (j % 7) == t)
+                                finish_item(q + 1, tab, nchunk, lt + j * A_THREADS, araw[j],
+                                            (uni || a.pro == SGD_PRO_NONE) ? &kuni : nullptr);
+                        __syncthreads();
+                    }
+                } else {
+                    __syncthreads();                                                               // tap 0
+                    stage_A_sync(q + 1, q + 1);                                                    // tap 1
+#pragma unroll
+                    for (int t = 1; t < 8; ++t) __syncthreads();
+                }
+                // tap 8: table of the tile that chunk q+2 opens (needed from tap 0 of chunk q+1 on)
+                if (q + 2 < Q && (q + 2) % nchunks == 0) build_pixtab((q + 2) / nchunks, lt, A_THREADS);
+                __syncthreads();
+            }
+            return;
+        } else {
+            constexpr int AJ = (BM * 8 + A_THREADS - 1) / A_THREADS;      // 128 rows * 8 quads / 384 threads (3)
+            f32x4 araw[NB_RING][AJ];                      // A(q) raw rows live in araw[q % 3]
+            stage_A_sync(0, 0);
+            if (Q > 1) stage_A_sync(1, 1);
+            auto issue = [&](int q, auto rc) {
+                constexpr int R = decltype(rc)::value;
+                q = q < Q ? q : Q - 1;
+                const int k = q / nchunks, chunk = q - k * nchunks;
+                const TabRef tab = tabref(k);
+                const int c = chunk * KC + c4 * 4;
+#pragma unroll
+                for (int j = 0; j < AJ; ++j) araw[R][j] = raw_item(tab, lt + j * A_THREADS, c);
+            };
+            auto finish = [&](int q, auto rc) {
+                constexpr int R = decltype(rc)::value;
+                const int k = q / nchunks, chunk = q - k * nchunks;
+                const TabRef tab = tabref(k);
+                Coef knone;
+                knone.p = f32x4{0.f, 0.f, 0.f, 0.f};
+                knone.q = knone.p;
+#pragma unroll
+                for (int j = 0; j < AJ; ++j)
+                    finish_item(q, tab, chunk, lt + j * A_THREADS, araw[R][j], a.pro == SGD_PRO_NONE ? &knone : nullptr);
+            };
+            typedef std::integral_constant<int, 0> R0;
+            typedef std::integral_constant<int, 1> R1;
+            typedef std::integral_constant<int, 2> R2;
+            issue(2, R2());
+            issue(3, R0());
+            issue(4, R1());
+            __syncthreads();
+            for (int step = 0; step < S; step += 3) {
+                if (step + 2 < S) finish(step + 2, R2());
+                issue(step + 5, R2());
+                __syncthreads();
+                if (step + 1 < S) {
+                    if (step + 3 < S) finish(step + 3, R0());
+                    issue(step + 6, R0());
+                    __syncthreads();
+                }
+                if (step + 2 < S) {
+                    if (step + 4 < S) finish(step + 4, R1());
+                    issue(step + 7, R1());
+                    __syncthreads();
+                }
+            }
+            return;
+        }
+    }
+
+    // =========================================================================================
+    // compute role
+    // =========================================================================================
     const int li = lane & 31, lh = lane >> 5;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
 
-    // XCD-aware tile order: blocks b, b+8, b+16.. share an XCD (and its L2); give each XCD a
-    // contiguous run of tiles with the N tiles of one M tile adjacent (they share the input tile).
-    const int total = g.mt * g.nt;
-    const int chunk = (total + 7) >> 3;
-    const int lin = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
-    if (lin >= total) return;
-    const int mtile = lin / g.nt, ntile = lin - mtile * g.nt;
-    const int n0c = ntile * BN;
-
-    const bool conv = a.mode == SGD_MODE_CONV3;
-    const int taps = conv ? 9 : 1;
-    const int cin = a.c0 + a.c1;
-    const int nchunks = (cin + KC - 1) / KC;
-    const int s = conv ? a.stride : 1;
-
-    // tile origin
-    int img0 = 0, ty0 = 0, tx0 = 0;      // CONV3
-    long m0 = 0;                          // FLAT
-    const int TW = 1 << g.tw_l2, TH = 1 << g.th_l2;
-    if (conv) {
-        int per_img = g.tiles_x * g.tiles_y;
-        int it = mtile / per_img, rem = mtile - it * per_img;
-        img0 = it * g.nb;
-        ty0 = (rem / g.tiles_x) * TH;
-        tx0 = (rem % g.tiles_x) * TW;
-    } else {
-        m0 = (long)mtile * BM;
-    }
-    const int M = conv ? a.n * a.ho * a.wo : a.m;
-
-    // per-lane LDS pixel bases of this wave's MFMA row tiles (row -> halo pixel for tap (0,0))
-    int pixbase[MT];
+    // per-lane LDS float offsets of this wave's MFMA row tiles (row -> halo pixel of tap (0,0))
+    int aoff[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         int r = wm * WM + mt * 32 + li;
-        if (conv) {
+        int p;
+        if (CONV) {
             int tx = r & (TW - 1), ty = (r >> g.tw_l2) & (TH - 1), nb = r >> (g.tw_l2 + g.th_l2);
-            pixbase[mt] = (nb * g.hh + ty * s) * g.hw + tx * s;
+            p = (nb * g.hh + ty * s) * g.hw + tx * s;
         } else {
-            pixbase[mt] = r;
+            p = r;
         }
+        aoff[mt] = p * LDA;
     }
+    const int boff = (wn * WN + li) * LDA;
 
     f32x16 acc[MT][NT];
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // ---- stage helpers -------------------------------------------------------------------
-    auto stage_A = [&](int kc0) {
-        const int items = g.pix * 8;
-        for (int idx = tid; idx < items; idx += 256) {
-            const int pix = idx >> 3, c4 = idx & 7;
-            const int c = kc0 + c4 * 4;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (c < cin) {
-                if (conv) {
-                    int hx = pix % g.hw, t = pix / g.hw;
-                    int hy = t % g.hh, nb = t / g.hh;
-                    int n = img0 + nb, y = ty0 * s - 1 + hy, x = tx0 * s - 1 + hx;
-                    if (n < a.n && y >= 0 && y < g.hc && x >= 0 && x < g.wc) v = load_act_conv<VEC>(a, n, y, x, c);
+    // One K step: [wait frags(cur)] [issue reads(next)] [MFMA block(cur)] per sub-step.  Strict
+    // alternation keeps at most ONE batch of LDS reads outstanding (they were issued one whole MFMA
+    // block earlier, so the explicit lgkmcnt(0) never stalls); the last sub-step's reads belong to the
+    // NEXT step and are issued before this step's barrier.
+    FragT fr[2];
+    auto do_step = [&](const float* const* ap, const float* bp, const float* const* nap, const float* nbp, bool more) {
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            __builtin_amdgcn_s_waitcnt(0xC07F);                        // lgkmcnt(0) only
+            __builtin_amdgcn_sched_barrier(0);
+            if (ks + 1 < NKS) fr[(ks + 1) & 1].load(ap, bp, ks + 1, lh);
+            else if (more) fr[(ks + 1) & 1].load(nap, nbp, 0, lh);
+            __builtin_amdgcn_sched_barrier(0);
+            if (!(g.dbg & 4)) fr[ks & 1].mma(acc);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+    };
+    const int rowstep = g.hw * LDA;                // LDS floats between halo rows
+    const int bslot_floats = BN * LDA;
+
+    __syncthreads();                               // pairs with the loaders' prologue barrier
+    {
+        const float* ap0[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) ap0[mt] = As + aoff[mt];
+        fr[0].load(ap0, Bs + boff, 0, lh);
+    }
+    int sstep = 0;
+    int aslot = 0, bslot = 0;                      // ring positions of the current chunk / step
+    for (int k = 0; k < ntiles; ++k) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int chunk = 0; chunk < nchunks; ++chunk) {
+            const int naslot = aslot + 1 == NA ? 0 : aslot + 1;
+            const float* acur = As + (size_t)aslot * a_floats;
+            const float* anext = As + (size_t)naslot * a_floats;
+            if (CONV) {
+                // 9 taps fully unrolled: tap offsets and weight-ring slots (9 % 3 == 0: every chunk starts
+                // at ring slot 0) are compile-time, so no scalar index math sits between the MFMA blocks.
+#pragma unroll
+                for (int tap = 0; tap < TAPS; ++tap) {
+                    const float* ap[MT];
+                    const float* nap[MT];
+                    const int toff = (tap / 3) * rowstep + (tap % 3) * LDA;
+                    const int ntap = tap + 1 == TAPS ? 0 : tap + 1;
+                    const int ntoff = (ntap / 3) * rowstep + (ntap % 3) * LDA;
+                    const float* nab = tap + 1 == TAPS ? anext : acur;
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) { ap[mt] = acur + toff + aoff[mt]; nap[mt] = nab + ntoff + aoff[mt]; }
+                    const float* bp = Bs + (tap % 3) * bslot_floats + boff;
+                    const float* nbp = Bs + (ntap % 3) * bslot_floats + boff;
+                    do_step(ap, bp, nap, nbp, sstep + 1 < S);
+                    ++sstep;
+                }
+            } else {
+                const int nbslot = bslot + 1 == NB_RING ? 0 : bslot + 1;
+                const float* ap[MT];
+                const float* nap[MT];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) { ap[mt] = acur + aoff[mt]; nap[mt] = anext + aoff[mt]; }
+                do_step(ap, Bs + bslot * bslot_floats + boff, nap, Bs + nbslot * bslot_floats + boff, sstep + 1 < S);
+                ++sstep;
+                bslot = nbslot;
+            }
+            aslot = naslot;
+        }
+
+        // ---- epilogue of tile k (the loaders are already staging tile k+1) ---------------------
+        // The MFMAs are issued with the WEIGHT fragment as the A operand, so an accumulator tile is
+        // [32 channels x 32 pixels]: a lane owns ONE pixel (lane & 31) and its 16 registers are four runs
+        // of 4 consecutive channels (8g + 4*(lane>>5) + 0..3).  => 16-byte residual loads / stores, and the
+        // row index math runs twice per lane instead of 32 times.
+        const Tile T = tile_at(g, lin_of(k), BN, TW, TH);
+        const int cb = T.n0c + wn * WN + 4 * lh;          // first channel of this lane's g = 0 run (nt = 0)
+        auto epilogue = [&](auto resmode) {
+            constexpr int RES = decltype(resmode)::value;     // 0 none, 1 same rows, 2 avg-pool of 2x map, 3 nearest of 1/2 map
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int row = wm * WM + mt * 32 + li;
+                int orow, n = 0, oy = 0, ox = 0;
+                bool ok;
+                if (CONV) {
+                    const int tx = row & (TW - 1), ty = (row >> g.tw_l2) & (TH - 1), nb = row >> (g.tw_l2 + g.th_l2);
+                    n = T.img0 + nb; oy = T.ty0 + ty; ox = T.tx0 + tx;
+                    ok = nb < g.nb && n < a.n;
+                    orow = (n * a.ho + oy) * a.wo + ox;
                 } else {
-                    long row = m0 + pix;
-                    if (row < M) {
-                        int n = (a.pro == SGD_PRO_AFFINE_NC) ? (int)(row / a.rows_per_n) : 0;
-                        v = prologue<VEC>(a, load_raw<VEC>(a, row, c), n, row, c);
-                    }
+                    orow = (int)T.m0 + row;
+                    ok = orow < M;
                 }
-            }
-            lds_store_act<PREC>(As + (size_t)pix * LDA, c4, v);
-        }
-    };
-    // weights: packed rows of KC-chunk granularity: [tap][cout_p][cin_p] with 4-byte elements
-    // (f32, or a (hi,lo) 16-bit pair pre-arranged in the same 8-group layout as the LDS rows).
-    constexpr int BITEMS = BN * 8 / 256;           // float4 per thread per tap slice (4 or 1)
-    f32x4 breg[BITEMS];
-    auto load_B = [&](int tap, int kc0) {
-        const float* wp = reinterpret_cast<const float*>(a.w) + ((size_t)tap * a.cout_p + n0c) * a.cin_p + kc0;
-#pragma unroll
-        for (int it = 0; it < BITEMS; ++it) {
-            int idx = tid + it * 256;
-            int row = idx >> 3, c4 = idx & 7;
-            breg[it] = ld4(wp + (size_t)row * a.cin_p + c4 * 4);
-        }
-    };
-    auto store_B = [&](int buf) {
-        float* bp = Bs + (size_t)buf * BN * LDA;
-#pragma unroll
-        for (int it = 0; it < BITEMS; ++it) {
-            int idx = tid + it * 256;
-            int row = idx >> 3, c4 = idx & 7;
-            *reinterpret_cast<f32x4*>(bp + row * LDA + c4 * 4) = breg[it];
-        }
-    };
-    auto compute = [&](int tap, int buf) {
-        const int tapoff = conv ? ((tap / 3) * g.hw + (tap % 3)) : 0;
-        const float* bp = Bs + (size_t)buf * BN * LDA + (wn * WN + li) * LDA;
-        if constexpr (PREC == SGD_PREC_F32) {
-#pragma unroll
-            for (int ks = 0; ks < KC / 8; ++ks) {
-                f32x4 av[MT], bv[NT];
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-                    av[mt] = *reinterpret_cast<const f32x4*>(As + (size_t)(pixbase[mt] + tapoff) * LDA + ks * 8 + lh * 4);
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-                    bv[nt] = *reinterpret_cast<const f32x4*>(bp + nt * 32 * LDA + ks * 8 + lh * 4);
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                        for (int nt = 0; nt < NT; ++nt)
-                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt][j], bv[nt][j], acc[mt][nt], 0, 0, 0);
-            }
-        } else {
-            typedef typename Split<PREC>::T T;
-            typedef T T8 __attribute__((ext_vector_type(8)));
-#pragma unroll
-            for (int ks = 0; ks < KC / 16; ++ks) {
-                // 16 channels per MFMA: lane half lh supplies channels 8*lh .. 8*lh+7 of the step
-                T8 ah[MT], al[MT], bh[NT], bl[NT];
-                const int goff = (ks * 2 + lh) * 8;      // float offset of the 8-group (32 B)
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-                    const float* p = As + (size_t)(pixbase[mt] + tapoff) * LDA + goff;
-                    ah[mt] = *reinterpret_cast<const T8*>(p);
-                    al[mt] = *reinterpret_cast<const T8*>(p + 4);
-                }
+                if (!ok) continue;
+                int rrow = orow;
+                if (RES == 2) rrow = (n * a.ho * 2 + 2 * oy) * (a.wo * 2) + 2 * ox;
+                if (RES == 3) rrow = (n * (a.ho >> 1) + (oy >> 1)) * (a.wo >> 1) + (ox >> 1);
+                if (!CONV && a.orows_in > 0)
+                    orow = (int)((unsigned)orow / (unsigned)a.orows_in) * a.orows_out + a.orow_off
+                           + (int)((unsigned)orow % (unsigned)a.orows_in);
+                float* yp = a.y + (long)orow * a.y_ld;
+                const float* rp = RES ? a.res + (long)rrow * a.cout : nullptr;
+                const bool vec = ((a.cout | a.y_ld) & 3) == 0;
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
-                    const float* p = bp + nt * 32 * LDA + goff;
-                    bh[nt] = *reinterpret_cast<const T8*>(p);
-                    bl[nt] = *reinterpret_cast<const T8*>(p + 4);
-                }
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
+                    for (int gq = 0; gq < 4; ++gq) {
+                        const int c = cb + nt * 32 + gq * 8;
+                        if (c >= a.cout) continue;
+                        f32x4 v;
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) {
-                        if constexpr (PREC == SGD_PREC_F16X3) {
-                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], bh[nt], acc[mt][nt], 0, 0, 0);
-                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bl[nt], acc[mt][nt], 0, 0, 0);
-                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+                        for (int j = 0; j < 4; ++j) v[j] = acc[mt][nt][gq * 4 + j];
+                        if (vec) {                                   // cout % 4 == 0: whole quad in range
+                            if (a.bias) v += ld4(a.bias + c);
+                            if (RES == 1 || RES == 3) v += ld4(rp + c);
+                            if (RES == 2) {
+                                const long rw = (long)a.wo * 2 * a.cout;
+                                v += 0.25f * (ld4(rp + c) + ld4(rp + a.cout + c) + ld4(rp + rw + c) + ld4(rp + rw + a.cout + c));
+                            }
+                            if (!(g.dbg & 8)) *reinterpret_cast<f32x4*>(yp + c) = v;
                         } else {
-                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mt], bh[nt], acc[mt][nt], 0, 0, 0);
-                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bl[nt], acc[mt][nt], 0, 0, 0);
-                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                if (c + j >= a.cout) continue;
+                                float x = v[j] + (a.bias ? a.bias[c + j] : 0.f);
+                                if (RES == 1 || RES == 3) x += rp[c + j];
+                                if (RES == 2) {
+                                    const long rw = (long)a.wo * 2 * a.cout;
+                                    x += 0.25f * (rp[c + j] + rp[a.cout + c + j] + rp[rw + c + j] + rp[rw + a.cout + c + j]);
+                                }
+                                yp[c + j] = x;
+                            }
                         }
                     }
-            }
-        }
-    };
-
-    // ---- main loop ------------------------------------------------------------------------
-    load_B(0, 0);
-    for (int ch = 0; ch < nchunks; ++ch) {
-        const int kc0 = ch * KC;
-        // (the barrier closing the previous chunk's last tap already ordered all As reads)
-        stage_A(kc0);
-        if (ch == 0) store_B(0);
-        __syncthreads();
-        for (int tap = 0; tap < taps; ++tap) {
-            const int step = ch * taps + tap;
-            const bool more = (tap + 1 < taps) || (ch + 1 < nchunks);
-            if (more) {
-                if (tap + 1 < taps) load_B(tap + 1, kc0);
-                else load_B(0, kc0 + KC);
-            }
-            compute(tap, step & 1);
-            if (more) store_B((step + 1) & 1);
-            __syncthreads();
-        }
-    }
-
-    // ---- epilogue --------------------------------------------------------------------------
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        const int col = n0c + wn * WN + nt * 32 + li;
-        if (col >= a.cout) continue;
-        const float bias = a.bias ? a.bias[col] : 0.f;
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = wm * WM + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                long orow;        // output row index
-                int n = 0, oy = 0, ox = 0;
-                if (conv) {
-                    int tx = row & (TW - 1), ty = (row >> g.tw_l2) & (TH - 1), nb = row >> (g.tw_l2 + g.th_l2);
-                    n = img0 + nb; oy = ty0 + ty; ox = tx0 + tx;
-                    if (n >= a.n) continue;
-                    orow = ((long)n * a.ho + oy) * a.wo + ox;
-                } else {
-                    orow = m0 + row;
-                    if (orow >= M) continue;
                 }
-                float v = acc[mt][nt][r] + bias;
-                if (a.res) {
-                    if (a.res_mode == SGD_RS_NONE) {
-                        v += a.res[orow * a.cout + col];
-                    } else if (a.res_mode == SGD_RS_AVGPOOL2) {
-                        const int rw = a.wo * 2;
-                        const float* rp = a.res + (((long)n * a.ho * 2 + 2 * oy) * rw + 2 * ox) * a.cout + col;
-                        v += 0.25f * (rp[0] + rp[a.cout] + rp[(long)rw * a.cout] + rp[(long)(rw + 1) * a.cout]);
-                    } else {
-                        const int rw = a.wo >> 1;
-                        v += a.res[(((long)n * (a.ho >> 1) + (oy >> 1)) * rw + (ox >> 1)) * a.cout + col];
-                    }
-                }
-                if (a.orows_in > 0) orow = (orow / a.orows_in) * a.orows_out + a.orow_off + orow % a.orows_in;
-                a.y[orow * a.y_ld + col] = v;
             }
-        }
+        };
+        if (!a.res) epilogue(std::integral_constant<int, 0>());
+        else if (a.res_mode == SGD_RS_NONE) epilogue(std::integral_constant<int, 1>());
+        else if (a.res_mode == SGD_RS_AVGPOOL2) epilogue(std::integral_constant<int, 2>());
+        else epilogue(std::integral_constant<int, 3>());
     }
 }
 
@@ -427,20 +759,25 @@ __global__ void pack_weight_kernel(const float* __restrict__ src, float* __restr
 inline int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 inline bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 
-template <int BN, int PREC>
-int launch(const KArgs& ka, bool vec, size_t smem, hipStream_t st) {
-    const int total = ka.g.mt * ka.g.nt;
-    const int grid = ((total + 7) / 8) * 8;
-    if (vec) {
-        static bool attr_v = false;
-        if (!attr_v) { (void)hipFuncSetAttribute((const void*)igemm_kernel<BN, PREC, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_v = true; }
-        hipLaunchKernelGGL((igemm_kernel<BN, PREC, true>), dim3(grid), dim3(256), smem, st, ka);
-    } else {
-        static bool attr_s = false;
-        if (!attr_s) { (void)hipFuncSetAttribute((const void*)igemm_kernel<BN, PREC, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_s = true; }
-        hipLaunchKernelGGL((igemm_kernel<BN, PREC, false>), dim3(grid), dim3(256), smem, st, ka);
+template <int BN, int PREC, bool VEC, int TAPS>
+int launch1(const KArgs& ka, size_t smem, hipStream_t st) {
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)igemm_kernel<BN, PREC, VEC, TAPS>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr = true;
     }
+    const int total = ka.g.mt * ka.g.nt;
+    int grid = ((total + 7) / 8) * 8;
+    if (grid > 256) grid = 256;                   // persistent: one block per CU walks its tiles
+    hipLaunchKernelGGL((igemm_kernel<BN, PREC, VEC, TAPS>), dim3(grid), dim3(NTHREADS), smem, st, ka);
     return sgd_check_launch();
+}
+
+template <int BN, int PREC>
+int launch(const KArgs& ka, bool vec, bool conv, size_t smem, hipStream_t st) {
+    if (conv) return vec ? launch1<BN, PREC, true, 9>(ka, smem, st) : launch1<BN, PREC, false, 9>(ka, smem, st);
+    return vec ? launch1<BN, PREC, true, 1>(ka, smem, st) : launch1<BN, PREC, false, 1>(ka, smem, st);
 }
 
 }  // namespace
@@ -493,6 +830,7 @@ extern "C" int sgd_igemm(const sgd_igemm_args* args, void* stream) {
     const int bn = pick_bn(a.cout);
     if (a.cout_p % bn != 0 || a.cout_p < a.cout || a.cin_p % KC != 0 || a.cin_p < cin) return SGD_ERR_ARG;
     const bool vec = (a.c0 % 4 == 0) && (a.c1 % 4 == 0);
+    int na;
     if (a.mode == SGD_MODE_CONV3) {
         if (a.n <= 0 || a.hi <= 0 || a.wi <= 0 || (a.stride != 1 && a.stride != 2)) return SGD_ERR_ARG;
         if (a.stride == 2 && a.resample != SGD_RS_NONE) return SGD_ERR_ARG;
@@ -503,17 +841,24 @@ extern "C" int sgd_igemm(const sgd_igemm_args* args, void* stream) {
         if (a.ho != ho || a.wo != wo) return SGD_ERR_ARG;
         if (!is_pow2(a.ho) || !is_pow2(a.wo) || a.ho < 2 || a.wo < 2) return SGD_ERR_ARG;
         if (a.res && a.res_mode == SGD_RS_UP2 && ((a.ho | a.wo) & 1)) return SGD_ERR_ARG;
+        if ((long)a.n * a.hi * a.wi >= (1L << 31)) return SGD_ERR_ARG;      // source rows are 32-bit in the tile table
         int tw = a.wo < 16 ? a.wo : 16;
-        int th = BM / tw; if (th > a.ho) th = a.ho; if (th > 8 && tw == 16) th = 8;
-        // keep th*tw <= 128 and a power of two
+        int th = BM / tw; if (th > a.ho) th = a.ho;
         while (th * tw > BM) th >>= 1;
+        if (a.stride == 2) { if (tw > 8) tw = 8; if (th > 8) th = 8; }   // big input halos: smaller spatial tile
         int nb = BM / (th * tw);
-        g.tw_l2 = ilog2(tw); g.th_l2 = ilog2(th); g.nb = nb;
-        g.tiles_x = a.wo / tw; g.tiles_y = a.ho / th;
         g.hh = a.stride == 2 ? 2 * th + 1 : th + 2;
         g.hw = a.stride == 2 ? 2 * tw + 1 : tw + 2;
+        // the double-buffered halo tile must fit LDS next to the weight ring; rows of images beyond nb
+        // are computed on don't-care data and masked in the epilogue
+        while (nb > 1 && (2 * (size_t)nb * g.hh * g.hw * LDA + (size_t)NB_RING * bn * LDA) * 4 + (size_t)nb * g.hh * g.hw * 16 > 150 * 1024)
+            nb >>= 1;
+        g.tw_l2 = ilog2(tw); g.th_l2 = ilog2(th); g.nb = nb;
+        g.tiles_x = a.wo / tw; g.tiles_y = a.ho / th;
         g.pix = nb * g.hh * g.hw;
         g.mt = ((a.n + nb - 1) / nb) * g.tiles_x * g.tiles_y;
+        g.fast_a = (a.resample != SGD_RS_AVGPOOL2 && g.pix <= FAST_PIX) ? 1 : 0;
+        na = 2;
     } else if (a.mode == SGD_MODE_FLAT) {
         if (a.m <= 0) return SGD_ERR_ARG;
         if (a.pro == SGD_PRO_AFFINE_NC && a.rows_per_n <= 0) return SGD_ERR_ARG;
@@ -521,15 +866,29 @@ extern "C" int sgd_igemm(const sgd_igemm_args* args, void* stream) {
         g.tw_l2 = g.th_l2 = 0; g.nb = 1; g.tiles_x = g.tiles_y = 1; g.hh = g.hw = 1; g.hc = g.wc = 1;
         g.pix = BM;
         g.mt = (a.m + BM - 1) / BM;
+        g.fast_a = 1;
+        na = 3;
     } else {
         return SGD_ERR_ARG;
     }
     g.nt = a.cout_p / bn;
-    const size_t smem = ((size_t)g.pix * LDA + 2 * (size_t)bn * LDA) * sizeof(float);
+    {
+        // epilogue uses 32-bit row indices
+        const long rows_out = a.mode == SGD_MODE_CONV3 ? (long)a.n * a.ho * a.wo : (long)a.m;
+        const long rows_res = a.res_mode == SGD_RS_AVGPOOL2 ? rows_out * 4 : rows_out;
+        if (rows_out >= (1L << 31) || rows_res >= (1L << 31)) return SGD_ERR_ARG;
+    }
+    {
+        static int dbg = -1;
+        if (dbg < 0) { const char* e = getenv("SGDM_DBG"); dbg = e ? atoi(e) : 0; }
+        g.dbg = dbg;
+    }
+    const size_t smem = ((size_t)na * g.pix * LDA + (size_t)NB_RING * bn * LDA) * sizeof(float) + (size_t)g.pix * 16;
     if (smem > 160 * 1024) return SGD_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
+    const bool conv = a.mode == SGD_MODE_CONV3;
 #define SGD_DISPATCH(P)                                                            \
-    (bn == 128 ? launch<128, P>(ka, vec, smem, st) : launch<32, P>(ka, vec, smem, st))
+    (bn == 128 ? launch<128, P>(ka, vec, conv, smem, st) : launch<32, P>(ka, vec, conv, smem, st))
     switch (a.prec) {
         case SGD_PREC_F32: return SGD_DISPATCH(SGD_PREC_F32);
         case SGD_PREC_F16X3: return SGD_DISPATCH(SGD_PREC_F16X3);
