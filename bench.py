@@ -74,12 +74,26 @@ def build_model(wl, device, prec, batch=None):
     return m, sd, data
 
 
+def host_cores():
+    """threads actually usable: min(affinity, cgroup CPU quota) -- the GPU box shows 256 logical CPUs but
+    grants a 16-CPU quota; oversubscribing makes the torch-CPU baseline 10x slower"""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
 def cpu_baseline(wl, sd, seconds_budget=25.0):
     """the oracle (CPU restatement of the reference UNet, pinned to the reference by tests/golden) timed
     on the host cores: CFG steps at bs=8, extrapolated linearly to the workload's 1000-step images/s."""
     from oracle import unet_ref as U
     from sgdm_amd.synth import synth_batch
-    torch.set_num_threads(os.cpu_count())
+    cores = host_cores()
+    torch.set_num_threads(cores)
     cfg = U.make_cfg(wl["kind"], wl["image"], model_channels=128, cond_dim=wl["cond_dim"],
                      condition_method=wl["method"], layout_dim=wl["layout_dim"],
                      cond_token_num=1 if wl["kind"] == "unetca_fast" else 0,
@@ -99,7 +113,7 @@ def cpu_baseline(wl, sd, seconds_budget=25.0):
             U.forward_with_cond_scale(cfg, sd, x, t, 2.0, cond, data.get("layout"))
             times.append(time.time() - t0)
     per_step = min(times)
-    return dict(value=B / (1000.0 * per_step), unit="images/s", cores=os.cpu_count(), kind="port",
+    return dict(value=B / (1000.0 * per_step), unit="images/s", cores=cores, kind="port",
                 sample=f"{len(times)} CFG UNet steps at bs={B} (UNet batch {2 * B}) of the same model on the host "
                        f"cores, best {per_step:.2f} s/step, extrapolated linearly to 1000 steps",
                 s_per_step_bs8=per_step)

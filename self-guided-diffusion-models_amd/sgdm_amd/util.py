@@ -1,0 +1,41 @@
+"""Small host helpers of the boundary (reference diffusion_utils/util.py:70-100,254-268 and
+diffusion_utils/lr_scheduler.py:36-98)."""
+import importlib
+
+
+def instantiate_from_config(config):
+    assert "target" in config
+    module, cls = config["target"].rsplit(".", 1)
+    return getattr(importlib.import_module(module, package=None), cls)(**config.get("params", dict()))
+
+
+class LambdaLinearScheduler:
+    """lr_scheduler.py:36-98: linear warm-up to f_max, then linear f_max -> f_min over the cycle"""
+
+    def __init__(self, warm_up_steps, f_min, f_max, f_start, cycle_lengths, verbosity_interval=0):
+        assert len(warm_up_steps) == len(f_min) == len(f_max) == len(f_start) == len(cycle_lengths)
+        self.lr_warm_up_steps, self.f_start, self.f_min, self.f_max = warm_up_steps, f_start, f_min, f_max
+        self.cycle_lengths = cycle_lengths
+        self.cum_cycles = [0]
+        for c in cycle_lengths:
+            self.cum_cycles.append(self.cum_cycles[-1] + c)
+        self.last_f = 0.0
+
+    def find_in_interval(self, n):
+        for interval, cl in enumerate(self.cum_cycles[1:]):
+            if n <= cl:
+                return interval
+
+    def schedule(self, n, **kwargs):
+        cycle = self.find_in_interval(n)
+        n = n - self.cum_cycles[cycle]
+        if n < self.lr_warm_up_steps[cycle]:
+            f = (self.f_max[cycle] - self.f_start[cycle]) / self.lr_warm_up_steps[cycle] * n + self.f_start[cycle]
+        else:
+            f = self.f_min[cycle] + (self.f_max[cycle] - self.f_min[cycle]) * (self.cycle_lengths[cycle] - n) / (
+                self.cycle_lengths[cycle])
+        self.last_f = f
+        return f
+
+    def __call__(self, n, **kwargs):
+        return self.schedule(n, **kwargs)

@@ -1,0 +1,169 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads and exports every symbol the header
+declares, the drop-in modules resolve through the reference's `target:` strings with reference-identical
+state_dict manifests, the plugin surface / EMA / LR schedule / schedule tables match the golden vectors,
+and the product path refuses to run without the GPU (no CPU fallback, no oracle import)."""
+import ctypes
+import os
+import re
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import PKG, ROOT, load_json, load_npz
+
+INDEX = load_json("unet_index.json")
+
+
+class AD(dict):
+    __getattr__ = dict.__getitem__
+
+
+def test_library_exports_every_declared_symbol():
+    from sgdm_amd import _lib as L
+    hdr = open(os.path.join(ROOT, "include", "sgdm_hip.h")).read()
+    declared = set(re.findall(r"^\s*(?:int|int64_t)\s+(sgd_\w+)\s*\(", hdr, flags=re.M))
+    assert declared == set(L.SIGNATURES), declared ^ set(L.SIGNATURES)
+    lib = L.load()                                    # binds every symbol or raises
+    assert lib.sgd_abi_version() == L.ABI_VERSION
+    assert ctypes.sizeof(L.IgemmArgs) == 168
+    # argument validation needs no GPU: invalid descriptors are rejected before any launch
+    assert lib.sgd_igemm(None, None) == 1
+    assert lib.sgd_packed_weight_bytes(128, 128, 3, 0) == 9 * 128 * 128 * 4
+    assert lib.sgd_packed_weight_bytes(3, 30, 3, 1) == 9 * 32 * 32 * 4
+
+
+def _build(name):
+    entry = INDEX[name]
+    kw = dict(entry["ctor"])
+    cond = AD(scale_type="imagen")
+    if entry["layout_dim"]:
+        cond[kw["condition_method"]] = AD(layout_dim=entry["layout_dim"])
+    target = ("dynamic.diffusionmodules.openaimodel.UNetModel" if entry["kind"] == "unet_fast"
+              else "dynamic.diffusionmodules.openaimodel_ca.UNetModel")      # config/dynamic/*.yaml:1
+    from diffusion_utils.util import instantiate_from_config
+    return instantiate_from_config(dict(target=target, params=dict(condition=cond, **kw))), entry
+
+
+@pytest.fixture(scope="module", autouse=True)
+def dropin_path():
+    p = os.path.join(PKG, "dropin")
+    sys.path.insert(0, p)
+    for m in [k for k in sys.modules if k.split(".")[0] in ("dynamic", "diffusion", "dynamic_input", "diffusion_utils")]:
+        del sys.modules[m]
+    yield
+    sys.path.remove(p)
+
+
+@pytest.mark.parametrize("name", sorted(INDEX))
+def test_dropin_targets_and_manifest(name):
+    m, entry = _build(name)
+    sd = m.state_dict()
+    params = dict(m.named_parameters())
+    mine = [[k, list(v.shape), ("param" if params[k].requires_grad else "frozen") if k in params else "buffer"]
+            for k, v in sd.items()]
+    assert mine == entry["manifest"]
+    # zero-initialised tensors of the reference (openaimodel.py:273-276,357,833-834)
+    assert float(sd["out.2.weight"].abs().sum()) == 0.0
+    assert float(sd["middle_block.0.out_layers.3.weight"].abs().sum()) == 0.0
+
+
+def test_no_cpu_fallback():
+    m, entry = _build("uf_label_c32_s16")
+    x = torch.zeros(2, 3, 16, 16)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(x, torch.zeros(2, dtype=torch.long), cond=torch.zeros(2, 10), cond_drop_prob=0.0)
+
+
+def test_product_never_imports_oracle():
+    for root, _, files in os.walk(PKG):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(root, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", src, flags=re.M), os.path.join(root, f)
+
+
+def test_plugin_surface_matches_reference():
+    from dynamic_input.condition import prepare_condition_kwargs, prepare_denoise_fn_kwargs_4sampling
+    gold = load_json("condition_plugin.json")
+    names = ("label", "cluster", "lostbboxmask", "segmask", "stegomask", "stego_attr", "id")
+
+    def mk(method, how, training):
+        hp = AD(cond_dim=5, condition_method=method, cond_drop_prob=0.1,
+                condition=AD(clusterlayout=AD(how=how), layout=AD(how=how)))
+        return AD(hparams=hp, training=training, device="cpu")
+
+    for key, want in gold.items():
+        parts = key.split("|")
+        b = {k: torch.ones(2, 3) * (i + 1) for i, k in enumerate(names)}
+        if parts[0] == "sampling":
+            method = None if parts[1] == "None" else parts[1]
+            how = None if parts[2] == "None" else parts[2]
+            r = prepare_denoise_fn_kwargs_4sampling(mk(method, how, False), b, dict(random_sample_condition=False), 2.0)
+            assert sorted(r.keys()) == want
+            continue
+        method = None if parts[0] == "None" else parts[0]
+        how = None if parts[1] == "None" else parts[1]
+        r = prepare_condition_kwargs(mk(method, how, bool(int(parts[2]))), b)
+        got = {}
+        for k, v in r.items():
+            got[k] = [n for n, bv in b.items() if torch.equal(bv.float(), v.float())][0] if torch.is_tensor(v) else v
+        assert got == want, key
+    with pytest.raises(ValueError):
+        prepare_condition_kwargs(mk("nonsense", None, True), {})
+
+
+def test_litema_matches_reference():
+    from dynamic.ema import LitEma
+    v = load_npz("diffusion.npz")
+    lin = torch.nn.Sequential(torch.nn.Linear(4, 3), torch.nn.Linear(3, 2))
+    shapes = [tuple(p.shape) for p in lin.parameters()]
+    sizes = [int(np.prod(s)) for s in shapes]
+    with torch.no_grad():
+        for p, a in zip(lin.parameters(), np.split(v["ema.init"], np.cumsum(sizes)[:-1])):
+            p.copy_(torch.from_numpy(a.copy()).reshape(p.shape))
+    ema = LitEma(lin)
+    deltas = np.split(v["ema.deltas"], np.cumsum(sizes * 3)[:-1])
+    for step in range(3):
+        with torch.no_grad():
+            for i, p in enumerate(lin.parameters()):
+                p.add_(torch.from_numpy(deltas[step * 4 + i].copy()).reshape(p.shape))
+        ema(lin)
+    assert list(ema.m_name2s_name.values()) == list(v["ema.keys"])
+    got = np.concatenate([dict(ema.named_buffers())[s].numpy().ravel() for s in ema.m_name2s_name.values()])
+    assert int(ema.num_updates) == int(v["ema.num_updates"])
+    assert np.allclose(got, v["ema.shadow"], rtol=0, atol=1e-6)
+    # store / copy_to / restore round trip
+    ema.store(lin.parameters())
+    ema.copy_to(lin)
+    assert np.allclose(np.concatenate([p.detach().numpy().ravel() for p in lin.parameters()]), got)
+    ema.restore(lin.parameters())
+
+
+def test_lr_lambda_matches_reference():
+    from diffusion_utils.lr_scheduler import LambdaLinearScheduler
+    v = load_npz("diffusion.npz")
+    sch = LambdaLinearScheduler(warm_up_steps=[500], cycle_lengths=[10000000000000], f_start=[1.e-6], f_max=[1.],
+                                f_min=[1.])
+    got = np.asarray([sch.schedule(int(n)) for n in v["lr.n"]], dtype=np.float64)
+    assert np.array_equal(got, v["lr.f"])
+
+
+def test_schedule_buffers_bit_exact():
+    from diffusion.ddpm import LatentDiffusion
+    import bench
+    v = load_npz("diffusion.npz")
+    d = LatentDiffusion(device="cpu", **bench.MODEL_PARAMS)
+    sd = d.sampler.state_dict()
+    for k in sd:
+        assert np.array_equal(sd[k].numpy(), v["sched." + k]), k
+    assert "lvlb_weights" not in sd                      # non-persistent (ddpm_sampler.py:96-97)
+    assert np.array_equal(d.sampler.lvlb_weights.numpy(), v["sched.lvlb_weights"])
+    ds = d.sampler_list["ddim"]
+    for S in (10, 50, 250):
+        for eta in (0.0, 1.0):
+            ds.make_schedule(dict(num_timesteps=S, ddim_eta=eta, alphas_cumprod=d.sampler.alphas_cumprod))
+            assert np.array_equal(ds.ddim_timesteps, v[f"ddim{S}.timesteps"])
+            assert np.array_equal(np.asarray(ds.ddim_sigmas, dtype=np.float64), v[f"ddim{S}.eta{eta}.sigmas"])
+            assert np.array_equal(np.asarray(ds.ddim_alphas, dtype=np.float64), v[f"ddim{S}.eta{eta}.alphas"])

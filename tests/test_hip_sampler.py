@@ -1,0 +1,136 @@
+"""Sampling loops of the HIP drop-in (LatentDiffusion.p_sample_loop through the reference API) against
+the trajectories recorded from the reference.  GPU only.
+
+Per SURVEY Appendix C: deterministic DDIM with random weights is an expansive map, so short free-running
+trajectories are a plumbing check at a loose tolerance; the gate proper is per evaluation with teacher
+forcing.  Native DDPM trajectories are well conditioned and are compared on uint8 output."""
+import pytest
+import torch
+
+from conftest import load_npz, rel_l2
+from test_hip_unet import build_model
+
+pytestmark = pytest.mark.gpu
+
+
+def _diffusion(model):
+    import bench
+    from sgdm_amd.diffusion import LatentDiffusion
+    d = LatentDiffusion(device="cuda", **bench.MODEL_PARAMS)
+    d.set_denoise_fn(model.forward, model.forward_with_cond_scale)
+    return d
+
+
+def _skw(method, steps, eta=0.0):
+    # dynamic_input/misc.py:128-141
+    return dict(sampling_method=method, vis=None, num_timesteps=steps, ddim_eta=eta, log_num_per_prog=10,
+                clip_denoised=True, dtp=1, temperature=1.0, noise_dropout=0, random_sample_condition=False,
+                return_inter_dict=True, disable_tqdm=True)
+
+
+def _cond():
+    from sgdm_amd.synth import synth_batch
+    return synth_batch("label", 2, 16, 10, seed=23)["cond"].cuda()
+
+
+@pytest.mark.parametrize("eta", [0.0, 1.0])
+def test_ddim10_trajectory_vs_reference(eta):
+    v = load_npz("diffusion.npz")
+    tag = f"ddim10.eta{eta}"
+    m, _ = build_model("uf_label_c32_s16", "f32")
+    d = _diffusion(m)
+    z = torch.from_numpy(v[tag + ".z"])
+    samples, inter = d.p_sample_loop("ddim", (2, 3, 16, 16), _skw("ddim", 10, eta),
+                                     denoise_sample_fn_kwargs=dict(cond=_cond(), layout=None, cond_scale=2.0),
+                                     condition_kwargs={}, x_T=torch.from_numpy(v[tag + ".x_T"]),
+                                     noise_fn=lambda i: z[i])
+    assert samples.dtype == torch.uint8 and tuple(samples.shape) == (2, 3, 16, 16)
+    assert tuple(inter["pred_x0"].shape) == (9, 2, 3, 16, 16)          # index 10 never visited (Appendix B)
+    assert rel_l2(inter["x_inter"].cpu(), v[tag + ".x_inter"]) < 1e-3
+    assert (samples.cpu().int() - torch.from_numpy(v[tag + ".samples_u8"]).int()).abs().max() <= 1
+    assert (inter["pred_x0"].cpu().int() - torch.from_numpy(v[tag + ".pred_x0_u8"]).int()).abs().max() <= 1
+
+
+def test_ddim_teacher_forced_steps_vs_oracle():
+    """the gate proper: every step fed the ORACLE's x_t; eps-combined update compared per step"""
+    from oracle import diffusion_ref as D
+    from oracle import unet_ref as U
+    from conftest import cfg_from_index
+    from sgdm_amd.synth import weights_from_seed
+    v = load_npz("diffusion.npz")
+    tag = "ddim10.eta1.0"
+    m, entry = build_model("uf_label_c32_s16", "f32")
+    d = _diffusion(m)
+    cfg, sd = cfg_from_index(entry), weights_from_seed(entry["manifest"], entry["seed"])
+    cond = _cond()
+    sched = D.make_schedule()
+    steps = D.make_ddim_timesteps(10)
+    tabs = D.make_ddim_tables(sched["alphas_cumprod"], steps, 1.0)
+    z = torch.from_numpy(v[tag + ".z"])
+    x = torch.from_numpy(v[tag + ".x_T"])
+    ds = d.sampler_list["ddim"]
+    skw = dict(_skw("ddim", 10, 1.0), alphas_cumprod=d.sampler.alphas_cumprod)
+    ds.make_schedule(skw)
+    import ctypes as C
+    from sgdm_amd import _lib as L
+    from sgdm_amd.diffusion import _StepRunner
+    runner = _StepRunner(d.denoise_sample_fn, dict(cond=cond, layout=None, cond_scale=2.0))
+    for i, step in enumerate(reversed(steps.tolist())):
+        index = 10 - i - 1
+        ts = torch.full((2,), int(step), dtype=torch.long)
+        with torch.no_grad():
+            eps_ref = U.forward_with_cond_scale(cfg, sd, x, ts, 2.0, cond.cpu(), None)
+        x_ref, x0_ref = D.ddim_step(tabs, index, x, eps_ref, z[i])
+        xd = x.cuda()
+        eps, mode, w, bb, cc = runner.eps(xd, ts.cuda())
+        coef = (C.c_float * 4)(float(ds.ddim_sqrt_one_minus_alphas[index]), float(ds.ddim_alphas[index]),
+                               float(ds.ddim_alphas_prev[index]), float(ds.ddim_sigmas[index]))
+        out, x0 = torch.empty_like(xd), torch.empty_like(xd)
+        zd = z[i].cuda()
+        L.check(L.load().sgd_ddim_step(C.c_void_p(xd.data_ptr()), C.c_void_p(eps.data_ptr()), C.c_void_p(zd.data_ptr()),
+                                       mode, w, coef, 1.0, 1, bb, cc, 256, C.c_void_p(out.data_ptr()),
+                                       C.c_void_p(x0.data_ptr()), torch.cuda.current_stream().cuda_stream), "ddim")
+        assert rel_l2(out.cpu(), x_ref) < 1e-4, index           # north_star: 1e-4 per evaluation
+        assert rel_l2(x0.cpu(), x0_ref) < 1e-4, index
+        x = x_ref                                                # teacher forcing
+
+
+def test_native_1000_step_trajectory_vs_reference():
+    """the BASELINE metric's sampler end to end; z by replaying the reference's RNG consumption order"""
+    v = load_npz("diffusion.npz")
+    B, S = 2, 16
+    m, _ = build_model("uf_label_c32_s16", "f32")        # (module init draws from the CPU generator: build first)
+    d = _diffusion(m)
+    torch.manual_seed(int(v["native1000.rng_seed"]))
+    x_T = torch.randn(B, 3, S, S)
+    assert torch.equal(x_T, torch.from_numpy(v["native1000.x_T"]))
+
+    def noise_fn(i):
+        torch.zeros(2 * B).float().uniform_(0, 1)        # the UNet's mask draw precedes z in the stream
+        return torch.randn(B, 3, S, S)
+
+    samples, inter = d.p_sample_loop("native", (B, 3, S, S), _skw("native", 1000),
+                                     denoise_sample_fn_kwargs=dict(cond=_cond(), layout=None, cond_scale=2.0),
+                                     condition_kwargs={}, x_T=x_T, noise_fn=noise_fn)
+    ref = torch.from_numpy(v["native1000.samples_u8"]).int()
+    diff = (samples.cpu().int() - ref).abs()
+    assert diff.max() <= 1
+    assert (diff != 0).float().mean() < 1e-2
+    assert tuple(inter["pred_x0"].shape) == (9, B, 3, S, S)
+    assert rel_l2(inter["x_inter"].cpu(), v["native1000.x_inter"]) < 1e-3
+
+
+def test_generic_denoiser_path_matches_fused_path():
+    """a denoise_sample_fn that is NOT the drop-in's bound method takes the generic (guided eps, NCHW) path"""
+    m, _ = build_model("uf_label_c32_s16", "f32")
+    d = _diffusion(m)
+    cond = _cond()
+    g = torch.Generator().manual_seed(3)
+    x_T = torch.randn(2, 3, 16, 16, generator=g)
+    z = torch.randn(10, 2, 3, 16, 16, generator=g)
+    kw = dict(denoise_sample_fn_kwargs=dict(cond=cond, layout=None, cond_scale=2.0), condition_kwargs={},
+              x_T=x_T, noise_fn=lambda i: z[i])
+    a, _ = d.p_sample_loop("ddim", (2, 3, 16, 16), _skw("ddim", 10, 1.0), **kw)
+    d.set_denoise_fn(m.forward, lambda x, t, **k: m.forward_with_cond_scale(x, t, **k))
+    b, _ = d.p_sample_loop("ddim", (2, 3, 16, 16), _skw("ddim", 10, 1.0), **kw)
+    assert (a.int() - b.int()).abs().max() <= 1
