@@ -113,7 +113,9 @@ int sgd_ln_apply(const float* x, const float* gamma, const float* beta, const fl
 int sgd_attention(const float* q, int32_t q_ld, int32_t q_hs,
                   const float* k, const float* v, int32_t kv_ld, int32_t kv_hs,
                   int32_t batch, int32_t heads, int32_t tq, int32_t tk, int32_t d, float scale,
-                  float* out, int32_t out_ld, void* stream);
+                  float* out, int32_t out_ld,
+                  float* lse /* [batch, heads, tq] log-sum-exp of the scaled logits for the backward, or NULL */,
+                  void* stream);
 
 /* --------------------------------------------------------------------------------------
  * Small glue kernels on the UNet boundary.
@@ -160,6 +162,74 @@ int sgd_to_uint8(const float* x, int64_t count, uint8_t* out, void* stream);
 /* guided eps only (forward_with_cond_scale return value): eps_nhwc [2b,h,w,c] -> NCHW [b,c,h,w] */
 int sgd_cfg_combine(const float* eps_nhwc, int32_t cfg_mode, float w, int32_t b, int32_t c, int32_t hw,
                     float* out_nchw, void* stream);
+
+
+/* weights of the adjoint convolution (input gradient): w_src is the FORWARD weight [cout, cin, k, k];
+ * the packed operator maps cout input channels to cin output channels with flipped taps, so
+ * sgd_igemm(dy, w_dgrad) == conv_transpose(dy, W) for stride 1 (autograd of nn.Conv2d, openaimodel.py:248,274). */
+int sgd_pack_weight_dgrad(const float* w_src, void* w_dst, int32_t cout_fwd, int32_t cin_fwd, int32_t ksize,
+                          int32_t prec, int32_t* cin_p, int32_t* cout_p /* HOST out */, void* stream);
+
+/* --------------------------------------------------------------------------------------
+ * Training step: backward kernels (autograd of the ops above; the reference gets these from
+ * torch.autograd through ResBlock / AttentionBlock, lightning_module.py:215-245 + PL's loss.backward()).
+ * -------------------------------------------------------------------------------------- */
+/* weight gradient of a fused conv / linear:  dW[co, ci, tap] = sum_rows gy[row, co] * act(x)[row shifted by tap, ci]
+ * `fwd` describes the FORWARD launch (its input side: x0/x1, prologue, resample, geometry are re-used to recompute the
+ * activated input; its w/bias/res/y fields are ignored).  Exact-fp32 MFMA.  Partial sums of `ksplit` row slices are
+ * written to `slabs` [ksplit][taps][cout][cin] and folded by sgd_wgrad_reduce into the reference layout. */
+int sgd_wgrad(const sgd_igemm_args* fwd /* HOST */, const float* gy, int32_t gy_ld, int32_t cout,
+              float* slabs, int32_t ksplit, void* stream);
+/* dw[co, ci, tap] (OIHW / [cout, cin]) = (accumulate ? dw : 0) + sum_k slabs[k][tap][co][ci] */
+int sgd_wgrad_reduce(const float* slabs, int32_t ksplit, int32_t taps, int32_t cout, int32_t cin,
+                     float* dw, int32_t accumulate, void* stream);
+/* out[c] = (accumulate ? out[c] : 0) + sum_rows g[row, c]   (bias gradients) */
+int sgd_colsum(const float* g, int32_t rows, int32_t c, int32_t ld, float* out, int32_t accumulate, void* stream);
+
+/* GroupNorm(+FiLM)+SiLU backward, split like the forward (util.py:199-216, openaimodel.py:246-247,312-316):
+ *   pre = a*x + b ; u = silu ? SiLU(pre) : pre ; the consumer returned gu = dL/du.
+ *   gu may live at another resolution (ResBlock up/down, openaimodel.py:301-306): gu_mode SGD_RS_NONE same rows,
+ *   SGD_RS_AVGPOOL2: forward pooled u 2x2 => gu is at 1/2 resolution, each x pixel receives gu/4;
+ *   SGD_RS_UP2: forward upsampled u x2 => gu is at 2x resolution, each x pixel receives the sum of its 2x2 block.
+ * sgd_gn_bwd_reduce: S[n, c, 2] = (sum gpre, sum gpre * x) over the hw rows, gpre = gu * SiLU'(pre)      */
+int sgd_gn_bwd_reduce(const float* x, int32_t n, int32_t h, int32_t w, int32_t c, int32_t c_total, int32_t c_off,
+                      const float* a, const float* b, int32_t silu,
+                      const float* gu, int32_t gu_ld, int32_t gu_mode, float* S, void* stream);
+/* per-(n,c) coefficients of dx = A*gpre + B*x + C from S and the forward statistics (`sums` of sgd_chan_stats),
+ * plus per-sample parameter gradients dgamma_nc / dbeta_nc [n, c] (sum over n with sgd_colsum) and the FiLM
+ * gradient dfilm[n, film_ld] (scale grad at +0, shift grad at +c; may be NULL). */
+int sgd_gn_bwd_coef(const float* S, const float* sums, const float* gamma, const float* beta,
+                    const float* film, int32_t film_ld, int32_t n, int32_t c, int32_t groups, int32_t hw, float eps,
+                    float* A, float* B, float* Cc, float* dgamma_nc, float* dbeta_nc /* [n, c]: fold with sgd_colsum */,
+                    float* dfilm, void* stream);
+/* dx[row, c_off + c] (+)= A*gu*SiLU'(a x + b) + B*x + C  (+ extra residual-path gradient gres, same gu_mode rules)
+ * written into dst (row stride dst_ld, channel offset dst_off); accumulate: add to what is there. */
+int sgd_gn_bwd_apply(const float* x, int32_t n, int32_t h, int32_t w, int32_t c, int32_t c_total, int32_t c_off,
+                     const float* a, const float* b, int32_t silu,
+                     const float* gu, int32_t gu_ld, int32_t gu_mode,
+                     const float* A, const float* B, const float* Cc,
+                     const float* gres, int32_t gres_ld, int32_t gres_mode,
+                     float* dst, int32_t dst_ld, int32_t dst_off, int32_t accumulate, void* stream);
+/* plain SiLU backward for the embedding MLPs: gx = g * SiLU'(x) (rows x c, contiguous) */
+int sgd_silu_bwd(const float* x, const float* g, int64_t count, float* gx, void* stream);
+
+/* legacy QKV attention backward (autograd of openaimodel.py:403-420), same addressing as sgd_attention:
+ * dq/dk/dv are written with the same row strides / head strides as q/k/v (i.e. into a gqkv tensor). */
+int sgd_attention_bwd(const float* q, int32_t q_ld, int32_t q_hs, const float* k, const float* v, int32_t kv_ld,
+                      int32_t kv_hs, const float* o /* forward output */, int32_t o_ld,
+                      const float* dout, int32_t dout_ld, const float* lse /* from sgd_attention */,
+                      float* dvec /* workspace [batch, heads, tq] */,
+                      int32_t batch, int32_t heads, int32_t tq, int32_t tk, int32_t d, float scale,
+                      float* dq, float* dk, float* dv, void* stream);
+
+/* q_sample + loss (diffusion/ddpm.py:54-86, ddpm_sampler.py:116-119):
+ *   x_noisy = sa[t]*x0 + s1ma[t]*noise      (NCHW in, NCHW out; tables are the float32 schedule buffers) */
+int sgd_q_sample(const float* x0, const float* noise, const int64_t* t, const float* sqrt_ac, const float* sqrt_1mac,
+                 int32_t b, int64_t chw, float* out, void* stream);
+/* per_sample[b] = mean_chw (noise - eps)^2 ; geps_nhwc = d(mean_b per_sample)/d eps laid out NHWC for the backward
+ * program (eps_nhwc is the UNet output in NHWC, noise NCHW) */
+int sgd_mse_loss(const float* eps_nhwc, const float* noise_nchw, int32_t b, int32_t c, int32_t hw,
+                 float* per_sample, float* geps_nhwc, void* stream);
 
 #ifdef __cplusplus
 }

@@ -21,7 +21,8 @@ template <int D>
 __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict__ q, int q_ld, int q_hs,
                                                         const float* __restrict__ k, const float* __restrict__ v,
                                                         int kv_ld, int kv_hs, int tq, int tk, float scale,
-                                                        float* __restrict__ out, int out_ld) {
+                                                        float* __restrict__ out, int out_ld,
+                                                        float* __restrict__ lse) {
     constexpr int LD = D + 4;
     constexpr int DT = (D + 31) / 32;             // 32-row tiles of the O^T accumulator
     __shared__ __attribute__((aligned(16))) float Ks[KT * LD];
@@ -119,6 +120,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
     }
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot;
+    if (lse && qi < tq && lh == 0) lse[((long)b * gridDim.y + head) * tq + qi] = m_run + __logf(l_tot);
     if (qi < tq) {
         float* op = out + ((long)b * tq + qi) * out_ld + head * D;
 #pragma unroll
@@ -131,11 +133,179 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
     }
 }
 
+
+// =============================================================================================
+// backward.  With LSE (from the forward) and D[q] = dO[q].O[q] both softmax statistics are known, so
+// every (key tile, query tile) pair is independent:
+//     S = scale q k^T, P = exp(S - LSE), dP = dO v^T, dS = P (dP - D)
+//     dV += P^T dO,  dK += scale dS^T q,  dQ += scale dS k
+// Two sweeps of ONE kernel shape (owner rows in registers as MFMA B fragments, the other side streamed
+// through LDS), so no gradient is ever summed across waves / workgroups (no atomics, deterministic):
+//   SWEEP 0 "kv": a wave owns 32 keys, loops over queries:  acc cols = key -> dK^T, dV^T accumulate over q
+//   SWEEP 1 "q" : a wave owns 32 queries, loops over keys:  acc cols = q   -> dQ^T accumulates over keys
+// =============================================================================================
+template <int D>
+__global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const float* __restrict__ o, int o_ld,
+                                                            const float* __restrict__ dout, int dout_ld, int heads,
+                                                            int tq, float* __restrict__ dvec) {
+    // dvec[b, head, q] = sum_d dout[b,q,head*D+d] * o[b,q,head*D+d]
+    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;      // over b*heads*tq
+    const long total = (long)gridDim.y * heads * tq;
+    (void)total;
+    const int b = blockIdx.y;
+    if (i >= (long)heads * tq) return;
+    const int head = i / tq, qi = i % tq;
+    const float* op = o + ((long)b * tq + qi) * o_ld + head * D;
+    const float* gp = dout + ((long)b * tq + qi) * dout_ld + head * D;
+    float s = 0.f;
+#pragma unroll
+    for (int d4 = 0; d4 < D / 4; ++d4) {
+        f32x4 a = *reinterpret_cast<const f32x4*>(op + d4 * 4), g = *reinterpret_cast<const f32x4*>(gp + d4 * 4);
+        s += a[0] * g[0] + a[1] * g[1] + a[2] * g[2] + a[3] * g[3];
+    }
+    dvec[((long)b * heads + head) * tq + qi] = s;
+}
+
+template <int D, int SWEEP>
+__global__ __launch_bounds__(256) void attention_bwd_kernel(
+    const float* __restrict__ q, int q_ld, int q_hs, const float* __restrict__ k, const float* __restrict__ v,
+    int kv_ld, int kv_hs, const float* __restrict__ dout, int dout_ld, const float* __restrict__ lse,
+    const float* __restrict__ dvec, int tq, int tk, float scale, float* __restrict__ dq, float* __restrict__ dk,
+    float* __restrict__ dv) {
+    constexpr int LD = D + 4;
+    constexpr int DT = (D + 31) / 32;
+    constexpr int TT = 64;                               // streamed rows per LDS tile
+    __shared__ __attribute__((aligned(16))) float Us[TT * LD];     // kv sweep: Q rows   | q sweep: K rows
+    __shared__ __attribute__((aligned(16))) float Ws[TT * LD];     // kv sweep: dO rows  | q sweep: V rows
+    __shared__ float Ls[TT], Ds[TT];                                // kv sweep: LSE / D of the streamed queries
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int head = blockIdx.y, b = blockIdx.z, heads = gridDim.y;
+    const int own_n = SWEEP == 0 ? tk : tq;              // rows on the owner side
+    const int str_n = SWEEP == 0 ? tq : tk;              // rows on the streamed side
+    const int oi = blockIdx.x * 128 + wave * 32 + li;    // this lane's owned row (key or query)
+    const int oc = oi < own_n ? oi : own_n - 1;
+
+    const float* qb = q + (long)b * tq * q_ld + head * q_hs;
+    const float* kb = k + (long)b * tk * kv_ld + head * kv_hs;
+    const float* vb = v + (long)b * tk * kv_ld + head * kv_hs;
+    const float* gb = dout + (long)b * tq * dout_ld + head * D;
+    const float* lseb = lse + ((long)b * heads + head) * tq;
+    const float* dvb = dvec + ((long)b * heads + head) * tq;
+
+    // owner fragments (MFMA B operands): X pairs with U (scores), Y pairs with W (dP)
+    f32x4 xf[D / 8], yf[D / 8];
+    {
+        const float* xp = SWEEP == 0 ? kb + (long)oc * kv_ld : qb + (long)oc * q_ld;
+        const float* yp = SWEEP == 0 ? vb + (long)oc * kv_ld : gb + (long)oc * dout_ld;
+#pragma unroll
+        for (int s = 0; s < D / 8; ++s) {
+            xf[s] = *reinterpret_cast<const f32x4*>(xp + s * 8 + lh * 4);
+            yf[s] = *reinterpret_cast<const f32x4*>(yp + s * 8 + lh * 4);
+        }
+    }
+    float own_lse = 0.f, own_d = 0.f;
+    if (SWEEP == 1) { own_lse = lseb[oc]; own_d = dvb[oc]; }
+
+    f32x16 accA[DT], accB[DT];        // kv: dK^T, dV^T   q: dQ^T (accB unused)
+#pragma unroll
+    for (int i = 0; i < DT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { accA[i][r] = 0.f; accB[i][r] = 0.f; }
+
+    for (int t0 = 0; t0 < str_n; t0 += TT) {
+        __syncthreads();
+        constexpr int VPR = D / 4;
+        for (int idx = tid; idx < TT * VPR; idx += 256) {
+            const int row = idx / VPR, c4 = idx % VPR;
+            f32x4 u = {0.f, 0.f, 0.f, 0.f}, w = {0.f, 0.f, 0.f, 0.f};
+            if (t0 + row < str_n) {
+                if (SWEEP == 0) {
+                    u = *reinterpret_cast<const f32x4*>(qb + (long)(t0 + row) * q_ld + c4 * 4);
+                    w = *reinterpret_cast<const f32x4*>(gb + (long)(t0 + row) * dout_ld + c4 * 4);
+                } else {
+                    u = *reinterpret_cast<const f32x4*>(kb + (long)(t0 + row) * kv_ld + c4 * 4);
+                    w = *reinterpret_cast<const f32x4*>(vb + (long)(t0 + row) * kv_ld + c4 * 4);
+                }
+            }
+            *reinterpret_cast<f32x4*>(Us + row * LD + c4 * 4) = u;
+            *reinterpret_cast<f32x4*>(Ws + row * LD + c4 * 4) = w;
+        }
+        if (SWEEP == 0 && tid < TT) {
+            const int r = t0 + tid;
+            Ls[tid] = r < str_n ? lseb[r] : 0.f;
+            Ds[tid] = r < str_n ? dvb[r] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int st = 0; st < TT / 32; ++st) {
+            if (t0 + st * 32 >= str_n) break;
+            // scores / dP tiles: rows = streamed rows (registers), cols = owned rows (lanes)
+            f32x16 sacc, pacc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; pacc[r] = 0.f; }
+#pragma unroll
+            for (int s = 0; s < D / 8; ++s) {
+                const f32x4 uf = *reinterpret_cast<const f32x4*>(Us + (st * 32 + li) * LD + s * 8 + lh * 4);
+                const f32x4 wf = *reinterpret_cast<const f32x4*>(Ws + (st * 32 + li) * LD + s * 8 + lh * 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(uf[j], xf[s][j], sacc, 0, 0, 0);
+                    pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[j], yf[s][j], pacc, 0, 0, 0);
+                }
+            }
+            // P and dS (in place: sacc <- P, pacc <- dS)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int srow = st * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;      // streamed row of this register
+                const bool ok = (t0 + srow < str_n) && (oi < own_n);
+                const float l = SWEEP == 0 ? Ls[srow] : own_lse;
+                const float dd = SWEEP == 0 ? Ds[srow] : own_d;
+                const float p = ok ? __expf(sacc[r] * scale - l) : 0.f;
+                sacc[r] = p;
+                pacc[r] = p * (pacc[r] - dd);
+            }
+            // gradient accumulation: contract the streamed rows
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int srow = st * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    float uf = 0.f, wf = 0.f;
+                    if (D >= 32 || li < D) {
+                        uf = Us[srow * LD + dt * 32 + li];
+                        if (SWEEP == 0) wf = Ws[srow * LD + dt * 32 + li];
+                    }
+                    accA[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(uf, pacc[r], accA[dt], 0, 0, 0);      // dK^T / dQ^T
+                    if (SWEEP == 0) accB[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf, sacc[r], accB[dt], 0, 0, 0);   // dV^T
+                }
+        }
+    }
+    if (oi < own_n) {
+        // acc rows = d (4 consecutive per register quad), cols = owned row (lane)
+        float* pa = SWEEP == 0 ? dk + ((long)b * tk + oi) * kv_ld + head * kv_hs : dq + ((long)b * tq + oi) * q_ld + head * q_hs;
+        float* pb = SWEEP == 0 ? dv + ((long)b * tk + oi) * kv_ld + head * kv_hs : nullptr;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const int dd = dt * 32 + gq * 8 + 4 * lh;
+                if (dd >= D) continue;
+                f32x4 va, vb2;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { va[j] = accA[dt][gq * 4 + j] * scale; vb2[j] = accB[dt][gq * 4 + j]; }
+                *reinterpret_cast<f32x4*>(pa + dd) = va;
+                if (SWEEP == 0) *reinterpret_cast<f32x4*>(pb + dd) = vb2;
+            }
+    }
+}
+
 }  // namespace
 
 extern "C" int sgd_attention(const float* q, int32_t q_ld, int32_t q_hs, const float* k, const float* v,
                              int32_t kv_ld, int32_t kv_hs, int32_t batch, int32_t heads, int32_t tq, int32_t tk,
-                             int32_t d, float scale, float* out, int32_t out_ld, void* stream) {
+                             int32_t d, float scale, float* out, int32_t out_ld, float* lse, void* stream) {
     SGD_CLEAR_ERR();
     if (!q || !k || !v || !out || batch <= 0 || heads <= 0 || tq <= 0 || tk <= 0) return SGD_ERR_ARG;
     if ((q_ld & 3) || (q_hs & 3) || (kv_ld & 3) || (kv_hs & 3)) return SGD_ERR_ARG;
@@ -143,10 +313,39 @@ extern "C" int sgd_attention(const float* q, int32_t q_ld, int32_t q_hs, const f
     dim3 grid((tq + 127) / 128, heads, batch);
     hipStream_t st = (hipStream_t)stream;
     switch (d) {
-        case 16: hipLaunchKernelGGL((attention_kernel<16>), grid, dim3(256), 0, st, q, q_ld, q_hs, k, v, kv_ld, kv_hs, tq, tk, scale, out, out_ld); break;
-        case 32: hipLaunchKernelGGL((attention_kernel<32>), grid, dim3(256), 0, st, q, q_ld, q_hs, k, v, kv_ld, kv_hs, tq, tk, scale, out, out_ld); break;
-        case 64: hipLaunchKernelGGL((attention_kernel<64>), grid, dim3(256), 0, st, q, q_ld, q_hs, k, v, kv_ld, kv_hs, tq, tk, scale, out, out_ld); break;
+        case 16: hipLaunchKernelGGL((attention_kernel<16>), grid, dim3(256), 0, st, q, q_ld, q_hs, k, v, kv_ld, kv_hs, tq, tk, scale, out, out_ld, lse); break;
+        case 32: hipLaunchKernelGGL((attention_kernel<32>), grid, dim3(256), 0, st, q, q_ld, q_hs, k, v, kv_ld, kv_hs, tq, tk, scale, out, out_ld, lse); break;
+        case 64: hipLaunchKernelGGL((attention_kernel<64>), grid, dim3(256), 0, st, q, q_ld, q_hs, k, v, kv_ld, kv_hs, tq, tk, scale, out, out_ld, lse); break;
         default: return SGD_ERR_ARG;
     }
+    return sgd_check_launch();
+}
+
+extern "C" int sgd_attention_bwd(const float* q, int32_t q_ld, int32_t q_hs, const float* k, const float* v,
+                                 int32_t kv_ld, int32_t kv_hs, const float* o, int32_t o_ld, const float* dout,
+                                 int32_t dout_ld, const float* lse, float* dvec, int32_t batch, int32_t heads,
+                                 int32_t tq, int32_t tk, int32_t d, float scale, float* dq, float* dk, float* dv,
+                                 void* stream) {
+    SGD_CLEAR_ERR();
+    if (!q || !k || !v || !o || !dout || !lse || !dvec || !dq || !dk || !dv || batch <= 0 || heads <= 0 || tq <= 0 ||
+        tk <= 0)
+        return SGD_ERR_ARG;
+    if ((q_ld & 3) || (q_hs & 3) || (kv_ld & 3) || (kv_hs & 3) || (o_ld & 3) || (dout_ld & 3)) return SGD_ERR_ARG;
+    if (kv_hs == 0 && heads > 1) return SGD_ERR_ARG;      // multi-query dK/dV need a sum over heads: not built yet
+    hipStream_t st = (hipStream_t)stream;
+    dim3 gp((heads * tq + 255) / 256, batch), gkv((tk + 127) / 128, heads, batch), gq((tq + 127) / 128, heads, batch);
+#define SGD_ATTN_BWD(DD)                                                                                              \
+    hipLaunchKernelGGL((attn_bwd_prep_kernel<DD>), gp, dim3(256), 0, st, o, o_ld, dout, dout_ld, heads, tq, dvec);      \
+    hipLaunchKernelGGL((attention_bwd_kernel<DD, 0>), gkv, dim3(256), 0, st, q, q_ld, q_hs, k, v, kv_ld, kv_hs, dout,   \
+                       dout_ld, lse, dvec, tq, tk, scale, dq, dk, dv);                                                 \
+    hipLaunchKernelGGL((attention_bwd_kernel<DD, 1>), gq, dim3(256), 0, st, q, q_ld, q_hs, k, v, kv_ld, kv_hs, dout,    \
+                       dout_ld, lse, dvec, tq, tk, scale, dq, dk, dv);
+    switch (d) {
+        case 16: SGD_ATTN_BWD(16) break;
+        case 32: SGD_ATTN_BWD(32) break;
+        case 64: SGD_ATTN_BWD(64) break;
+        default: return SGD_ERR_ARG;
+    }
+#undef SGD_ATTN_BWD
     return sgd_check_launch();
 }

@@ -1,0 +1,463 @@
+// Backward kernels of the training step (gfx950): weight gradients, GroupNorm/SiLU backward, bias
+// gradients, q_sample and the MSE loss.  Input gradients of convolutions / linears are the FORWARD
+// kernel (igemm.hip) run on adjoint-packed weights (sgd_pack_weight_dgrad).
+#include "sgdm_common.h"
+#include "../../include/sgdm_hip.h"
+#include "prologue.h"
+
+namespace {
+
+__device__ __forceinline__ float dsilu(float z) {
+    const float s = 1.0f / (1.0f + __expf(-z));
+    return s * (1.0f + z * (1.0f - s));
+}
+
+// =============================================================================================
+// weight gradient.  GEMM view: D[co, ci] = sum_k GY[k, co] * U[k(+tap), ci], k = output rows.
+// Block = 256 threads (4 waves 2x2, each 64 co x 64 ci) owns one (tap, co tile, ci tile, k slice);
+// K tiles of 64 rows are staged in LDS as [row][128 ch] (NHWC rows as they are: no transpose needed,
+// the f32 MFMA takes one scalar per lane and consecutive lanes read consecutive channels).
+// =============================================================================================
+constexpr int WK = 64;          // rows per K tile
+constexpr int WT = 128;         // co / ci tile
+constexpr int WLD = WT + 4;
+
+struct WArgs {
+    sgd_igemm_args a;           // forward descriptor (input side)
+    const float* gy;
+    int gy_ld, cout, ksplit, taps, rows, co_tiles, ci_tiles, ktiles, hc, wc;
+    float* slabs;
+};
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void wgrad_kernel(const WArgs w) {
+    const sgd_igemm_args& a = w.a;
+    __shared__ __attribute__((aligned(16))) float Gs[WK * WLD];
+    __shared__ __attribute__((aligned(16))) float Us[WK * WLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    int bid = blockIdx.x;
+    const int ks = bid % w.ksplit; bid /= w.ksplit;
+    const int cit = bid % w.ci_tiles; bid /= w.ci_tiles;
+    const int cot = bid % w.co_tiles; bid /= w.co_tiles;
+    const int tap = bid;
+    const int co0 = cot * WT, ci0 = cit * WT;
+    const int cin = a.c0 + a.c1;
+    const bool conv = a.mode == SGD_MODE_CONV3;
+    const int dy = conv ? tap / 3 - 1 : 0, dx = conv ? tap % 3 - 1 : 0;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // this block's K tiles: ks, ks + ksplit, ...
+    for (int kt = ks; kt < w.ktiles; kt += w.ksplit) {
+        const int row0 = kt * WK;
+        __syncthreads();
+        // ---- stage GY tile [64 rows][128 co] and the activated input tile [64 rows (shifted)][128 ci]
+        for (int idx = tid; idx < WK * (WT / 4); idx += 256) {
+            const int r = idx >> 5, q = idx & 31;
+            const int row = row0 + r;
+            f32x4 gv = {0.f, 0.f, 0.f, 0.f}, uv = {0.f, 0.f, 0.f, 0.f};
+            if (row < w.rows) {
+                const int co = co0 + q * 4;
+                if (co + 3 < w.cout) gv = ld4(w.gy + (long)row * w.gy_ld + co);
+                else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) if (co + j < w.cout) gv[j] = w.gy[(long)row * w.gy_ld + co + j];
+                }
+                const int c = ci0 + q * 4;
+                if (c < cin) {
+                    if (conv) {
+                        // output pixel (n, oy, ox) -> conv-input pixel (oy*s + dy, ox*s + dx)
+                        const int ox = row % a.wo, t = row / a.wo;
+                        const int oy = t % a.ho, n = t / a.ho;
+                        const int y = oy * a.stride + dy, x = ox * a.stride + dx;
+                        if (y >= 0 && y < w.hc && x >= 0 && x < w.wc) {
+                            if (a.resample == SGD_RS_AVGPOOL2) {
+#pragma unroll
+                                for (int sy = 0; sy < 2; ++sy)
+#pragma unroll
+                                    for (int sx = 0; sx < 2; ++sx) {
+                                        long rr = ((long)n * a.hi + 2 * y + sy) * a.wi + 2 * x + sx;
+                                        uv += apply_pro(a, load_raw<VEC>(a, rr, c), load_coef<VEC>(a, n, rr, c), c);
+                                    }
+                                uv = uv * 0.25f;
+                            } else {
+                                long rr = a.resample == SGD_RS_UP2 ? ((long)n * a.hi + (y >> 1)) * a.wi + (x >> 1)
+                                                                   : ((long)n * a.hi + y) * a.wi + x;
+                                uv = apply_pro(a, load_raw<VEC>(a, rr, c), load_coef<VEC>(a, n, rr, c), c);
+                            }
+                        }
+                    } else {
+                        const int n = a.pro == SGD_PRO_AFFINE_NC ? row / a.rows_per_n : 0;
+                        uv = apply_pro(a, load_raw<VEC>(a, row, c), load_coef<VEC>(a, n, row, c), c);
+                    }
+                }
+            }
+            *reinterpret_cast<f32x4*>(Gs + r * WLD + q * 4) = gv;
+            *reinterpret_cast<f32x4*>(Us + r * WLD + q * 4) = uv;
+        }
+        __syncthreads();
+        // ---- 32 k-pairs: A[i = co][k] = Gs[k][co], B[k][j = ci] = Us[k][ci]
+#pragma unroll 4
+        for (int s = 0; s < WK / 2; ++s) {
+            const float* gp = Gs + (2 * s + lh) * WLD + wm * 64 + li;
+            const float* up = Us + (2 * s + lh) * WLD + wn * 64 + li;
+            const float a0 = gp[0], a1 = gp[32], b0 = up[0], b1 = up[32];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+    }
+    // ---- slab store: D rows = co (registers), cols = ci (lanes)
+    float* slab = w.slabs + ((long)ks * w.taps + tap) * w.cout * cin;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int ci = ci0 + wn * 64 + nt * 32 + li;
+            if (ci >= cin) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (co < w.cout) slab[(long)co * cin + ci] = acc[mt][nt][r];
+            }
+        }
+}
+
+__global__ void wgrad_reduce_kernel(const float* __restrict__ slabs, int ksplit, int taps, int cout, int cin,
+                                    float* __restrict__ dw, int accumulate) {
+    const long per = (long)taps * cout * cin;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < per; i += (long)gridDim.x * blockDim.x) {
+        // i indexes [tap][co][ci]
+        const int ci = i % cin;
+        const long t = i / cin;
+        const int co = t % cout, tap = t / cout;
+        float s = 0.f;
+        for (int k = 0; k < ksplit; ++k) s += slabs[k * per + i];
+        const long o = ((long)co * cin + ci) * taps + tap;
+        dw[o] = accumulate ? dw[o] + s : s;
+    }
+}
+
+// column sums: block per 32-column slab, 8 quads x 32 row lanes (like chan_stats)
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ g, int rows, int c, int ld,
+                                                     float* __restrict__ out, int accumulate) {
+    const int col = blockIdx.x * 32 + (threadIdx.x & 31), rl = threadIdx.x >> 5;     // 8 row lanes
+    float s = 0.f;
+    if (col < c)
+        for (int r = rl; r < rows; r += 8) s += g[(long)r * ld + col];
+    __shared__ float red[8][32];
+    red[rl][threadIdx.x & 31] = s;
+    __syncthreads();
+    if (threadIdx.x < 32 && col < c) {
+        double t = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += red[k][threadIdx.x];
+        out[col] = accumulate ? out[col] + (float)t : (float)t;
+    }
+}
+
+// =============================================================================================
+// GroupNorm(+FiLM)+SiLU backward
+// =============================================================================================
+// gradient arriving at the activated tensor for x-pixel (n, y, x), channels cq..cq+3 of the gu tensor
+__device__ __forceinline__ f32x4 fetch_g(const float* g, int ld, int mode, int n, int y, int x, int h, int w, int cq) {
+    if (mode == SGD_RS_NONE) return ld4(g + (((long)n * h + y) * w + x) * ld + cq);
+    if (mode == SGD_RS_AVGPOOL2)       // forward pooled 2x2: each input pixel gets a quarter of the pooled gradient
+        return 0.25f * ld4(g + (((long)n * (h >> 1) + (y >> 1)) * (w >> 1) + (x >> 1)) * ld + cq);
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};    // forward upsampled x2: sum over the 2x2 block that copied this pixel
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) s += ld4(g + (((long)n * 2 * h + 2 * y + dy) * (2 * w) + 2 * x + dx) * ld + cq);
+    return s;
+}
+
+// block per (n, 32-channel slab): 8 channel quads x 32 row lanes
+__global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const float* __restrict__ x, int h, int w, int c,
+                                                            int c_total, int c_off, const float* __restrict__ a,
+                                                            const float* __restrict__ b, int silu,
+                                                            const float* __restrict__ gu, int gu_ld, int gu_mode,
+                                                            float* __restrict__ S) {
+    const int slabs = (c + 31) / 32;
+    const int n = blockIdx.x / slabs, slab = blockIdx.x % slabs;
+    const int q = threadIdx.x & 7, rl = threadIdx.x >> 3;
+    const int ch = slab * 32 + q * 4;
+    const int hw = h * w;
+    float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+    if (ch < c) {
+        const f32x4 av = ld4(a + (long)n * c_total + c_off + ch), bv = ld4(b + (long)n * c_total + c_off + ch);
+        for (int p = rl; p < hw; p += 32) {
+            const f32x4 xv = ld4(x + ((long)n * hw + p) * c + ch);
+            f32x4 gv = fetch_g(gu, gu_ld, gu_mode, n, p / w, p % w, h, w, c_off + ch);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float gp = gv[j];
+                if (silu) gp *= dsilu(av[j] * xv[j] + bv[j]);
+                s1[j] += gp;
+                s2[j] += gp * xv[j];
+            }
+        }
+    }
+    __shared__ double red[32][8][8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { red[rl][q][j] = s1[j]; red[rl][q][4 + j] = s2[j]; }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int qq = threadIdx.x >> 3, jj = threadIdx.x & 7;
+        double t = 0;
+        for (int r = 0; r < 32; ++r) t += red[r][qq][jj];
+        const int cc = slab * 32 + qq * 4 + (jj & 3);
+        if (cc < c) S[((long)n * c_total + c_off + cc) * 2 + (jj >> 2)] = (float)t;
+    }
+}
+
+__global__ void gn_bwd_coef_kernel(const float* __restrict__ S, const float* __restrict__ sums,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   const float* __restrict__ film, int film_ld, int n, int c, int groups, int hw,
+                                   float eps, float* __restrict__ A, float* __restrict__ B, float* __restrict__ Cc,
+                                   float* __restrict__ dg_nc, float* __restrict__ db_nc, float* __restrict__ dfilm) {
+    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (i >= (long)n * c) return;
+    const int nn = i / c, cc = i % c;
+    const int cpg = c / groups, g0 = (cc / cpg) * cpg;
+    double s = 0, ss = 0;
+    for (int k = 0; k < cpg; ++k) {
+        s += sums[((long)nn * c + g0 + k) * 2];
+        ss += sums[((long)nn * c + g0 + k) * 2 + 1];
+    }
+    const double m = (double)cpg * hw;
+    const double mean = s / m;
+    double var = ss / m - mean * mean;
+    if (var < 0) var = 0;
+    const double r = 1.0 / sqrt(var + (double)eps);
+    // group means of dxhat and dxhat*xhat
+    double m1 = 0, m2 = 0;
+    for (int k = 0; k < cpg; ++k) {
+        const long j = (long)nn * c + g0 + k;
+        const double sc = film ? 1.0 + film[(long)nn * film_ld + g0 + k] : 1.0;
+        const double gp = gamma[g0 + k] * sc;
+        const double S1 = S[j * 2], X = r * (S[j * 2 + 1] - mean * S1);
+        m1 += gp * S1;
+        m2 += gp * X;
+    }
+    m1 /= m;
+    m2 /= m;
+    const double sc = film ? 1.0 + film[(long)nn * film_ld + cc] : 1.0;
+    const double S1 = S[i * 2], X = r * (S[i * 2 + 1] - mean * S1);
+    A[i] = (float)(r * gamma[cc] * sc);
+    B[i] = (float)(-r * r * m2);
+    Cc[i] = (float)(r * r * m2 * mean - r * m1);
+    dg_nc[i] = (float)(X * sc);
+    db_nc[i] = (float)(S1 * sc);
+    if (dfilm) {
+        dfilm[(long)nn * film_ld + cc] = (float)(X * gamma[cc] + S1 * beta[cc]);      // d/d scale
+        dfilm[(long)nn * film_ld + c + cc] = (float)S1;                               // d/d shift
+    }
+}
+
+__global__ void gn_bwd_apply_kernel(const float* __restrict__ x, int n, int h, int w, int c, int c_total, int c_off,
+                                    const float* __restrict__ a, const float* __restrict__ b, int silu,
+                                    const float* __restrict__ gu, int gu_ld, int gu_mode,
+                                    const float* __restrict__ A, const float* __restrict__ B,
+                                    const float* __restrict__ Cc, const float* __restrict__ gres, int gres_ld,
+                                    int gres_mode, float* __restrict__ dst, int dst_ld, int dst_off, int accumulate) {
+    const int cq = c >> 2;
+    const long total = (long)n * h * w * cq;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int ch = (int)(i % cq) * 4;
+        const long row = i / cq;
+        const int p = row % (h * w), nn = row / (h * w);
+        const int y = p / w, xx = p % w;
+        const long ci = (long)nn * c_total + c_off + ch;
+        const f32x4 xv = ld4(x + row * c + ch);
+        f32x4 gv = fetch_g(gu, gu_ld, gu_mode, nn, y, xx, h, w, c_off + ch);
+        if (silu) {
+            const f32x4 av = ld4(a + ci), bv = ld4(b + ci);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) gv[j] *= dsilu(av[j] * xv[j] + bv[j]);
+        }
+        f32x4 o = ld4(A + ci) * gv + ld4(B + ci) * xv + ld4(Cc + ci);
+        if (gres) o += fetch_g(gres, gres_ld, gres_mode, nn, y, xx, h, w, c_off + ch);
+        float* dp = dst + row * dst_ld + dst_off + ch;
+        if (accumulate) o += ld4(dp);
+        *reinterpret_cast<f32x4*>(dp) = o;
+    }
+}
+
+__global__ void silu_bwd_kernel(const float* __restrict__ x, const float* __restrict__ g, long count,
+                                float* __restrict__ gx) {
+    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (i < count) gx[i] = g[i] * dsilu(x[i]);
+}
+
+__global__ void q_sample_kernel(const float* __restrict__ x0, const float* __restrict__ noise,
+                                const int64_t* __restrict__ t, const float* __restrict__ sa,
+                                const float* __restrict__ s1, int b, long chw, float* __restrict__ out) {
+    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (i >= (long)b * chw) return;
+    const int n = i / chw;
+    const int64_t tt = t[n];
+    out[i] = sa[tt] * x0[i] + s1[tt] * noise[i];              // ddpm_sampler.py:116-119
+}
+
+// one block per sample: per-sample mean of squared error + gradient wrt eps (NHWC)
+__global__ __launch_bounds__(256) void mse_loss_kernel(const float* __restrict__ eps, const float* __restrict__ noise,
+                                                       int b, int c, int hw, float* __restrict__ per_sample,
+                                                       float* __restrict__ geps) {
+    const int n = blockIdx.x;
+    const int chw = c * hw;
+    const float gscale = -2.0f / ((float)chw * (float)b);     // d mean_b(mean_chw((noise-eps)^2)) / d eps
+    double s = 0;
+    for (int i = threadIdx.x; i < chw; i += 256) {
+        const int p = i / c, cc = i % c;                      // NHWC walk
+        const float d = noise[((long)n * c + cc) * hw + p] - eps[(long)n * chw + i];
+        s += (double)d * d;
+        if (geps) geps[(long)n * chw + i] = gscale * d;
+    }
+    s = wave_sum_d(s);
+    __shared__ double red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) per_sample[n] = (float)((red[0] + red[1] + red[2] + red[3]) / chw);
+}
+
+inline unsigned nblk(long total, int cap = 1 << 20) {
+    long b = (total + 255) / 256;
+    return (unsigned)(b > cap ? cap : b);
+}
+
+}  // namespace
+
+extern "C" int sgd_wgrad(const sgd_igemm_args* fwd, const float* gy, int32_t gy_ld, int32_t cout, float* slabs,
+                         int32_t ksplit, void* stream) {
+    SGD_CLEAR_ERR();
+    if (!fwd || !gy || !slabs || cout <= 0 || ksplit <= 0 || gy_ld < cout) return SGD_ERR_ARG;
+    WArgs w;
+    w.a = *fwd;
+    const sgd_igemm_args& a = w.a;
+    if (!a.x0 || a.c0 <= 0 || a.c1 < 0 || (a.c1 > 0 && !a.x1)) return SGD_ERR_ARG;
+    if (a.pro != SGD_PRO_NONE && (!a.pa || !a.pb)) return SGD_ERR_ARG;
+    const int cin = a.c0 + a.c1;
+    if (a.mode == SGD_MODE_CONV3) {
+        if (a.stride != 1 && a.stride != 2) return SGD_ERR_ARG;
+        w.hc = a.resample == SGD_RS_AVGPOOL2 ? a.hi / 2 : (a.resample == SGD_RS_UP2 ? a.hi * 2 : a.hi);
+        w.wc = a.resample == SGD_RS_AVGPOOL2 ? a.wi / 2 : (a.resample == SGD_RS_UP2 ? a.wi * 2 : a.wi);
+        w.taps = 9;
+        w.rows = a.n * a.ho * a.wo;
+    } else if (a.mode == SGD_MODE_FLAT) {
+        w.hc = w.wc = 1;
+        w.taps = 1;
+        w.rows = a.m;
+    } else {
+        return SGD_ERR_ARG;
+    }
+    if (w.rows <= 0) return SGD_ERR_ARG;
+    w.gy = gy; w.gy_ld = gy_ld; w.cout = cout; w.slabs = slabs;
+    w.co_tiles = (cout + WT - 1) / WT;
+    w.ci_tiles = (cin + WT - 1) / WT;
+    w.ktiles = (w.rows + WK - 1) / WK;
+    w.ksplit = ksplit > w.ktiles ? w.ktiles : ksplit;
+    if (w.ksplit != ksplit) return SGD_ERR_ARG;          // caller sizes the slabs: must agree
+    const bool vec = (a.c0 % 4 == 0) && (a.c1 % 4 == 0);
+    const long grid = (long)w.taps * w.co_tiles * w.ci_tiles * w.ksplit;
+    if (grid > 0x7fffffffL) return SGD_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (vec) hipLaunchKernelGGL((wgrad_kernel<true>), dim3((unsigned)grid), dim3(256), 0, st, w);
+    else hipLaunchKernelGGL((wgrad_kernel<false>), dim3((unsigned)grid), dim3(256), 0, st, w);
+    return sgd_check_launch();
+}
+
+extern "C" int sgd_wgrad_reduce(const float* slabs, int32_t ksplit, int32_t taps, int32_t cout, int32_t cin,
+                                float* dw, int32_t accumulate, void* stream) {
+    SGD_CLEAR_ERR();
+    if (!slabs || !dw || ksplit <= 0 || taps <= 0 || cout <= 0 || cin <= 0) return SGD_ERR_ARG;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nblk((long)taps * cout * cin, 8192)), dim3(256), 0,
+                       (hipStream_t)stream, slabs, ksplit, taps, cout, cin, dw, accumulate);
+    return sgd_check_launch();
+}
+
+extern "C" int sgd_colsum(const float* g, int32_t rows, int32_t c, int32_t ld, float* out, int32_t accumulate,
+                          void* stream) {
+    SGD_CLEAR_ERR();
+    if (!g || !out || rows <= 0 || c <= 0 || ld < c) return SGD_ERR_ARG;
+    hipLaunchKernelGGL(colsum_kernel, dim3((c + 31) / 32), dim3(256), 0, (hipStream_t)stream, g, rows, c, ld, out,
+                       accumulate);
+    return sgd_check_launch();
+}
+
+extern "C" int sgd_gn_bwd_reduce(const float* x, int32_t n, int32_t h, int32_t w, int32_t c, int32_t c_total,
+                                 int32_t c_off, const float* a, const float* b, int32_t silu, const float* gu,
+                                 int32_t gu_ld, int32_t gu_mode, float* S, void* stream) {
+    SGD_CLEAR_ERR();
+    if (!x || !a || !b || !gu || !S || n <= 0 || h <= 0 || w <= 0 || c <= 0 || (c & 3) || (c_off & 3) ||
+        c_off + c > c_total || (gu_ld & 3))
+        return SGD_ERR_ARG;
+    if (gu_mode == SGD_RS_AVGPOOL2 && ((h | w) & 1)) return SGD_ERR_ARG;
+    hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(n * ((c + 31) / 32)), dim3(256), 0, (hipStream_t)stream, x, h, w, c,
+                       c_total, c_off, a, b, silu, gu, gu_ld, gu_mode, S);
+    return sgd_check_launch();
+}
+
+extern "C" int sgd_gn_bwd_coef(const float* S, const float* sums, const float* gamma, const float* beta,
+                               const float* film, int32_t film_ld, int32_t n, int32_t c, int32_t groups, int32_t hw,
+                               float eps, float* A, float* B, float* Cc, float* dgamma_nc, float* dbeta_nc,
+                               float* dfilm, void* stream) {
+    SGD_CLEAR_ERR();
+    if (!S || !sums || !gamma || !beta || !A || !B || !Cc || !dgamma_nc || !dbeta_nc || n <= 0 || c <= 0 ||
+        groups <= 0 || c % groups || hw <= 0)
+        return SGD_ERR_ARG;
+    if ((film || dfilm) && film_ld < 2 * c) return SGD_ERR_ARG;
+    hipLaunchKernelGGL(gn_bwd_coef_kernel, dim3(nblk((long)n * c)), dim3(256), 0, (hipStream_t)stream, S, sums, gamma,
+                       beta, film, film_ld, n, c, groups, hw, eps, A, B, Cc, dgamma_nc, dbeta_nc, dfilm);
+    return sgd_check_launch();
+}
+
+extern "C" int sgd_gn_bwd_apply(const float* x, int32_t n, int32_t h, int32_t w, int32_t c, int32_t c_total,
+                                int32_t c_off, const float* a, const float* b, int32_t silu, const float* gu,
+                                int32_t gu_ld, int32_t gu_mode, const float* A, const float* B, const float* Cc,
+                                const float* gres, int32_t gres_ld, int32_t gres_mode, float* dst, int32_t dst_ld,
+                                int32_t dst_off, int32_t accumulate, void* stream) {
+    SGD_CLEAR_ERR();
+    if (!x || !a || !b || !gu || !A || !B || !Cc || !dst || n <= 0 || h <= 0 || w <= 0 || c <= 0 || (c & 3) ||
+        (c_off & 3) || c_off + c > c_total || (gu_ld & 3) || (dst_ld & 3) || (dst_off & 3) || (gres && (gres_ld & 3)))
+        return SGD_ERR_ARG;
+    hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(nblk((long)n * h * w * (c / 4), 65536)), dim3(256), 0,
+                       (hipStream_t)stream, x, n, h, w, c, c_total, c_off, a, b, silu, gu, gu_ld, gu_mode, A, B, Cc,
+                       gres, gres_ld, gres_mode, dst, dst_ld, dst_off, accumulate);
+    return sgd_check_launch();
+}
+
+extern "C" int sgd_silu_bwd(const float* x, const float* g, int64_t count, float* gx, void* stream) {
+    SGD_CLEAR_ERR();
+    if (!x || !g || !gx || count <= 0) return SGD_ERR_ARG;
+    hipLaunchKernelGGL(silu_bwd_kernel, dim3(nblk(count)), dim3(256), 0, (hipStream_t)stream, x, g, (long)count, gx);
+    return sgd_check_launch();
+}
+
+extern "C" int sgd_q_sample(const float* x0, const float* noise, const int64_t* t, const float* sqrt_ac,
+                            const float* sqrt_1mac, int32_t b, int64_t chw, float* out, void* stream) {
+    SGD_CLEAR_ERR();
+    if (!x0 || !noise || !t || !sqrt_ac || !sqrt_1mac || !out || b <= 0 || chw <= 0) return SGD_ERR_ARG;
+    hipLaunchKernelGGL(q_sample_kernel, dim3(nblk((long)b * chw)), dim3(256), 0, (hipStream_t)stream, x0, noise, t,
+                       sqrt_ac, sqrt_1mac, b, (long)chw, out);
+    return sgd_check_launch();
+}
+
+extern "C" int sgd_mse_loss(const float* eps_nhwc, const float* noise_nchw, int32_t b, int32_t c, int32_t hw,
+                            float* per_sample, float* geps_nhwc, void* stream) {
+    SGD_CLEAR_ERR();
+    if (!eps_nhwc || !noise_nchw || !per_sample || b <= 0 || c <= 0 || hw <= 0) return SGD_ERR_ARG;
+    hipLaunchKernelGGL(mse_loss_kernel, dim3(b), dim3(256), 0, (hipStream_t)stream, eps_nhwc, noise_nchw, b, c, hw,
+                       per_sample, geps_nhwc);
+    return sgd_check_launch();
+}

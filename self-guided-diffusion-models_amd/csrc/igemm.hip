@@ -26,6 +26,7 @@
 
 #include "sgdm_common.h"
 #include "../../include/sgdm_hip.h"
+#include "prologue.h"
 
 namespace {
 
@@ -54,79 +55,6 @@ struct KArgs {
     sgd_igemm_args a;
     Geo g;
 };
-
-__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
-
-// raw input vector: 4 consecutive channels starting at c of source row `row` (virtual concat x0|x1)
-template <bool VEC>
-__device__ __forceinline__ f32x4 load_raw(const sgd_igemm_args& a, long row, int c) {
-    f32x4 v;
-    if (VEC) {
-        if (c < a.c0) v = ld4(a.x0 + row * a.c0 + c);
-        else v = ld4(a.x1 + row * a.c1 + (c - a.c0));
-    } else {
-        const int ct = a.c0 + a.c1;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            int cc = c + j;
-            float s = 0.f;
-            if (cc < ct) s = (cc < a.c0) ? a.x0[row * a.c0 + cc] : a.x1[row * a.c1 + (cc - a.c0)];
-            v[j] = s;
-        }
-    }
-    return v;
-}
-
-// prologue coefficients of one item
-struct Coef {
-    f32x4 p, q;       // AFFINE_NC: a, b       LN_ROW: p[0] = mean, p[1] = rstd
-};
-
-template <bool VEC>
-__device__ __forceinline__ Coef load_coef(const sgd_igemm_args& a, int n, long row, int c) {
-    Coef k;
-    k.p = f32x4{0.f, 0.f, 0.f, 0.f};
-    k.q = k.p;
-    const int ct = a.c0 + a.c1;
-    if (a.pro == SGD_PRO_AFFINE_NC) {
-        if (VEC) {
-            k.p = ld4(a.pa + (long)n * ct + c);
-            k.q = ld4(a.pb + (long)n * ct + c);
-        } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                bool ok = c + j < ct;
-                k.p[j] = ok ? a.pa[(long)n * ct + c + j] : 0.f;
-                k.q[j] = ok ? a.pb[(long)n * ct + c + j] : 0.f;
-            }
-        }
-    } else if (a.pro == SGD_PRO_LN_ROW) {
-        k.p[0] = a.pa[row * 2];
-        k.p[1] = a.pa[row * 2 + 1];
-    }
-    return k;
-}
-
-__device__ __forceinline__ f32x4 apply_pro(const sgd_igemm_args& a, f32x4 v, const Coef& k, int c) {
-    if (a.pro == SGD_PRO_AFFINE_NC) {
-        v = v * k.p + k.q;
-    } else if (a.pro == SGD_PRO_LN_ROW) {
-        const int ct = a.c0 + a.c1;
-        f32x4 g, b;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            bool ok = c + j < ct;
-            g[j] = ok ? a.pb[c + j] : 0.f;
-            b[j] = (ok && a.pc) ? a.pc[c + j] : 0.f;
-        }
-        v = (v - k.p[0]) * k.p[1] * g + b;
-    }
-    if (a.pro_silu) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = sgd_silu(v[j]);
-    }
-    return v;
-}
 
 // ---------------------------------------------------------------------------------------------
 // LDS element packing per precision
@@ -732,7 +660,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
 // ---------------------------------------------------------------------------------------------
 template <int PREC>
 __global__ void pack_weight_kernel(const float* __restrict__ src, float* __restrict__ dst, int cout, int cin,
-                                   int ks, int cout_p, int cin_p) {
+                                   int ks, int cout_p, int cin_p, int transpose) {
     const long total = (long)ks * ks * cout_p * cin_p;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         int ci = i % cin_p;
@@ -740,7 +668,12 @@ __global__ void pack_weight_kernel(const float* __restrict__ src, float* __restr
         int co = t % cout_p;
         int tap = t / cout_p;
         float v = 0.f;
-        if (ci < cin && co < cout) v = src[((long)co * cin + ci) * ks * ks + tap];
+        if (ci < cin && co < cout) {
+            // forward: dst[tap][co][ci] = W[co][ci][tap].  dgrad (adjoint conv): the packed "output" index co
+            // walks W's input channels, "input" index ci walks W's output channels, taps are flipped.
+            if (!transpose) v = src[((long)co * cin + ci) * ks * ks + tap];
+            else v = src[((long)ci * cout + co) * ks * ks + (ks * ks - 1 - tap)];
+        }
         if constexpr (PREC == SGD_PREC_F32) {
             dst[i] = v;
         } else {
@@ -794,8 +727,8 @@ extern "C" int64_t sgd_packed_weight_bytes(int32_t cout, int32_t cin, int32_t ks
     return (int64_t)ksize * ksize * cout_p * cin_p * 4;
 }
 
-extern "C" int sgd_pack_weight(const float* w_src, void* w_dst, int32_t cout, int32_t cin, int32_t ksize,
-                               int32_t prec, int32_t* cin_p_out, int32_t* cout_p_out, void* stream) {
+static int pack_weight_impl(const float* w_src, void* w_dst, int32_t cout, int32_t cin, int32_t ksize, int32_t prec,
+                            int32_t* cin_p_out, int32_t* cout_p_out, int transpose, void* stream) {
     SGD_CLEAR_ERR();
     if (!w_src || !w_dst || cout <= 0 || cin <= 0 || (ksize != 1 && ksize != 3)) return SGD_ERR_ARG;
     const int bn = pick_bn(cout);
@@ -808,11 +741,23 @@ extern "C" int sgd_pack_weight(const float* w_src, void* w_dst, int32_t cout, in
     if (grid > 4096) grid = 4096;
     hipStream_t st = (hipStream_t)stream;
     float* dst = reinterpret_cast<float*>(w_dst);
-    if (prec == SGD_PREC_F32) hipLaunchKernelGGL((pack_weight_kernel<SGD_PREC_F32>), dim3(grid), dim3(256), 0, st, w_src, dst, cout, cin, ksize, cout_p, cin_p);
-    else if (prec == SGD_PREC_F16X3) hipLaunchKernelGGL((pack_weight_kernel<SGD_PREC_F16X3>), dim3(grid), dim3(256), 0, st, w_src, dst, cout, cin, ksize, cout_p, cin_p);
-    else if (prec == SGD_PREC_BF16X3) hipLaunchKernelGGL((pack_weight_kernel<SGD_PREC_BF16X3>), dim3(grid), dim3(256), 0, st, w_src, dst, cout, cin, ksize, cout_p, cin_p);
+    if (prec == SGD_PREC_F32) hipLaunchKernelGGL((pack_weight_kernel<SGD_PREC_F32>), dim3(grid), dim3(256), 0, st, w_src, dst, cout, cin, ksize, cout_p, cin_p, transpose);
+    else if (prec == SGD_PREC_F16X3) hipLaunchKernelGGL((pack_weight_kernel<SGD_PREC_F16X3>), dim3(grid), dim3(256), 0, st, w_src, dst, cout, cin, ksize, cout_p, cin_p, transpose);
+    else if (prec == SGD_PREC_BF16X3) hipLaunchKernelGGL((pack_weight_kernel<SGD_PREC_BF16X3>), dim3(grid), dim3(256), 0, st, w_src, dst, cout, cin, ksize, cout_p, cin_p, transpose);
     else return SGD_ERR_ARG;
     return sgd_check_launch();
+}
+
+extern "C" int sgd_pack_weight(const float* w_src, void* w_dst, int32_t cout, int32_t cin, int32_t ksize,
+                               int32_t prec, int32_t* cin_p_out, int32_t* cout_p_out, void* stream) {
+    return pack_weight_impl(w_src, w_dst, cout, cin, ksize, prec, cin_p_out, cout_p_out, 0, stream);
+}
+
+// weights of the adjoint convolution (dgrad): w_src is the FORWARD weight [cout_fwd, cin_fwd, k, k]; the packed
+// operator maps cout_fwd input channels to cin_fwd output channels with flipped taps.
+extern "C" int sgd_pack_weight_dgrad(const float* w_src, void* w_dst, int32_t cout_fwd, int32_t cin_fwd, int32_t ksize,
+                                     int32_t prec, int32_t* cin_p_out, int32_t* cout_p_out, void* stream) {
+    return pack_weight_impl(w_src, w_dst, cin_fwd, cout_fwd, ksize, prec, cin_p_out, cout_p_out, 1, stream);
 }
 
 extern "C" int sgd_igemm(const sgd_igemm_args* args, void* stream) {

@@ -1,0 +1,79 @@
+// Loader-side helpers shared by the forward implicit-GEMM kernel and the weight-gradient kernel:
+// raw input fetch over a virtual channel concat and the fused prologue (GroupNorm apply / LayerNorm, SiLU).
+#pragma once
+#include "sgdm_common.h"
+#include "../../include/sgdm_hip.h"
+
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+
+// raw input vector: 4 consecutive channels starting at c of source row `row` (virtual concat x0|x1)
+template <bool VEC>
+__device__ __forceinline__ f32x4 load_raw(const sgd_igemm_args& a, long row, int c) {
+    f32x4 v;
+    if (VEC) {
+        if (c < a.c0) v = ld4(a.x0 + row * a.c0 + c);
+        else v = ld4(a.x1 + row * a.c1 + (c - a.c0));
+    } else {
+        const int ct = a.c0 + a.c1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int cc = c + j;
+            float s = 0.f;
+            if (cc < ct) s = (cc < a.c0) ? a.x0[row * a.c0 + cc] : a.x1[row * a.c1 + (cc - a.c0)];
+            v[j] = s;
+        }
+    }
+    return v;
+}
+
+// prologue coefficients of one item
+struct Coef {
+    f32x4 p, q;       // AFFINE_NC: a, b       LN_ROW: p[0] = mean, p[1] = rstd
+};
+
+template <bool VEC>
+__device__ __forceinline__ Coef load_coef(const sgd_igemm_args& a, int n, long row, int c) {
+    Coef k;
+    k.p = f32x4{0.f, 0.f, 0.f, 0.f};
+    k.q = k.p;
+    const int ct = a.c0 + a.c1;
+    if (a.pro == SGD_PRO_AFFINE_NC) {
+        if (VEC) {
+            k.p = ld4(a.pa + (long)n * ct + c);
+            k.q = ld4(a.pb + (long)n * ct + c);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                bool ok = c + j < ct;
+                k.p[j] = ok ? a.pa[(long)n * ct + c + j] : 0.f;
+                k.q[j] = ok ? a.pb[(long)n * ct + c + j] : 0.f;
+            }
+        }
+    } else if (a.pro == SGD_PRO_LN_ROW) {
+        k.p[0] = a.pa[row * 2];
+        k.p[1] = a.pa[row * 2 + 1];
+    }
+    return k;
+}
+
+__device__ __forceinline__ f32x4 apply_pro(const sgd_igemm_args& a, f32x4 v, const Coef& k, int c) {
+    if (a.pro == SGD_PRO_AFFINE_NC) {
+        v = v * k.p + k.q;
+    } else if (a.pro == SGD_PRO_LN_ROW) {
+        const int ct = a.c0 + a.c1;
+        f32x4 g, b;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            bool ok = c + j < ct;
+            g[j] = ok ? a.pb[c + j] : 0.f;
+            b[j] = (ok && a.pc) ? a.pc[c + j] : 0.f;
+        }
+        v = (v - k.p[0]) * k.p[1] * g + b;
+    }
+    if (a.pro_silu) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = sgd_silu(v[j]);
+    }
+    return v;
+}
+

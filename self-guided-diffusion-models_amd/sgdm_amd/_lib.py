@@ -47,7 +47,20 @@ SIGNATURES = {
     "sgd_gn_coef": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, vp, vp, vp]),
     "sgd_ln_stats": (i32, [vp, i32, i32, f32, vp, vp]),
     "sgd_ln_apply": (i32, [vp, vp, vp, vp, i32, i32, f32, vp, vp]),
-    "sgd_attention": (i32, [vp, i32, i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, vp, i32, vp]),
+    "sgd_attention": (i32, [vp, i32, i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, vp, i32, vp, vp]),
+    "sgd_attention_bwd": (i32, [vp, i32, i32, vp, vp, i32, i32, vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, i32, f32,
+                              vp, vp, vp, vp]),
+    "sgd_pack_weight_dgrad": (i32, [vp, vp, i32, i32, i32, i32, C.POINTER(i32), C.POINTER(i32), vp]),
+    "sgd_wgrad": (i32, [C.POINTER(IgemmArgs), vp, i32, i32, vp, i32, vp]),
+    "sgd_wgrad_reduce": (i32, [vp, i32, i32, i32, i32, vp, i32, vp]),
+    "sgd_colsum": (i32, [vp, i32, i32, i32, vp, i32, vp]),
+    "sgd_gn_bwd_reduce": (i32, [vp, i32, i32, i32, i32, i32, i32, vp, vp, i32, vp, i32, i32, vp, vp]),
+    "sgd_gn_bwd_coef": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, vp, vp, vp, vp, vp, vp, vp]),
+    "sgd_gn_bwd_apply": (i32, [vp, i32, i32, i32, i32, i32, i32, vp, vp, i32, vp, i32, i32, vp, vp, vp, vp, i32, i32,
+                             vp, i32, i32, i32, vp]),
+    "sgd_silu_bwd": (i32, [vp, vp, i64, vp, vp]),
+    "sgd_q_sample": (i32, [vp, vp, vp, vp, vp, i32, i64, vp, vp]),
+    "sgd_mse_loss": (i32, [vp, vp, i32, i32, i32, vp, vp, vp]),
     "sgd_timestep_embedding": (i32, [vp, vp, i32, i32, i32, vp, vp]),
     "sgd_cond_select": (i32, [vp, i32, vp, vp, i32, i32, i32, vp, vp]),
     "sgd_pack_input": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp]),

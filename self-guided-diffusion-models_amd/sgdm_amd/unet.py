@@ -691,7 +691,7 @@ class UNetModel(UNetModelBase):
         # legacy layout: channel = head*3d + {q: 0, k: d, v: 2d}; scale = (d^-1/4)^2 applied to q.k
         eng.prog.add(p + ".attn", eng.lib.sgd_attention, _ptr(qkv), 3 * ch, 3 * d,
                      C.c_void_p(qkv.data_ptr() + 4 * d), C.c_void_p(qkv.data_ptr() + 8 * d), 3 * ch, 3 * d,
-                     n, heads, T, T, d, 1.0 / math.sqrt(d), _ptr(att), ch)
+                     n, heads, T, T, d, 1.0 / math.sqrt(d), _ptr(att), ch, C.c_void_p(0))
         y = eng.buf(n, hh, ww, ch)
         eng.igemm(p + ".proj_out", att, ch, y, ch, eng.pack([p + ".proj_out.weight"], 1), m=n * T,
                   bias=P(p + ".proj_out.bias"), res=t)
@@ -855,7 +855,7 @@ class UNetModelCA(UNetModelBase):
         att = eng.buf(n, T, heads * d)
         eng.prog.add(p + ".attn", lib.sgd_attention, _ptr(q), heads * d, d, _ptr(kv),
                      C.c_void_p(kv.data_ptr() + 4 * d), 2 * d, 0, n, heads, T, J, d, d ** -0.5, _ptr(att),
-                     heads * d)
+                     heads * d, C.c_void_p(0))
         o = eng.buf(n, T, ch)
         eng.igemm(p + ".to_out.0", att, heads * d, o, ch, eng.pack([p + ".to_out.0.weight"], 1), m=n * T)
         y = eng.buf(n, hh, ww, ch)

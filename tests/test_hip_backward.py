@@ -1,0 +1,214 @@
+"""Backward kernels of the training step through the C-ABI vs torch-CPU autograd of the same op.  GPU only."""
+import ctypes as C
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import max_rel
+from test_hip_kernels import _lib, _nhwc, _p, _stream
+
+pytestmark = pytest.mark.gpu
+
+
+def _igemm_args(L, x, x1=None, conv=None, m=0, rows_per_n=0, pa=None, pb=None, silu=0, stride=1, resample=0):
+    a = L.IgemmArgs()
+    a.x0, a.c0 = x.data_ptr(), x.shape[-1]
+    if x1 is not None:
+        a.x1, a.c1 = x1.data_ptr(), x1.shape[-1]
+    if conv is not None:
+        n, hi, wi, ho, wo = conv
+        a.mode, a.n, a.hi, a.wi, a.ho, a.wo, a.stride, a.resample = L.MODE_CONV3, n, hi, wi, ho, wo, stride, resample
+    else:
+        a.mode, a.m, a.rows_per_n, a.stride = L.MODE_FLAT, m, rows_per_n, 1
+    if pa is not None:
+        a.pro, a.pa, a.pb = L.PRO_AFFINE_NC, pa.data_ptr(), pb.data_ptr()
+    a.pro_silu = silu
+    return a
+
+
+@pytest.mark.parametrize("prec,tol", [("f32", 2e-6), ("f16x3", 2e-5)])
+@pytest.mark.parametrize("shape", [(2, 64, 16, 128), (3, 128, 8, 96), (2, 32, 4, 32)])
+def test_conv_dgrad_is_forward_kernel_on_adjoint_weights(shape, prec, tol):
+    L, lib = _lib()
+    n, cin, h, cout = shape
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(n, cin, h, h, generator=g, requires_grad=True)
+    w = torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(cin * 9)
+    gy = torch.randn(n, cout, h, h, generator=g)
+    F.conv2d(x, w, padding=1).backward(gy)
+    p = L.PREC_BY_NAME[prec]
+    wd = w.cuda()
+    buf = torch.empty(lib.sgd_packed_weight_bytes(cin, cout, 3, p) // 4, device="cuda")
+    cp, op = C.c_int32(), C.c_int32()
+    L.check(lib.sgd_pack_weight_dgrad(_p(wd), _p(buf), cout, cin, 3, p, C.byref(cp), C.byref(op), _stream()), "packT")
+    gyd = _nhwc(gy).cuda()
+    out = torch.full((n, h, h, cin), float("nan"), device="cuda")
+    a = _igemm_args(L, gyd, conv=(n, h, h, h, h))
+    a.w, a.cin_p, a.cout_p, a.y, a.cout, a.y_ld, a.prec = buf.data_ptr(), cp.value, op.value, out.data_ptr(), cin, cin, p
+    L.check(lib.sgd_igemm(C.byref(a), _stream()), "dgrad")
+    assert max_rel(out.cpu().permute(0, 3, 1, 2), x.grad) < tol
+
+
+def _wgrad(L, lib, fwd, gy, cout, cin, taps, ksplit):
+    slabs = torch.full((ksplit, taps, cout, cin), float("nan"), device="cuda")
+    L.check(lib.sgd_wgrad(C.byref(fwd), _p(gy), gy.shape[-1], cout, _p(slabs), ksplit, _stream()), "wgrad")
+    dw = torch.full((cout, cin, taps), float("nan"), device="cuda")
+    L.check(lib.sgd_wgrad_reduce(_p(slabs), ksplit, taps, cout, cin, _p(dw), 0, _stream()), "reduce")
+    L.check(lib.sgd_wgrad_reduce(_p(slabs), ksplit, taps, cout, cin, _p(dw), 1, _stream()), "reduce+")     # accumulate
+    return dw.cpu() / 2
+
+
+@pytest.mark.parametrize("mode", ["plain", "fused_concat", "down", "up"])
+def test_conv_wgrad(mode):
+    L, lib = _lib()
+    g = torch.Generator().manual_seed(12)
+    n, h, cout = 3, 16, 160
+    c0, c1 = (64, 32) if mode == "fused_concat" else (96, 0)
+    cin = c0 + c1
+    x0 = torch.randn(n, c0, h, h, generator=g)
+    x1 = torch.randn(n, c1, h, h, generator=g) if c1 else None
+    w = (torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(cin * 9)).requires_grad_(True)
+    pa, pb = torch.randn(n, cin, generator=g), torch.randn(n, cin, generator=g)
+    xin = torch.cat([x0, x1], 1) if c1 else x0
+    if mode == "plain":
+        u, ho, rs, fused = xin, h, 0, False
+    else:
+        u = F.silu(xin * pa[:, :, None, None] + pb[:, :, None, None])
+        fused = True
+        if mode == "down":
+            u, ho, rs = F.avg_pool2d(u, 2), h // 2, 1
+        elif mode == "up":
+            u, ho, rs = F.interpolate(u, scale_factor=2, mode="nearest"), h * 2, 2
+        else:
+            ho, rs = h, 0
+    gy = torch.randn(n, cout, ho, ho, generator=g)
+    F.conv2d(u, w, padding=1).backward(gy)
+    x0d = _nhwc(x0).cuda()
+    x1d = _nhwc(x1).cuda() if c1 else None
+    pad, pbd = pa.cuda(), pb.cuda()
+    fwd = _igemm_args(L, x0d, x1d, conv=(n, h, h, ho, ho), pa=pad if fused else None, pb=pbd if fused else None,
+                      silu=1 if fused else 0, resample=rs)
+    gyd = _nhwc(gy).cuda()
+    dw = _wgrad(L, lib, fwd, gyd, cout, cin, 9, 3)
+    assert max_rel(dw.reshape(cout, cin, 3, 3), w.grad) < 5e-6
+
+
+def test_linear_wgrad_and_bias():
+    L, lib = _lib()
+    g = torch.Generator().manual_seed(13)
+    m, k, nout = 333, 200, 72
+    x = torch.randn(m, k, generator=g)
+    w = (torch.randn(nout, k, generator=g) / math.sqrt(k)).requires_grad_(True)
+    b = torch.zeros(nout, requires_grad=True)
+    gy = torch.randn(m, nout, generator=g)
+    F.linear(F.silu(x), w, b).backward(gy)
+    xd, gyd = x.cuda(), gy.cuda()
+    fwd = _igemm_args(L, xd, m=m, silu=1)
+    dw = _wgrad(L, lib, fwd, gyd, nout, k, 1, 3)
+    assert max_rel(dw.reshape(nout, k), w.grad) < 5e-6
+    db = torch.zeros(nout, device="cuda")
+    L.check(lib.sgd_colsum(_p(gyd), m, nout, nout, _p(db), 0, _stream()), "colsum")
+    assert max_rel(db.cpu(), b.grad) < 2e-6
+
+
+@pytest.mark.parametrize("gu_mode", [0, 1, 2])
+@pytest.mark.parametrize("silu,film", [(1, True), (0, False)])
+def test_groupnorm_silu_backward(gu_mode, silu, film):
+    """x -> GN(+FiLM) [-> SiLU] [-> avgpool / nearest-up] -> gu ; plus an identity-skip gradient through the
+    same resample (ResBlock up/down, openaimodel.py:301-306)"""
+    L, lib = _lib()
+    g = torch.Generator().manual_seed(14)
+    n, c, h = 3, 96, 8
+    x = (torch.randn(n, c, h, h, generator=g) * 2 + 0.3).requires_grad_(True)
+    gamma = torch.randn(c, generator=g).requires_grad_(True)
+    beta = torch.randn(c, generator=g).requires_grad_(True)
+    fl = torch.randn(n, 2 * c, generator=g).requires_grad_(True)
+    y = F.group_norm(x, 32, gamma, beta, 1e-5)
+    if film:
+        y = y * (1 + fl[:, :c, None, None]) + fl[:, c:, None, None]
+    u = F.silu(y) if silu else y
+    rs = {0: lambda t: t, 1: lambda t: F.avg_pool2d(t, 2), 2: lambda t: F.interpolate(t, scale_factor=2, mode="nearest")}[gu_mode]
+    u2, skip = rs(u), rs(x)
+    gu, gs = torch.randn(u2.shape, generator=g), torch.randn(u2.shape, generator=g)
+    (u2 * gu + skip * gs).sum().backward()
+    # ---- HIP: forward stats/coefs, then the three backward kernels
+    xd = _nhwc(x.detach()).cuda()
+    hw = h * h
+    sums = torch.empty(n, c, 2, device="cuda")
+    L.check(lib.sgd_chan_stats(_p(xd), n, hw, c, _p(sums), c, 0, _stream()), "stats")
+    gd, bd, fd = gamma.detach().cuda(), beta.detach().cuda(), fl.detach().cuda()
+    a, b = torch.empty(n, c, device="cuda"), torch.empty(n, c, device="cuda")
+    L.check(lib.sgd_gn_coef(_p(sums), _p(gd), _p(bd), _p(fd) if film else None, 2 * c, n, c, 32, hw, 1e-5, _p(a),
+                            _p(b), _stream()), "coef")
+    gud, gsd = _nhwc(gu).cuda(), _nhwc(gs).cuda()
+    S = torch.empty(n, c, 2, device="cuda")
+    L.check(lib.sgd_gn_bwd_reduce(_p(xd), n, h, h, c, c, 0, _p(a), _p(b), silu, _p(gud), c, gu_mode, _p(S), _stream()),
+            "reduce")
+    A, B, Cc = (torch.empty(n, c, device="cuda") for _ in range(3))
+    dg, db = torch.empty(n, c, device="cuda"), torch.empty(n, c, device="cuda")
+    dfilm = torch.zeros(n, 2 * c, device="cuda")
+    L.check(lib.sgd_gn_bwd_coef(_p(S), _p(sums), _p(gd), _p(bd), _p(fd) if film else None, 2 * c, n, c, 32, hw, 1e-5,
+                                _p(A), _p(B), _p(Cc), _p(dg), _p(db), _p(dfilm) if film else None, _stream()), "bcoef")
+    dx = torch.full((n, h, h, c), float("nan"), device="cuda")
+    L.check(lib.sgd_gn_bwd_apply(_p(xd), n, h, h, c, c, 0, _p(a), _p(b), silu, _p(gud), c, gu_mode, _p(A), _p(B),
+                                 _p(Cc), _p(gsd), c, gu_mode, _p(dx), c, 0, 0, _stream()), "apply")
+    assert max_rel(dx.cpu().permute(0, 3, 1, 2), x.grad) < 2e-5
+    assert max_rel(dg.cpu().sum(0), gamma.grad) < 2e-5
+    assert max_rel(db.cpu().sum(0), beta.grad) < 2e-5
+    if film:
+        assert max_rel(dfilm.cpu(), fl.grad) < 2e-5
+
+
+@pytest.mark.parametrize("b,heads,t,d", [(2, 8, 256, 64), (2, 4, 64, 32), (1, 8, 16, 16), (1, 2, 100, 64)])
+def test_attention_backward(b, heads, t, d):
+    L, lib = _lib()
+    g = torch.Generator().manual_seed(15)
+    ch = heads * d
+    qkv = torch.randn(b, t, 3 * ch, generator=g).requires_grad_(True)        # channel-last legacy layout
+    x = qkv.reshape(b, t, heads, 3, d)
+    q, k, v = x[:, :, :, 0].permute(0, 2, 1, 3), x[:, :, :, 1].permute(0, 2, 1, 3), x[:, :, :, 2].permute(0, 2, 1, 3)
+    w = torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(d), -1)
+    o = (w @ v).permute(0, 2, 1, 3).reshape(b, t, ch)
+    go = torch.randn(b, t, ch, generator=g)
+    o.backward(go)
+    qd = qkv.detach().cuda()
+    out = torch.empty(b, t, ch, device="cuda")
+    lse = torch.empty(b, heads, t, device="cuda")
+    kp, vp = C.c_void_p(qd.data_ptr() + 4 * d), C.c_void_p(qd.data_ptr() + 8 * d)
+    L.check(lib.sgd_attention(_p(qd), 3 * ch, 3 * d, kp, vp, 3 * ch, 3 * d, b, heads, t, t, d, 1 / math.sqrt(d),
+                              _p(out), ch, _p(lse), _stream()), "attn")
+    assert max_rel(out.cpu(), o.detach()) < 3e-6
+    gqkv = torch.full((b, t, 3 * ch), float("nan"), device="cuda")
+    dvec = torch.empty(b, heads, t, device="cuda")
+    god = go.cuda()
+    L.check(lib.sgd_attention_bwd(_p(qd), 3 * ch, 3 * d, kp, vp, 3 * ch, 3 * d, _p(out), ch, _p(god), ch, _p(lse),
+                                  _p(dvec), b, heads, t, t, d, 1 / math.sqrt(d), _p(gqkv),
+                                  C.c_void_p(gqkv.data_ptr() + 4 * d), C.c_void_p(gqkv.data_ptr() + 8 * d), _stream()),
+            "attn_bwd")
+    assert max_rel(gqkv.cpu(), qkv.grad) < 1e-5
+
+
+def test_q_sample_and_mse_loss():
+    L, lib = _lib()
+    from oracle import diffusion_ref as D
+    g = torch.Generator().manual_seed(16)
+    b, c, hw = 5, 3, 64
+    x0, noise = torch.randn(b, c, 8, 8, generator=g), torch.randn(b, c, 8, 8, generator=g)
+    t = torch.tensor([0, 999, 500, 1, 37])
+    sched = D.make_schedule()
+    ref = D.q_sample(sched, x0, t, noise)
+    out = torch.empty(b, c, 8, 8, device="cuda")
+    sa, s1 = sched["sqrt_alphas_cumprod"].cuda(), sched["sqrt_one_minus_alphas_cumprod"].cuda()
+    x0d, nd, td = x0.cuda(), noise.cuda(), t.cuda()
+    L.check(lib.sgd_q_sample(_p(x0d), _p(nd), _p(td), _p(sa), _p(s1), b, c * hw, _p(out), _stream()), "q_sample")
+    assert max_rel(out.cpu(), ref) < 1e-6
+    eps = torch.randn(b, c, 8, 8, generator=g).requires_grad_(True)
+    per = ((noise - eps) ** 2).reshape(b, -1).mean(1)
+    per.mean().backward()
+    ed = _nhwc(eps.detach()).cuda()
+    ps, ge = torch.empty(b, device="cuda"), torch.empty(b, 8, 8, c, device="cuda")
+    L.check(lib.sgd_mse_loss(_p(ed), _p(nd), b, c, hw, _p(ps), _p(ge), _stream()), "mse")
+    assert max_rel(ps.cpu(), per.detach()) < 1e-6
+    assert max_rel(ge.cpu().permute(0, 3, 1, 2), eps.grad) < 1e-6

@@ -217,7 +217,7 @@ def test_attention_legacy(b, heads, t, d):
     out = torch.full((b, t, ch), float("nan"), device="cuda")
     L.check(lib.sgd_attention(_p(qd), 3 * ch, 3 * d, C.c_void_p(qd.data_ptr() + 4 * d),
                               C.c_void_p(qd.data_ptr() + 8 * d), 3 * ch, 3 * d, b, heads, t, t, d,
-                              1 / math.sqrt(d), _p(out), ch, _stream()), "attn")
+                              1 / math.sqrt(d), _p(out), ch, None, _stream()), "attn")
     assert max_rel(out.cpu().permute(0, 2, 1), ref) < 3e-6
 
 
@@ -234,7 +234,7 @@ def test_attention_multiquery_273_keys():
     qd, kvd = q.cuda(), kv.cuda()
     out = torch.full((b, t, heads * d), float("nan"), device="cuda")
     L.check(lib.sgd_attention(_p(qd), heads * d, d, _p(kvd), C.c_void_p(kvd.data_ptr() + 4 * d), 2 * d, 0, b, heads,
-                              t, j, d, d ** -0.5, _p(out), heads * d, _stream()), "attn")
+                              t, j, d, d ** -0.5, _p(out), heads * d, None, _stream()), "attn")
     assert max_rel(out.cpu(), ref) < 3e-6
 
 
@@ -253,7 +253,7 @@ def test_attention_softmax_large_logits():
     qd = q.cuda()
     out = torch.empty(b, t, d, device="cuda")
     L.check(lib.sgd_attention(_p(qd), d, d, _p(kv), C.c_void_p(kv.data_ptr() + 4 * d), 2 * d, 0, b, heads, t, t, d,
-                              d ** -0.5, _p(out), d, _stream()), "attn")
+                              d ** -0.5, _p(out), d, None, _stream()), "attn")
     assert max_rel(out.cpu(), ref) < 3e-6
 
 
