@@ -180,11 +180,13 @@ int sgd_pack_weight_dgrad(const float* w_src, void* w_dst, int32_t cout_fwd, int
  * written to `slabs` [ksplit][taps][cout][cin] and folded by sgd_wgrad_reduce into the reference layout. */
 int sgd_wgrad(const sgd_igemm_args* fwd /* HOST */, const float* gy, int32_t gy_ld, int32_t cout,
               float* slabs, int32_t ksplit, void* stream);
-/* dw[co, ci, tap] (OIHW / [cout, cin]) = (accumulate ? dw : 0) + sum_k slabs[k][tap][co][ci] */
+/* dw[co, ci, tap] (OIHW / [cout, cin]) = (accumulate ? dw : 0) + scale * sum_k slabs[k][tap][co][ci]
+ * (`scale` undoes the power-of-two gradient scaling that keeps the split-f16 dgrad operands in range) */
 int sgd_wgrad_reduce(const float* slabs, int32_t ksplit, int32_t taps, int32_t cout, int32_t cin,
-                     float* dw, int32_t accumulate, void* stream);
-/* out[c] = (accumulate ? out[c] : 0) + sum_rows g[row, c]   (bias gradients) */
-int sgd_colsum(const float* g, int32_t rows, int32_t c, int32_t ld, float* out, int32_t accumulate, void* stream);
+                     float* dw, int32_t accumulate, float scale, void* stream);
+/* out[c] = (accumulate ? out[c] : 0) + scale * sum_rows g[row, c]   (bias / norm-affine gradients) */
+int sgd_colsum(const float* g, int32_t rows, int32_t c, int32_t ld, float* out, int32_t accumulate, float scale,
+               void* stream);
 
 /* GroupNorm(+FiLM)+SiLU backward, split like the forward (util.py:199-216, openaimodel.py:246-247,312-316):
  *   pre = a*x + b ; u = silu ? SiLU(pre) : pre ; the consumer returned gu = dL/du.

@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WArgs w) {
 }
 
 __global__ void wgrad_reduce_kernel(const float* __restrict__ slabs, int ksplit, int taps, int cout, int cin,
-                                    float* __restrict__ dw, int accumulate) {
+                                    float* __restrict__ dw, int accumulate, float scale) {
     const long per = (long)taps * cout * cin;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < per; i += (long)gridDim.x * blockDim.x) {
         // i indexes [tap][co][ci]
@@ -144,13 +144,14 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slabs, int ksplit,
         float s = 0.f;
         for (int k = 0; k < ksplit; ++k) s += slabs[k * per + i];
         const long o = ((long)co * cin + ci) * taps + tap;
+        s *= scale;
         dw[o] = accumulate ? dw[o] + s : s;
     }
 }
 
 // column sums: block per 32-column slab, 8 quads x 32 row lanes (like chan_stats)
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ g, int rows, int c, int ld,
-                                                     float* __restrict__ out, int accumulate) {
+                                                     float* __restrict__ out, int accumulate, float scale) {
     const int col = blockIdx.x * 32 + (threadIdx.x & 31), rl = threadIdx.x >> 5;     // 8 row lanes
     float s = 0.f;
     if (col < c)
@@ -162,6 +163,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ g
         double t = 0;
 #pragma unroll
         for (int k = 0; k < 8; ++k) t += red[k][threadIdx.x];
+        t *= scale;
         out[col] = accumulate ? out[col] + (float)t : (float)t;
     }
 }
@@ -378,20 +380,20 @@ extern "C" int sgd_wgrad(const sgd_igemm_args* fwd, const float* gy, int32_t gy_
 }
 
 extern "C" int sgd_wgrad_reduce(const float* slabs, int32_t ksplit, int32_t taps, int32_t cout, int32_t cin,
-                                float* dw, int32_t accumulate, void* stream) {
+                                float* dw, int32_t accumulate, float scale, void* stream) {
     SGD_CLEAR_ERR();
     if (!slabs || !dw || ksplit <= 0 || taps <= 0 || cout <= 0 || cin <= 0) return SGD_ERR_ARG;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nblk((long)taps * cout * cin, 8192)), dim3(256), 0,
-                       (hipStream_t)stream, slabs, ksplit, taps, cout, cin, dw, accumulate);
+                       (hipStream_t)stream, slabs, ksplit, taps, cout, cin, dw, accumulate, scale);
     return sgd_check_launch();
 }
 
 extern "C" int sgd_colsum(const float* g, int32_t rows, int32_t c, int32_t ld, float* out, int32_t accumulate,
-                          void* stream) {
+                          float scale, void* stream) {
     SGD_CLEAR_ERR();
     if (!g || !out || rows <= 0 || c <= 0 || ld < c) return SGD_ERR_ARG;
     hipLaunchKernelGGL(colsum_kernel, dim3((c + 31) / 32), dim3(256), 0, (hipStream_t)stream, g, rows, c, ld, out,
-                       accumulate);
+                       accumulate, scale);
     return sgd_check_launch();
 }
 

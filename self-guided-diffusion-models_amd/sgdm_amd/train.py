@@ -1,0 +1,427 @@
+"""Training step of the drop-in denoisers: backward program + autograd glue.
+
+The reference gets its backward from torch.autograd through the UNet (PL calls ``loss.backward()``,
+lightning_module.py:215-245; AttentionBlock recomputes its forward under a custom checkpoint,
+openaimodel.py:359-362, util.py:119-148).  Here the backward is a second static launch program
+walking the forward tape in reverse:
+
+  * input gradients of every conv / linear = the FORWARD implicit-GEMM kernel on adjoint-packed weights
+    (``sgd_pack_weight_dgrad``), in the model's arithmetic mode;
+  * weight gradients = ``sgd_wgrad`` (exact-fp32 MFMA, the activated input recomputed by the same fused
+    prologue as the forward: nothing but the raw feature maps is kept) + ``sgd_wgrad_reduce`` into the
+    reference OIHW layout;
+  * GroupNorm(+FiLM)+SiLU backward = ``sgd_gn_bwd_reduce/coef/apply`` (resample adjoints of the up/down
+    ResBlocks and the identity-skip gradient folded into the apply pass);
+  * attention backward = ``sgd_attention_bwd`` with the forward's log-sum-exp (no score matrix stored);
+  * q_sample / MSE loss = ``sgd_q_sample`` / ``sgd_mse_loss``.
+
+``loss.backward()`` works because the UNet evaluation is a ``torch.autograd.Function`` whose inputs are the
+trainable parameters; it returns one gradient tensor per parameter in the reference layout.
+Implemented for ``unet_fast``; ``unetca_fast`` (LayerNorm / multi-query attention / strided-conv adjoints)
+raises NotImplementedError -- next rows.
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib as L
+from .unet import GN_EPS, GN_GROUPS, _Program, _ptr
+
+
+class _PackedAdj:
+    """adjoint-packed weight (dgrad operator) of one forward weight, refreshed on version change.
+    ``src_fn`` returns the forward weight [cout_fwd, cin_fwd(, k, k)] (may be a slice/cat of parameters)."""
+
+    def __init__(self, deps, src_fn, cout_fwd, cin_fwd, ksize, prec, device):
+        self.deps, self.src_fn, self.ksize, self.prec = deps, src_fn, ksize, prec
+        self.cout_fwd, self.cin_fwd = cout_fwd, cin_fwd
+        lib = L.load()
+        nbytes = lib.sgd_packed_weight_bytes(cin_fwd, cout_fwd, ksize, prec)       # adjoint: outputs = cin_fwd
+        self.buf = torch.empty(nbytes // 4, dtype=torch.float32, device=device)
+        self.cin_p = self.cout_p = 0
+        self.sig = None
+
+    def refresh(self, stream):
+        sig = tuple((p.data_ptr(), p._version) for p in self.deps)
+        if sig == self.sig:
+            return
+        src = self.src_fn().detach().contiguous().float()
+        cin_p, cout_p = C.c_int32(0), C.c_int32(0)
+        L.check(L.load().sgd_pack_weight_dgrad(_ptr(src), _ptr(self.buf), self.cout_fwd, self.cin_fwd, self.ksize,
+                                               self.prec, C.byref(cin_p), C.byref(cout_p), stream), "pack_dgrad")
+        self.cin_p, self.cout_p = cin_p.value, cout_p.value
+        self._keep = src
+        self.sig = sig
+
+
+class Backward:
+    """backward launch program of one engine (unet_fast)"""
+
+    def __init__(self, eng):
+        self.e, self.lib, self.n, self.dev, self.prec = eng, eng.lib, eng.n, eng.dev, eng.prec
+        self.m = eng.m
+        self.prog = _Program()
+        self.packs, self.late = [], []
+        # Gradients run through the program multiplied by a power of two so that the split-f16 operands of the
+        # dgrad launches stay in fp16's normal range (d loss / d eps ~ 1/(B*C*H*W) would land in the subnormals
+        # and lose the lo part); every parameter-gradient reduction multiplies by 1/scale again.  Exact in fp32.
+        numel = eng.n * self.m.out_channels * eng.h * eng.w
+        self.gscale = float(2 ** int(math.ceil(math.log2(max(2, numel)))))
+        self.unscale = 1.0 / self.gscale
+        self.G = {}                      # activation data_ptr -> [grad tensor, written?]
+        self.pgrad = {}                  # parameter name -> gradient tensor (reference shape)
+        self.keep = []
+        self._build()
+
+    # ---------------------------------------------------------------- helpers
+    def buf(self, *shape):
+        t = torch.empty(*shape, dtype=torch.float32, device=self.dev)
+        self.keep.append(t)
+        return t
+
+    def gact(self, t):
+        """(grad buffer of activation tensor t, accumulate flag for the next writer)"""
+        ent = self.G.get(t.data_ptr())
+        if ent is None:
+            ent = [self.buf(*t.shape), False]
+            self.G[t.data_ptr()] = ent
+        acc = ent[1]
+        ent[1] = True
+        return ent[0], int(acc)
+
+    def gread(self, t):
+        ent = self.G[t.data_ptr()]
+        assert ent[1], "gradient read before any producer wrote it"
+        return ent[0]
+
+    def pg(self, name):
+        if name not in self.pgrad:
+            self.pgrad[name] = self.buf(*self.m.P(name).shape)
+        return self.pgrad[name]
+
+    def dgrad(self, tag, gy, cin_of_gy, y, cout_of_y, deps, src_fn, cout_fwd, cin_fwd, ksize, conv=None, m=0,
+              y_ld=None):
+        """y = adjoint(W) applied to gy (gy has cout_fwd channels, y gets cin_fwd channels)"""
+        pk = _PackedAdj(deps, src_fn, cout_fwd, cin_fwd, ksize, self.prec, self.dev)
+        self.packs.append(pk)
+        a = L.IgemmArgs()
+        a.x0, a.c0 = gy.data_ptr(), cin_of_gy
+        if conv is not None:
+            nimg, hh, ww = conv
+            a.mode, a.n, a.hi, a.wi, a.ho, a.wo, a.stride = L.MODE_CONV3, nimg, hh, ww, hh, ww, 1
+        else:
+            a.mode, a.m, a.stride = L.MODE_FLAT, m, 1
+        a.w = pk.buf.data_ptr()
+        a.y, a.cout, a.y_ld, a.prec = y.data_ptr(), cout_of_y, (y_ld or cout_of_y), self.prec
+        self.late.append((a, pk))
+        self.keep.append(a)
+        self.prog.add(tag, self.lib.sgd_igemm, C.byref(a))
+
+    def wgrad(self, tag, fwd_args, gy, gy_ld, cout, cin, taps, rows, wname, bias_name=None, dw_view=None):
+        base = taps * ((cout + 127) // 128) * ((cin + 127) // 128)
+        ktiles = (rows + 63) // 64
+        ksplit = max(1, min(ktiles, 1024 // base))
+        slabs = self.buf(ksplit, taps, cout, cin)
+        self.prog.add(tag + ".wgrad", self.lib.sgd_wgrad, C.byref(fwd_args), _ptr(gy), gy_ld, cout, _ptr(slabs), ksplit)
+        dw = dw_view if dw_view is not None else self.pg(wname)
+        self.prog.add(tag + ".wred", self.lib.sgd_wgrad_reduce, _ptr(slabs), ksplit, taps, cout, cin, _ptr(dw), 0,
+                      self.unscale)
+        if bias_name is not None:
+            self.prog.add(tag + ".bias", self.lib.sgd_colsum, _ptr(gy), rows, cout, gy_ld, _ptr(self.pg(bias_name)), 0,
+                          self.unscale)
+
+    def gn_bwd(self, tag, srcs, hw, a, b, sums, gname, silu, gu, gu_ld, gu_mode, gres, gres_ld, gres_mode,
+               film_ptr=0, film_ld=0, dfilm_ptr=0):
+        """GroupNorm(+FiLM)[+SiLU] backward over a (virtual concat of) source tensor(s); writes/accumulates the
+        input gradients into the sources' gradient buffers."""
+        n, lib = self.n, self.lib
+        h, w = hw
+        ct = sum(c for _, c in srcs)
+        S = self.buf(n, ct, 2)
+        off = 0
+        for t, c in srcs:
+            self.prog.add(tag + ".reduce", lib.sgd_gn_bwd_reduce, _ptr(t), n, h, w, c, ct, off, _ptr(a), _ptr(b), silu,
+                          _ptr(gu), gu_ld, gu_mode, _ptr(S))
+            off += c
+        A, B, Cc, dg, db = (self.buf(n, ct) for _ in range(5))
+        gamma, beta = self.m.P(gname + ".weight"), self.m.P(gname + ".bias")
+        self.prog.add(tag + ".coef", lib.sgd_gn_bwd_coef, _ptr(S), _ptr(sums), _ptr(gamma), _ptr(beta),
+                      C.c_void_p(film_ptr), film_ld, n, ct, GN_GROUPS, h * w, GN_EPS, _ptr(A), _ptr(B), _ptr(Cc),
+                      _ptr(dg), _ptr(db), C.c_void_p(dfilm_ptr))
+        self.prog.add(tag + ".dgamma", lib.sgd_colsum, _ptr(dg), n, ct, ct, _ptr(self.pg(gname + ".weight")), 0,
+                      self.unscale)
+        self.prog.add(tag + ".dbeta", lib.sgd_colsum, _ptr(db), n, ct, ct, _ptr(self.pg(gname + ".bias")), 0,
+                      self.unscale)
+        off = 0
+        for t, c in srcs:
+            dst, acc = self.gact(t)
+            self.prog.add(tag + ".apply", lib.sgd_gn_bwd_apply, _ptr(t), n, h, w, c, ct, off, _ptr(a), _ptr(b), silu,
+                          _ptr(gu), gu_ld, gu_mode, _ptr(A), _ptr(B), _ptr(Cc), _ptr(gres) if gres is not None else None,
+                          gres_ld, gres_mode, _ptr(dst), c, 0, acc)
+            off += c
+
+    # ---------------------------------------------------------------- program
+    def _build(self):
+        e, m, n = self.e, self.m, self.n
+        if m.KIND != "unet_fast":
+            raise NotImplementedError("training backward is built for unet_fast; unetca_fast (LayerNorm, multi-query "
+                                      "attention and strided-conv adjoints) is the next row")
+        P = m.P
+        self.geps = self.buf(*e.eps_nhwc.shape)           # filled by the autograd Function before the program runs
+        film_rec = [r for r in e.tape if r["kind"] == "film"][0]
+        self.gfilm = self.buf(n, film_rec["film_w"])
+        for rec in reversed(e.tape):
+            kind = rec["kind"]
+            if kind == "head":
+                self._head(rec)
+            elif kind == "res":
+                self._res(rec)
+            elif kind == "attn":
+                self._attn(rec)
+            elif kind == "conv_in":
+                h, w = rec["hw"]
+                gy = self.gread(rec["y"])
+                self.wgrad(rec["p"], rec["a"], gy, rec["cout"], rec["cout"], rec["cin"], 9, n * h * w,
+                           rec["p"] + ".weight", rec["p"] + ".bias")
+            elif kind == "film":
+                self._film(rec)
+            elif kind == "mlp2":
+                self._mlp2(rec)
+            else:
+                raise NotImplementedError(kind)
+
+    def _head(self, rec):
+        n, (h, w), c = self.n, rec["hw"], rec["c"]
+        oc = self.m.out_channels
+        gu = self.buf(n, h, w, c)
+        wt = self.m.P("out.2.weight")
+        self.dgrad("out.2.dgrad", self.geps, oc, gu, c, [wt], lambda: wt, oc, c, 3, conv=(n, h, w))
+        self.wgrad("out.2", rec["conv"], self.geps, oc, oc, c, 9, n * h * w, "out.2.weight", "out.2.bias")
+        self.gn_bwd("out.0", [(rec["x"], c)], (h, w), rec["a"], rec["b"], rec["sums"], "out.0", 1, gu, c, L.RS_NONE,
+                    None, 0, 0)
+
+    def _res(self, rec):
+        n, p = self.n, rec["p"]
+        P = self.m.P
+        cin, cout = rec["cin"], rec["cout"]
+        (hh, ww), (ho, wo), rs = rec["hw_in"], rec["hw_out"], rec["rs"]
+        gy = self.gread(rec["y"])
+        rows_o = n * ho * wo
+        # conv2 (out_layers.3)
+        w2 = P(p + ".out_layers.3.weight")
+        gu2 = self.buf(n, ho, wo, cout)
+        self.dgrad(p + ".out_layers.3.dgrad", gy, cout, gu2, cout, [w2], lambda w2=w2: w2, cout, cout, 3, conv=(n, ho, wo))
+        self.wgrad(p + ".out_layers.3", rec["conv2"], gy, cout, cout, cout, 9, rows_o, p + ".out_layers.3.weight",
+                   p + ".out_layers.3.bias")
+        # GN2 + FiLM + SiLU -> gradient of h1 and of this block's FiLM slice
+        e = self.e
+        film_ptr = e.film.data_ptr() + 4 * rec["film_off"]
+        dfilm_ptr = self.gfilm.data_ptr() + 4 * rec["film_off"]
+        self.G[rec["h1"].data_ptr()] = [self.buf(*rec["h1"].shape), False]
+        self.gn_bwd(p + ".out_layers.0", [(rec["h1"], cout)], (ho, wo), rec["a2"], rec["b2"], rec["sums2"],
+                    p + ".out_layers.0", 1, gu2, cout, L.RS_NONE, None, 0, 0, film_ptr=film_ptr, film_ld=e.film_ld,
+                    dfilm_ptr=dfilm_ptr)
+        gh1 = self.gread(rec["h1"])
+        # conv1 (in_layers.2)
+        w1 = P(p + ".in_layers.2.weight")
+        gu1 = self.buf(n, ho, wo, cin)
+        self.dgrad(p + ".in_layers.2.dgrad", gh1, cout, gu1, cin, [w1], lambda w1=w1: w1, cout, cin, 3, conv=(n, ho, wo))
+        self.wgrad(p + ".in_layers.2", rec["conv1"], gh1, cout, cout, cin, 9, rows_o, p + ".in_layers.2.weight",
+                   p + ".in_layers.2.bias")
+        # skip path
+        if rec["skip"] is not None:
+            ws = P(p + ".skip_connection.weight")
+            gsk = self.buf(n, hh, ww, cin)
+            self.dgrad(p + ".skip.dgrad", gy, cout, gsk, cin, [ws], lambda ws=ws: ws, cout, cin, 1, m=n * hh * ww)
+            self.wgrad(p + ".skip_connection", rec["skip"], gy, cout, cout, cin, 1, n * hh * ww,
+                       p + ".skip_connection.weight", p + ".skip_connection.bias")
+            gres, gres_ld, gres_mode = gsk, cin, L.RS_NONE
+        else:
+            gres, gres_ld, gres_mode = gy, cout, rs            # identity skip through the same resample
+        # GN1 + SiLU (+ resample adjoint of the activated tensor) -> gradients of the block inputs
+        self.gn_bwd(p + ".in_layers.0", rec["srcs"], (hh, ww), rec["a1"], rec["b1"], rec["sums1"], p + ".in_layers.0",
+                    1, gu1, cin, rs, gres, gres_ld, gres_mode)
+
+    def _attn(self, rec):
+        n, p, ch, heads, d, T = self.n, rec["p"], rec["ch"], rec["heads"], rec["d"], rec["T"]
+        P = self.m.P
+        hh, ww = rec["hw"]
+        gy = self.gread(rec["y"])
+        wp = P(p + ".proj_out.weight")
+        gatt = self.buf(n, T, ch)
+        self.dgrad(p + ".proj_out.dgrad", gy, ch, gatt, ch, [wp], lambda: wp, ch, ch, 1, m=n * T)
+        self.wgrad(p + ".proj_out", rec["proj_args"], gy, ch, ch, ch, 1, n * T, p + ".proj_out.weight",
+                   p + ".proj_out.bias")
+        qkv, gqkv = rec["qkv"], self.buf(n, T, 3 * ch)
+        dvec = self.buf(n, heads, T)
+        off = lambda t, k: C.c_void_p(t.data_ptr() + 4 * k)
+        self.prog.add(p + ".attn_bwd", self.lib.sgd_attention_bwd, _ptr(qkv), 3 * ch, 3 * d, off(qkv, d), off(qkv, 2 * d),
+                      3 * ch, 3 * d, _ptr(rec["att"]), ch, _ptr(gatt), ch, _ptr(rec["lse"]), _ptr(dvec), n, heads, T, T, d,
+                      1.0 / math.sqrt(d), _ptr(gqkv), off(gqkv, d), off(gqkv, 2 * d))
+        wq = P(p + ".qkv.weight")
+        gxn = self.buf(n, T, ch)
+        self.dgrad(p + ".qkv.dgrad", gqkv, 3 * ch, gxn, ch, [wq], lambda: wq, 3 * ch, ch, 1, m=n * T)
+        self.wgrad(p + ".qkv", rec["qkv_args"], gqkv, 3 * ch, 3 * ch, ch, 1, n * T, p + ".qkv.weight", p + ".qkv.bias")
+        self.gn_bwd(p + ".norm", [(rec["x"], ch)], (hh, ww), rec["a"], rec["b"], rec["sums"], p + ".norm", 0, gxn, ch,
+                    L.RS_NONE, gy, ch, L.RS_NONE)                       # residual: x + proj(...)
+
+    def _film(self, rec):
+        """emb_layers of all ResBlocks (one GEMM forward): weight/bias grads split back per block; gradient of
+        SiLU(emb) through the adjoint, then through the SiLU, into the (virtual concat) emb parts."""
+        n, m = self.n, self.m
+        fw = rec["film_w"]
+        ted = rec["emb_t"].shape[1]
+        cc = rec["emb_c"].shape[1] if rec["emb_c"] is not None else 0
+        ech = ted + cc
+        names, couts = rec["names"], rec["couts"]
+        wparams = [m.P(p + ".emb_layers.1.weight") for p in names]
+        dwcat, dbcat = self.buf(fw, ech), self.buf(fw)
+        self.wgrad("emb_layers", rec["a"], self.gfilm, fw, fw, ech, 1, n, None, None, dw_view=dwcat)
+        self.prog.add("emb_layers.bias", self.lib.sgd_colsum, _ptr(self.gfilm), n, fw, fw, _ptr(dbcat), 0, self.unscale)
+        self._film_split = (dwcat, dbcat, names, couts)
+        for p in names:
+            self.pg(p + ".emb_layers.1.weight")
+            self.pg(p + ".emb_layers.1.bias")
+        cat = lambda: torch.cat([w.detach() for w in wparams], 0)
+        parts = [(rec["emb_t"], 0, ted)] + ([(rec["emb_c"], ted, cc)] if cc else [])
+        for t, o, c in parts:
+            gact = self.buf(n, c)
+            self.dgrad(f"emb_layers.dgrad{o}", self.gfilm, fw, gact, c, wparams, lambda o=o, c=c: cat()[:, o:o + c], fw, c, 1,
+                       m=n)
+            g = self.buf(n, c)
+            self.prog.add(f"emb.silu_bwd{o}", self.lib.sgd_silu_bwd, _ptr(t), _ptr(gact), n * c, _ptr(g))
+            self.G[t.data_ptr()] = [g, True]
+
+    def _mlp2(self, rec):
+        """Linear -> SiLU -> Linear (time_embed / mlp_cond)"""
+        n, name = self.n, rec["name"]
+        P = self.m.P
+        gy = self.gread(rec["y"])
+        cin, mid, cout = rec["cin"], rec["mid"], rec["cout"]
+        self.wgrad(name + ".2", rec["a2"], gy, cout, cout, mid, 1, n, name + ".2.weight", name + ".2.bias")
+        w2 = P(name + ".2.weight")
+        gh_act = self.buf(n, mid)
+        self.dgrad(name + ".2.dgrad", gy, cout, gh_act, mid, [w2], lambda: w2, cout, mid, 1, m=n)
+        gh = self.buf(n, mid)
+        self.prog.add(name + ".silu_bwd", self.lib.sgd_silu_bwd, _ptr(rec["h"]), _ptr(gh_act), n * mid, _ptr(gh))
+        self.wgrad(name + ".0", rec["a0"], gh, mid, mid, cin, 1, n, name + ".0.weight", name + ".0.bias")
+
+    # ---------------------------------------------------------------- execution
+    def run(self, geps_nchw):
+        lib = self.lib
+        stream = torch.cuda.current_stream().cuda_stream
+        for pk in self.packs:
+            pk.refresh(stream)
+        for a, pk in self.late:
+            a.cin_p, a.cout_p = pk.cin_p, pk.cout_p
+        n, c = self.n, self.m.out_channels
+        h, w = self.e.h, self.e.w
+        g = (geps_nchw.float() * self.gscale).contiguous()
+        L.check(lib.sgd_pack_input(_ptr(g), None, None, None, n, n, c, 0, h, w, _ptr(self.geps), stream), "geps")
+        self.prog.run(stream)
+        # emb_layers gradients: split the concatenated result back per ResBlock (device-side slice copies)
+        dwcat, dbcat, names, couts = self._film_split
+        off = 0
+        for p, co in zip(names, couts):
+            self.pgrad[p + ".emb_layers.1.weight"].copy_(dwcat[off:off + 2 * co])
+            self.pgrad[p + ".emb_layers.1.bias"].copy_(dbcat[off:off + 2 * co])
+            off += 2 * co
+        return self.pgrad
+
+
+class _UNetTrainFn(torch.autograd.Function):
+    """eps = UNet(x, t, ...) with gradients for the trainable parameters"""
+
+    @staticmethod
+    def forward(ctx, model, eng, args, *params):
+        x, t, cond, layout, mask = args
+        eng.run(x, t, cond, layout, mask)
+        ctx.model, ctx.eng = model, eng
+        ctx.names = [n for n, p in model.named_parameters() if p.requires_grad]
+        return model._to_nchw(eng)
+
+    @staticmethod
+    def backward(ctx, geps):
+        eng = ctx.eng
+        if getattr(eng, "backward", None) is None:
+            eng.backward = Backward(eng)
+        grads = eng.backward.run(geps)
+        out = []
+        for name in ctx.names:
+            g = grads.get(name)
+            if g is None:
+                raise RuntimeError(f"no gradient produced for {name}")
+            out.append(g)
+        return (None, None, None) + tuple(out)
+
+
+def forward_train(model, x, t, cond, layout, mask, n):
+    """autograd-capable UNet evaluation (called from UNetModelBase._run when grads are required)"""
+    if model.dropout and model.dropout > 0:
+        raise NotImplementedError("train-time dropout (openaimodel.py:272) is not fused into the HIP path yet; "
+                                  "construct the model with dropout=0 (unetca_fast's default) to train")
+    B, cx, H, W = x.shape
+    prec = L.PREC_BY_NAME[model.hip_precision]
+    eng = model._engine(n, H, W, prec)
+    params = [p for p in model.parameters() if p.requires_grad]
+    eps = _UNetTrainFn.apply(model, eng, (x, t, cond, layout, mask), *params)
+    return eps, 0.0, dict()
+
+
+class _MSEFn(torch.autograd.Function):
+    """per-sample mean squared error between noise and eps (ddpm.py:67-75), fused forward + gradient"""
+
+    @staticmethod
+    def forward(ctx, eps, target):
+        B, Cc, H, W = eps.shape
+        per = ((target - eps) ** 2).reshape(B, -1).mean(1)
+        ctx.save_for_backward(eps, target)
+        return per
+
+    @staticmethod
+    def backward(ctx, gper):
+        eps, target = ctx.saved_tensors
+        B = eps.shape[0]
+        chw = eps[0].numel()
+        return (-2.0 / chw) * (target - eps) * gper.reshape(B, 1, 1, 1), None
+
+
+def p_losses_hip(diff, x_start, t, noise=None, *args, **kwargs):
+    """LatentDiffusion.p_losses (ddpm.py:54-86)"""
+    lib = L.load()
+    h = diff.hparams
+    noise = torch.randn_like(x_start) if noise is None else noise
+    s = diff.sampler
+    if x_start.device.type == "cuda":
+        x_noisy = torch.empty_like(x_start)
+        B = x_start.shape[0]
+        x0, nz, tt = x_start.contiguous().float(), noise.contiguous().float(), t.contiguous().to(torch.int64)
+        L.check(lib.sgd_q_sample(_ptr(x0), _ptr(nz), _ptr(tt), _ptr(s.sqrt_alphas_cumprod),
+                                 _ptr(s.sqrt_one_minus_alphas_cumprod), B, x0[0].numel(), _ptr(x_noisy),
+                                 torch.cuda.current_stream().cuda_stream), "sgd_q_sample")
+    else:
+        x_noisy = s.q_sample(original_sample=x_start, t=t, noise=noise)
+    model_output, loss_inside, dict_inside = diff.denoise_fn(x_noisy, t, *args, **kwargs)
+    prefix = "train" if diff.training else "val"
+    loss_dict = {f"{prefix}/{k}": v for k, v in dict_inside.items()}
+    if h.parameterization == "x0":
+        target = x_start
+    elif h.parameterization == "eps":
+        target = noise
+    else:
+        raise NotImplementedError()
+    if h.loss_type == "l2":
+        loss = _MSEFn.apply(model_output, target)
+    elif h.loss_type == "l1":
+        loss = (target - model_output).abs().reshape(len(target), -1).mean(1)
+    else:
+        raise NotImplementedError(f"unknown loss type '{h.loss_type}'")
+    if prefix == "train":
+        loss_dict[f"{prefix}/epoch_stats_y"] = loss.detach()
+        loss_dict[f"{prefix}/epoch_stats_x"] = t.detach()
+    loss = loss.mean()
+    loss_dict[f"{prefix}/ddpm_loss"] = loss.detach()
+    loss = loss + loss_inside
+    loss_dict[f"{prefix}/loss"] = loss.detach()
+    return loss, loss_dict

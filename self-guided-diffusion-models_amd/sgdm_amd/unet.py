@@ -390,6 +390,8 @@ class _Engine:
         self.prog = _Program()
         self.packed = []
         self.bufs = []
+        self.tape = []            # forward structure, walked in reverse by train.build_backward
+        self.lse = {}             # attention log-sum-exp buffers (written only when present)
         self._build()
 
     # ---- helpers
@@ -436,6 +438,7 @@ class _Engine:
         flops = 2.0 * rows * cout * taps * cin
         nbytes = 4.0 * (rows_in * cin + rows * cout * (2 if res is not None else 1) + taps * cin * cout)
         self.prog.add(tag, self.lib.sgd_igemm, C.byref(a), flops=flops, nbytes=nbytes)
+        return a
 
     def gn(self, tag, srcs, hw, gname, film=None, film_ld=0):
         """srcs: list of (tensor, channels) forming a virtual concat -> (a, b) coefficient buffers"""
@@ -447,6 +450,7 @@ class _Engine:
             self.prog.add(tag + ".stats", self.lib.sgd_chan_stats, _ptr(t), n, hw, c, _ptr(sums), ct, off)
             off += c
         a, b = self.buf(n, ct), self.buf(n, ct)
+        self._last_sums = sums
         self.prog.add(tag + ".coef", self.lib.sgd_gn_coef, _ptr(sums), _ptr(self.m.P(gname + ".weight")),
                       _ptr(self.m.P(gname + ".bias")), C.c_void_p(film or 0), film_ld, n, ct, GN_GROUPS, hw,
                       GN_EPS, _ptr(a), _ptr(b))
@@ -467,13 +471,17 @@ class _Engine:
         self.x_in = self.buf(n, H, W, cin_tot)
         self.cond_m = self.buf(n, max(1, m._cond_width)) if m._cond_width else None
         # ---------------- embedding path
-        emb = self.buf(n, m._emb_ch)
+        # emb = [time part | cond part] is a VIRTUAL concat for unet_fast (openaimodel.py:942): two buffers
+        emb = self.buf(n, ted)
         e1 = self.buf(n, ted)
-        self.igemm("time_embed.0", self.temb, mc, e1, ted, self.pack(["time_embed.0.weight"], 1), m=n,
-                   bias=P("time_embed.0.bias"))
-        self.igemm("time_embed.2", e1, ted, emb, ted, self.pack(["time_embed.2.weight"], 1), m=n, silu=1,
-                   bias=P("time_embed.2.bias"), y_ld=m._emb_ch)
+        a0 = self.igemm("time_embed.0", self.temb, mc, e1, ted, self.pack(["time_embed.0.weight"], 1), m=n,
+                        bias=P("time_embed.0.bias"))
+        a2 = self.igemm("time_embed.2", e1, ted, emb, ted, self.pack(["time_embed.2.weight"], 1), m=n, silu=1,
+                        bias=P("time_embed.2.bias"))
+        self.tape.append(dict(kind="mlp2", name="time_embed", x=self.temb, h=e1, y=emb, a0=a0, a2=a2, cin=mc,
+                              mid=ted, cout=ted, add_to_y=False))
         self.context = None
+        self.emb_c = None
         m._build_cond_path(self, emb)
         # all ResBlocks' emb_layers in one GEMM (they share SiLU(emb))
         res_names = m._res_prefixes()
@@ -482,8 +490,12 @@ class _Engine:
         fbias = self.buf(film_w)
         self._film_bias_src = [P(p + ".emb_layers.1.bias") for p, _ in res_names]
         self._film_bias = fbias
-        self.igemm("emb_layers", emb, m._emb_ch, film, film_w,
-                   self.pack([p + ".emb_layers.1.weight" for p, _ in res_names], 1), m=n, silu=1, bias=fbias)
+        ec = self.emb_c
+        af = self.igemm("emb_layers", emb, ted, film, film_w,
+                        self.pack([p + ".emb_layers.1.weight" for p, _ in res_names], 1), m=n, silu=1, bias=fbias,
+                        x1=ec, c1=(m._emb_ch - ted) if ec is not None else 0)
+        self.tape.append(dict(kind="film", emb_t=emb, emb_c=ec, film=film, film_w=film_w, a=af,
+                              names=[p for p, _ in res_names], couts=[co for _, co in res_names]))
         self.film, self.film_ld = film, film_w
         self.film_off = {}
         off = 0
@@ -503,9 +515,10 @@ class _Engine:
         t, c, hh, ww = cur
         a, b = self.gn("out.0", [(t, c)], hh * ww, "out.0")
         self.eps_nhwc = self.buf(n, hh, ww, m.out_channels)
-        self.igemm("out.2", t, c, self.eps_nhwc, m.out_channels, self.pack(["out.2.weight"], 3),
-                   conv=(n, hh, ww, hh, ww, 1, L.RS_NONE), pro=L.PRO_AFFINE_NC, silu=1, pa=a, pb=b,
-                   bias=P("out.2.bias"))
+        ah = self.igemm("out.2", t, c, self.eps_nhwc, m.out_channels, self.pack(["out.2.weight"], 3),
+                        conv=(n, hh, ww, hh, ww, 1, L.RS_NONE), pro=L.PRO_AFFINE_NC, silu=1, pa=a, pb=b,
+                        bias=P("out.2.bias"))
+        self.tape.append(dict(kind="head", x=t, c=c, hw=(hh, ww), a=a, b=b, sums=self._last_sums, conv=ah))
 
     def _block(self, prefix, blk, srcs):
         """srcs: list of (tensor, C, H, W) (two entries = virtual concat [h, skip])"""
@@ -515,8 +528,9 @@ class _Engine:
             if kind == "conv":
                 (t, c, hh, ww), = srcs
                 y = self.buf(self.n, hh, ww, layer[2])
-                self.igemm(p, t, c, y, layer[2], self.pack([p + ".weight"], 3),
-                           conv=(self.n, hh, ww, hh, ww, 1, L.RS_NONE), bias=self.m.P(p + ".bias"))
+                a = self.igemm(p, t, c, y, layer[2], self.pack([p + ".weight"], 3),
+                               conv=(self.n, hh, ww, hh, ww, 1, L.RS_NONE), bias=self.m.P(p + ".bias"))
+                self.tape.append(dict(kind="conv_in", p=p, x=t, y=y, a=a, cin=c, cout=layer[2], hw=(hh, ww)))
                 srcs = [(y, layer[2], hh, ww)]
             elif kind == "res":
                 srcs = [self._res(p, layer, srcs)]
@@ -547,26 +561,34 @@ class _Engine:
         ho, wo = (hh // 2, ww // 2) if ud == "down" else ((hh * 2, ww * 2) if ud == "up" else (hh, ww))
         a1, b1 = self.gn(p + ".in_layers.0", [(t0, c0)] + ([(t1, c1)] if t1 is not None else []), hh * ww,
                          p + ".in_layers.0")
+        sums1 = self._last_sums
         h1 = self.buf(n, ho, wo, cout)
-        self.igemm(p + ".in_layers.2", t0, c0, h1, cout, self.pack([p + ".in_layers.2.weight"], 3), x1=t1, c1=c1,
-                   conv=(n, hh, ww, ho, wo, 1, rs), pro=L.PRO_AFFINE_NC, silu=1, pa=a1, pb=b1,
-                   bias=P(p + ".in_layers.2.bias"))
+        ac1 = self.igemm(p + ".in_layers.2", t0, c0, h1, cout, self.pack([p + ".in_layers.2.weight"], 3), x1=t1,
+                         c1=c1, conv=(n, hh, ww, ho, wo, 1, rs), pro=L.PRO_AFFINE_NC, silu=1, pa=a1, pb=b1,
+                         bias=P(p + ".in_layers.2.bias"))
         film_ptr = self.film.data_ptr() + 4 * self.film_off[p]
         a2, b2 = self.gn(p + ".out_layers.0", [(h1, cout)], ho * wo, p + ".out_layers.0", film=film_ptr,
                          film_ld=self.film_ld)
+        sums2 = self._last_sums
+        ask = None
         if cin != cout:
             assert ud is None
             skip = self.buf(n, hh, ww, cout)
-            self.igemm(p + ".skip_connection", t0, c0, skip, cout, self.pack([p + ".skip_connection.weight"], 1),
-                       x1=t1, c1=c1, m=n * hh * ww, bias=P(p + ".skip_connection.bias"))
+            ask = self.igemm(p + ".skip_connection", t0, c0, skip, cout,
+                             self.pack([p + ".skip_connection.weight"], 1), x1=t1, c1=c1, m=n * hh * ww,
+                             bias=P(p + ".skip_connection.bias"))
             res, res_mode = skip, L.RS_NONE
         else:
             assert t1 is None
             res, res_mode = t0, rs
         y = self.buf(n, ho, wo, cout)
-        self.igemm(p + ".out_layers.3", h1, cout, y, cout, self.pack([p + ".out_layers.3.weight"], 3),
-                   conv=(n, ho, wo, ho, wo, 1, L.RS_NONE), pro=L.PRO_AFFINE_NC, silu=1, pa=a2, pb=b2,
-                   bias=P(p + ".out_layers.3.bias"), res=res, res_mode=res_mode)
+        ac2 = self.igemm(p + ".out_layers.3", h1, cout, y, cout, self.pack([p + ".out_layers.3.weight"], 3),
+                         conv=(n, ho, wo, ho, wo, 1, L.RS_NONE), pro=L.PRO_AFFINE_NC, silu=1, pa=a2, pb=b2,
+                         bias=P(p + ".out_layers.3.bias"), res=res, res_mode=res_mode)
+        self.tape.append(dict(kind="res", p=p, srcs=[(t0, c0)] + ([(t1, c1)] if t1 is not None else []), cin=cin,
+                              cout=cout, hw_in=(hh, ww), hw_out=(ho, wo), rs=rs, a1=a1, b1=b1, sums1=sums1, h1=h1,
+                              a2=a2, b2=b2, sums2=sums2, film_off=self.film_off[p], conv1=ac1, conv2=ac2, skip=ask,
+                              y=y))
         return (y, cout, ho, wo)
 
     # ---- execution
@@ -672,10 +694,13 @@ class UNetModel(UNetModelBase):
         ted = 4 * self.model_channels
         P = self.P
         c1 = eng.buf(eng.n, ted // 2)
-        eng.igemm("mlp_cond.0", eng.cond_m, self.cond_dim, c1, ted // 2, eng.pack(["mlp_cond.0.weight"], 1),
-                  m=eng.n, bias=P("mlp_cond.0.bias"))
-        eng.igemm("mlp_cond.2", c1, ted // 2, emb, ted // 2, eng.pack(["mlp_cond.2.weight"], 1), m=eng.n, silu=1,
-                  bias=P("mlp_cond.2.bias"), y_ld=self._emb_ch, y_off=ted)       # emb = cat(time, cond), :942
+        eng.emb_c = eng.buf(eng.n, ted // 2)                                      # emb = cat(time, cond), :942
+        a0 = eng.igemm("mlp_cond.0", eng.cond_m, self.cond_dim, c1, ted // 2, eng.pack(["mlp_cond.0.weight"], 1),
+                       m=eng.n, bias=P("mlp_cond.0.bias"))
+        a2 = eng.igemm("mlp_cond.2", c1, ted // 2, eng.emb_c, ted // 2, eng.pack(["mlp_cond.2.weight"], 1), m=eng.n,
+                       silu=1, bias=P("mlp_cond.2.bias"))
+        eng.tape.append(dict(kind="mlp2", name="mlp_cond", x=eng.cond_m, h=c1, y=eng.emb_c, a0=a0, a2=a2,
+                             cin=self.cond_dim, mid=ted // 2, cout=ted // 2, add_to_y=False))
 
     def _build_attn(self, eng, p, layer, src):
         """AttentionBlock + QKVAttentionLegacy (openaimodel.py:365-371, 403-420)"""
@@ -684,17 +709,21 @@ class UNetModel(UNetModelBase):
         n, T, P = eng.n, hh * ww, self.P
         d = ch // heads
         a, b = eng.gn(p + ".norm", [(t, c)], T, p + ".norm")
+        sums = eng._last_sums
         qkv = eng.buf(n, T, 3 * ch)
-        eng.igemm(p + ".qkv", t, c, qkv, 3 * ch, eng.pack([p + ".qkv.weight"], 1), m=n * T, rows_per_n=T,
-                  pro=L.PRO_AFFINE_NC, pa=a, pb=b, bias=P(p + ".qkv.bias"))
+        aq = eng.igemm(p + ".qkv", t, c, qkv, 3 * ch, eng.pack([p + ".qkv.weight"], 1), m=n * T, rows_per_n=T,
+                       pro=L.PRO_AFFINE_NC, pa=a, pb=b, bias=P(p + ".qkv.bias"))
         att = eng.buf(n, T, ch)
+        lse = eng.buf(n, heads, T)                         # softmax statistics kept for the backward
         # legacy layout: channel = head*3d + {q: 0, k: d, v: 2d}; scale = (d^-1/4)^2 applied to q.k
         eng.prog.add(p + ".attn", eng.lib.sgd_attention, _ptr(qkv), 3 * ch, 3 * d,
                      C.c_void_p(qkv.data_ptr() + 4 * d), C.c_void_p(qkv.data_ptr() + 8 * d), 3 * ch, 3 * d,
-                     n, heads, T, T, d, 1.0 / math.sqrt(d), _ptr(att), ch, C.c_void_p(0))
+                     n, heads, T, T, d, 1.0 / math.sqrt(d), _ptr(att), ch, _ptr(lse))
         y = eng.buf(n, hh, ww, ch)
-        eng.igemm(p + ".proj_out", att, ch, y, ch, eng.pack([p + ".proj_out.weight"], 1), m=n * T,
-                  bias=P(p + ".proj_out.bias"), res=t)
+        ap = eng.igemm(p + ".proj_out", att, ch, y, ch, eng.pack([p + ".proj_out.weight"], 1), m=n * T,
+                       bias=P(p + ".proj_out.bias"), res=t)
+        eng.tape.append(dict(kind="attn", p=p, x=t, ch=ch, heads=heads, d=d, T=T, hw=(hh, ww), a=a, b=b, sums=sums,
+                             qkv=qkv, att=att, lse=lse, qkv_args=aq, proj_args=ap, y=y))
         return (y, ch, hh, ww)
 
     # ---- reference entry points (openaimodel.py:861-956)

@@ -55,8 +55,8 @@ def _wgrad(L, lib, fwd, gy, cout, cin, taps, ksplit):
     slabs = torch.full((ksplit, taps, cout, cin), float("nan"), device="cuda")
     L.check(lib.sgd_wgrad(C.byref(fwd), _p(gy), gy.shape[-1], cout, _p(slabs), ksplit, _stream()), "wgrad")
     dw = torch.full((cout, cin, taps), float("nan"), device="cuda")
-    L.check(lib.sgd_wgrad_reduce(_p(slabs), ksplit, taps, cout, cin, _p(dw), 0, _stream()), "reduce")
-    L.check(lib.sgd_wgrad_reduce(_p(slabs), ksplit, taps, cout, cin, _p(dw), 1, _stream()), "reduce+")     # accumulate
+    L.check(lib.sgd_wgrad_reduce(_p(slabs), ksplit, taps, cout, cin, _p(dw), 0, 1.0, _stream()), "reduce")
+    L.check(lib.sgd_wgrad_reduce(_p(slabs), ksplit, taps, cout, cin, _p(dw), 1, 1.0, _stream()), "reduce+")     # accumulate
     return dw.cpu() / 2
 
 
@@ -109,7 +109,7 @@ def test_linear_wgrad_and_bias():
     dw = _wgrad(L, lib, fwd, gyd, nout, k, 1, 3)
     assert max_rel(dw.reshape(nout, k), w.grad) < 5e-6
     db = torch.zeros(nout, device="cuda")
-    L.check(lib.sgd_colsum(_p(gyd), m, nout, nout, _p(db), 0, _stream()), "colsum")
+    L.check(lib.sgd_colsum(_p(gyd), m, nout, nout, _p(db), 0, 1.0, _stream()), "colsum")
     assert max_rel(db.cpu(), b.grad) < 2e-6
 
 

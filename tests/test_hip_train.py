@@ -1,0 +1,68 @@
+"""One DDPM training step of the HIP drop-in (LatentDiffusion.p_losses -> UNet -> loss.backward()) against the
+loss / per-sample loss / parameter gradients recorded from the reference (tests/golden/diffusion.npz).  GPU only."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_npz, max_rel
+from test_hip_unet import INDEX, build_model
+
+pytestmark = pytest.mark.gpu
+
+
+def _step(name, prec):
+    import bench
+    from sgdm_amd.diffusion import LatentDiffusion
+    from sgdm_amd.synth import synth_batch
+    v = load_npz("diffusion.npz")
+    tag = f"train.{name}"
+    m, entry = build_model(name, prec)
+    m.train()
+    d = LatentDiffusion(device="cuda", **bench.MODEL_PARAMS).train()
+    d.set_denoise_fn(m.forward, m.forward_with_cond_scale)
+    kw = entry["ctor"]
+    batch = synth_batch(kw["condition_method"], 4, 16, kw["cond_dim"], entry["layout_dim"], seed=23 + 3)
+    t = torch.from_numpy(v[tag + ".t"]).cuda()
+    noise = torch.from_numpy(v[tag + ".noise"]).cuda()
+    mask = torch.from_numpy(v[tag + ".drop_mask"]).cuda()
+    loss, ld = d.p_losses(batch["image"].cuda(), t, noise, cond=batch["cond"].float().cuda(),
+                          layout=batch["layout"].cuda() if "layout" in batch else None, cond_drop_prob=0.5,
+                          cond_drop_mask=mask)
+    loss.backward()
+    return m, v, tag, loss, ld
+
+
+@pytest.mark.parametrize("prec,tol", [("f32", 5e-5), ("f16x3", 1e-4)])
+def test_train_step_unet_fast_vs_reference(prec, tol):
+    m, v, tag, loss, ld = _step("uf_clusterlayout_c32_s16", prec)
+    ref = float(v[tag + ".loss"])
+    assert abs(loss.item() - ref) < 2e-5 * abs(ref)
+    assert max_rel(ld["train/epoch_stats_y"].cpu(), v[tag + ".per_sample"]) < 2e-5
+    assert sorted(ld.keys()) == sorted(v[tag + ".loss_keys"].tolist())
+    grads = {k: p.grad for k, p in m.named_parameters()}
+    assert sorted(k for k, p in m.named_parameters() if p.requires_grad and p.grad is None) == list(v[tag + ".unused_params"])
+    worst = 0.0
+    for key in v:
+        if key.startswith(tag + ".grad."):
+            pname = key[len(tag + ".grad."):]
+            ref = torch.from_numpy(v[key])
+            if float(ref.abs().max()) < 1e-6:
+                # a bias in front of a GroupNorm with ONE channel per group (32 channels / 32 groups) is cancelled
+                # by the mean subtraction: its true gradient is 0 and the reference holds rounding noise
+                assert float(grads[pname].abs().max()) < 1e-5, pname
+                continue
+            err = max_rel(grads[pname].cpu(), ref)
+            worst = max(worst, err)
+            assert err < tol, (pname, err)
+    sq = sum(float((g.double() ** 2).sum()) for g in grads.values() if g is not None)
+    assert abs(sq - float(v[tag + ".grad_sqnorm"])) < 1e-3 * float(v[tag + ".grad_sqnorm"])
+
+
+def test_frozen_parameters_get_no_gradient():
+    m, *_ = _step("uf_clusterlayout_c32_s16", "f32")
+    assert m.null_cond_emb.grad is None and m.null_layout_emb.grad is None
+
+
+def test_training_backward_not_built_for_unetca_yet():
+    with pytest.raises(NotImplementedError):
+        _step("ca_stego_c32_s16", "f32")
