@@ -184,9 +184,10 @@ int sgd_wgrad(const sgd_igemm_args* fwd /* HOST */, const float* gy, int32_t gy_
  * (`scale` undoes the power-of-two gradient scaling that keeps the split-f16 dgrad operands in range) */
 int sgd_wgrad_reduce(const float* slabs, int32_t ksplit, int32_t taps, int32_t cout, int32_t cin,
                      float* dw, int32_t accumulate, float scale, void* stream);
-/* out[c] = (accumulate ? out[c] : 0) + scale * sum_rows g[row, c]   (bias / norm-affine gradients) */
+/* out[c] = (accumulate ? out[c] : 0) + scale * sum_rows g[row, c]   (bias / norm-affine gradients).
+ * Deterministic two-stage reduction through `work` [work_chunks, c] (caller-owned scratch, e.g. 256 chunks). */
 int sgd_colsum(const float* g, int32_t rows, int32_t c, int32_t ld, float* out, int32_t accumulate, float scale,
-               void* stream);
+               float* work, int32_t work_chunks, void* stream);
 
 /* GroupNorm(+FiLM)+SiLU backward, split like the forward (util.py:199-216, openaimodel.py:246-247,312-316):
  *   pre = a*x + b ; u = silu ? SiLU(pre) : pre ; the consumer returned gu = dL/du.

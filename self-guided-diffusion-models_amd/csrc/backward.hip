@@ -149,23 +149,36 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slabs, int ksplit,
     }
 }
 
-// column sums: block per 32-column slab, 8 quads x 32 row lanes (like chan_stats)
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ g, int rows, int c, int ld,
-                                                     float* __restrict__ out, int accumulate, float scale) {
+// column sums, deterministic two-stage: stage 1 = grid (32-column slab, row chunk), 8 row lanes x 32 columns
+// per block, partial sums to work[chunk][c]; stage 2 folds the chunks (fixed order, double accumulation).
+__global__ __launch_bounds__(256) void colsum_stage1_kernel(const float* __restrict__ g, int rows, int c, int ld,
+                                                            int chunks, float* __restrict__ work) {
     const int col = blockIdx.x * 32 + (threadIdx.x & 31), rl = threadIdx.x >> 5;     // 8 row lanes
+    const int chunk = blockIdx.y;
+    const long per = ((long)rows + chunks - 1) / chunks;
+    const long r0 = chunk * per, r1 = (r0 + per < rows) ? r0 + per : rows;
     float s = 0.f;
     if (col < c)
-        for (int r = rl; r < rows; r += 8) s += g[(long)r * ld + col];
+        for (long r = r0 + rl; r < r1; r += 8) s += g[r * ld + col];
     __shared__ float red[8][32];
     red[rl][threadIdx.x & 31] = s;
     __syncthreads();
     if (threadIdx.x < 32 && col < c) {
-        double t = 0;
+        float t = 0;
 #pragma unroll
         for (int k = 0; k < 8; ++k) t += red[k][threadIdx.x];
-        t *= scale;
-        out[col] = accumulate ? out[col] + (float)t : (float)t;
+        work[(long)chunk * c + col] = t;
     }
+}
+
+__global__ void colsum_stage2_kernel(const float* __restrict__ work, int chunks, int c, float* __restrict__ out,
+                                     int accumulate, float scale) {
+    const int col = blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= c) return;
+    double t = 0;
+    for (int k = 0; k < chunks; ++k) t += work[(long)k * c + col];
+    t *= scale;
+    out[col] = accumulate ? out[col] + (float)t : (float)t;
 }
 
 // =============================================================================================
@@ -389,11 +402,15 @@ extern "C" int sgd_wgrad_reduce(const float* slabs, int32_t ksplit, int32_t taps
 }
 
 extern "C" int sgd_colsum(const float* g, int32_t rows, int32_t c, int32_t ld, float* out, int32_t accumulate,
-                          float scale, void* stream) {
+                          float scale, float* work, int32_t work_chunks, void* stream) {
     SGD_CLEAR_ERR();
-    if (!g || !out || rows <= 0 || c <= 0 || ld < c) return SGD_ERR_ARG;
-    hipLaunchKernelGGL(colsum_kernel, dim3((c + 31) / 32), dim3(256), 0, (hipStream_t)stream, g, rows, c, ld, out,
-                       accumulate, scale);
+    if (!g || !out || !work || rows <= 0 || c <= 0 || ld < c || work_chunks <= 0) return SGD_ERR_ARG;
+    int chunks = (rows + 255) / 256;
+    if (chunks > work_chunks) chunks = work_chunks;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(colsum_stage1_kernel, dim3((c + 31) / 32, chunks), dim3(256), 0, st, g, rows, c, ld, chunks, work);
+    hipLaunchKernelGGL(colsum_stage2_kernel, dim3((c + 255) / 256), dim3(256), 0, st, work, chunks, c, out, accumulate,
+                       scale);
     return sgd_check_launch();
 }
 

@@ -53,7 +53,7 @@ SIGNATURES = {
     "sgd_pack_weight_dgrad": (i32, [vp, vp, i32, i32, i32, i32, C.POINTER(i32), C.POINTER(i32), vp]),
     "sgd_wgrad": (i32, [C.POINTER(IgemmArgs), vp, i32, i32, vp, i32, vp]),
     "sgd_wgrad_reduce": (i32, [vp, i32, i32, i32, i32, vp, i32, f32, vp]),
-    "sgd_colsum": (i32, [vp, i32, i32, i32, vp, i32, f32, vp]),
+    "sgd_colsum": (i32, [vp, i32, i32, i32, vp, i32, f32, vp, i32, vp]),
     "sgd_gn_bwd_reduce": (i32, [vp, i32, i32, i32, i32, i32, i32, vp, vp, i32, vp, i32, i32, vp, vp]),
     "sgd_gn_bwd_coef": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, vp, vp, vp, vp, vp, vp, vp]),
     "sgd_gn_bwd_apply": (i32, [vp, i32, i32, i32, i32, i32, i32, vp, vp, i32, vp, i32, i32, vp, vp, vp, vp, i32, i32,

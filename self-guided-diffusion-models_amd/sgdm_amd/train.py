@@ -72,6 +72,8 @@ class Backward:
         self.G = {}                      # activation data_ptr -> [grad tensor, written?]
         self.pgrad = {}                  # parameter name -> gradient tensor (reference shape)
         self.keep = []
+        self.CW = 256                    # row chunks of the two-stage column sums
+        self.cwork = torch.empty(self.CW, 8192, dtype=torch.float32, device=self.dev)
         self._build()
 
     # ---------------------------------------------------------------- helpers
@@ -129,7 +131,7 @@ class Backward:
                       self.unscale)
         if bias_name is not None:
             self.prog.add(tag + ".bias", self.lib.sgd_colsum, _ptr(gy), rows, cout, gy_ld, _ptr(self.pg(bias_name)), 0,
-                          self.unscale)
+                          self.unscale, _ptr(self.cwork), self.CW)
 
     def gn_bwd(self, tag, srcs, hw, a, b, sums, gname, silu, gu, gu_ld, gu_mode, gres, gres_ld, gres_mode,
                film_ptr=0, film_ld=0, dfilm_ptr=0):
@@ -150,9 +152,9 @@ class Backward:
                       C.c_void_p(film_ptr), film_ld, n, ct, GN_GROUPS, h * w, GN_EPS, _ptr(A), _ptr(B), _ptr(Cc),
                       _ptr(dg), _ptr(db), C.c_void_p(dfilm_ptr))
         self.prog.add(tag + ".dgamma", lib.sgd_colsum, _ptr(dg), n, ct, ct, _ptr(self.pg(gname + ".weight")), 0,
-                      self.unscale)
+                      self.unscale, _ptr(self.cwork), self.CW)
         self.prog.add(tag + ".dbeta", lib.sgd_colsum, _ptr(db), n, ct, ct, _ptr(self.pg(gname + ".bias")), 0,
-                      self.unscale)
+                      self.unscale, _ptr(self.cwork), self.CW)
         off = 0
         for t, c in srcs:
             dst, acc = self.gact(t)
@@ -278,7 +280,8 @@ class Backward:
         wparams = [m.P(p + ".emb_layers.1.weight") for p in names]
         dwcat, dbcat = self.buf(fw, ech), self.buf(fw)
         self.wgrad("emb_layers", rec["a"], self.gfilm, fw, fw, ech, 1, n, None, None, dw_view=dwcat)
-        self.prog.add("emb_layers.bias", self.lib.sgd_colsum, _ptr(self.gfilm), n, fw, fw, _ptr(dbcat), 0, self.unscale)
+        self.prog.add("emb_layers.bias", self.lib.sgd_colsum, _ptr(self.gfilm), n, fw, fw, _ptr(dbcat), 0, self.unscale,
+                      _ptr(self.cwork), self.CW)
         self._film_split = (dwcat, dbcat, names, couts)
         for p in names:
             self.pg(p + ".emb_layers.1.weight")

@@ -109,7 +109,8 @@ def test_linear_wgrad_and_bias():
     dw = _wgrad(L, lib, fwd, gyd, nout, k, 1, 3)
     assert max_rel(dw.reshape(nout, k), w.grad) < 5e-6
     db = torch.zeros(nout, device="cuda")
-    L.check(lib.sgd_colsum(_p(gyd), m, nout, nout, _p(db), 0, 1.0, _stream()), "colsum")
+    work = torch.empty(16, nout, device="cuda")
+    L.check(lib.sgd_colsum(_p(gyd), m, nout, nout, _p(db), 0, 1.0, _p(work), 16, _stream()), "colsum")
     assert max_rel(db.cpu(), b.grad) < 2e-6
 
 
