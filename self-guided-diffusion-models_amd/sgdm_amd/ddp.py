@@ -1,0 +1,107 @@
+"""Data-parallel gradient exchange for the HIP training step (replaces ``pl.trainer.strategy=ddp``,
+reference config/pl/default.yaml:2, README.md:84-94).
+
+One process per GPU (``torch.distributed``, backend "nccl" == RCCL on ROCm).  The backward program writes every
+parameter gradient into ONE flat arena laid out in production order (last layers first), cut into buckets.
+As soon as the launches that fill a bucket have been issued, an event is recorded on the compute stream and the
+bucket's all-reduce is enqueued on a side stream, so the exchange over xGMI runs under the rest of the backward.
+xGMI is point-to-point (7 links x ~153 GB/s per GPU): a few LARGE buckets (default 64 MB, 301 MB of gradients
+=> 5 collectives) keep every link busy without the fixed per-collective cost of torch DDP's 25 MB default.
+
+Unlike torch DDP nothing is broadcast per step: EMA shadows and schedule tables are rank-deterministic
+(SURVEY.md 2.3 "drop"), and parameters without a gradient are pre-zeroed in the arena so all ranks reduce
+identical byte ranges (the reference needs ``ddp_find_unused_parameters_true`` for that, README.md:90-94).
+
+Device-agnostic on purpose: the same code runs on CPU tensors over gloo in tests/test_ddp_gloo.py.
+"""
+import torch
+import torch.distributed as dist
+
+
+class GradArena:
+    """flat gradient storage + bucket bookkeeping"""
+
+    def __init__(self, shapes, device, bucket_bytes=64 << 20, dtype=torch.float32):
+        """shapes: ordered [(name, shape)] in the order the backward produces the gradients"""
+        self.names = [n for n, _ in shapes]
+        self.views, self.offsets = {}, {}
+        total = 0
+        for name, shape in shapes:
+            numel = 1
+            for s in shape:
+                numel *= int(s)
+            self.offsets[name] = (total, numel)
+            total += (numel + 3) // 4 * 4                    # keep every view 16-byte aligned
+        self.flat = torch.zeros(max(total, 4), dtype=dtype, device=device)
+        for name, shape in shapes:
+            off, numel = self.offsets[name]
+            self.views[name] = self.flat[off:off + numel].view(*shape)
+        per = max(1, bucket_bytes // self.flat.element_size())
+        self.buckets = []                                     # (start, end, last parameter name inside)
+        start = 0
+        for name in self.names:
+            off, numel = self.offsets[name]
+            end = off + (numel + 3) // 4 * 4
+            if end - start >= per:
+                self.buckets.append((start, end, name))
+                start = end
+        if start < total or not self.buckets:
+            self.buckets.append((start, max(total, 4), self.names[-1] if self.names else None))
+        self.bucket_of = {}
+        for bi, (s, e, _) in enumerate(self.buckets):
+            for name in self.names:
+                off, _n = self.offsets[name]
+                if s <= off < e:
+                    self.bucket_of[name] = bi
+
+    def grad(self, name):
+        return self.views[name]
+
+
+class BucketReducer:
+    """overlapped all-reduce(avg) of the arena's buckets on a side stream"""
+
+    def __init__(self, arena, group=None, average=True):
+        """average=False: the producer already scaled its gradients by 1/world (folded into the
+        un-scaling of the backward program), the collective is a plain SUM"""
+        self.arena, self.group, self.average = arena, group, average
+        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.cuda = arena.flat.is_cuda
+        self.stream = torch.cuda.Stream() if self.cuda else None
+        self.pending = []
+        self.done = set()
+
+    def start(self):
+        self.pending, self.done = [], set()
+
+    def bucket_ready(self, bi):
+        """call right after the last launch writing into bucket ``bi`` has been issued on the current stream"""
+        if self.world == 1 or bi in self.done:
+            return
+        self.done.add(bi)
+        s, e, _ = self.arena.buckets[bi]
+        chunk = self.arena.flat[s:e]
+        if self.cuda:
+            ev = torch.cuda.Event()
+            ev.record()                                       # on the compute stream
+            with torch.cuda.stream(self.stream):
+                self.stream.wait_event(ev)
+                w = dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                self.pending.append((w, chunk))
+        else:
+            w = dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self.pending.append((w, chunk))
+
+    def finish(self):
+        """flush the buckets not yet sent, wait for all collectives, average"""
+        if self.world == 1:
+            return
+        for bi in range(len(self.arena.buckets)):
+            self.bucket_ready(bi)
+        for w, _ in self.pending:
+            w.wait()
+        if self.cuda:
+            torch.cuda.current_stream().wait_stream(self.stream)
+        if self.average:
+            self.arena.flat.mul_(1.0 / self.world)
+        self.pending = []

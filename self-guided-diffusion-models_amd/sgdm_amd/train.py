@@ -58,17 +58,21 @@ class _PackedAdj:
 class Backward:
     """backward launch program of one engine (unet_fast)"""
 
-    def __init__(self, eng):
+    def __init__(self, eng, arena=None, reducer=None):
+        """arena / reducer (sgdm_amd.ddp): parameter gradients are views of one flat buffer cut into buckets and
+        each bucket's all-reduce is enqueued on a side stream as soon as the launches filling it are issued."""
         self.e, self.lib, self.n, self.dev, self.prec = eng, eng.lib, eng.n, eng.dev, eng.prec
         self.m = eng.m
         self.prog = _Program()
         self.packs, self.late = [], []
+        self.arena, self.reducer = arena, reducer
+        self.world = reducer.world if reducer is not None else 1
         # Gradients run through the program multiplied by a power of two so that the split-f16 operands of the
         # dgrad launches stay in fp16's normal range (d loss / d eps ~ 1/(B*C*H*W) would land in the subnormals
         # and lose the lo part); every parameter-gradient reduction multiplies by 1/scale again.  Exact in fp32.
         numel = eng.n * self.m.out_channels * eng.h * eng.w
         self.gscale = float(2 ** int(math.ceil(math.log2(max(2, numel)))))
-        self.unscale = 1.0 / self.gscale
+        self.unscale = 1.0 / (self.gscale * self.world)      # + the 1/world of the gradient average (SUM all-reduce)
         self.G = {}                      # activation data_ptr -> [grad tensor, written?]
         self.pgrad = {}                  # parameter name -> gradient tensor (reference shape)
         self.keep = []
@@ -99,8 +103,21 @@ class Backward:
 
     def pg(self, name):
         if name not in self.pgrad:
-            self.pgrad[name] = self.buf(*self.m.P(name).shape)
+            self.pgrad[name] = self.arena.grad(name) if self.arena is not None else self.buf(*self.m.P(name).shape)
         return self.pgrad[name]
+
+    def wrote(self, name):
+        """program point right after the launch that completes parameter `name`: overlapped bucket send"""
+        if self.reducer is None or self.world == 1:
+            return
+        bi = self.arena.bucket_of[name]
+        if self.arena.buckets[bi][2] == name:
+            red = self.reducer
+
+            def bucket_ready(stream, bi=bi):
+                red.bucket_ready(bi)
+                return 0
+            self.prog.add(f"bucket{bi}.allreduce", bucket_ready)
 
     def dgrad(self, tag, gy, cin_of_gy, y, cout_of_y, deps, src_fn, cout_fwd, cin_fwd, ksize, conv=None, m=0,
               y_ld=None):
@@ -129,9 +146,12 @@ class Backward:
         dw = dw_view if dw_view is not None else self.pg(wname)
         self.prog.add(tag + ".wred", self.lib.sgd_wgrad_reduce, _ptr(slabs), ksplit, taps, cout, cin, _ptr(dw), 0,
                       self.unscale)
+        if dw_view is None:
+            self.wrote(wname)
         if bias_name is not None:
             self.prog.add(tag + ".bias", self.lib.sgd_colsum, _ptr(gy), rows, cout, gy_ld, _ptr(self.pg(bias_name)), 0,
                           self.unscale, _ptr(self.cwork), self.CW)
+            self.wrote(bias_name)
 
     def gn_bwd(self, tag, srcs, hw, a, b, sums, gname, silu, gu, gu_ld, gu_mode, gres, gres_ld, gres_mode,
                film_ptr=0, film_ld=0, dfilm_ptr=0):
@@ -153,8 +173,10 @@ class Backward:
                       _ptr(dg), _ptr(db), C.c_void_p(dfilm_ptr))
         self.prog.add(tag + ".dgamma", lib.sgd_colsum, _ptr(dg), n, ct, ct, _ptr(self.pg(gname + ".weight")), 0,
                       self.unscale, _ptr(self.cwork), self.CW)
+        self.wrote(gname + ".weight")
         self.prog.add(tag + ".dbeta", lib.sgd_colsum, _ptr(db), n, ct, ct, _ptr(self.pg(gname + ".bias")), 0,
                       self.unscale, _ptr(self.cwork), self.CW)
+        self.wrote(gname + ".bias")
         off = 0
         for t, c in srcs:
             dst, acc = self.gact(t)
@@ -282,10 +304,22 @@ class Backward:
         self.wgrad("emb_layers", rec["a"], self.gfilm, fw, fw, ech, 1, n, None, None, dw_view=dwcat)
         self.prog.add("emb_layers.bias", self.lib.sgd_colsum, _ptr(self.gfilm), n, fw, fw, _ptr(dbcat), 0, self.unscale,
                       _ptr(self.cwork), self.CW)
-        self._film_split = (dwcat, dbcat, names, couts)
+        views = []
+        off = 0
+        for p, co in zip(names, couts):
+            views.append((self.pg(p + ".emb_layers.1.weight"), dwcat[off:off + 2 * co]))
+            views.append((self.pg(p + ".emb_layers.1.bias"), dbcat[off:off + 2 * co]))
+            off += 2 * co
+
+        def film_split(stream):
+            # the concatenated emb_layers gradient back into the per-ResBlock parameters (device-side slice copies)
+            for dst, src in views:
+                dst.copy_(src)
+            return 0
+        self.prog.add("emb_layers.split", film_split)
         for p in names:
-            self.pg(p + ".emb_layers.1.weight")
-            self.pg(p + ".emb_layers.1.bias")
+            self.wrote(p + ".emb_layers.1.weight")
+            self.wrote(p + ".emb_layers.1.bias")
         cat = lambda: torch.cat([w.detach() for w in wparams], 0)
         parts = [(rec["emb_t"], 0, ted)] + ([(rec["emb_c"], ted, cc)] if cc else [])
         for t, o, c in parts:
@@ -322,14 +356,11 @@ class Backward:
         h, w = self.e.h, self.e.w
         g = (geps_nchw.float() * self.gscale).contiguous()
         L.check(lib.sgd_pack_input(_ptr(g), None, None, None, n, n, c, 0, h, w, _ptr(self.geps), stream), "geps")
+        if self.reducer is not None:
+            self.reducer.start()
         self.prog.run(stream)
-        # emb_layers gradients: split the concatenated result back per ResBlock (device-side slice copies)
-        dwcat, dbcat, names, couts = self._film_split
-        off = 0
-        for p, co in zip(names, couts):
-            self.pgrad[p + ".emb_layers.1.weight"].copy_(dwcat[off:off + 2 * co])
-            self.pgrad[p + ".emb_layers.1.bias"].copy_(dbcat[off:off + 2 * co])
-            off += 2 * co
+        if self.reducer is not None:
+            self.reducer.finish()            # flush the tail bucket, join the side stream
         return self.pgrad
 
 
@@ -348,7 +379,7 @@ class _UNetTrainFn(torch.autograd.Function):
     def backward(ctx, geps):
         eng = ctx.eng
         if getattr(eng, "backward", None) is None:
-            eng.backward = Backward(eng)
+            eng.backward = make_backward(eng)
         grads = eng.backward.run(geps)
         out = []
         for name in ctx.names:
@@ -357,6 +388,22 @@ class _UNetTrainFn(torch.autograd.Function):
                 raise RuntimeError(f"no gradient produced for {name}")
             out.append(g)
         return (None, None, None) + tuple(out)
+
+
+def make_backward(eng):
+    """single process: plain gradient buffers.  torch.distributed initialised with world > 1: a dry build learns the
+    order in which the backward produces the parameter gradients, then the real program writes them into a flat
+    arena in that order and overlaps the bucketed RCCL all-reduce with the remaining launches."""
+    import torch.distributed as dist
+    world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    if world == 1 or not getattr(eng.m, "hip_ddp", True):
+        return Backward(eng)
+    from .ddp import BucketReducer, GradArena
+    dry = Backward(eng)
+    order = [(name, tuple(g.shape)) for name, g in dry.pgrad.items()]
+    del dry
+    arena = GradArena(order, eng.dev, bucket_bytes=getattr(eng.m, "hip_bucket_bytes", 64 << 20))
+    return Backward(eng, arena, BucketReducer(arena, average=False))
 
 
 def forward_train(model, x, t, cond, layout, mask, n):

@@ -150,7 +150,7 @@ class _Program:
 
     def add(self, name, fn, *args, flops=0.0, nbytes=0.0):
         self.ops.append((name, fn, args))
-        self.meta.append((fn.__name__, flops, nbytes))
+        self.meta.append((getattr(fn, "__name__", "op"), flops, nbytes))
 
     def run(self, stream):
         for name, fn, args in self.ops:

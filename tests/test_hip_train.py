@@ -66,3 +66,63 @@ def test_frozen_parameters_get_no_gradient():
 def test_training_backward_not_built_for_unetca_yet():
     with pytest.raises(NotImplementedError):
         _step("ca_stego_c32_s16", "f32")
+
+
+def _ddp_rank(rank, world, port, outdir):
+    import os
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)       # 1-GPU box: both ranks share cuda:0, gloo moves the buckets
+    grads = _grads_for_seed(100 + rank, ddp=True)
+    torch.save({k: v.cpu() for k, v in grads.items()}, os.path.join(outdir, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _grads_for_seed(seed, ddp):
+    import bench
+    from sgdm_amd.diffusion import LatentDiffusion
+    from sgdm_amd.synth import synth_batch
+    m, entry = build_model("uf_clusterlayout_c32_s16", "f32")
+    m.train()
+    m.hip_ddp = ddp
+    m.hip_bucket_bytes = 1 << 20                                       # force many buckets on the tiny model
+    d = LatentDiffusion(device="cuda", **bench.MODEL_PARAMS).train()
+    d.set_denoise_fn(m.forward, m.forward_with_cond_scale)
+    kw = entry["ctor"]
+    batch = synth_batch(kw["condition_method"], 4, 16, kw["cond_dim"], entry["layout_dim"], seed=seed)
+    g = torch.Generator().manual_seed(seed)
+    t = torch.randint(0, 1000, (4,), generator=g).cuda()
+    noise = torch.randn(4, 3, 16, 16, generator=g).cuda()
+    mask = torch.tensor([False, True, False, False]).cuda()
+    loss, _ = d.p_losses(batch["image"].cuda(), t, noise, cond=batch["cond"].float().cuda(),
+                         layout=batch["layout"].cuda(), cond_drop_prob=0.5, cond_drop_mask=mask)
+    loss.backward()
+    return {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}
+
+
+def test_ddp_bucketed_allreduce_two_ranks():
+    """world_size 2: every rank must end with the MEAN of the per-rank gradients (torch DDP semantics), produced by
+    the arena + overlapped bucket all-reduce inside the backward program"""
+    import socket
+    import tempfile
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    with tempfile.TemporaryDirectory() as td:
+        ctx = mp.get_context("spawn")
+        procs = [ctx.Process(target=_ddp_rank, args=(r, 2, port, td)) for r in range(2)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(timeout=300)
+            assert p.exitcode == 0
+        got = [torch.load(f"{td}/rank{r}.pt") for r in range(2)]
+    ref0, ref1 = _grads_for_seed(100, ddp=False), _grads_for_seed(101, ddp=False)
+    for k in ref0:
+        exp = 0.5 * (ref0[k].cpu() + ref1[k].cpu())
+        if float(exp.abs().max()) < 1e-6:
+            continue
+        for r in range(2):
+            assert max_rel(got[r][k], exp) < 1e-5, (k, r)
+    assert set(got[0]) == set(ref0)
