@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define SGD_ABI_VERSION 1
+#define SGD_ABI_VERSION 2
 int sgd_abi_version(void);
 
 /* --------------------------------------------------------------------------------------
@@ -74,7 +74,16 @@ typedef struct sgd_igemm_args {
        (orows_in == 0: identity).  Lets to_kv / to_context write into the shared K/V buffer. */
     int32_t orows_in, orows_out, orow_off;
     int32_t prec;          /* SGD_PREC_* */
+    /* train-time dropout on the activated input (nn.Dropout in ResBlock.out_layers, openaimodel.py:272):
+     * element (row, channel) is kept iff sgd_drop_hash(seed, row*C + channel) >= drop_p, survivors scaled by
+     * 1/(1-p).  Counter-based: forward, wgrad and the GroupNorm backward recompute the same mask, nothing stored. */
+    float drop_p;          /* 0: off */
+    uint32_t drop_seed;
 } sgd_igemm_args;
+
+/* the keep/drop hash, shared by device code and host tests:
+ *   h = seed ^ (lo * 0x9E3779B1) ^ (hi * 0x632BE5AB); h ^= h>>16; h *= 0x85EBCA6B; h ^= h>>13; h *= 0xC2B2AE35; h ^= h>>16;
+ *   keep  <=>  (h >> 8) >= (uint32_t)(p * 16777216)                                       (lo/hi = halves of the index) */
 
 int sgd_igemm(const sgd_igemm_args* args /* HOST pointer */, void* stream);
 
@@ -197,7 +206,8 @@ int sgd_colsum(const float* g, int32_t rows, int32_t c, int32_t ld, float* out, 
  * sgd_gn_bwd_reduce: S[n, c, 2] = (sum gpre, sum gpre * x) over the hw rows, gpre = gu * SiLU'(pre)      */
 int sgd_gn_bwd_reduce(const float* x, int32_t n, int32_t h, int32_t w, int32_t c, int32_t c_total, int32_t c_off,
                       const float* a, const float* b, int32_t silu,
-                      const float* gu, int32_t gu_ld, int32_t gu_mode, float* S, void* stream);
+                      const float* gu, int32_t gu_ld, int32_t gu_mode, float drop_p, uint32_t drop_seed,
+                      float* S, void* stream);
 /* per-(n,c) coefficients of dx = A*gpre + B*x + C from S and the forward statistics (`sums` of sgd_chan_stats),
  * plus per-sample parameter gradients dgamma_nc / dbeta_nc [n, c] (sum over n with sgd_colsum) and the FiLM
  * gradient dfilm[n, film_ld] (scale grad at +0, shift grad at +c; may be NULL). */
@@ -209,7 +219,7 @@ int sgd_gn_bwd_coef(const float* S, const float* sums, const float* gamma, const
  * written into dst (row stride dst_ld, channel offset dst_off); accumulate: add to what is there. */
 int sgd_gn_bwd_apply(const float* x, int32_t n, int32_t h, int32_t w, int32_t c, int32_t c_total, int32_t c_off,
                      const float* a, const float* b, int32_t silu,
-                     const float* gu, int32_t gu_ld, int32_t gu_mode,
+                     const float* gu, int32_t gu_ld, int32_t gu_mode, float drop_p, uint32_t drop_seed,
                      const float* A, const float* B, const float* Cc,
                      const float* gres, int32_t gres_ld, int32_t gres_mode,
                      float* dst, int32_t dst_ld, int32_t dst_off, int32_t accumulate, void* stream);

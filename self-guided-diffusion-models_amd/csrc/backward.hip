@@ -86,18 +86,18 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WArgs w) {
 #pragma unroll
                                     for (int sx = 0; sx < 2; ++sx) {
                                         long rr = ((long)n * a.hi + 2 * y + sy) * a.wi + 2 * x + sx;
-                                        uv += apply_pro(a, load_raw<VEC>(a, rr, c), load_coef<VEC>(a, n, rr, c), c);
+                                        uv += apply_pro(a, load_raw<VEC>(a, rr, c), load_coef<VEC>(a, n, rr, c), c, rr);
                                     }
                                 uv = uv * 0.25f;
                             } else {
                                 long rr = a.resample == SGD_RS_UP2 ? ((long)n * a.hi + (y >> 1)) * a.wi + (x >> 1)
                                                                    : ((long)n * a.hi + y) * a.wi + x;
-                                uv = apply_pro(a, load_raw<VEC>(a, rr, c), load_coef<VEC>(a, n, rr, c), c);
+                                uv = apply_pro(a, load_raw<VEC>(a, rr, c), load_coef<VEC>(a, n, rr, c), c, rr);
                             }
                         }
                     } else {
                         const int n = a.pro == SGD_PRO_AFFINE_NC ? row / a.rows_per_n : 0;
-                        uv = apply_pro(a, load_raw<VEC>(a, row, c), load_coef<VEC>(a, n, row, c), c);
+                        uv = apply_pro(a, load_raw<VEC>(a, row, c), load_coef<VEC>(a, n, row, c), c, row);
                     }
                 }
             }
@@ -197,11 +197,21 @@ __device__ __forceinline__ f32x4 fetch_g(const float* g, int ld, int mode, int n
     return s;
 }
 
+// gradient through the train-time dropout that sits between the activation and the consumer conv
+__device__ __forceinline__ f32x4 drop_mask(f32x4 g, float p, uint32_t seed, long base) {
+    const uint32_t thr = (uint32_t)(p * 16777216.f);
+    const float inv = 1.0f / (1.0f - p);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) g[j] = sgd_drop_keep(seed, base + j, thr) ? g[j] * inv : 0.f;
+    return g;
+}
+
 // block per (n, 32-channel slab): 8 channel quads x 32 row lanes
 __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const float* __restrict__ x, int h, int w, int c,
                                                             int c_total, int c_off, const float* __restrict__ a,
                                                             const float* __restrict__ b, int silu,
                                                             const float* __restrict__ gu, int gu_ld, int gu_mode,
+                                                            float drop_p, uint32_t drop_seed,
                                                             float* __restrict__ S) {
     const int slabs = (c + 31) / 32;
     const int n = blockIdx.x / slabs, slab = blockIdx.x % slabs;
@@ -214,6 +224,7 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const float* __restr
         for (int p = rl; p < hw; p += 32) {
             const f32x4 xv = ld4(x + ((long)n * hw + p) * c + ch);
             f32x4 gv = fetch_g(gu, gu_ld, gu_mode, n, p / w, p % w, h, w, c_off + ch);
+            if (drop_p > 0.f) gv = drop_mask(gv, drop_p, drop_seed, ((long)n * hw + p) * c_total + c_off + ch);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 float gp = gv[j];
@@ -282,7 +293,8 @@ __global__ void gn_bwd_coef_kernel(const float* __restrict__ S, const float* __r
 
 __global__ void gn_bwd_apply_kernel(const float* __restrict__ x, int n, int h, int w, int c, int c_total, int c_off,
                                     const float* __restrict__ a, const float* __restrict__ b, int silu,
-                                    const float* __restrict__ gu, int gu_ld, int gu_mode,
+                                    const float* __restrict__ gu, int gu_ld, int gu_mode, float drop_p,
+                                    uint32_t drop_seed,
                                     const float* __restrict__ A, const float* __restrict__ B,
                                     const float* __restrict__ Cc, const float* __restrict__ gres, int gres_ld,
                                     int gres_mode, float* __restrict__ dst, int dst_ld, int dst_off, int accumulate) {
@@ -296,6 +308,7 @@ __global__ void gn_bwd_apply_kernel(const float* __restrict__ x, int n, int h, i
         const long ci = (long)nn * c_total + c_off + ch;
         const f32x4 xv = ld4(x + row * c + ch);
         f32x4 gv = fetch_g(gu, gu_ld, gu_mode, nn, y, xx, h, w, c_off + ch);
+        if (drop_p > 0.f) gv = drop_mask(gv, drop_p, drop_seed, row * c_total + c_off + ch);
         if (silu) {
             const f32x4 av = ld4(a + ci), bv = ld4(b + ci);
 #pragma unroll
@@ -416,14 +429,15 @@ extern "C" int sgd_colsum(const float* g, int32_t rows, int32_t c, int32_t ld, f
 
 extern "C" int sgd_gn_bwd_reduce(const float* x, int32_t n, int32_t h, int32_t w, int32_t c, int32_t c_total,
                                  int32_t c_off, const float* a, const float* b, int32_t silu, const float* gu,
-                                 int32_t gu_ld, int32_t gu_mode, float* S, void* stream) {
+                                 int32_t gu_ld, int32_t gu_mode, float drop_p, uint32_t drop_seed, float* S,
+                                 void* stream) {
     SGD_CLEAR_ERR();
     if (!x || !a || !b || !gu || !S || n <= 0 || h <= 0 || w <= 0 || c <= 0 || (c & 3) || (c_off & 3) ||
         c_off + c > c_total || (gu_ld & 3))
         return SGD_ERR_ARG;
     if (gu_mode == SGD_RS_AVGPOOL2 && ((h | w) & 1)) return SGD_ERR_ARG;
     hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(n * ((c + 31) / 32)), dim3(256), 0, (hipStream_t)stream, x, h, w, c,
-                       c_total, c_off, a, b, silu, gu, gu_ld, gu_mode, S);
+                       c_total, c_off, a, b, silu, gu, gu_ld, gu_mode, drop_p, drop_seed, S);
     return sgd_check_launch();
 }
 
@@ -443,7 +457,8 @@ extern "C" int sgd_gn_bwd_coef(const float* S, const float* sums, const float* g
 
 extern "C" int sgd_gn_bwd_apply(const float* x, int32_t n, int32_t h, int32_t w, int32_t c, int32_t c_total,
                                 int32_t c_off, const float* a, const float* b, int32_t silu, const float* gu,
-                                int32_t gu_ld, int32_t gu_mode, const float* A, const float* B, const float* Cc,
+                                int32_t gu_ld, int32_t gu_mode, float drop_p, uint32_t drop_seed, const float* A,
+                                const float* B, const float* Cc,
                                 const float* gres, int32_t gres_ld, int32_t gres_mode, float* dst, int32_t dst_ld,
                                 int32_t dst_off, int32_t accumulate, void* stream) {
     SGD_CLEAR_ERR();
@@ -451,7 +466,7 @@ extern "C" int sgd_gn_bwd_apply(const float* x, int32_t n, int32_t h, int32_t w,
         (c_off & 3) || c_off + c > c_total || (gu_ld & 3) || (dst_ld & 3) || (dst_off & 3) || (gres && (gres_ld & 3)))
         return SGD_ERR_ARG;
     hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(nblk((long)n * h * w * (c / 4), 65536)), dim3(256), 0,
-                       (hipStream_t)stream, x, n, h, w, c, c_total, c_off, a, b, silu, gu, gu_ld, gu_mode, A, B, Cc,
+                       (hipStream_t)stream, x, n, h, w, c, c_total, c_off, a, b, silu, gu, gu_ld, gu_mode, drop_p, drop_seed, A, B, Cc,
                        gres, gres_ld, gres_mode, dst, dst_ld, dst_off, accumulate);
     return sgd_check_launch();
 }

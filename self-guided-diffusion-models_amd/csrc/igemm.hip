@@ -354,11 +354,11 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
 #pragma unroll
                         for (int dx = 0; dx < 2; ++dx) {
                             long r = (long)e.x + dy * a.wi + dx;
-                            v += apply_pro(a, load_raw<VEC>(a, r, c), load_coef<VEC>(a, e.y, r, c), c);
+                            v += apply_pro(a, load_raw<VEC>(a, r, c), load_coef<VEC>(a, e.y, r, c), c, r);
                         }
                     v = v * 0.25f;
                 } else {
-                    v = apply_pro(a, load_raw<VEC>(a, e.x, c), load_coef<VEC>(a, e.y, e.x, c), c);
+                    v = apply_pro(a, load_raw<VEC>(a, e.x, c), load_coef<VEC>(a, e.y, e.x, c), c, e.x);
                 }
             }
             lds_store_act<PREC>(abuf + (size_t)pix * LDA, c4, v);
@@ -378,7 +378,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
                 const int pix = idx >> 3;
                 const int2 e = entry(tab, pix);
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (c < cin && e.x >= 0) v = apply_pro(a, raw, kuni ? *kuni : load_coef<VEC>(a, e.y, e.x, c), c);
+                if (c < cin && e.x >= 0) v = apply_pro(a, raw, kuni ? *kuni : load_coef<VEC>(a, e.y, e.x, c), c, e.x);
                 lds_store_act<PREC>(abuf + (size_t)pix * LDA, c4, v);
             }
         };

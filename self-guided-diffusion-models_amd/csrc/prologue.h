@@ -56,7 +56,7 @@ __device__ __forceinline__ Coef load_coef(const sgd_igemm_args& a, int n, long r
     return k;
 }
 
-__device__ __forceinline__ f32x4 apply_pro(const sgd_igemm_args& a, f32x4 v, const Coef& k, int c) {
+__device__ __forceinline__ f32x4 apply_pro(const sgd_igemm_args& a, f32x4 v, const Coef& k, int c, long row) {
     if (a.pro == SGD_PRO_AFFINE_NC) {
         v = v * k.p + k.q;
     } else if (a.pro == SGD_PRO_LN_ROW) {
@@ -73,6 +73,13 @@ __device__ __forceinline__ f32x4 apply_pro(const sgd_igemm_args& a, f32x4 v, con
     if (a.pro_silu) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = sgd_silu(v[j]);
+    }
+    if (a.drop_p > 0.f) {
+        const uint32_t thr = (uint32_t)(a.drop_p * 16777216.f);
+        const float inv = 1.0f / (1.0f - a.drop_p);
+        const long base = row * (a.c0 + a.c1) + c;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = sgd_drop_keep(a.drop_seed, base + j, thr) ? v[j] * inv : 0.f;
     }
     return v;
 }

@@ -16,6 +16,13 @@ __device__ __forceinline__ float sgd_silu(float v) {
     return v / (1.0f + __expf(-v));
 }
 
+// counter-based dropout mask (include/sgdm_hip.h: sgd_igemm_args.drop_p)
+__device__ __forceinline__ bool sgd_drop_keep(uint32_t seed, long idx, uint32_t thr24) {
+    uint32_t h = seed ^ ((uint32_t)idx * 0x9E3779B1u) ^ ((uint32_t)((unsigned long)idx >> 32) * 0x632BE5ABu);
+    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+    return (h >> 8) >= thr24;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

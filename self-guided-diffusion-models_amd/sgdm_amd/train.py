@@ -154,7 +154,7 @@ class Backward:
             self.wrote(bias_name)
 
     def gn_bwd(self, tag, srcs, hw, a, b, sums, gname, silu, gu, gu_ld, gu_mode, gres, gres_ld, gres_mode,
-               film_ptr=0, film_ld=0, dfilm_ptr=0):
+               film_ptr=0, film_ld=0, dfilm_ptr=0, drop=(0.0, 0)):
         """GroupNorm(+FiLM)[+SiLU] backward over a (virtual concat of) source tensor(s); writes/accumulates the
         input gradients into the sources' gradient buffers."""
         n, lib = self.n, self.lib
@@ -164,7 +164,7 @@ class Backward:
         off = 0
         for t, c in srcs:
             self.prog.add(tag + ".reduce", lib.sgd_gn_bwd_reduce, _ptr(t), n, h, w, c, ct, off, _ptr(a), _ptr(b), silu,
-                          _ptr(gu), gu_ld, gu_mode, _ptr(S))
+                          _ptr(gu), gu_ld, gu_mode, drop[0], drop[1], _ptr(S))
             off += c
         A, B, Cc, dg, db = (self.buf(n, ct) for _ in range(5))
         gamma, beta = self.m.P(gname + ".weight"), self.m.P(gname + ".bias")
@@ -181,7 +181,8 @@ class Backward:
         for t, c in srcs:
             dst, acc = self.gact(t)
             self.prog.add(tag + ".apply", lib.sgd_gn_bwd_apply, _ptr(t), n, h, w, c, ct, off, _ptr(a), _ptr(b), silu,
-                          _ptr(gu), gu_ld, gu_mode, _ptr(A), _ptr(B), _ptr(Cc), _ptr(gres) if gres is not None else None,
+                          _ptr(gu), gu_ld, gu_mode, drop[0], drop[1], _ptr(A), _ptr(B), _ptr(Cc),
+                          _ptr(gres) if gres is not None else None,
                           gres_ld, gres_mode, _ptr(dst), c, 0, acc)
             off += c
 
@@ -245,7 +246,7 @@ class Backward:
         self.G[rec["h1"].data_ptr()] = [self.buf(*rec["h1"].shape), False]
         self.gn_bwd(p + ".out_layers.0", [(rec["h1"], cout)], (ho, wo), rec["a2"], rec["b2"], rec["sums2"],
                     p + ".out_layers.0", 1, gu2, cout, L.RS_NONE, None, 0, 0, film_ptr=film_ptr, film_ld=e.film_ld,
-                    dfilm_ptr=dfilm_ptr)
+                    dfilm_ptr=dfilm_ptr, drop=(rec["drop_p"], rec["drop_seed"]))
         gh1 = self.gread(rec["h1"])
         # conv1 (in_layers.2)
         w1 = P(p + ".in_layers.2.weight")
@@ -370,7 +371,7 @@ class _UNetTrainFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, eng, args, *params):
         x, t, cond, layout, mask = args
-        eng.run(x, t, cond, layout, mask)
+        eng.run(x, t, cond, layout, mask, train=True)
         ctx.model, ctx.eng = model, eng
         ctx.names = [n for n, p in model.named_parameters() if p.requires_grad]
         return model._to_nchw(eng)
@@ -408,9 +409,6 @@ def make_backward(eng):
 
 def forward_train(model, x, t, cond, layout, mask, n):
     """autograd-capable UNet evaluation (called from UNetModelBase._run when grads are required)"""
-    if model.dropout and model.dropout > 0:
-        raise NotImplementedError("train-time dropout (openaimodel.py:272) is not fused into the HIP path yet; "
-                                  "construct the model with dropout=0 (unetca_fast's default) to train")
     B, cx, H, W = x.shape
     prec = L.PREC_BY_NAME[model.hip_precision]
     eng = model._engine(n, H, W, prec)

@@ -391,7 +391,9 @@ class _Engine:
         self.packed = []
         self.bufs = []
         self.tape = []            # forward structure, walked in reverse by train.build_backward
+        self.drops = []           # (igemm args, p box, seed box) of the launches that apply train-time dropout
         self.lse = {}             # attention log-sum-exp buffers (written only when present)
+        self._p_drop = 0.0
         self._build()
 
     # ---- helpers
@@ -585,7 +587,10 @@ class _Engine:
         ac2 = self.igemm(p + ".out_layers.3", h1, cout, y, cout, self.pack([p + ".out_layers.3.weight"], 3),
                          conv=(n, ho, wo, ho, wo, 1, L.RS_NONE), pro=L.PRO_AFFINE_NC, silu=1, pa=a2, pb=b2,
                          bias=P(p + ".out_layers.3.bias"), res=res, res_mode=res_mode)
-        self.tape.append(dict(kind="res", p=p, srcs=[(t0, c0)] + ([(t1, c1)] if t1 is not None else []), cin=cin,
+        pbox, sbox = C.c_float(0.0), C.c_uint32(0)
+        self.drops.append((ac2, pbox, sbox))                  # nn.Dropout sits in front of conv2 (openaimodel.py:272)
+        self.tape.append(dict(kind="res", drop_p=pbox, drop_seed=sbox, p=p,
+                              srcs=[(t0, c0)] + ([(t1, c1)] if t1 is not None else []), cin=cin,
                               cout=cout, hw_in=(hh, ww), hw_out=(ho, wo), rs=rs, a1=a1, b1=b1, sums1=sums1, h1=h1,
                               a2=a2, b2=b2, sums2=sums2, film_off=self.film_off[p], conv1=ac1, conv2=ac2, skip=ask,
                               y=y))
@@ -602,10 +607,17 @@ class _Engine:
             self._film_bias.copy_(torch.cat([b.detach().reshape(-1) for b in self._film_bias_src]))
             self._film_sig = sig
 
-    def run(self, x, t, cond, layout, mask):
+    def run(self, x, t, cond, layout, mask, train=False):
         m, n, lib = self.m, self.n, self.lib
         stream = torch.cuda.current_stream().cuda_stream
         self.refresh(stream)
+        p_drop = float(m.dropout) if (train and m.dropout) else 0.0      # (grad mode is off inside autograd.Function)
+        if p_drop != self._p_drop or p_drop > 0:
+            seeds = torch.randint(0, 2 ** 31 - 1, (len(self.drops),)).tolist() if p_drop > 0 else [0] * len(self.drops)
+            for (a, pbox, sbox), sd in zip(self.drops, seeds):
+                a.drop_p, a.drop_seed = p_drop, sd
+                pbox.value, sbox.value = p_drop, sd
+            self._p_drop = p_drop
         B = x.shape[0]
         assert n % B == 0
         x = x.contiguous().float()

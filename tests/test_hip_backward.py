@@ -145,7 +145,7 @@ def test_groupnorm_silu_backward(gu_mode, silu, film):
                             _p(b), _stream()), "coef")
     gud, gsd = _nhwc(gu).cuda(), _nhwc(gs).cuda()
     S = torch.empty(n, c, 2, device="cuda")
-    L.check(lib.sgd_gn_bwd_reduce(_p(xd), n, h, h, c, c, 0, _p(a), _p(b), silu, _p(gud), c, gu_mode, _p(S), _stream()),
+    L.check(lib.sgd_gn_bwd_reduce(_p(xd), n, h, h, c, c, 0, _p(a), _p(b), silu, _p(gud), c, gu_mode, 0.0, 0, _p(S), _stream()),
             "reduce")
     A, B, Cc = (torch.empty(n, c, device="cuda") for _ in range(3))
     dg, db = torch.empty(n, c, device="cuda"), torch.empty(n, c, device="cuda")
@@ -153,7 +153,7 @@ def test_groupnorm_silu_backward(gu_mode, silu, film):
     L.check(lib.sgd_gn_bwd_coef(_p(S), _p(sums), _p(gd), _p(bd), _p(fd) if film else None, 2 * c, n, c, 32, hw, 1e-5,
                                 _p(A), _p(B), _p(Cc), _p(dg), _p(db), _p(dfilm) if film else None, _stream()), "bcoef")
     dx = torch.full((n, h, h, c), float("nan"), device="cuda")
-    L.check(lib.sgd_gn_bwd_apply(_p(xd), n, h, h, c, c, 0, _p(a), _p(b), silu, _p(gud), c, gu_mode, _p(A), _p(B),
+    L.check(lib.sgd_gn_bwd_apply(_p(xd), n, h, h, c, c, 0, _p(a), _p(b), silu, _p(gud), c, gu_mode, 0.0, 0, _p(A), _p(B),
                                  _p(Cc), _p(gsd), c, gu_mode, _p(dx), c, 0, 0, _stream()), "apply")
     assert max_rel(dx.cpu().permute(0, 3, 1, 2), x.grad) < 2e-5
     assert max_rel(dg.cpu().sum(0), gamma.grad) < 2e-5

@@ -126,3 +126,74 @@ def test_ddp_bucketed_allreduce_two_ranks():
         for r in range(2):
             assert max_rel(got[r][k], exp) < 1e-5, (k, r)
     assert set(got[0]) == set(ref0)
+
+
+def _host_keep_mask(seed, n_rows, c, p):
+    """numpy re-statement of sgd_drop_keep (include/sgdm_hip.h) for element index row*c + channel"""
+    idx = np.arange(n_rows * c, dtype=np.uint64)
+    lo, hi = (idx & 0xFFFFFFFF).astype(np.uint64), (idx >> np.uint64(32)).astype(np.uint64)
+    h = (np.uint64(seed) ^ (lo * np.uint64(0x9E3779B1)) ^ (hi * np.uint64(0x632BE5AB))) & np.uint64(0xFFFFFFFF)
+    h ^= h >> np.uint64(16); h = (h * np.uint64(0x85EBCA6B)) & np.uint64(0xFFFFFFFF)
+    h ^= h >> np.uint64(13); h = (h * np.uint64(0xC2B2AE35)) & np.uint64(0xFFFFFFFF)
+    h ^= h >> np.uint64(16)
+    return ((h >> np.uint64(8)) >= np.uint64(int(np.float32(p) * np.float32(16777216.0)))).reshape(n_rows, c)
+
+
+def test_train_step_with_dropout_matches_oracle_on_the_same_masks():
+    """train-time dropout (openaimodel.py:272) is a counter-based mask recomputed by forward, wgrad and the
+    GroupNorm backward; feed the very same masks to the oracle and compare loss + all gradients"""
+    import bench
+    from conftest import cfg_from_index
+    from oracle import diffusion_ref as D
+    from oracle import unet_ref as U
+    from sgdm_amd import _lib as L
+    from sgdm_amd.diffusion import LatentDiffusion
+    from sgdm_amd.synth import synth_batch, weights_from_seed
+    name = "uf_clusterlayout_c32_s16"
+    m, entry = build_model(name, "f32")
+    m.dropout = 0.25
+    m.train()
+    d = LatentDiffusion(device="cuda", **bench.MODEL_PARAMS).train()
+    d.set_denoise_fn(m.forward, m.forward_with_cond_scale)
+    kw = entry["ctor"]
+    batch = synth_batch(kw["condition_method"], 4, 16, kw["cond_dim"], entry["layout_dim"], seed=31)
+    g = torch.Generator().manual_seed(31)
+    t = torch.randint(0, 1000, (4,), generator=g)
+    noise = torch.randn(4, 3, 16, 16, generator=g)
+    mask = torch.tensor([False, True, False, False])
+    loss, _ = d.p_losses(batch["image"].cuda(), t.cuda(), noise.cuda(), cond=batch["cond"].float().cuda(),
+                         layout=batch["layout"].cuda(), cond_drop_prob=0.5, cond_drop_mask=mask.cuda())
+    loss.backward()
+    eng = m._engines[(4, 16, 16, L.PREC_F32)]
+    # rebuild the masks on the host from the seeds the engine used
+    masks, kept = {}, []
+    for rec in eng.tape:
+        if rec["kind"] != "res":
+            continue
+        n_, ho, wo, co = rec["h1"].shape
+        keep = _host_keep_mask(rec["drop_seed"].value, n_ * ho * wo, co, 0.25)
+        kept.append(keep.mean())
+        masks[rec["p"]] = torch.from_numpy(keep.reshape(n_, ho, wo, co).transpose(0, 3, 1, 2).astype(np.float32)) / 0.75
+    assert abs(np.mean(kept) - 0.75) < 0.01
+    cfg = cfg_from_index(entry)
+    sd = {k: tt.clone().requires_grad_(kind == "param")
+          for (k, _, kind), tt in zip(entry["manifest"], weights_from_seed(entry["manifest"], entry["seed"]).values())}
+    fn = lambda xn, tt: U.unet_forward(cfg, sd, xn, tt, batch["cond"].float(), batch["layout"], mask, dropout_masks=masks)
+    l, _, _, _ = D.p_losses(D.make_schedule(), fn, batch["image"], t, noise)
+    l.backward()
+    assert abs(loss.item() - l.item()) < 2e-5 * abs(l.item())
+    bad = []
+    for k, p in m.named_parameters():
+        if p.requires_grad and float(sd[k].grad.abs().max()) > 1e-6:
+            e = max_rel(p.grad.cpu(), sd[k].grad)
+            if e > 5e-5:
+                bad.append((k, e))
+    assert not bad, bad[:5]
+    # eval mode: dropout off, deterministic
+    m.eval()
+    with torch.no_grad():
+        e1 = m(batch["image"].cuda(), t.cuda(), cond=batch["cond"].float().cuda(), layout=batch["layout"].cuda(),
+               cond_drop_prob=0.0)[0]
+        e2 = m(batch["image"].cuda(), t.cuda(), cond=batch["cond"].float().cuda(), layout=batch["layout"].cuda(),
+               cond_drop_prob=0.0)[0]
+    assert torch.equal(e1, e2)
