@@ -119,6 +119,46 @@ def cpu_baseline(wl, sd, seconds_budget=25.0):
                 s_per_step_bs8=per_step)
 
 
+def train_step_bench(model, diff, data, cond, layout, B, world, barrier, wl, steps=4, warmup=2):
+    """train-step ms (max over ranks): forward_tao -> loss.backward() (bucketed all-reduce inside) -> AdamW -> EMA"""
+    import torch.distributed as dist
+    from sgdm_amd.ema import LitEma
+    if model.KIND != "unet_fast":
+        return dict(ms=None, note="training backward is built for unet_fast only (unetca_fast: next row)")
+    dev = next(model.parameters()).device
+    model.train()
+    diff.train()
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=0.01)      # optim/adamw.yaml, data lr/wd
+    ema = LitEma(model)
+    x = data["image"].to(dev)
+
+    def step():
+        loss, _ = diff.forward_tao(x, cond=cond, layout=layout, cond_drop_prob=0.1)
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+        ema(model)
+        return loss
+
+    for _ in range(warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    model.eval()
+    diff.eval()
+    return dict(ms=round(1000.0 * float(tt.item()) / steps, 2), batch_per_gpu=B, global_batch=B * world, steps=steps,
+                dropout=float(model.dropout), loss=round(float(loss.item()), 4),
+                includes="q_sample + UNet fwd/bwd + bucketed RCCL grad all-reduce (overlapped) + AdamW + EMA",
+                algorithmic_tflop=round(3 * B * wl["gflop_per_eval_img"] / 1e3, 3))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -129,6 +169,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--no-train", action="store_true")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -185,6 +226,12 @@ def main():
     value = world * B / (1000.0 * (elapsed / args.steps))
     assert torch.isfinite(x).all()
 
+    # ---- second half of BASELINE.json's metric: DDPM train-step time (q_sample + UNet fwd/bwd + RCCL gradient
+    # all-reduce overlapped with backward + AdamW + EMA), per-GPU batch of the config, dropout as configured
+    train = None
+    if not args.no_train:
+        train = train_step_bench(model, diff, data, cond, layout, B, world, barrier, wl)
+
     out = None
     if rank == 0:
         # ---- instrumented pass: HIP events around every launch of the UNet program (same stream)
@@ -224,7 +271,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": wl["desc"], "batch_per_gpu": B, "unet_batch": 2 * B, "precision_mode": args.prec,
                        "algorithmic_tflop_per_step": round(2 * B * wl["gflop_per_eval_img"] / 1e3, 3)},
-            "roofline": roof, "cpu_baseline": cpu,
+            "roofline": roof, "cpu_baseline": cpu, "train_step": train,
         }
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -17,7 +17,6 @@ a = ap.parse_args()
 dev = torch.device("cuda", 0)
 wl = bench.WORKLOADS["c2"]
 m, sd, data = bench.build_model(wl, dev, a.prec, a.batch)
-m.dropout = 0.0
 m.train()
 d = LatentDiffusion(device="cuda", **bench.MODEL_PARAMS).train()
 d.set_denoise_fn(m.forward, m.forward_with_cond_scale)
