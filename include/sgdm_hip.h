@@ -38,7 +38,8 @@ int sgd_abi_version(void);
  *   time/cond MLPs, emb_layers  openaimodel.py:570-574,603-607,262-268
  * -------------------------------------------------------------------------------------- */
 enum { SGD_MODE_FLAT = 0, SGD_MODE_CONV3 = 1 };
-enum { SGD_RS_NONE = 0, SGD_RS_AVGPOOL2 = 1, SGD_RS_UP2 = 2 };
+enum { SGD_RS_NONE = 0, SGD_RS_AVGPOOL2 = 1, SGD_RS_UP2 = 2,
+       SGD_RS_ZEROUP2 = 3 /* x2 zero insertion: input of the adjoint of a stride-2 conv (Downsample backward) */ };
 enum { SGD_PRO_NONE = 0, SGD_PRO_AFFINE_NC = 1, SGD_PRO_LN_ROW = 2 };
 enum { SGD_PREC_F32 = 0, SGD_PREC_F16X3 = 1, SGD_PREC_BF16X3 = 2 };
 
@@ -226,8 +227,19 @@ int sgd_gn_bwd_apply(const float* x, int32_t n, int32_t h, int32_t w, int32_t c,
 /* plain SiLU backward for the embedding MLPs: gx = g * SiLU'(x) (rows x c, contiguous) */
 int sgd_silu_bwd(const float* x, const float* g, int64_t count, float* gx, void* stream);
 
+/* LayerNorm backward (autograd of crossattetion_lr.py:36-43 / nn.LayerNorm): g = dL/dy for y = xhat*gamma + beta.
+ * dst (+)= dL/dx (+ gres, the gradient of a residual branch around the norm, may be NULL);
+ * gxhat[row, c] = g*xhat (column-sum it for dgamma; dbeta = column sum of g); gxhat may be NULL. */
+int sgd_ln_bwd(const float* x, const float* g, const float* gamma, int32_t rows, int32_t c, float eps,
+               float* dst, int32_t accumulate, float* gxhat, const float* gres, void* stream);
+/* adjoint of nearest-upsample x2 (mode SGD_RS_UP2: g at 2x res) / avg-pool 2x2 (SGD_RS_AVGPOOL2: g at 1/2 res):
+ * dst[n,h,w,c] (+)= resample^T(g)   (openaimodel_ca.py:128 Upsample, openaimodel.py:200 Downsample) */
+int sgd_resample_bwd(const float* g, int32_t n, int32_t h, int32_t w, int32_t c, int32_t mode, float* dst,
+                     int32_t accumulate, void* stream);
+
 /* legacy QKV attention backward (autograd of openaimodel.py:403-420), same addressing as sgd_attention:
- * dq/dk/dv are written with the same row strides / head strides as q/k/v (i.e. into a gqkv tensor). */
+ * dq/dk/dv are written with the same row strides / head strides as q/k/v (i.e. into a gqkv tensor).
+ * Multi-query (kv_hs == 0, crossattetion_lr.py:115-137): dk/dv are summed over the heads inside the kernel. */
 int sgd_attention_bwd(const float* q, int32_t q_ld, int32_t q_hs, const float* k, const float* v, int32_t kv_ld,
                       int32_t kv_hs, const float* o /* forward output */, int32_t o_ld,
                       const float* dout, int32_t dout_ld, const float* lse /* from sgd_attention */,

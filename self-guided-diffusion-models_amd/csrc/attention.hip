@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(
     const float* __restrict__ q, int q_ld, int q_hs, const float* __restrict__ k, const float* __restrict__ v,
     int kv_ld, int kv_hs, const float* __restrict__ dout, int dout_ld, const float* __restrict__ lse,
     const float* __restrict__ dvec, int tq, int tk, float scale, float* __restrict__ dq, float* __restrict__ dk,
-    float* __restrict__ dv) {
+    float* __restrict__ dv, int heads, int mq) {
     constexpr int LD = D + 4;
     constexpr int DT = (D + 31) / 32;
     constexpr int TT = 64;                               // streamed rows per LDS tile
@@ -181,12 +181,22 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
-    const int head = blockIdx.y, b = blockIdx.z, heads = gridDim.y;
+    // multi-query (kv_hs == 0): the kv sweep walks all heads inside one block so dK/dV of the shared keys are
+    // summed in registers (gridDim.y == 1, `heads` passed explicitly); otherwise one head per block.
+    const int b = blockIdx.z;
+    const int head0 = mq ? 0 : blockIdx.y, head1 = mq ? heads : blockIdx.y + 1;
     const int own_n = SWEEP == 0 ? tk : tq;              // rows on the owner side
     const int str_n = SWEEP == 0 ? tq : tk;              // rows on the streamed side
     const int oi = blockIdx.x * 128 + wave * 32 + li;    // this lane's owned row (key or query)
     const int oc = oi < own_n ? oi : own_n - 1;
 
+    f32x16 accA[DT], accB[DT];        // kv: dK^T, dV^T   q: dQ^T (accB unused)
+#pragma unroll
+    for (int i = 0; i < DT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { accA[i][r] = 0.f; accB[i][r] = 0.f; }
+    int head = head0;
+    for (; head < head1; ++head) {
     const float* qb = q + (long)b * tq * q_ld + head * q_hs;
     const float* kb = k + (long)b * tk * kv_ld + head * kv_hs;
     const float* vb = v + (long)b * tk * kv_ld + head * kv_hs;
@@ -207,12 +217,6 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(
     }
     float own_lse = 0.f, own_d = 0.f;
     if (SWEEP == 1) { own_lse = lseb[oc]; own_d = dvb[oc]; }
-
-    f32x16 accA[DT], accB[DT];        // kv: dK^T, dV^T   q: dQ^T (accB unused)
-#pragma unroll
-    for (int i = 0; i < DT; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { accA[i][r] = 0.f; accB[i][r] = 0.f; }
 
     for (int t0 = 0; t0 < str_n; t0 += TT) {
         __syncthreads();
@@ -282,6 +286,8 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(
                 }
         }
     }
+    }
+    head = head0;
     if (oi < own_n) {
         // acc rows = d (4 consecutive per register quad), cols = owned row (lane)
         float* pa = SWEEP == 0 ? dk + ((long)b * tk + oi) * kv_ld + head * kv_hs : dq + ((long)b * tq + oi) * q_ld + head * q_hs;
@@ -331,15 +337,15 @@ extern "C" int sgd_attention_bwd(const float* q, int32_t q_ld, int32_t q_hs, con
         tk <= 0)
         return SGD_ERR_ARG;
     if ((q_ld & 3) || (q_hs & 3) || (kv_ld & 3) || (kv_hs & 3) || (o_ld & 3) || (dout_ld & 3)) return SGD_ERR_ARG;
-    if (kv_hs == 0 && heads > 1) return SGD_ERR_ARG;      // multi-query dK/dV need a sum over heads: not built yet
     hipStream_t st = (hipStream_t)stream;
-    dim3 gp((heads * tq + 255) / 256, batch), gkv((tk + 127) / 128, heads, batch), gq((tq + 127) / 128, heads, batch);
+    const int mq = (kv_hs == 0 && heads > 1) ? 1 : 0;
+    dim3 gp((heads * tq + 255) / 256, batch), gkv((tk + 127) / 128, mq ? 1 : heads, batch), gq((tq + 127) / 128, heads, batch);
 #define SGD_ATTN_BWD(DD)                                                                                              \
     hipLaunchKernelGGL((attn_bwd_prep_kernel<DD>), gp, dim3(256), 0, st, o, o_ld, dout, dout_ld, heads, tq, dvec);      \
     hipLaunchKernelGGL((attention_bwd_kernel<DD, 0>), gkv, dim3(256), 0, st, q, q_ld, q_hs, k, v, kv_ld, kv_hs, dout,   \
-                       dout_ld, lse, dvec, tq, tk, scale, dq, dk, dv);                                                 \
+                       dout_ld, lse, dvec, tq, tk, scale, dq, dk, dv, heads, mq);                                      \
     hipLaunchKernelGGL((attention_bwd_kernel<DD, 1>), gq, dim3(256), 0, st, q, q_ld, q_hs, k, v, kv_ld, kv_hs, dout,    \
-                       dout_ld, lse, dvec, tq, tk, scale, dq, dk, dv);
+                       dout_ld, lse, dvec, tq, tk, scale, dq, dk, dv, heads, 0);
     switch (d) {
         case 16: SGD_ATTN_BWD(16) break;
         case 32: SGD_ATTN_BWD(32) break;

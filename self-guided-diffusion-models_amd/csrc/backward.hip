@@ -322,6 +322,25 @@ __global__ void gn_bwd_apply_kernel(const float* __restrict__ x, int n, int h, i
     }
 }
 
+
+// adjoint of the 2x resamplers applied to a gradient map (Upsample / avg-pool Downsample layers):
+//   mode UP2 (forward nearest-upsampled): dst[n,y,x,:] (+)= sum of the 2x2 block of g (g at 2x resolution)
+//   mode AVGPOOL2 (forward pooled)      : dst[n,y,x,:] (+)= g[n,y/2,x/2,:] / 4      (g at 1/2 resolution)
+__global__ void resample_bwd_kernel(const float* __restrict__ g, int n, int h, int w, int c, int mode,
+                                    float* __restrict__ dst, int accumulate) {
+    const int cq = c >> 2;
+    const long total = (long)n * h * w * cq;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int ch = (int)(i % cq) * 4;
+        const long row = i / cq;
+        const int p = row % (h * w), nn = row / (h * w);
+        f32x4 o = fetch_g(g, c, mode, nn, p / w, p % w, h, w, ch);
+        float* dp = dst + row * c + ch;
+        if (accumulate) o += ld4(dp);
+        *reinterpret_cast<f32x4*>(dp) = o;
+    }
+}
+
 __global__ void silu_bwd_kernel(const float* __restrict__ x, const float* __restrict__ g, long count,
                                 float* __restrict__ gx) {
     const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
@@ -493,5 +512,15 @@ extern "C" int sgd_mse_loss(const float* eps_nhwc, const float* noise_nchw, int3
     if (!eps_nhwc || !noise_nchw || !per_sample || b <= 0 || c <= 0 || hw <= 0) return SGD_ERR_ARG;
     hipLaunchKernelGGL(mse_loss_kernel, dim3(b), dim3(256), 0, (hipStream_t)stream, eps_nhwc, noise_nchw, b, c, hw,
                        per_sample, geps_nhwc);
+    return sgd_check_launch();
+}
+
+extern "C" int sgd_resample_bwd(const float* g, int32_t n, int32_t h, int32_t w, int32_t c, int32_t mode, float* dst,
+                                int32_t accumulate, void* stream) {
+    SGD_CLEAR_ERR();
+    if (!g || !dst || n <= 0 || h <= 0 || w <= 0 || c <= 0 || (c & 3) || (mode != SGD_RS_UP2 && mode != SGD_RS_AVGPOOL2))
+        return SGD_ERR_ARG;
+    hipLaunchKernelGGL(resample_bwd_kernel, dim3(nblk((long)n * h * w * (c / 4), 65536)), dim3(256), 0,
+                       (hipStream_t)stream, g, n, h, w, c, mode, dst, accumulate);
     return sgd_check_launch();
 }

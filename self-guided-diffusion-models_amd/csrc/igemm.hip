@@ -232,6 +232,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
                 if (n < a.n && y >= 0 && y < g.hc && x >= 0 && x < g.wc) {
                     if (a.resample == SGD_RS_UP2) e.x = (n * a.hi + (y >> 1)) * a.wi + (x >> 1);
                     else if (a.resample == SGD_RS_AVGPOOL2) e.x = (n * a.hi + 2 * y) * a.wi + 2 * x;
+                    else if (a.resample == SGD_RS_ZEROUP2) e.x = ((y | x) & 1) ? -1 : (n * a.hi + (y >> 1)) * a.wi + (x >> 1);
                     else e.x = (n * a.hi + y) * a.wi + x;
                     e.y = n;
                 }
@@ -779,8 +780,9 @@ extern "C" int sgd_igemm(const sgd_igemm_args* args, void* stream) {
     if (a.mode == SGD_MODE_CONV3) {
         if (a.n <= 0 || a.hi <= 0 || a.wi <= 0 || (a.stride != 1 && a.stride != 2)) return SGD_ERR_ARG;
         if (a.stride == 2 && a.resample != SGD_RS_NONE) return SGD_ERR_ARG;
-        g.hc = a.resample == SGD_RS_AVGPOOL2 ? a.hi / 2 : (a.resample == SGD_RS_UP2 ? a.hi * 2 : a.hi);
-        g.wc = a.resample == SGD_RS_AVGPOOL2 ? a.wi / 2 : (a.resample == SGD_RS_UP2 ? a.wi * 2 : a.wi);
+        const bool up = a.resample == SGD_RS_UP2 || a.resample == SGD_RS_ZEROUP2;
+        g.hc = a.resample == SGD_RS_AVGPOOL2 ? a.hi / 2 : (up ? a.hi * 2 : a.hi);
+        g.wc = a.resample == SGD_RS_AVGPOOL2 ? a.wi / 2 : (up ? a.wi * 2 : a.wi);
         if (a.resample == SGD_RS_AVGPOOL2 && ((a.hi | a.wi) & 1)) return SGD_ERR_ARG;
         const int ho = a.stride == 2 ? (g.hc + 1) / 2 : g.hc, wo = a.stride == 2 ? (g.wc + 1) / 2 : g.wc;
         if (a.ho != ho || a.wo != wo) return SGD_ERR_ARG;

@@ -117,6 +117,62 @@ __global__ __launch_bounds__(256) void ln_kernel(const float* __restrict__ x, co
     }
 }
 
+
+// LayerNorm backward, one wave per row (row in registers, c <= 1024):
+//   y = xhat*gamma + beta ;  dx = rstd * (g*gamma - mean(g*gamma) - xhat * mean(g*gamma*xhat))
+// dx is written (or accumulated) into dst; gxhat[row, c] = g * xhat is emitted for the dgamma column sum.
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                     const float* __restrict__ gamma, int rows, int c, float eps,
+                                                     float* __restrict__ dst, int accumulate,
+                                                     float* __restrict__ gxhat, const float* __restrict__ gres) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float* xp = x + (long)row * c;
+    const float* gp = g + (long)row * c;
+    float v[16], gg[16];
+    float s = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        int cc = lane + k * 64;
+        v[k] = cc < c ? xp[cc] : 0.f;
+        gg[k] = cc < c ? gp[cc] : 0.f;
+        s += v[k];
+    }
+    const float mean = wave_sum(s) / c;
+    float q = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        int cc = lane + k * 64;
+        float d = cc < c ? v[k] - mean : 0.f;
+        q += d * d;
+    }
+    const float rstd = rsqrtf(wave_sum(q) / c + eps);
+    float m1 = 0, m2 = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        int cc = lane + k * 64;
+        if (cc < c) {
+            const float xh = (v[k] - mean) * rstd, gw = gg[k] * gamma[cc];
+            v[k] = xh;
+            m1 += gw;
+            m2 += gw * xh;
+        }
+    }
+    m1 = wave_sum(m1) / c;
+    m2 = wave_sum(m2) / c;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        int cc = lane + k * 64;
+        if (cc < c) {
+            float dx = rstd * (gg[k] * gamma[cc] - m1 - v[k] * m2);
+            if (gres) dx += gres[(long)row * c + cc];             // gradient of a residual branch around the norm
+            float* dp = dst + (long)row * c + cc;
+            *dp = accumulate ? *dp + dx : dx;
+            if (gxhat) gxhat[(long)row * c + cc] = gg[k] * v[k];
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int sgd_chan_stats(const float* x, int32_t n, int32_t hw, int32_t c, float* sums, int32_t c_total,
@@ -156,5 +212,14 @@ extern "C" int sgd_ln_apply(const float* x, const float* gamma, const float* bet
     if (!x || !gamma || !out || rows <= 0 || c <= 0 || c > 1024) return SGD_ERR_ARG;
     hipLaunchKernelGGL((ln_kernel<true>), dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, gamma, beta,
                        res, rows, c, eps, out);
+    return sgd_check_launch();
+}
+
+extern "C" int sgd_ln_bwd(const float* x, const float* g, const float* gamma, int32_t rows, int32_t c, float eps,
+                          float* dst, int32_t accumulate, float* gxhat, const float* gres, void* stream) {
+    SGD_CLEAR_ERR();
+    if (!x || !g || !gamma || !dst || rows <= 0 || c <= 0 || c > 1024) return SGD_ERR_ARG;
+    hipLaunchKernelGGL(ln_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, g, gamma, rows, c, eps,
+                       dst, accumulate, gxhat, gres);
     return sgd_check_launch();
 }

@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libsgdm_hip.so")
 
 MODE_FLAT, MODE_CONV3 = 0, 1
-RS_NONE, RS_AVGPOOL2, RS_UP2 = 0, 1, 2
+RS_NONE, RS_AVGPOOL2, RS_UP2, RS_ZEROUP2 = 0, 1, 2, 3
 PRO_NONE, PRO_AFFINE_NC, PRO_LN_ROW = 0, 1, 2
 PREC_F32, PREC_F16X3, PREC_BF16X3 = 0, 1, 2
 PREC_BY_NAME = {"f32": PREC_F32, "f16x3": PREC_F16X3, "bf16x3": PREC_BF16X3}
@@ -60,6 +60,8 @@ SIGNATURES = {
     "sgd_gn_bwd_apply": (i32, [vp, i32, i32, i32, i32, i32, i32, vp, vp, i32, vp, i32, i32, f32, C.c_uint32, vp, vp, vp, vp, i32, i32,
                              vp, i32, i32, i32, vp]),
     "sgd_silu_bwd": (i32, [vp, vp, i64, vp, vp]),
+    "sgd_ln_bwd": (i32, [vp, vp, vp, i32, i32, f32, vp, i32, vp, vp, vp]),
+    "sgd_resample_bwd": (i32, [vp, i32, i32, i32, i32, i32, vp, i32, vp]),
     "sgd_q_sample": (i32, [vp, vp, vp, vp, vp, i32, i64, vp, vp]),
     "sgd_mse_loss": (i32, [vp, vp, i32, i32, i32, vp, vp, vp]),
     "sgd_timestep_embedding": (i32, [vp, vp, i32, i32, i32, vp, vp]),

@@ -120,19 +120,26 @@ class Backward:
             self.prog.add(f"bucket{bi}.allreduce", bucket_ready)
 
     def dgrad(self, tag, gy, cin_of_gy, y, cout_of_y, deps, src_fn, cout_fwd, cin_fwd, ksize, conv=None, m=0,
-              y_ld=None):
-        """y = adjoint(W) applied to gy (gy has cout_fwd channels, y gets cin_fwd channels)"""
+              y_ld=None, zero_up=False, acc=False):
+        """y (+)= adjoint(W) applied to gy (gy has cout_fwd channels, y gets cin_fwd channels).
+        zero_up: adjoint of a stride-2 conv (gy is zero-upsampled x2 inside the loader); acc: add into y."""
         pk = _PackedAdj(deps, src_fn, cout_fwd, cin_fwd, ksize, self.prec, self.dev)
         self.packs.append(pk)
         a = L.IgemmArgs()
         a.x0, a.c0 = gy.data_ptr(), cin_of_gy
         if conv is not None:
-            nimg, hh, ww = conv
-            a.mode, a.n, a.hi, a.wi, a.ho, a.wo, a.stride = L.MODE_CONV3, nimg, hh, ww, hh, ww, 1
+            nimg, hh, ww = conv                    # dims of gy
+            if zero_up:
+                a.mode, a.n, a.hi, a.wi, a.ho, a.wo, a.stride, a.resample = (L.MODE_CONV3, nimg, hh, ww, 2 * hh, 2 * ww, 1,
+                                                                          L.RS_ZEROUP2)
+            else:
+                a.mode, a.n, a.hi, a.wi, a.ho, a.wo, a.stride = L.MODE_CONV3, nimg, hh, ww, hh, ww, 1
         else:
             a.mode, a.m, a.stride = L.MODE_FLAT, m, 1
         a.w = pk.buf.data_ptr()
         a.y, a.cout, a.y_ld, a.prec = y.data_ptr(), cout_of_y, (y_ld or cout_of_y), self.prec
+        if acc:
+            a.res, a.res_mode = y.data_ptr(), L.RS_NONE
         self.late.append((a, pk))
         self.keep.append(a)
         self.prog.add(tag, self.lib.sgd_igemm, C.byref(a))
@@ -152,6 +159,26 @@ class Backward:
             self.prog.add(tag + ".bias", self.lib.sgd_colsum, _ptr(gy), rows, cout, gy_ld, _ptr(self.pg(bias_name)), 0,
                           self.unscale, _ptr(self.cwork), self.CW)
             self.wrote(bias_name)
+
+    def colsum(self, tag, g_ptr, rows, c, ld, pname):
+        self.prog.add(tag, self.lib.sgd_colsum, g_ptr, rows, c, ld, _ptr(self.pg(pname)), 0, self.unscale,
+                      _ptr(self.cwork), self.CW)
+        self.wrote(pname)
+
+    def ln_bwd(self, tag, x, g, rows, c, gamma_name, dst, acc, beta_name=None, gres=None):
+        """LayerNorm backward: dst (+)= dx (+ gres); dgamma (and dbeta when the norm has a trainable bias)"""
+        gxh = self.buf(rows, c)
+        self.prog.add(tag, self.lib.sgd_ln_bwd, _ptr(x), _ptr(g), _ptr(self.m.P(gamma_name)), rows, c, 1e-5, _ptr(dst),
+                      int(acc), _ptr(gxh), _ptr(gres) if gres is not None else None)
+        self.colsum(tag + ".dgamma", _ptr(gxh), rows, c, c, gamma_name)
+        if beta_name is not None:
+            self.colsum(tag + ".dbeta", _ptr(g), rows, c, c, beta_name)
+
+    def copy_op(self, tag, dst, src_view):
+        def op(stream):
+            dst.copy_(src_view)
+            return 0
+        self.prog.add(tag, op)
 
     def gn_bwd(self, tag, srcs, hw, a, b, sums, gname, silu, gu, gu_ld, gu_mode, gres, gres_ld, gres_mode,
                film_ptr=0, film_ld=0, dfilm_ptr=0, drop=(0.0, 0)):
@@ -189,9 +216,6 @@ class Backward:
     # ---------------------------------------------------------------- program
     def _build(self):
         e, m, n = self.e, self.m, self.n
-        if m.KIND != "unet_fast":
-            raise NotImplementedError("training backward is built for unet_fast; unetca_fast (LayerNorm, multi-query "
-                                      "attention and strided-conv adjoints) is the next row")
         P = m.P
         self.geps = self.buf(*e.eps_nhwc.shape)           # filled by the autograd Function before the program runs
         film_rec = [r for r in e.tape if r["kind"] == "film"][0]
@@ -213,6 +237,18 @@ class Backward:
                 self._film(rec)
             elif kind == "mlp2":
                 self._mlp2(rec)
+            elif kind == "attn_lr":
+                self._attn_lr(rec)
+            elif kind == "down":
+                self._down(rec)
+            elif kind == "up":
+                self._up(rec)
+            elif kind == "norm_cond":
+                self._norm_cond(rec)
+            elif kind == "linear":
+                gy = self.gread(rec["y"])
+                self.wgrad(rec["name"], rec["a"], gy, rec["cout"], rec["cout"], rec["cin"], 1, n,
+                           rec["name"] + ".weight", rec["name"] + ".bias")
             else:
                 raise NotImplementedError(kind)
 
@@ -290,6 +326,93 @@ class Backward:
         self.wgrad(p + ".qkv", rec["qkv_args"], gqkv, 3 * ch, 3 * ch, ch, 1, n * T, p + ".qkv.weight", p + ".qkv.bias")
         self.gn_bwd(p + ".norm", [(rec["x"], ch)], (hh, ww), rec["a"], rec["b"], rec["sums"], p + ".norm", 0, gxn, ch,
                     L.RS_NONE, gy, ch, L.RS_NONE)                       # residual: x + proj(...)
+
+    def _down(self, rec):
+        """Downsample = conv3x3 stride 2 (openaimodel_ca.py:167-174)"""
+        n, p, c = self.n, rec["p"], rec["c"]
+        hh, ww = rec["hw_in"]
+        gy = self.gread(rec["y"])
+        w = self.m.P(p + ".op.weight")
+        dst, acc = self.gact(rec["x"])
+        self.dgrad(p + ".op.dgrad", gy, c, dst, c, [w], lambda: w, c, c, 3, conv=(n, hh // 2, ww // 2), zero_up=True,
+                   acc=bool(acc))
+        self.wgrad(p + ".op", rec["a"], gy, c, c, c, 9, n * (hh // 2) * (ww // 2), p + ".op.weight", p + ".op.bias")
+
+    def _up(self, rec):
+        """Upsample = nearest x2 + conv3x3 (openaimodel_ca.py:128-131)"""
+        n, p, c = self.n, rec["p"], rec["c"]
+        hh, ww = rec["hw_in"]
+        gy = self.gread(rec["y"])
+        w = self.m.P(p + ".conv.weight")
+        gu = self.buf(n, 2 * hh, 2 * ww, c)
+        self.dgrad(p + ".conv.dgrad", gy, c, gu, c, [w], lambda: w, c, c, 3, conv=(n, 2 * hh, 2 * ww))
+        dst, acc = self.gact(rec["x"])
+        self.prog.add(p + ".up_adj", self.lib.sgd_resample_bwd, _ptr(gu), n, hh, ww, c, L.RS_UP2, _ptr(dst), acc)
+        self.wgrad(p + ".conv", rec["a"], gy, c, c, c, 9, n * 4 * hh * ww, p + ".conv.weight", p + ".conv.bias")
+
+    def _attn_lr(self, rec):
+        """Attention_LR backward (autograd of crossattetion_lr.py:81-142)"""
+        n, p, ch, heads, d, T, J, ntok = (self.n, rec["p"], rec["ch"], rec["heads"], rec["d"], rec["T"], rec["J"],
+                                          rec["ntok"])
+        P, lib = self.m.P, self.lib
+        x, gy = rec["x"], self.gread(rec["y"])
+        rows = n * T
+        # y = x + LN_out(o):  LN_out backward (gamma trainable, beta is a buffer)
+        go = self.buf(n, T, ch)
+        self.ln_bwd(p + ".to_out.1", rec["o"], gy, rows, ch, p + ".to_out.1.gamma", go, 0)
+        wo = P(p + ".to_out.0.weight")
+        gatt = self.buf(n, T, heads * d)
+        self.dgrad(p + ".to_out.0.dgrad", go, ch, gatt, heads * d, [wo], lambda: wo, ch, heads * d, 1, m=rows)
+        self.wgrad(p + ".to_out.0", rec["aout"], go, ch, ch, heads * d, 1, rows, p + ".to_out.0.weight")
+        # multi-query attention core
+        q, kv = rec["q"], rec["kv"]
+        gq, gkv = self.buf(n, T, heads * d), self.buf(n, J, 2 * d)
+        dvec = self.buf(n, heads, T)
+        self.prog.add(p + ".attn_bwd", lib.sgd_attention_bwd, _ptr(q), heads * d, d, _ptr(kv),
+                      C.c_void_p(kv.data_ptr() + 4 * d), 2 * d, 0, _ptr(rec["att"]), heads * d, _ptr(gatt), heads * d,
+                      _ptr(rec["lse"]), _ptr(dvec), n, heads, T, J, d, d ** -0.5, _ptr(gq), _ptr(gkv),
+                      C.c_void_p(gkv.data_ptr() + 4 * d))
+        # to_q / to_kv share LN(x): gradient of the normalised input is the sum of both adjoints
+        wq, wkv = P(p + ".to_q.weight"), P(p + ".to_kv.weight")
+        gxn = self.buf(n, T, ch)
+        self.dgrad(p + ".to_q.dgrad", gq, heads * d, gxn, ch, [wq], lambda: wq, heads * d, ch, 1, m=rows)
+        self.wgrad(p + ".to_q", rec["aq"], gq, heads * d, heads * d, ch, 1, rows, p + ".to_q.weight")
+        gkv_self = self.buf(n, T, 2 * d)
+        self.copy_op(p + ".gkv_self", gkv_self, gkv[:, ntok + 1:, :])
+        self.dgrad(p + ".to_kv.dgrad", gkv_self, 2 * d, gxn, ch, [wkv], lambda: wkv, 2 * d, ch, 1, m=rows, acc=True)
+        self.wgrad(p + ".to_kv", rec["akv"], gkv_self, 2 * d, 2 * d, ch, 1, rows, p + ".to_kv.weight")
+        # null key/value: summed over the batch
+        self.colsum(p + ".null_kv", C.c_void_p(gkv.data_ptr() + 4 * ntok * 2 * d), n, 2 * d, J * 2 * d, p + ".null_kv")
+        # context keys/values -> to_context.1 (Linear) -> to_context.0 (LayerNorm) -> shared context tokens
+        ctx = rec["ctx"]
+        gckv = self.buf(n, ntok, 2 * d)
+        self.copy_op(p + ".gkv_ctx", gckv, gkv[:, :ntok, :])
+        wc = P(p + ".to_context.1.weight")
+        self.wgrad(p + ".to_context.1", rec["actx"], gckv, 2 * d, 2 * d, ctx, 1, n * ntok, p + ".to_context.1.weight",
+                   p + ".to_context.1.bias")
+        gcn = self.buf(n, ntok, ctx)
+        self.dgrad(p + ".to_context.1.dgrad", gckv, 2 * d, gcn, ctx, [wc], lambda: wc, 2 * d, ctx, 1, m=n * ntok)
+        cdst, cacc = self.gact(rec["context"])
+        self.ln_bwd(p + ".to_context.0", rec["context"], gcn, n * ntok, ctx, p + ".to_context.0.weight", cdst, cacc,
+                    beta_name=p + ".to_context.0.bias")
+        # input LayerNorm (gamma trainable, beta buffer) + the residual path
+        dst, acc = self.gact(x)
+        self.ln_bwd(p + ".norm", x, gxn, rows, ch, p + ".norm.gamma", dst, acc, gres=gy)
+
+    def _norm_cond(self, rec):
+        """context = LayerNorm(cat(time tokens, cond tokens)) (openaimodel_ca.py:973,1017)"""
+        n, ntok, ctx, wt = self.n, rec["ntok"], rec["ctx"], rec["wt"]
+        gctx = self.gread(rec["context"])
+        graw = self.buf(n, ntok, ctx)
+        self.ln_bwd("norm_cond", rec["raw"], gctx, n * ntok, ctx, "norm_cond.weight", graw, 0, beta_name="norm_cond.bias")
+        g2 = graw.view(n, ntok * ctx)
+        gt = self.buf(n, wt)
+        self.copy_op("norm_cond.split_t", gt, g2[:, :wt])
+        self.G[rec["raw_t"].data_ptr()] = [gt, True]
+        if rec["raw_c"] is not None:
+            gc = self.buf(n, ntok * ctx - wt)
+            self.copy_op("norm_cond.split_c", gc, g2[:, wt:])
+            self.G[rec["raw_c"].data_ptr()] = [gc, True]
 
     def _film(self, rec):
         """emb_layers of all ResBlocks (one GEMM forward): weight/bias grads split back per block; gradient of
@@ -384,10 +507,7 @@ class _UNetTrainFn(torch.autograd.Function):
         grads = eng.backward.run(geps)
         out = []
         for name in ctx.names:
-            g = grads.get(name)
-            if g is None:
-                raise RuntimeError(f"no gradient produced for {name}")
-            out.append(g)
+            out.append(grads.get(name))      # None: parameter not on the path (e.g. to_cond_tokens_2d, README.md:90-94)
         return (None, None, None) + tuple(out)
 
 

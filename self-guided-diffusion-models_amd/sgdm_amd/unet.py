@@ -541,14 +541,16 @@ class _Engine:
             elif kind == "down":
                 (t, c, hh, ww), = srcs
                 y = self.buf(self.n, hh // 2, ww // 2, c)
-                self.igemm(p + ".op", t, c, y, c, self.pack([p + ".op.weight"], 3),
-                           conv=(self.n, hh, ww, hh // 2, ww // 2, 2, L.RS_NONE), bias=self.m.P(p + ".op.bias"))
+                a = self.igemm(p + ".op", t, c, y, c, self.pack([p + ".op.weight"], 3),
+                               conv=(self.n, hh, ww, hh // 2, ww // 2, 2, L.RS_NONE), bias=self.m.P(p + ".op.bias"))
+                self.tape.append(dict(kind="down", p=p, x=t, y=y, c=c, hw_in=(hh, ww), a=a))
                 srcs = [(y, c, hh // 2, ww // 2)]
             elif kind == "up":
                 (t, c, hh, ww), = srcs
                 y = self.buf(self.n, hh * 2, ww * 2, c)
-                self.igemm(p + ".conv", t, c, y, c, self.pack([p + ".conv.weight"], 3),
-                           conv=(self.n, hh, ww, hh * 2, ww * 2, 1, L.RS_UP2), bias=self.m.P(p + ".conv.bias"))
+                a = self.igemm(p + ".conv", t, c, y, c, self.pack([p + ".conv.weight"], 3),
+                               conv=(self.n, hh, ww, hh * 2, ww * 2, 1, L.RS_UP2), bias=self.m.P(p + ".conv.bias"))
+                self.tape.append(dict(kind="up", p=p, x=t, y=y, c=c, hw_in=(hh, ww), a=a))
                 srcs = [(y, c, hh * 2, ww * 2)]
         return srcs[0]
 
@@ -849,23 +851,34 @@ class UNetModelCA(UNetModelBase):
         ted = 4 * mc
         ntok = NUM_TIME_TOKENS + (NUM_COND_TOKENS if self.cond_token_num == 1 else 0)
         raw = eng.buf(n, ntok, ctx)
+        raw2 = raw.view(n, ntok * ctx)
+        wt = ctx * NUM_TIME_TOKENS
+        raw_t, raw_c = raw2[:, :wt], raw2[:, wt:]           # strided views: keys of the token gradients
         t1 = eng.buf(n, mc)
-        eng.igemm("to_time_tokens.0", eng.temb, mc, t1, mc, eng.pack(["to_time_tokens.0.weight"], 1), m=n,
-                  bias=P("to_time_tokens.0.bias"))
-        eng.igemm("to_time_tokens.2", t1, mc, raw, ctx * NUM_TIME_TOKENS, eng.pack(["to_time_tokens.2.weight"], 1),
-                  m=n, silu=1, bias=P("to_time_tokens.2.bias"), y_ld=ntok * ctx)
+        a0 = eng.igemm("to_time_tokens.0", eng.temb, mc, t1, mc, eng.pack(["to_time_tokens.0.weight"], 1), m=n,
+                       bias=P("to_time_tokens.0.bias"))
+        a2 = eng.igemm("to_time_tokens.2", t1, mc, raw, wt, eng.pack(["to_time_tokens.2.weight"], 1),
+                       m=n, silu=1, bias=P("to_time_tokens.2.bias"), y_ld=ntok * ctx)
+        eng.tape.append(dict(kind="mlp2", name="to_time_tokens", x=eng.temb, h=t1, y=raw_t, a0=a0, a2=a2, cin=mc,
+                             mid=mc, cout=wt, add_to_y=False))
         if self.cond_token_num == 1:
-            eng.igemm("to_cond_tokens.0", eng.cond_m, self.cond_dim, raw, ctx * NUM_COND_TOKENS,
-                      eng.pack(["to_cond_tokens.0.weight"], 1), m=n, bias=P("to_cond_tokens.0.bias"),
-                      y_ld=ntok * ctx, y_off=ctx * NUM_TIME_TOKENS)
+            al = eng.igemm("to_cond_tokens.0", eng.cond_m, self.cond_dim, raw, ctx * NUM_COND_TOKENS,
+                           eng.pack(["to_cond_tokens.0.weight"], 1), m=n, bias=P("to_cond_tokens.0.bias"),
+                           y_ld=ntok * ctx, y_off=wt)
+            eng.tape.append(dict(kind="linear", name="to_cond_tokens.0", y=raw_c, a=al, cin=self.cond_dim,
+                                 cout=ctx * NUM_COND_TOKENS))
             c1 = eng.buf(n, ted)
-            eng.igemm("cond_mlp.0", eng.cond_m, self.cond_dim, c1, ted, eng.pack(["cond_mlp.0.weight"], 1), m=n,
-                      bias=P("cond_mlp.0.bias"))
-            eng.igemm("cond_mlp.2", c1, ted, emb, ted, eng.pack(["cond_mlp.2.weight"], 1), m=n, silu=1,
-                      bias=P("cond_mlp.2.bias"), res=emb)                         # emb = emb + cond_condensed, :977
+            b0 = eng.igemm("cond_mlp.0", eng.cond_m, self.cond_dim, c1, ted, eng.pack(["cond_mlp.0.weight"], 1), m=n,
+                           bias=P("cond_mlp.0.bias"))
+            b2 = eng.igemm("cond_mlp.2", c1, ted, emb, ted, eng.pack(["cond_mlp.2.weight"], 1), m=n, silu=1,
+                           bias=P("cond_mlp.2.bias"), res=emb)                    # emb = emb + cond_condensed, :977
+            eng.tape.append(dict(kind="mlp2", name="cond_mlp", x=eng.cond_m, h=c1, y=emb, a0=b0, a2=b2,
+                                 cin=self.cond_dim, mid=ted, cout=ted, add_to_y=True))
         context = eng.buf(n, ntok, ctx)
         eng.prog.add("norm_cond", eng.lib.sgd_ln_apply, _ptr(raw), _ptr(P("norm_cond.weight")),
                      _ptr(P("norm_cond.bias")), C.c_void_p(0), n * ntok, ctx, LN_EPS, _ptr(context))
+        eng.tape.append(dict(kind="norm_cond", raw=raw, raw_t=raw_t, raw_c=raw_c if self.cond_token_num == 1 else None,
+                             context=context, ntok=ntok, ctx=ctx, wt=wt))
         eng.context, eng.ntok = context, ntok
 
     def _build_attn(self, eng, p, layer, src):
@@ -880,28 +893,32 @@ class UNetModelCA(UNetModelBase):
         eng.prog.add(p + ".norm", lib.sgd_ln_stats, _ptr(t), n * T, c, LN_EPS, _ptr(st))
         q = eng.buf(n, T, heads * d)
         gamma, beta = P(p + ".norm.gamma"), P(p + ".norm.beta")
-        eng.igemm(p + ".to_q", t, c, q, heads * d, eng.pack([p + ".to_q.weight"], 1), m=n * T, pro=L.PRO_LN_ROW,
-                  pa=st, pb=gamma, pc=beta)
+        aq = eng.igemm(p + ".to_q", t, c, q, heads * d, eng.pack([p + ".to_q.weight"], 1), m=n * T,
+                       pro=L.PRO_LN_ROW, pa=st, pb=gamma, pc=beta)
         kv = eng.buf(n, J, 2 * d)
-        eng.igemm(p + ".to_kv", t, c, kv, 2 * d, eng.pack([p + ".to_kv.weight"], 1), m=n * T, pro=L.PRO_LN_ROW,
-                  pa=st, pb=gamma, pc=beta, orows=(T, J, ntok + 1))
+        akv = eng.igemm(p + ".to_kv", t, c, kv, 2 * d, eng.pack([p + ".to_kv.weight"], 1), m=n * T,
+                        pro=L.PRO_LN_ROW, pa=st, pb=gamma, pc=beta, orows=(T, J, ntok + 1))
         cst = eng.buf(n * ntok, 2)
         eng.prog.add(p + ".to_context.0", lib.sgd_ln_stats, _ptr(eng.context), n * ntok, self.context_dim, LN_EPS,
                      _ptr(cst))
-        eng.igemm(p + ".to_context.1", eng.context, self.context_dim, kv, 2 * d,
-                  eng.pack([p + ".to_context.1.weight"], 1), m=n * ntok, pro=L.PRO_LN_ROW, pa=cst,
-                  pb=P(p + ".to_context.0.weight"), pc=P(p + ".to_context.0.bias"),
-                  bias=P(p + ".to_context.1.bias"), orows=(ntok, J, 0))
+        actx = eng.igemm(p + ".to_context.1", eng.context, self.context_dim, kv, 2 * d,
+                         eng.pack([p + ".to_context.1.weight"], 1), m=n * ntok, pro=L.PRO_LN_ROW, pa=cst,
+                         pb=P(p + ".to_context.0.weight"), pc=P(p + ".to_context.0.bias"),
+                         bias=P(p + ".to_context.1.bias"), orows=(ntok, J, 0))
         eng.prog.add(p + ".null_kv", lib.sgd_fill_null_kv, _ptr(P(p + ".null_kv")), n, J, ntok, d, _ptr(kv))
         att = eng.buf(n, T, heads * d)
+        lse = eng.buf(n, heads, T)
         eng.prog.add(p + ".attn", lib.sgd_attention, _ptr(q), heads * d, d, _ptr(kv),
                      C.c_void_p(kv.data_ptr() + 4 * d), 2 * d, 0, n, heads, T, J, d, d ** -0.5, _ptr(att),
-                     heads * d, C.c_void_p(0))
+                     heads * d, _ptr(lse))
         o = eng.buf(n, T, ch)
-        eng.igemm(p + ".to_out.0", att, heads * d, o, ch, eng.pack([p + ".to_out.0.weight"], 1), m=n * T)
+        aout = eng.igemm(p + ".to_out.0", att, heads * d, o, ch, eng.pack([p + ".to_out.0.weight"], 1), m=n * T)
         y = eng.buf(n, hh, ww, ch)
         eng.prog.add(p + ".to_out.1", lib.sgd_ln_apply, _ptr(o), _ptr(P(p + ".to_out.1.gamma")),
                      _ptr(P(p + ".to_out.1.beta")), _ptr(t), n * T, ch, LN_EPS, _ptr(y))
+        eng.tape.append(dict(kind="attn_lr", p=p, x=t, ch=ch, heads=heads, d=d, T=T, J=J, ntok=ntok, hw=(hh, ww), q=q,
+                             kv=kv, att=att, lse=lse, o=o, aq=aq, akv=akv, actx=actx, aout=aout, y=y,
+                             context=eng.context, ctx=self.context_dim))
         return (y, ch, hh, ww)
 
     # ---- reference entry points (openaimodel_ca.py:879-1033)

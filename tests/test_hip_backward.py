@@ -213,3 +213,96 @@ def test_q_sample_and_mse_loss():
     L.check(lib.sgd_mse_loss(_p(ed), _p(nd), b, c, hw, _p(ps), _p(ge), _stream()), "mse")
     assert max_rel(ps.cpu(), per.detach()) < 1e-6
     assert max_rel(ge.cpu().permute(0, 3, 1, 2), eps.grad) < 1e-6
+
+
+def test_attention_backward_multiquery():
+    """Attention_LR core (crossattetion_lr.py:115-137): 8 heads share K/V of 16+1+256 rows; dK/dV summed over heads"""
+    L, lib = _lib()
+    g = torch.Generator().manual_seed(17)
+    b, heads, t, j, d = 2, 8, 256, 273, 64
+    q = torch.randn(b, t, heads * d, generator=g).requires_grad_(True)
+    kv = torch.randn(b, j, 2 * d, generator=g).requires_grad_(True)
+    qh = q.reshape(b, t, heads, d).permute(0, 2, 1, 3) * d ** -0.5
+    attn = torch.einsum("bhid,bjd->bhij", qh, kv[..., :d]).softmax(-1)
+    o = torch.einsum("bhij,bjd->bhid", attn, kv[..., d:]).permute(0, 2, 1, 3).reshape(b, t, heads * d)
+    go = torch.randn(b, t, heads * d, generator=g)
+    o.backward(go)
+    qd, kvd, god = q.detach().cuda(), kv.detach().cuda(), go.cuda()
+    out = torch.empty(b, t, heads * d, device="cuda")
+    lse = torch.empty(b, heads, t, device="cuda")
+    vp = C.c_void_p(kvd.data_ptr() + 4 * d)
+    L.check(lib.sgd_attention(_p(qd), heads * d, d, _p(kvd), vp, 2 * d, 0, b, heads, t, j, d, d ** -0.5, _p(out),
+                              heads * d, _p(lse), _stream()), "attn")
+    gq = torch.full((b, t, heads * d), float("nan"), device="cuda")
+    gkv = torch.full((b, j, 2 * d), float("nan"), device="cuda")
+    dvec = torch.empty(b, heads, t, device="cuda")
+    L.check(lib.sgd_attention_bwd(_p(qd), heads * d, d, _p(kvd), vp, 2 * d, 0, _p(out), heads * d, _p(god), heads * d,
+                                  _p(lse), _p(dvec), b, heads, t, j, d, d ** -0.5, _p(gq), _p(gkv),
+                                  C.c_void_p(gkv.data_ptr() + 4 * d), _stream()), "attn_bwd")
+    assert max_rel(gq.cpu(), q.grad) < 1e-5
+    assert max_rel(gkv.cpu(), kv.grad) < 1e-5
+
+
+@pytest.mark.parametrize("rows,c", [(300, 512), (48, 32)])
+def test_layernorm_backward(rows, c):
+    L, lib = _lib()
+    g = torch.Generator().manual_seed(18)
+    x = (torch.randn(rows, c, generator=g) * 2 + 0.5).requires_grad_(True)
+    gamma = torch.randn(c, generator=g).requires_grad_(True)
+    beta = torch.randn(c, generator=g).requires_grad_(True)
+    gy = torch.randn(rows, c, generator=g)
+    F.layer_norm(x, (c,), gamma, beta, 1e-5).backward(gy)
+    xd, gd, gmd = x.detach().cuda(), gy.cuda(), gamma.detach().cuda()
+    dx = torch.ones(rows, c, device="cuda")
+    gxh = torch.empty(rows, c, device="cuda")
+    L.check(lib.sgd_ln_bwd(_p(xd), _p(gd), _p(gmd), rows, c, 1e-5, _p(dx), 1, _p(gxh), None, _stream()), "ln_bwd")
+    assert max_rel(dx.cpu() - 1, x.grad) < 2e-5
+    assert max_rel(gxh.cpu().sum(0), gamma.grad) < 2e-5
+
+
+@pytest.mark.parametrize("prec,tol", [("f32", 2e-6), ("f16x3", 2e-5)])
+def test_strided_conv_dgrad_by_zero_insertion(prec, tol):
+    """Downsample conv (stride 2, openaimodel_ca.py:167-174): input gradient = forward kernel on adjoint weights over
+    the zero-upsampled output gradient"""
+    L, lib = _lib()
+    g = torch.Generator().manual_seed(19)
+    n, c, h = 2, 64, 16
+    x = torch.randn(n, c, h, h, generator=g, requires_grad=True)
+    w = (torch.randn(c, c, 3, 3, generator=g) / math.sqrt(c * 9)).requires_grad_(True)
+    gy = torch.randn(n, c, h // 2, h // 2, generator=g)
+    F.conv2d(x, w, stride=2, padding=1).backward(gy)
+    p = L.PREC_BY_NAME[prec]
+    wd = w.detach().cuda()
+    buf = torch.empty(lib.sgd_packed_weight_bytes(c, c, 3, p) // 4, device="cuda")
+    cp, op = C.c_int32(), C.c_int32()
+    L.check(lib.sgd_pack_weight_dgrad(_p(wd), _p(buf), c, c, 3, p, C.byref(cp), C.byref(op), _stream()), "packT")
+    gyd = _nhwc(gy).cuda()
+    out = torch.full((n, h, h, c), float("nan"), device="cuda")
+    a = _igemm_args(L, gyd, conv=(n, h // 2, h // 2, h, h), resample=L.RS_ZEROUP2)
+    a.w, a.cin_p, a.cout_p, a.y, a.cout, a.y_ld, a.prec = buf.data_ptr(), cp.value, op.value, out.data_ptr(), c, c, p
+    L.check(lib.sgd_igemm(C.byref(a), _stream()), "dgrad_s2")
+    assert max_rel(out.cpu().permute(0, 3, 1, 2), x.grad) < tol
+    # and its weight gradient (stride 2 in the wgrad loader)
+    xd = _nhwc(x.detach()).cuda()
+    fwd = _igemm_args(L, xd, conv=(n, h, h, h // 2, h // 2), stride=2)
+    dw = _wgrad(L, lib, fwd, gyd, c, c, 9, 2)
+    assert max_rel(dw.reshape(c, c, 3, 3), w.grad) < 5e-6
+
+
+def test_resample_adjoints():
+    L, lib = _lib()
+    g = torch.Generator().manual_seed(20)
+    n, c, h = 2, 32, 8
+    x = torch.randn(n, c, h, h, generator=g, requires_grad=True)
+    gu = torch.randn(n, c, 2 * h, 2 * h, generator=g)
+    F.interpolate(x, scale_factor=2, mode="nearest").backward(gu)
+    dst = torch.zeros(n, h, h, c, device="cuda")
+    gud = _nhwc(gu).cuda()
+    L.check(lib.sgd_resample_bwd(_p(gud), n, h, h, c, L.RS_UP2, _p(dst), 0, _stream()), "up_adj")
+    assert max_rel(dst.cpu().permute(0, 3, 1, 2), x.grad) < 2e-6
+    x.grad = None
+    gp = torch.randn(n, c, h // 2, h // 2, generator=g)
+    F.avg_pool2d(x, 2).backward(gp)
+    gpd = _nhwc(gp).cuda()
+    L.check(lib.sgd_resample_bwd(_p(gpd), n, h, h, c, L.RS_AVGPOOL2, _p(dst), 0, _stream()), "pool_adj")
+    assert max_rel(dst.cpu().permute(0, 3, 1, 2), x.grad) < 2e-6

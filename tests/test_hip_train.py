@@ -63,9 +63,27 @@ def test_frozen_parameters_get_no_gradient():
     assert m.null_cond_emb.grad is None and m.null_layout_emb.grad is None
 
 
-def test_training_backward_not_built_for_unetca_yet():
-    with pytest.raises(NotImplementedError):
-        _step("ca_stego_c32_s16", "f32")
+@pytest.mark.parametrize("prec,tol", [("f32", 5e-5), ("f16x3", 1e-4)])
+def test_train_step_unetca_vs_reference(prec, tol):
+    """unetca_fast (Attention_LR, strided-conv Downsample, nearest+conv Upsample, token path) train step"""
+    m, v, tag, loss, ld = _step("ca_stego_c32_s16", prec)
+    ref = float(v[tag + ".loss"])
+    assert abs(loss.item() - ref) < 2e-5 * abs(ref)
+    assert max_rel(ld["train/epoch_stats_y"].cpu(), v[tag + ".per_sample"]) < 2e-5
+    grads = {k: p.grad for k, p in m.named_parameters()}
+    # the reference leaves exactly these without a gradient (needs ddp_find_unused_parameters, README.md:90-94)
+    assert sorted(k for k, p in m.named_parameters() if p.requires_grad and p.grad is None) == list(v[tag + ".unused_params"])
+    for key in v:
+        if key.startswith(tag + ".grad."):
+            pname = key[len(tag + ".grad."):]
+            ref_g = torch.from_numpy(v[key])
+            if float(ref_g.abs().max()) < 1e-6:
+                assert float(grads[pname].abs().max()) < 1e-5, pname
+                continue
+            err = max_rel(grads[pname].cpu(), ref_g)
+            assert err < tol, (pname, err)
+    sq = sum(float((g.double() ** 2).sum()) for g in grads.values() if g is not None)
+    assert abs(sq - float(v[tag + ".grad_sqnorm"])) < 1e-3 * float(v[tag + ".grad_sqnorm"])
 
 
 def _ddp_rank(rank, world, port, outdir):
