@@ -123,8 +123,6 @@ def train_step_bench(model, diff, data, cond, layout, B, world, barrier, wl, ste
     """train-step ms (max over ranks): forward_tao -> loss.backward() (bucketed all-reduce inside) -> AdamW -> EMA"""
     import torch.distributed as dist
     from sgdm_amd.ema import LitEma
-    if model.KIND != "unet_fast":
-        return dict(ms=None, note="training backward is built for unet_fast only (unetca_fast: next row)")
     dev = next(model.parameters()).device
     model.train()
     diff.train()
@@ -170,6 +168,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-train", action="store_true")
+    ap.add_argument("--train-batch", type=int, default=80, help="per-GPU batch of the train-step leg (metric: bs=80)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -230,7 +229,14 @@ def main():
     # all-reduce overlapped with backward + AdamW + EMA), per-GPU batch of the config, dropout as configured
     train = None
     if not args.no_train:
-        train = train_step_bench(model, diff, data, cond, layout, B, world, barrier, wl)
+        from sgdm_amd.synth import synth_batch
+        TB = args.train_batch
+        tdata = synth_batch(wl["method"], TB, S, wl["cond_dim"], wl["layout_dim"], seed=29 + rank)
+        tcond = tdata.get("cond")
+        if tcond is not None:
+            tcond = tcond.to(dev) if wl["kind"] == "unet_fast" else tcond.float().to(dev)
+        tlayout = tdata["layout"].to(dev) if "layout" in tdata else None
+        train = train_step_bench(model, diff, tdata, tcond, tlayout, TB, world, barrier, wl)
 
     out = None
     if rank == 0:
