@@ -119,6 +119,18 @@ def cpu_baseline(wl, sd, seconds_budget=25.0):
                 s_per_step_bs8=per_step)
 
 
+def pmc_traffic(args, B):
+    """HBM bytes per igemm launch from the PMC passes committed under profiles/ (tools/pmc_hbm.sh: FETCH_SIZE and
+    WRITE_SIZE in separate rocprofv3 --pmc runs of this same bench command, gfx950 FETCH_SIZE x2 correction).
+    PMC collection needs the profiler around the process, so it cannot be taken live inside this run; null when no
+    committed pass matches the workload/precision/batch being benchmarked."""
+    path = os.path.join(ROOT, "profiles", f"r1_pmc_hbm_{args.workload}.json")
+    if not os.path.exists(path) or args.prec != "f16x3" or B != WORKLOADS[args.workload]["batch"]:
+        return None
+    k = json.load(open(path))["kernels"].get("igemm_kernel")
+    return round(k["hbm_bytes_per_launch"]) if k else None
+
+
 def train_step_bench(model, diff, data, cond, layout, B, world, barrier, wl, steps=4, warmup=2):
     """train-step ms (max over ranks): forward_tao -> loss.backward() (bucketed all-reduce inside) -> AdamW -> EMA"""
     import torch.distributed as dist
@@ -258,7 +270,8 @@ def main():
             ach = ig_fl / (ig_ms * 1e-3) / 1e12
             roof = dict(bound="mfma", kernel="igemm_kernel (fused implicit-GEMM conv/linear, all launches of one UNet eval)",
                         achieved=round(ach, 2), peak=round(peak, 1), unit="TFLOP/s", frac=round(ach / peak, 4),
-                        traffic=None, launches_per_step=ig_n, avg_launch_ms=round(ig_ms / ig_n, 4),
+                        traffic=pmc_traffic(args, B), launches_per_step=ig_n,
+                        algorithmic_bytes_per_launch=round(ig_nb / ig_n), avg_launch_ms=round(ig_ms / ig_n, 4),
                         igemm_ms_per_step=round(ig_ms, 3), all_kernels_ms_per_step=round(tot_ms, 3),
                         algorithmic_gflop_per_step=round(ig_fl / 1e9, 1),
                         hbm_algorithmic_frac=round((ig_nb / (ig_ms * 1e-3)) / 8.0e12, 4),
