@@ -46,6 +46,22 @@ def _compile(src, force):
     return obj
 
 
+def build_probe():
+    """diagnostic variant of the conv kernel (ablation knobs + per-wave cycle stamps), tools/ only"""
+    os.makedirs(OBJ, exist_ok=True)
+    out = os.path.join(LIBDIR, "libsgdm_hip_probe.so")
+    objs = []
+    for src in _sources():
+        obj = os.path.join(OBJ, src[:-4] + ".probe.o")
+        r = subprocess.run([HIPCC, *FLAGS, "-DSGDM_PROBE", "-c", os.path.join(CSRC, src), "-o", obj],
+                           capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(r.stderr)
+        objs.append(obj)
+    subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out, *objs], check=True)
+    return out
+
+
 def build_lib(force=False):
     os.makedirs(OBJ, exist_ok=True)
     os.makedirs(LIBDIR, exist_ok=True)
@@ -62,4 +78,4 @@ def build_lib(force=False):
 
 
 if __name__ == "__main__":
-    print(build_lib(force="--force" in sys.argv))
+    print(build_probe() if "--probe" in sys.argv else build_lib(force="--force" in sys.argv))

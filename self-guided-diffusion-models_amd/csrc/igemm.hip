@@ -37,7 +37,7 @@ constexpr int NB_RING = 3;    // weight-slice ring depth
 constexpr int NTHREADS = 768;  // 4 compute waves + 6 input-tile loader waves + 2 weight loader waves
 constexpr int A_THREADS = 384;
 constexpr int B_THREADS = 128;
-constexpr int FAST_PIX = 256;  // halo tiles up to this many pixels use the split-phase A loader
+constexpr int FAST_PIX = 192;  // halo tiles up to this many pixels (16x8 outputs + halo = 180) use the split-phase A loader
 
 struct Geo {
     int tw_l2, th_l2;         // log2 of the spatial tile (CONV3)
@@ -48,8 +48,35 @@ struct Geo {
     int mt, nt;               // number of M / N tiles
     int hc, wc;               // conv-input dims (after resample)
     int fast_a;               // 1: split-phase A loader (stride 1, no avg-pool, pix*8 <= JMAX*256)
-    int dbg;                  // SGDM_DBG bits: 1 skip A staging, 2 skip B staging, 4 skip MFMA, 8 skip stores (timing experiments only)
+#ifdef SGDM_PROBE
+    int dbg;                  // SGDM_DBG bits: 1 skip A staging, 2 skip B staging, 4 skip MFMA, 8 skip stores
+    unsigned long long* stamp;   // [block][wave][4]: total cycles, cycles inside barriers, barriers, epilogue cycles
+    unsigned long long* trace;   // [16 blocks][wave][512 barriers][2]: arrival / release time of every barrier
+#endif
 };
+
+// Diagnostic build only (build.py --probe -> libsgdm_hip_probe.so, never loaded by the product path): ablation knobs
+// and per-wave cycle accounting.  In the shipped library the knobs fold to constants and no stamp executes.
+#ifdef SGDM_PROBE
+#define DBG(bit) (g.dbg & (bit))
+#define SYNC() do { const unsigned long long t0_ = __builtin_amdgcn_s_memtime(); __syncthreads(); \
+                    const unsigned long long t1_ = __builtin_amdgcn_s_memtime(); \
+                    if (g.trace && blockIdx.x < 16 && pr_nbar < 512 && (threadIdx.x & 63) == 0) { \
+                        unsigned long long* tp_ = g.trace + (((size_t)blockIdx.x * (NTHREADS / 64) + (threadIdx.x >> 6)) * 512 + pr_nbar) * 2; \
+                        tp_[0] = t0_; tp_[1] = t1_; } \
+                    pr_bar += t1_ - t0_; ++pr_nbar; } while (0)
+#define PROBE_BEGIN() unsigned long long pr_bar = 0, pr_nbar = 0, pr_epi = 0; const unsigned long long pr_t0 = __builtin_amdgcn_s_memtime()
+#define PROBE_END(role) do { if (g.stamp && (threadIdx.x & 63) == 0) { \
+        unsigned long long* sp_ = g.stamp + ((size_t)blockIdx.x * (NTHREADS / 64) + (threadIdx.x >> 6)) * 4; \
+        sp_[0] = __builtin_amdgcn_s_memtime() - pr_t0; sp_[1] = pr_bar; sp_[2] = pr_nbar; sp_[3] = pr_epi; } } while (0)
+#define PROBE_EPI(expr) do { const unsigned long long t0_ = __builtin_amdgcn_s_memtime(); expr; pr_epi += __builtin_amdgcn_s_memtime() - t0_; } while (0)
+#else
+#define DBG(bit) 0
+#define SYNC() __syncthreads()
+#define PROBE_BEGIN()
+#define PROBE_END(role)
+#define PROBE_EPI(expr) expr
+#endif
 
 struct KArgs {
     sgd_igemm_args a;
@@ -191,7 +218,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
     const int a_floats = g.pix * LDA;
     float* As = smem;                                       // [NA][pix][LDA]
     float* Bs = smem + (size_t)NA * a_floats;               // [NB_RING][BN][LDA]
-    int2* pixtab = reinterpret_cast<int2*>(Bs + NB_RING * BN * LDA);   // [2][pix] (source row or -1, image n)
+    int2* pixtab = reinterpret_cast<int2*>(Bs + NB_RING * BN * LDA);   // [3][pix] (source row or -1, image n)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
@@ -220,7 +247,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
     auto build_pixtab = [&](int k, int t0, int nthr) {
         if (k >= ntiles) return;
         const Tile T = tile_at(g, lin_of(k), BN, TW, TH);
-        int2* tab = pixtab + (size_t)(k & 1) * g.pix;
+        int2* tab = pixtab + (size_t)(k % 3) * g.pix;
         for (int pix = t0; pix < g.pix; pix += nthr) {
             int2 e;
             e.x = -1;
@@ -248,9 +275,15 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
     };
     build_pixtab(0, tid, NTHREADS);
     build_pixtab(1, tid, NTHREADS);
+    build_pixtab(2, tid, NTHREADS);
     __syncthreads();
+    PROBE_BEGIN();
 
     if (tid >= 256) {
+        // The four MFMA waves are the oldest waves of their SIMDs and would win every issue arbitration, leaving the
+        // loaders ~2.5 vector instructions per MFMA.  A loader instruction delays the next MFMA's ISSUE by a few cycles
+        // but not the matrix pipe (32 cycles per MFMA, 8 of them on the issue port), so the loaders go first.
+        __builtin_amdgcn_s_setprio(2);
         // =====================================================================================
         // loader roles.  Each wave runs ONE kind of global load in a branch-free steady state so the
         // compiler's in-order vmcnt bookkeeping stays exact (a conditional load anywhere degrades every
@@ -276,7 +309,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
             auto load_next = [&](auto rc) {
                 constexpr int R = decltype(rc)::value;
                 const float* wp = wtile + (size_t)ctap * tap_stride + cchunk * KC;
-                if (!(g.dbg & 2)) {
+                if (!(DBG(2))) {
 #pragma unroll
                 for (int it = 0; it < BITEMS; ++it) breg[R][it] = ld4(wp + (size_t)(it * 16) * a.cin_p);
                 }
@@ -293,7 +326,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
             auto store_B = [&](int step, auto rc) {
                 constexpr int R = decltype(rc)::value;
                 float* bp = Bs + (size_t)(step % NB_RING) * BN * LDA + (lt >> 3) * LDA + (lt & 7) * 4;
-                if (!(g.dbg & 2)) {
+                if (!(DBG(2))) {
 #pragma unroll
                 for (int it = 0; it < BITEMS; ++it) *reinterpret_cast<f32x4*>(bp + it * 16 * LDA) = breg[R][it];
                 }
@@ -305,22 +338,25 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
             load_next(R2());
             load_next(R0());
             load_next(R1());
-            __syncthreads();
-            for (int step = 0; step < S; step += 3) {
-                store_B(step + 2, R2());
-                load_next(R2());
-                __syncthreads();
-                if (step + 1 < S) {
-                    store_B(step + 3, R0());
-                    load_next(R0());
-                    __syncthreads();
-                }
-                if (step + 2 < S) {
-                    store_B(step + 4, R1());
-                    load_next(R1());
-                    __syncthreads();
-                }
+            SYNC();
+            // steady state without any conditional around the loads/stores (S % 3 == 0 for CONV3: 9 taps per chunk),
+            // so the waits in front of the LDS stores stay at vmcnt(16+): only the slice loaded three steps ago
+            auto body = [&](int step, auto rc) {
+                PROBE_EPI(store_B(step + 2, rc));
+                load_next(rc);
+                SYNC();
+            };
+            int step = 0;
+            for (; step + 3 <= S; step += 3) {
+                body(step, R2());
+                body(step + 1, R0());
+                body(step + 2, R1());
             }
+            if (step < S) {
+                body(step, R2());
+                if (step + 1 < S) body(step + 1, R0());
+            }
+            PROBE_END(2);
             return;
         }
         // -------------------------------------------------------------------- A loader
@@ -331,7 +367,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
         struct TabRef { const int2* tab; long m0; };
         auto tabref = [&](int k) {
             TabRef t;
-            t.tab = pixtab + (size_t)(k & 1) * g.pix;
+            t.tab = pixtab + (size_t)(k % 3) * g.pix;
             t.m0 = CONV ? 0 : tile_at(g, lin_of(k), BN, TW, TH).m0;
             return t;
         };
@@ -383,57 +419,201 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
                 lds_store_act<PREC>(abuf + (size_t)pix * LDA, c4, v);
             }
         };
+        // branch-free: out-of-tile items, padding pixels and channels past cin load a valid (clamped) address
+        // and are zeroed in finish_item
         auto raw_item = [&](const TabRef& tab, int idx, int c) -> f32x4 {
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (idx < items && c < cin) {
-                const int2 e = entry(tab, idx >> 3);
-                if (e.x >= 0) v = load_raw<VEC>(a, e.x, c);
-            }
-            return v;
+            const int ii = idx < items ? idx : items - 1;
+            const int2 e = entry(tab, ii >> 3);
+            return load_raw<VEC>(a, e.x >= 0 ? e.x : 0, c < cin ? c : 0);
         };
 
         if (CONV) {
             constexpr int AJ = (FAST_PIX * 8 + A_THREADS - 1) / A_THREADS;   // item slots per thread (6)
             stage_A_sync(0, 0);
-            __syncthreads();
-            const bool uni = g.nb == 1 && a.pro == SGD_PRO_AFFINE_NC;
-            f32x4 araw[AJ];
-            for (int q = 0; q < Q; ++q) {
-                // stream chunk q is being computed; stage chunk q+1 (clamped) into ring slot q+1
-                const int nq = q + 1 < Q ? q + 1 : q;
-                const int nk = nq / nchunks, nchunk = nq - nk * nchunks;
-                const TabRef tab = tabref(nk);
-                if (g.dbg & 1) {
+            if (DBG(1)) {
+                SYNC();
+                for (int q = 0; q < Q; ++q)
 #pragma unroll
-                    for (int t = 0; t < 8; ++t) __syncthreads();
-                } else if (g.fast_a) {
-                    const int c = nchunk * KC + c4 * 4;
+                    for (int t = 0; t < 9; ++t) SYNC();
+            } else if (g.fast_a) {
+                // Split-phase staging, one item per K step: at tap t (1..AJ) a thread transforms the raw row quad it
+                // requested NINE steps earlier (chunk q+1) into LDS and re-uses the register for the same item of chunk
+                // q+2.  Every tap carries the same small amount of loader work (the per-step barrier makes the slowest
+                // wave of a step the pace of the block), no load is consumed sooner than 3 steps after its issue and
+                // none sits behind a branch (the in-order vmcnt stays exact).
+                const bool uni = VEC && g.nb == 1 && a.pro == SGD_PRO_AFFINE_NC;
+                const bool kshared = uni || a.pro == SGD_PRO_NONE;
+                const bool lean = VEC && kshared && a.drop_p == 0.f;       // the ResBlock convs of the sampler
+                f32x4 araw[AJ];
+                Coef kq;
+                struct Ctx { const int2* tab; int c; int chunk; long ko; };
+                auto ctx_of = [&](int q) {
+                    q = q < Q ? q : Q - 1;
+                    Ctx cx;
+                    const int k = q / nchunks;
+                    cx.chunk = q - k * nchunks;
+                    cx.tab = pixtab + (size_t)(k % 3) * g.pix;
+                    cx.c = cx.chunk * KC + c4 * 4;
+                    // per-image GroupNorm coefficients of this thread's channel quad (tile = one image)
+                    cx.ko = (long)tile_at(g, lin_of(k), BN, TW, TH).img0 * cin + (cx.c < cin ? cx.c : 0);
+                    return cx;
+                };
+                auto issue_item = [&](const Ctx& cx, int j) {
+                    TabRef tr;
+                    tr.tab = cx.tab;
+                    tr.m0 = 0;
+                    araw[j] = raw_item(tr, lt + j * A_THREADS, cx.c);
+                };
+                auto issue_coef = [&](const Ctx& cx) {
+                    // other prologues read 32 harmless bytes of the input instead of branching around the loads
+                    kq.p = ld4(uni ? a.pa + cx.ko : a.x0);
+                    kq.q = ld4(uni ? a.pb + cx.ko : a.x0);
+                };
+                auto finish = [&](int slot, const Ctx& cx, int j) {
+                    TabRef tr;
+                    tr.tab = cx.tab;
+                    tr.m0 = 0;
+                    finish_item(slot, tr, cx.chunk, lt + j * A_THREADS, araw[j], kshared ? &kq : nullptr);
+                };
+                auto run = [&]() {
+                    Ctx cx1 = ctx_of(1), cx2 = ctx_of(2);
 #pragma unroll
-                    for (int j = 0; j < AJ; ++j) araw[j] = raw_item(tab, lt + j * A_THREADS, c);   // tap 0
-                    Coef kuni;
-                    kuni.p = f32x4{0.f, 0.f, 0.f, 0.f};
-                    kuni.q = kuni.p;
-                    if (uni && c < cin) kuni = load_coef<VEC>(a, tile_at(g, lin_of(nk), BN, TW, TH).img0, 0, c);
-                    __syncthreads();
+                    for (int j = 0; j < AJ; ++j) issue_item(cx1, j);
+                    issue_coef(cx1);
+                    SYNC();
+                    for (int q = 0; q < Q; ++q) {
+                        SYNC();                                                                    // tap 0
 #pragma unroll
-                    for (int t = 1; t < 8; ++t) {                                                  // taps 1..7
-#pragma unroll
-                        for (int j = 0; j < AJ; ++j)
-                            if (1 + (j % 7) == t)
-                                finish_item(q + 1, tab, nchunk, lt + j * A_THREADS, araw[j],
-                                            (uni || a.pro == SGD_PRO_NONE) ? &kuni : nullptr);
-                        __syncthreads();
+                        for (int t = 1; t < 8; ++t) {                                              // taps 1..7
+                            if (t <= AJ) {
+                                finish(q + 1, cx1, t - 1);
+                                issue_item(cx2, t - 1);
+                            }
+                            if (t == 7) {
+                                cx1 = cx2;
+                                cx2 = ctx_of(q + 3);
+                                issue_coef(cx1);
+                            }
+                            SYNC();
+                        }
+                        // tap 8: table of the tile that chunk q+3 opens (its rows are requested from tap 1 of chunk q+1 on)
+                        if (q + 3 < Q && (q + 3) % nchunks == 0) build_pixtab((q + 3) / nchunks, lt, A_THREADS);
+                        SYNC();
                     }
+                };
+                // The common case (the sampler's ResBlock convs: per-image GroupNorm affine (+SiLU) or no prologue, whole
+                // 32-channel chunks from one source, no dropout) gets its own loop with the per-tile work hoisted: source rows
+                // and padding flags are read from the tile table once per tile, the chunk's source pointer / stride /
+                // coefficient pointer are wave-uniform scalars.  ~45 vector instructions per item: next to a saturated
+                // matrix pipe a SIMD issues only ~4 other vector instructions per MFMA, so loader VALU count is what
+                // paces a K step.  The second input-tile wave of a SIMD (waves 8, 9) works at taps 5..8, the first
+                // (waves 4..7) at taps 1..4, so the two never stack on one step.
+                auto run_lean = [&](auto latec) {
+                    constexpr bool LATE = decltype(latec)::value;
+                    constexpr int T0 = LATE ? 5 : 1;
+                    int pixj[AJ], rows2[AJ];
+                    bool live[AJ];
+#pragma unroll
+                    for (int j = 0; j < AJ; ++j) {
+                        const int idx = lt + j * A_THREADS;
+                        live[j] = idx < items;
+                        pixj[j] = (live[j] ? idx : items - 1) >> 3;
+                    }
+                    unsigned valid1 = 0, valid2 = 0;
+                    auto load_rows = [&](int k) {
+                        const int2* tab = pixtab + (size_t)(k % 3) * g.pix;
+                        valid2 = 0;
+#pragma unroll
+                        for (int j = 0; j < AJ; ++j) {
+                            const int ex = tab[pixj[j]].x;
+                            rows2[j] = ex < 0 ? 0 : ex;
+                            if (ex >= 0 && live[j]) valid2 |= 1u << j;
+                        }
+                    };
+                    struct S { int k, chunk; const float* src; int stride; const float* ka; const float* kb; };
+                    auto fill = [&](S& c) {              // derived fields of (k, chunk)
+                        const int ch = c.chunk * KC;
+                        if (ch < a.c0) { c.src = a.x0 + ch; c.stride = a.c0; }
+                        else { c.src = a.x1 + (ch - a.c0); c.stride = a.c1; }
+                        const long ko = (long)tile_at(g, lin_of(c.k), BN, TW, TH).img0 * cin + ch;
+                        c.ka = uni ? a.pa + ko : a.x0;   // no prologue: 32 harmless bytes instead of a branch around the load
+                        c.kb = uni ? a.pb + ko : a.x0;
+                    };
+                    auto advance = [&](S c) {            // next chunk of the stream, clamped at its end
+                        if (++c.chunk == nchunks) {
+                            if (c.k + 1 < ntiles) { c.chunk = 0; ++c.k; }
+                            else c.chunk = nchunks - 1;
+                        }
+                        fill(c);
+                        return c;
+                    };
+                    auto issue_item = [&](const S& c, int j) { araw[j] = ld4(c.src + (long)rows2[j] * c.stride + c4 * 4); };
+                    auto issue_coef = [&](const S& c) { kq.p = ld4(c.ka + c4 * 4); kq.q = ld4(c.kb + c4 * 4); };
+                    auto finish = [&](int slot, int j) {
+                        if (live[j]) {
+                            f32x4 v = araw[j];
+                            if (uni) v = v * kq.p + kq.q;
+                            if (a.pro_silu) {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) v[e] = sgd_silu(v[e]);
+                            }
+                            if (!((valid1 >> j) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};
+                            lds_store_act<PREC>(As + (size_t)(slot % NA) * a_floats + (size_t)pixj[j] * LDA, c4, v);
+                        }
+                    };
+                    S s1, s2;
+                    s2.k = 0; s2.chunk = 0; fill(s2);
+                    s2 = advance(s2);                                   // chunk 1
+                    s1 = s2;
+                    load_rows(s2.k);
+#pragma unroll
+                    for (int j = 0; j < AJ; ++j) issue_item(s2, j);
+                    if (!LATE) issue_coef(s2);
+                    SYNC();
+                    for (int q = 0; q < Q; ++q) {
+                        // tap 0: chunk q+1 becomes the one being transformed, chunk q+2 the one being requested
+                        s1 = s2;
+                        valid1 = valid2;
+                        s2 = advance(s2);
+                        if (s2.k != s1.k) load_rows(s2.k);
+                        if (LATE) issue_coef(s1);
+                        SYNC();
+#pragma unroll
+                        for (int t = 1; t < 8; ++t) {                                              // taps 1..7
+                            if (t >= T0 && t < T0 + AJ) {
+                                finish(q + 1, t - T0);
+                                issue_item(s2, t - T0);
+                            }
+                            if (!LATE && t == 7) issue_coef(s2);
+                            SYNC();
+                        }
+                        if (LATE) {                                                                // tap 8
+                            finish(q + 1, 8 - T0);
+                            issue_item(s2, 8 - T0);
+                        }
+                        if (q + 3 < Q && (q + 3) % nchunks == 0) build_pixtab((q + 3) / nchunks, lt, A_THREADS);
+                        SYNC();
+                    }
+                };
+                const bool lean2 = lean && cin % KC == 0 && (a.c1 == 0 || a.c0 % KC == 0);
+                if (lean2) {
+                    if (wave >= 8) run_lean(std::true_type());
+                    else run_lean(std::false_type());
                 } else {
-                    __syncthreads();                                                               // tap 0
+                    run();
+                }
+            } else {
+                SYNC();
+                for (int q = 0; q < Q; ++q) {
+                    SYNC();                                                                        // tap 0
                     stage_A_sync(q + 1, q + 1);                                                    // tap 1
 #pragma unroll
-                    for (int t = 1; t < 8; ++t) __syncthreads();
+                    for (int t = 1; t < 8; ++t) SYNC();
+                    if (q + 3 < Q && (q + 3) % nchunks == 0) build_pixtab((q + 3) / nchunks, lt, A_THREADS);
+                    SYNC();
                 }
-                // tap 8: table of the tile that chunk q+2 opens (needed from tap 0 of chunk q+1 on)
-                if (q + 2 < Q && (q + 2) % nchunks == 0) build_pixtab((q + 2) / nchunks, lt, A_THREADS);
-                __syncthreads();
             }
+            PROBE_END(1);
             return;
         } else {
             constexpr int AJ = (BM * 8 + A_THREADS - 1) / A_THREADS;      // 128 rows * 8 quads / 384 threads (3)
@@ -449,8 +629,9 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
 #pragma unroll
                 for (int j = 0; j < AJ; ++j) araw[R][j] = raw_item(tab, lt + j * A_THREADS, c);
             };
-            auto finish = [&](int q, auto rc) {
+            auto finish = [&](int slot, auto rc) {
                 constexpr int R = decltype(rc)::value;
+                const int q = slot < Q ? slot : Q - 1;
                 const int k = q / nchunks, chunk = q - k * nchunks;
                 const TabRef tab = tabref(k);
                 Coef knone;
@@ -458,7 +639,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
                 knone.q = knone.p;
 #pragma unroll
                 for (int j = 0; j < AJ; ++j)
-                    finish_item(q, tab, chunk, lt + j * A_THREADS, araw[R][j], a.pro == SGD_PRO_NONE ? &knone : nullptr);
+                    finish_item(slot, tab, chunk, lt + j * A_THREADS, araw[R][j], a.pro == SGD_PRO_NONE ? &knone : nullptr);
             };
             typedef std::integral_constant<int, 0> R0;
             typedef std::integral_constant<int, 1> R1;
@@ -466,22 +647,23 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
             issue(2, R2());
             issue(3, R0());
             issue(4, R1());
-            __syncthreads();
-            for (int step = 0; step < S; step += 3) {
-                if (step + 2 < S) finish(step + 2, R2());
-                issue(step + 5, R2());
-                __syncthreads();
-                if (step + 1 < S) {
-                    if (step + 3 < S) finish(step + 3, R0());
-                    issue(step + 6, R0());
-                    __syncthreads();
-                }
-                if (step + 2 < S) {
-                    if (step + 4 < S) finish(step + 4, R1());
-                    issue(step + 7, R1());
-                    __syncthreads();
-                }
+            SYNC();
+            auto body = [&](int step, auto rc) {
+                finish(step + 2, rc);               // chunks past the end: clamped duplicates into ring slots nobody reads
+                issue(step + 5, rc);
+                SYNC();
+            };
+            int step = 0;
+            for (; step + 3 <= S; step += 3) {
+                body(step, R2());
+                body(step + 1, R0());
+                body(step + 2, R1());
             }
+            if (step < S) {
+                body(step, R2());
+                if (step + 1 < S) body(step + 1, R0());
+            }
+            PROBE_END(1);
             return;
         }
     }
@@ -523,15 +705,15 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
             if (ks + 1 < NKS) fr[(ks + 1) & 1].load(ap, bp, ks + 1, lh);
             else if (more) fr[(ks + 1) & 1].load(nap, nbp, 0, lh);
             __builtin_amdgcn_sched_barrier(0);
-            if (!(g.dbg & 4)) fr[ks & 1].mma(acc);
+            if (!(DBG(4))) fr[ks & 1].mma(acc);
             __builtin_amdgcn_sched_barrier(0);
         }
-        __syncthreads();
+        SYNC();
     };
     const int rowstep = g.hw * LDA;                // LDS floats between halo rows
     const int bslot_floats = BN * LDA;
 
-    __syncthreads();                               // pairs with the loaders' prologue barrier
+    SYNC();                               // pairs with the loaders' prologue barrier
     {
         const float* ap0[MT];
 #pragma unroll
@@ -631,7 +813,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
                                 const long rw = (long)a.wo * 2 * a.cout;
                                 v += 0.25f * (ld4(rp + c) + ld4(rp + a.cout + c) + ld4(rp + rw + c) + ld4(rp + rw + a.cout + c));
                             }
-                            if (!(g.dbg & 8)) *reinterpret_cast<f32x4*>(yp + c) = v;
+                            if (!(DBG(8))) *reinterpret_cast<f32x4*>(yp + c) = v;
                         } else {
 #pragma unroll
                             for (int j = 0; j < 4; ++j) {
@@ -649,11 +831,13 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
                 }
             }
         };
+        PROBE_EPI(
         if (!a.res) epilogue(std::integral_constant<int, 0>());
         else if (a.res_mode == SGD_RS_NONE) epilogue(std::integral_constant<int, 1>());
         else if (a.res_mode == SGD_RS_AVGPOOL2) epilogue(std::integral_constant<int, 2>());
-        else epilogue(std::integral_constant<int, 3>());
+        else epilogue(std::integral_constant<int, 3>()));
     }
+    PROBE_END(0);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -825,12 +1009,17 @@ extern "C" int sgd_igemm(const sgd_igemm_args* args, void* stream) {
         const long rows_res = a.res_mode == SGD_RS_AVGPOOL2 ? rows_out * 4 : rows_out;
         if (rows_out >= (1L << 31) || rows_res >= (1L << 31)) return SGD_ERR_ARG;
     }
+#ifdef SGDM_PROBE
     {
-        static int dbg = -1;
-        if (dbg < 0) { const char* e = getenv("SGDM_DBG"); dbg = e ? atoi(e) : 0; }
-        g.dbg = dbg;
+        const char* e = getenv("SGDM_DBG");
+        g.dbg = e ? atoi(e) : 0;
+        const char* sp = getenv("SGDM_STAMP_PTR");       // device buffer of gridDim * 12 * 4 u64 (tools/probe_conv.py)
+        g.stamp = sp ? reinterpret_cast<unsigned long long*>(strtoull(sp, nullptr, 0)) : nullptr;
+        const char* tp = getenv("SGDM_TRACE_PTR");
+        g.trace = tp ? reinterpret_cast<unsigned long long*>(strtoull(tp, nullptr, 0)) : nullptr;
     }
-    const size_t smem = ((size_t)na * g.pix * LDA + (size_t)NB_RING * bn * LDA) * sizeof(float) + (size_t)g.pix * 16;
+#endif
+    const size_t smem = ((size_t)na * g.pix * LDA + (size_t)NB_RING * bn * LDA) * sizeof(float) + (size_t)g.pix * 24;
     if (smem > 160 * 1024) return SGD_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     const bool conv = a.mode == SGD_MODE_CONV3;

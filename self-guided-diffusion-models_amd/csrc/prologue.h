@@ -11,8 +11,10 @@ template <bool VEC>
 __device__ __forceinline__ f32x4 load_raw(const sgd_igemm_args& a, long row, int c) {
     f32x4 v;
     if (VEC) {
-        if (c < a.c0) v = ld4(a.x0 + row * a.c0 + c);
-        else v = ld4(a.x1 + row * a.c1 + (c - a.c0));
+        // pointer select, ONE unconditional load: a branch around a load would make every later
+        // s_waitcnt vmcnt of the calling loader conservative (the counter is in-order)
+        const float* p = (c < a.c0) ? a.x0 + row * a.c0 + c : a.x1 + row * a.c1 + (c - a.c0);
+        v = ld4(p);
     } else {
         const int ct = a.c0 + a.c1;
 #pragma unroll

@@ -12,8 +12,8 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 #define SGD_WAVE 64
 
 __device__ __forceinline__ float sgd_silu(float v) {
-    // x * sigmoid(x); __expf -> v_exp_f32 path, 1 ulp-ish; the reference uses aten silu (fp32)
-    return v / (1.0f + __expf(-v));
+    // x * sigmoid(x); v_exp_f32 and v_rcp_f32 are 1 ulp each; the reference uses aten silu (fp32)
+    return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));
 }
 
 // counter-based dropout mask (include/sgdm_hip.h: sgd_igemm_args.drop_p)

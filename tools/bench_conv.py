@@ -13,6 +13,7 @@ ap.add_argument("--cout", type=int, default=128); ap.add_argument("--hw", type=i
 ap.add_argument("--prec", default="f16x3"); ap.add_argument("--reps", type=int, default=20)
 ap.add_argument("--plain", action="store_true", help="no GN/SiLU prologue, no residual")
 ap.add_argument("--ks", type=int, default=3)
+ap.add_argument("--zeros", action="store_true", help="all-zero operands (DVFS diagnostic: clock under load vs data)")
 a = ap.parse_args()
 lib = L.load(); prec = L.PREC_BY_NAME[a.prec]
 dev = "cuda"
@@ -22,6 +23,8 @@ w = torch.randn(cout, cin, a.ks, a.ks, device=dev) / (cin * a.ks * a.ks) ** 0.5
 bias = torch.randn(cout, device=dev); res = torch.randn(n, hw, hw, cout, device=dev)
 pa, pb = torch.randn(n, cin, device=dev), torch.randn(n, cin, device=dev)
 y = torch.empty(n, hw, hw, cout, device=dev)
+if a.zeros:
+    for t_ in (x, w, bias, res, pa, pb): t_.zero_()
 buf = torch.empty(lib.sgd_packed_weight_bytes(cout, cin, a.ks, prec) // 4, device=dev)
 cp, op = C.c_int32(), C.c_int32()
 st = torch.cuda.current_stream().cuda_stream
@@ -44,4 +47,4 @@ for _ in range(a.reps): lib.sgd_igemm(C.byref(g), st)
 e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / a.reps
 fl = 2.0 * n * hw * hw * cout * cin * a.ks * a.ks
-print(f"n={n} cin={cin} cout={cout} hw={hw} ks={a.ks} prec={a.prec} plain={a.plain}: {ms:.4f} ms  {fl/ms/1e9:.1f} TFLOP/s")
+print(f"n={n} cin={cin} cout={cout} hw={hw} ks={a.ks} prec={a.prec} plain={a.plain} zeros={a.zeros}: {ms:.4f} ms  {fl/ms/1e9:.1f} TFLOP/s")

@@ -3,7 +3,8 @@
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 C="$1"; shift
-rm -rf /tmp/pmc; rocprofv3 --pmc $C --output-format csv -d /tmp/pmc -- python3 "$@" > /tmp/pmc.log 2>&1
+S="$1"; shift; case "$S" in /*) ;; *) S="$R/$S";; esac
+rm -rf /tmp/pmc; rocprofv3 --pmc $C --output-format csv -d /tmp/pmc -- python3 "$S" "$@" > /tmp/pmc.log 2>&1
 f=$(find /tmp/pmc -name "*counter_collection.csv" | head -1)
 python3 - "$f" <<PY
 import csv, sys, collections
