@@ -59,17 +59,17 @@ struct Geo {
 // and per-wave cycle accounting.  In the shipped library the knobs fold to constants and no stamp executes.
 #ifdef SGDM_PROBE
 #define DBG(bit) (g.dbg & (bit))
-#define SYNC() do { const unsigned long long t0_ = __builtin_amdgcn_s_memtime(); __syncthreads(); \
+#define SYNC() do { if (g.stamp) { const unsigned long long t0_ = __builtin_amdgcn_s_memtime(); __syncthreads(); \
                     const unsigned long long t1_ = __builtin_amdgcn_s_memtime(); \
                     if (g.trace && blockIdx.x < 16 && pr_nbar < 512 && (threadIdx.x & 63) == 0) { \
                         unsigned long long* tp_ = g.trace + (((size_t)blockIdx.x * (NTHREADS / 64) + (threadIdx.x >> 6)) * 512 + pr_nbar) * 2; \
                         tp_[0] = t0_; tp_[1] = t1_; } \
-                    pr_bar += t1_ - t0_; ++pr_nbar; } while (0)
+                    pr_bar += t1_ - t0_; ++pr_nbar; } else if (!DBG(64)) { __syncthreads(); } } while (0)
 #define PROBE_BEGIN() unsigned long long pr_bar = 0, pr_nbar = 0, pr_epi = 0; const unsigned long long pr_t0 = __builtin_amdgcn_s_memtime()
 #define PROBE_END(role) do { if (g.stamp && (threadIdx.x & 63) == 0) { \
         unsigned long long* sp_ = g.stamp + ((size_t)blockIdx.x * (NTHREADS / 64) + (threadIdx.x >> 6)) * 4; \
         sp_[0] = __builtin_amdgcn_s_memtime() - pr_t0; sp_[1] = pr_bar; sp_[2] = pr_nbar; sp_[3] = pr_epi; } } while (0)
-#define PROBE_EPI(expr) do { const unsigned long long t0_ = __builtin_amdgcn_s_memtime(); expr; pr_epi += __builtin_amdgcn_s_memtime() - t0_; } while (0)
+#define PROBE_EPI(expr) do { if (g.stamp) { const unsigned long long t0_ = __builtin_amdgcn_s_memtime(); expr; pr_epi += __builtin_amdgcn_s_memtime() - t0_; } else { expr; } } while (0)
 #else
 #define DBG(bit) 0
 #define SYNC() __syncthreads()
@@ -125,6 +125,8 @@ template <int PREC, int MT, int NT> struct Frag {
     typedef typename Split<PREC>::T T;
     typedef T T8 __attribute__((ext_vector_type(8)));
     static constexpr int NKS = KC / 16;           // 16 channels per sub-step
+    static constexpr int NREADS = 2 * (MT + NT);  // ds_read_b128 per sub-step
+    static constexpr int NMMA = 3 * MT * NT;      // MFMAs per sub-step
     T8 ah[MT], al[MT], bh[NT], bl[NT];
     __device__ __forceinline__ void load(const float* const* ap, const float* bp, int ks, int lh) {
         const int goff = (ks * 2 + lh) * 8;       // float offset of this lane-half's 8-channel group
@@ -158,6 +160,8 @@ template <int PREC, int MT, int NT> struct Frag {
 };
 template <int MT, int NT> struct Frag<SGD_PREC_F32, MT, NT> {
     static constexpr int NKS = KC / 8;            // 8 channels per sub-step (4 MFMA k-pairs)
+    static constexpr int NREADS = MT + NT;
+    static constexpr int NMMA = 4 * MT * NT;
     f32x4 a[MT], b[NT];
     __device__ __forceinline__ void load(const float* const* ap, const float* bp, int ks, int lh) {
 #pragma unroll
@@ -280,10 +284,274 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
     PROBE_BEGIN();
 
     if (tid >= 256) {
-        // The four MFMA waves are the oldest waves of their SIMDs and would win every issue arbitration, leaving the
-        // loaders ~2.5 vector instructions per MFMA.  A loader instruction delays the next MFMA's ISSUE by a few cycles
-        // but not the matrix pipe (32 cycles per MFMA, 8 of them on the issue port), so the loaders go first.
-        __builtin_amdgcn_s_setprio(2);
+        if constexpr (CONV) {
+            // =================================================================================
+            // unified loader (the sampler's ResBlock convs: stride 1, per-image GroupNorm affine (+SiLU) or no prologue,
+            // whole 32-channel chunks from one source, no dropout).  All eight loader waves do the same thing every K step:
+            //   weights: 1/8 of slice B(step+2) registers -> LDS, request 1/8 of B(step+5)      (2 x 16 B per thread)
+            //   inputs : at this wave's taps (waves 4-7: 1..3, waves 8-11: 5..7) transform ONE raw row quad requested
+            //            nine steps earlier into LDS and request the same item of the next chunk
+            // Spreading the weight slice over all loader waves matters because a wave's global loads issue serially
+            // (~50-120 cycles each with every CU streaming): two dedicated waves needed ~950 cycles per step for their
+            // 8 loads each and paced the block.  Everything is branch-free so the in-order vmcnt waits stay exact.
+            // =================================================================================
+            const bool uni = VEC && g.nb == 1 && a.pro == SGD_PRO_AFFINE_NC;
+            const bool lean2 = g.fast_a && VEC && (uni || a.pro == SGD_PRO_NONE) && a.drop_p == 0.f && cin % KC == 0
+                               && (a.c1 == 0 || a.c0 % KC == 0) && !DBG(3);
+            if (lean2) {
+                constexpr int LT = NTHREADS - 256;                       // 512 loader threads
+                constexpr int AJ = (FAST_PIX * 8 + LT - 1) / LT;         // input items per thread per chunk (3)
+                constexpr int BI = BN == 128 ? 2 : 1;                    // weight quads per thread per slice
+                const int lt = tid - 256;
+                const int c4 = lt & 7;                                   // channel quad (inputs and weights alike)
+                const int items = g.pix * 8;
+                auto go = [&](auto latec) {
+                    constexpr bool LATE = decltype(latec)::value;
+                    constexpr int T0 = LATE ? 5 : 1;
+                    typedef std::integral_constant<int, 0> R0;
+                    typedef std::integral_constant<int, 1> R1;
+                    typedef std::integral_constant<int, 2> R2;
+                    // ---- weights
+                    const int brow = BN == 128 ? (lt >> 3) : ((lt & 255) >> 3);   // BN = 32: the upper half duplicates
+                    f32x4 breg[NB_RING][BI];
+                    const float* wthr = reinterpret_cast<const float*>(a.w) + (size_t)brow * a.cin_p + c4 * 4;
+                    const size_t tap_stride = (size_t)a.cout_p * a.cin_p;
+                    int ck = 0, ctap = 0, cchunk = 0;
+                    const float* wtile = wthr + (size_t)tile_at(g, lin_of(0), BN, TW, TH).n0c * a.cin_p;
+                    auto load_next = [&](auto rc) {
+                        constexpr int R = decltype(rc)::value;
+                        const float* wp = wtile + (size_t)ctap * tap_stride + cchunk * KC;
+#pragma unroll
+                        for (int it = 0; it < BI; ++it) breg[R][it] = ld4(wp + (size_t)(it * 64) * a.cin_p);
+                        if (++ctap == TAPS) {
+                            ctap = 0;
+                            if (++cchunk == nchunks) {
+                                cchunk = 0;
+                                if (++ck == ntiles) { ck = ntiles - 1; cchunk = nchunks - 1; ctap = TAPS - 1; }
+                                else wtile = wthr + (size_t)tile_at(g, lin_of(ck), BN, TW, TH).n0c * a.cin_p;
+                            }
+                        }
+                    };
+                    float* const bdst = Bs + brow * LDA + c4 * 4;
+                    auto store_B = [&](int slot, auto rc) {
+                        constexpr int R = decltype(rc)::value;
+#pragma unroll
+                        for (int it = 0; it < BI; ++it)
+                            *reinterpret_cast<f32x4*>(bdst + (size_t)slot * BN * LDA + it * 64 * LDA) = breg[R][it];
+                    };
+                    // ---- inputs
+                    int pixj[AJ], rows2[AJ];
+                    bool live[AJ];
+#pragma unroll
+                    for (int j = 0; j < AJ; ++j) {
+                        const int idx = lt + j * LT;
+                        live[j] = idx < items;
+                        pixj[j] = (live[j] ? idx : items - 1) >> 3;
+                    }
+                    unsigned valid1 = 0, valid2 = 0;
+                    auto load_rows = [&](int k) {
+                        const int2* tab = pixtab + (size_t)(k % 3) * g.pix;
+                        valid2 = 0;
+#pragma unroll
+                        for (int j = 0; j < AJ; ++j) {
+                            const int ex = tab[pixj[j]].x;
+                            rows2[j] = ex < 0 ? 0 : ex;
+                            if (ex >= 0 && live[j]) valid2 |= 1u << j;
+                        }
+                    };
+                    struct S { int k, chunk; const float* src; int stride; const float* ka; const float* kb; };
+                    auto fill = [&](S& c) {
+                        const int ch = c.chunk * KC;
+                        if (ch < a.c0) { c.src = a.x0 + ch; c.stride = a.c0; }
+                        else { c.src = a.x1 + (ch - a.c0); c.stride = a.c1; }
+                        const long ko = (long)tile_at(g, lin_of(c.k), BN, TW, TH).img0 * cin + ch;
+                        c.ka = uni ? a.pa + ko : a.x0;   // no prologue: 32 harmless bytes instead of a branch around the load
+                        c.kb = uni ? a.pb + ko : a.x0;
+                    };
+                    auto advance = [&](S c) {
+                        if (++c.chunk == nchunks) {
+                            if (c.k + 1 < ntiles) { c.chunk = 0; ++c.k; }
+                            else c.chunk = nchunks - 1;
+                        }
+                        fill(c);
+                        return c;
+                    };
+                    f32x4 araw[AJ];
+                    Coef kq;
+                    auto transform = [&](f32x4 v, bool ok) {
+                        if (uni) v = v * kq.p + kq.q;
+                        if (a.pro_silu) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = sgd_silu(v[e]);
+                        }
+                        if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
+                        return v;
+                    };
+                    auto issue_item = [&](const S& c, int j) { araw[j] = ld4(c.src + (long)rows2[j] * c.stride + c4 * 4); };
+                    auto issue_coef = [&](const S& c) { kq.p = ld4(c.ka + c4 * 4); kq.q = ld4(c.kb + c4 * 4); };
+                    auto finish = [&](int slot, int j) {
+                        if (live[j])
+                            lds_store_act<PREC>(As + (size_t)(slot % NA) * a_floats + (size_t)pixj[j] * LDA, c4,
+                                                transform(araw[j], (valid1 >> j) & 1u));
+                    };
+                    // ---- prologue: weight slices 0..4 in flight / staged, chunk 0 staged synchronously, chunk 1 requested
+                    load_next(R0());
+                    load_next(R1());
+                    S s1, s2;
+                    s2.k = 0; s2.chunk = 0; fill(s2);
+                    load_rows(0);
+                    valid1 = valid2;
+                    issue_coef(s2);
+#pragma unroll
+                    for (int j = 0; j < AJ; ++j) issue_item(s2, j);
+#pragma unroll
+                    for (int j = 0; j < AJ; ++j) finish(0, j);
+                    store_B(0, R0());
+                    store_B(1, R1());
+                    load_next(R2());
+                    load_next(R0());
+                    load_next(R1());
+                    s2 = advance(s2);                                   // chunk 1
+                    if (s2.k != 0) load_rows(s2.k);
+#pragma unroll
+                    for (int j = 0; j < AJ; ++j) issue_item(s2, j);
+                    if (!LATE) issue_coef(s2);
+                    SYNC();
+                    for (int q = 0; q < Q; ++q) {
+                        // tap 0: chunk q+1 becomes the one being transformed, chunk q+2 the one being requested
+                        store_B(2, R2());
+                        load_next(R2());
+                        s1 = s2;
+                        valid1 = valid2;
+                        s2 = advance(s2);
+                        if (s2.k != s1.k) load_rows(s2.k);
+                        if (LATE) issue_coef(s1);
+                        SYNC();
+#pragma unroll
+                        for (int t = 1; t < 9; ++t) {                                              // taps 1..8
+                            if (t % 3 == 1) { store_B(0, R0()); load_next(R0()); }
+                            else if (t % 3 == 2) { store_B(1, R1()); load_next(R1()); }
+                            else { store_B(2, R2()); load_next(R2()); }
+                            if (t >= T0 && t < T0 + AJ) {
+                                finish(q + 1, t - T0);
+                                issue_item(s2, t - T0);
+                            }
+                            if (!LATE && t == 7) issue_coef(s2);
+                            if (t == 8 && q + 3 < Q && (q + 3) % nchunks == 0) build_pixtab((q + 3) / nchunks, lt, LT);
+                            SYNC();
+                        }
+                    }
+                };
+                if (wave >= 8) go(std::true_type());
+                else go(std::false_type());
+                PROBE_END(1);
+                return;
+            }
+        } else {
+            // =================================================================================
+            // unified loader, 1x1 convs / linears (skip connections, attention qkv / proj_out): every K step needs a
+            // fresh 128 x 32 input tile AND a fresh weight slice, so each of the 512 loader threads moves two input quads
+            // and two weight quads per step through a 3-deep register ring (requested 3 steps before they are staged).
+            // Lean cases only: no prologue, or a per-image GroupNorm affine whose image boundaries fall on tile
+            // boundaries (rows_per_n % 128 == 0), so the coefficients of a tile are one (n, channel quad) vector.
+            // =================================================================================
+            const bool tile_uni = a.pro == SGD_PRO_AFFINE_NC && a.rows_per_n % BM == 0;
+            const bool leanf = VEC && (a.pro == SGD_PRO_NONE || tile_uni) && a.drop_p == 0.f && cin % KC == 0
+                               && (a.c1 == 0 || a.c0 % KC == 0) && !DBG(3);
+            if (leanf) {
+                constexpr int AI = BM * 8 / (NTHREADS - 256);             // input quads per thread per step (2)
+                constexpr int BI = BN == 128 ? 2 : 1;
+                const int lt = tid - 256;
+                const int c4 = lt & 7;
+                const int arow = lt >> 3;                                 // + 64 j
+                const int brow = BN == 128 ? (lt >> 3) : ((lt & 255) >> 3);
+                typedef std::integral_constant<int, 0> R0;
+                typedef std::integral_constant<int, 1> R1;
+                typedef std::integral_constant<int, 2> R2;
+                f32x4 araw[NB_RING][AI], breg[NB_RING][BI];
+                Coef kq[NB_RING];
+                struct Cur { int k, chunk; int m0; const float* wt; const float* ka; const float* kb; };
+                auto open_tile = [&](Cur& c) {                           // per-tile scalars
+                    const Tile T = tile_at(g, lin_of(c.k), BN, TW, TH);
+                    c.m0 = (int)T.m0;
+                    c.wt = reinterpret_cast<const float*>(a.w) + (size_t)(T.n0c + brow) * a.cin_p + c4 * 4;
+                    const long ko = tile_uni ? (long)(c.m0 / a.rows_per_n) * cin : 0;
+                    c.ka = tile_uni ? a.pa + ko + c4 * 4 : a.x0;          // no prologue: harmless bytes, no branch
+                    c.kb = tile_uni ? a.pb + ko + c4 * 4 : a.x0;
+                };
+                auto advance = [&](Cur& c) {
+                    if (++c.chunk == nchunks) {
+                        if (c.k + 1 < ntiles) { c.chunk = 0; ++c.k; open_tile(c); }
+                        else c.chunk = nchunks - 1;
+                    }
+                };
+                Cur ci, cf;
+                ci.k = 0; ci.chunk = 0; open_tile(ci);
+                cf = ci;
+                auto issue = [&](auto rc) {                              // request the chunk under the issue cursor
+                    constexpr int R = decltype(rc)::value;
+                    const int ch = ci.chunk * KC;
+                    const float* src;
+                    int stride;
+                    if (ch < a.c0) { src = a.x0 + ch; stride = a.c0; }
+                    else { src = a.x1 + (ch - a.c0); stride = a.c1; }
+#pragma unroll
+                    for (int it = 0; it < BI; ++it) breg[R][it] = ld4(ci.wt + ch + (size_t)(it * 64) * a.cin_p);
+                    kq[R].p = ld4(ci.ka + (tile_uni ? ch : 0));
+                    kq[R].q = ld4(ci.kb + (tile_uni ? ch : 0));
+#pragma unroll
+                    for (int j = 0; j < AI; ++j) {
+                        int row = ci.m0 + arow + j * 64;
+                        row = row < M ? row : M - 1;
+                        araw[R][j] = ld4(src + (long)row * stride + c4 * 4);
+                    }
+                    advance(ci);
+                };
+                auto finish = [&](int slot, auto rc) {                   // stage the chunk under the finish cursor
+                    constexpr int R = decltype(rc)::value;
+#pragma unroll
+                    for (int it = 0; it < BI; ++it)
+                        *reinterpret_cast<f32x4*>(Bs + (size_t)slot * BN * LDA + (brow + it * 64) * LDA + c4 * 4) = breg[R][it];
+#pragma unroll
+                    for (int j = 0; j < AI; ++j) {
+                        f32x4 v = araw[R][j];
+                        if (tile_uni) v = v * kq[R].p + kq[R].q;
+                        if (a.pro_silu) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = sgd_silu(v[e]);
+                        }
+                        if (cf.m0 + arow + j * 64 >= M) v = f32x4{0.f, 0.f, 0.f, 0.f};
+                        lds_store_act<PREC>(As + (size_t)slot * a_floats + (size_t)(arow + j * 64) * LDA, c4, v);
+                    }
+                    advance(cf);
+                };
+                issue(R0());
+                issue(R1());
+                finish(0, R0());
+                finish(1, R1());
+                issue(R2());
+                issue(R0());
+                issue(R1());
+                SYNC();
+                auto body = [&](int slot, auto rc) {
+                    finish(slot, rc);
+                    issue(rc);
+                    SYNC();
+                };
+                int step = 0;
+                for (; step + 3 <= S; step += 3) {
+                    body(2, R2());
+                    body(0, R0());
+                    body(1, R1());
+                }
+                if (step < S) {
+                    body(2, R2());
+                    if (step + 1 < S) body(0, R0());
+                }
+                PROBE_END(1);
+                return;
+            }
+        }
         // =====================================================================================
         // loader roles.  Each wave runs ONE kind of global load in a branch-free steady state so the
         // compiler's in-order vmcnt bookkeeping stays exact (a conditional load anywhere degrades every
@@ -702,10 +970,24 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
         for (int ks = 0; ks < NKS; ++ks) {
             __builtin_amdgcn_s_waitcnt(0xC07F);                        // lgkmcnt(0) only
             __builtin_amdgcn_sched_barrier(0);
+            if (!(DBG(128))) {
             if (ks + 1 < NKS) fr[(ks + 1) & 1].load(ap, bp, ks + 1, lh);
-            else if (more) fr[(ks + 1) & 1].load(nap, nbp, 0, lh);
-            __builtin_amdgcn_sched_barrier(0);
+            else fr[(ks + 1) & 1].load(nap, nbp, 0, lh);
+            }   // unconditional (a branch here would block the interleave); past the
+                                                            // last step it reads a valid ring slot nobody needs
             if (!(DBG(4))) fr[ks & 1].mma(acc);
+            // The four MFMA waves reach this point together (barrier-synchronised), so a burst of 8 ds_read_b128 per
+            // wave fills the LDS queue and the in-order wave cannot issue its MFMAs until its reads are accepted
+            // (measured: LDS phase and MFMA phase fully serialised).  Interleave: one MFMA, two reads, ... then the
+            // rest of the MFMAs cover the latency of the last reads.
+            if (!(DBG(32))) {
+#pragma unroll
+                for (int i = 0; i < FragT::NREADS / 2; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, FragT::NMMA - FragT::NREADS / 2, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
         SYNC();

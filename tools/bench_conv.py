@@ -13,8 +13,11 @@ ap.add_argument("--cout", type=int, default=128); ap.add_argument("--hw", type=i
 ap.add_argument("--prec", default="f16x3"); ap.add_argument("--reps", type=int, default=20)
 ap.add_argument("--plain", action="store_true", help="no GN/SiLU prologue, no residual")
 ap.add_argument("--ks", type=int, default=3)
+ap.add_argument("--dbg", type=int, default=-1, help="use the probe library with this SGDM_DBG ablation mask (no stamps)")
 ap.add_argument("--zeros", action="store_true", help="all-zero operands (DVFS diagnostic: clock under load vs data)")
 a = ap.parse_args()
+if a.dbg >= 0:
+    L.LIB_PATH = os.path.join(os.path.dirname(L.LIB_PATH), "libsgdm_hip_probe.so"); os.environ["SGDM_DBG"] = str(a.dbg)
 lib = L.load(); prec = L.PREC_BY_NAME[a.prec]
 dev = "cuda"
 n, cin, cout, hw = a.n, a.cin, a.cout, a.hw
@@ -47,4 +50,4 @@ for _ in range(a.reps): lib.sgd_igemm(C.byref(g), st)
 e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / a.reps
 fl = 2.0 * n * hw * hw * cout * cin * a.ks * a.ks
-print(f"n={n} cin={cin} cout={cout} hw={hw} ks={a.ks} prec={a.prec} plain={a.plain} zeros={a.zeros}: {ms:.4f} ms  {fl/ms/1e9:.1f} TFLOP/s")
+print(f"n={n} cin={cin} cout={cout} hw={hw} ks={a.ks} prec={a.prec} plain={a.plain} zeros={a.zeros} dbg={a.dbg}: {ms:.4f} ms  {fl/ms/1e9:.1f} TFLOP/s")
