@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define SGD_ABI_VERSION 2
+#define SGD_ABI_VERSION 3
 int sgd_abi_version(void);
 
 /* --------------------------------------------------------------------------------------
@@ -80,6 +80,12 @@ typedef struct sgd_igemm_args {
      * 1/(1-p).  Counter-based: forward, wgrad and the GroupNorm backward recompute the same mask, nothing stored. */
     float drop_p;          /* 0: off */
     uint32_t drop_seed;
+    /* GroupNorm statistics of the OUTPUT, produced by the epilogue (the consumer's group_norm,
+     * openaimodel.py:246-247, then needs no extra pass over y): per-(image, tile-part, channel) partial
+     * (sum, sum of squares) of the stored values, layout [n, parts, 2, cout]; parts =
+     * sgd_igemm_stats_parts(args) (0: this geometry cannot produce them; leave stats NULL).  Folded into
+     * the sums[n, c, 2] layout of sgd_chan_stats by sgd_stats_reduce.  NULL: off. */
+    float* stats;
 } sgd_igemm_args;
 
 /* the keep/drop hash, shared by device code and host tests:
@@ -87,6 +93,8 @@ typedef struct sgd_igemm_args {
  *   keep  <=>  (h >> 8) >= (uint32_t)(p * 16777216)                                       (lo/hi = halves of the index) */
 
 int sgd_igemm(const sgd_igemm_args* args /* HOST pointer */, void* stream);
+/* number of per-image partial-statistics slots the epilogue of this launch writes (see args->stats) */
+int sgd_igemm_stats_parts(const sgd_igemm_args* args /* HOST pointer */);
 
 /* bytes of the packed weight buffer for given dims; w_src is [cout, cin, k, k] (OIHW) or [cout, cin] */
 int64_t sgd_packed_weight_bytes(int32_t cout, int32_t cin, int32_t ksize, int32_t prec);
@@ -101,6 +109,9 @@ int sgd_pack_weight(const float* w_src, void* w_dst, int32_t cout, int32_t cin, 
  * -------------------------------------------------------------------------------------- */
 int sgd_chan_stats(const float* x, int32_t n, int32_t hw, int32_t c,
                    float* sums /* [n, c_total, 2] */, int32_t c_total, int32_t c_off, void* stream);
+/* sums[n, c_off + c, 2] = sum over parts of partial[n, parts, 2, c] (partials written by sgd_igemm's epilogue) */
+int sgd_stats_reduce(const float* partial, int32_t n, int32_t parts, int32_t c,
+                     float* sums /* [n, c_total, 2] */, int32_t c_total, int32_t c_off, void* stream);
 int sgd_gn_coef(const float* sums, const float* gamma, const float* beta,
                 const float* film /* [n, film_ld] scale at +0, shift at +c; or NULL */, int32_t film_ld,
                 int32_t n, int32_t c, int32_t groups, int32_t hw, float eps,

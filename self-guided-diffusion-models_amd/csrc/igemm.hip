@@ -47,6 +47,7 @@ struct Geo {
     int pix;                  // nb*hh*hw (CONV3) or 128 (FLAT)
     int mt, nt;               // number of M / N tiles
     int hc, wc;               // conv-input dims (after resample)
+    int sparts;               // statistics slots per image (args.stats), 0: unsupported geometry
     int fast_a;               // 1: split-phase A loader (stride 1, no avg-pool, pix*8 <= JMAX*256)
 #ifdef SGDM_PROBE
     int dbg;                  // SGDM_DBG bits: 1 skip A staging, 2 skip B staging, 4 skip MFMA, 8 skip stores
@@ -185,6 +186,18 @@ template <int MT, int NT> struct Frag<SGD_PREC_F32, MT, NT> {
 // stream of K steps, so the loaders are already staging tile t+1 while the compute waves finish and
 // store tile t (no per-tile prologue / epilogue bubble on the matrix pipe).
 // ---------------------------------------------------------------------------------------------
+template <int CTRL, int ROWMASK> __device__ __forceinline__ float dpp_add(float v) {
+    return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROWMASK, 0xF, true));
+}
+// sum over the 32 lanes that share (lane >> 5), DPP only (no LDS round trip); the total lands in lanes 16..31 / 48..63
+__device__ __forceinline__ float half_wave_sum_hi(float v) {
+    v = dpp_add<0xB1, 0xF>(v);       // quad_perm [1,0,3,2]
+    v = dpp_add<0x4E, 0xF>(v);       // quad_perm [2,3,0,1]
+    v = dpp_add<0x141, 0xF>(v);      // row_half_mirror
+    v = dpp_add<0x140, 0xF>(v);      // row_mirror: every lane holds its row-of-16 total
+    return dpp_add<0x142, 0xA>(v);   // row_bcast15 into rows 1 and 3: + the total of the row below
+}
+
 struct Tile {
     int n0c;                 // first output column
     int img0, ty0, tx0;      // CONV3 origin
@@ -1055,61 +1068,115 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
         const int cb = T.n0c + wn * WN + 4 * lh;          // first channel of this lane's g = 0 run (nt = 0)
         auto epilogue = [&](auto resmode) {
             constexpr int RES = decltype(resmode)::value;     // 0 none, 1 same rows, 2 avg-pool of 2x map, 3 nearest of 1/2 map
+            // per M block: output row / residual row of this lane's pixel
+            bool okm[MT];
+            float* ypm[MT];
+            const float* rpm[MT];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const int row = wm * WM + mt * 32 + li;
                 int orow, n = 0, oy = 0, ox = 0;
-                bool ok;
                 if (CONV) {
                     const int tx = row & (TW - 1), ty = (row >> g.tw_l2) & (TH - 1), nb = row >> (g.tw_l2 + g.th_l2);
                     n = T.img0 + nb; oy = T.ty0 + ty; ox = T.tx0 + tx;
-                    ok = nb < g.nb && n < a.n;
+                    okm[mt] = nb < g.nb && n < a.n;
                     orow = (n * a.ho + oy) * a.wo + ox;
                 } else {
                     orow = (int)T.m0 + row;
-                    ok = orow < M;
+                    okm[mt] = orow < M;
                 }
-                if (!ok) continue;
+                if (!okm[mt]) orow = 0;                      // keep the addresses valid; the lane is masked below
                 int rrow = orow;
                 if (RES == 2) rrow = (n * a.ho * 2 + 2 * oy) * (a.wo * 2) + 2 * ox;
                 if (RES == 3) rrow = (n * (a.ho >> 1) + (oy >> 1)) * (a.wo >> 1) + (ox >> 1);
+                if (!okm[mt]) rrow = 0;
                 if (!CONV && a.orows_in > 0)
                     orow = (int)((unsigned)orow / (unsigned)a.orows_in) * a.orows_out + a.orow_off
                            + (int)((unsigned)orow % (unsigned)a.orows_in);
-                float* yp = a.y + (long)orow * a.y_ld;
-                const float* rp = RES ? a.res + (long)rrow * a.cout : nullptr;
-                const bool vec = ((a.cout | a.y_ld) & 3) == 0;
+                ypm[mt] = a.y + (long)orow * a.y_ld;
+                rpm[mt] = RES ? a.res + (long)rrow * a.cout : nullptr;
+            }
+            const bool vec = ((a.cout | a.y_ld) & 3) == 0;
+            if (vec) {
+                // cout % 4 == 0: 16-byte quads.  Quad-outer / row-inner: the residual loads of both rows are in flight
+                // together, and the GroupNorm statistics of a quad (args.stats) live in 8 registers at a time.
+                float* sp = nullptr;
+                if (a.stats) {
+                    int n_img, part;
+                    if (CONV) {
+                        n_img = T.img0;
+                        part = ((T.ty0 >> g.th_l2) * g.tiles_x + (T.tx0 >> g.tw_l2)) * (BM / WM) + wm;
+                    } else {
+                        n_img = (int)(T.m0 / a.rows_per_n);
+                        part = (int)((T.m0 % a.rows_per_n) / BM) * (BM / WM) + wm;
+                    }
+                    sp = a.stats + ((long)n_img * g.sparts + part) * 2 * a.cout;
+                }
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
 #pragma unroll
                     for (int gq = 0; gq < 4; ++gq) {
                         const int c = cb + nt * 32 + gq * 8;
-                        if (c >= a.cout) continue;
-                        f32x4 v;
+                        if (c >= a.cout) continue;            // uniform within a lane half
+                        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+                        if (a.bias) bv = ld4(a.bias + c);
+                        f32x4 rv[MT];
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) v[j] = acc[mt][nt][gq * 4 + j];
-                        if (vec) {                                   // cout % 4 == 0: whole quad in range
-                            if (a.bias) v += ld4(a.bias + c);
-                            if (RES == 1 || RES == 3) v += ld4(rp + c);
+                        for (int mt = 0; mt < MT; ++mt) {
+                            rv[mt] = bv;
+                            if (RES == 1 || RES == 3) rv[mt] += ld4(rpm[mt] + c);
                             if (RES == 2) {
                                 const long rw = (long)a.wo * 2 * a.cout;
-                                v += 0.25f * (ld4(rp + c) + ld4(rp + a.cout + c) + ld4(rp + rw + c) + ld4(rp + rw + a.cout + c));
+                                const float* rp = rpm[mt];
+                                rv[mt] += 0.25f * (ld4(rp + c) + ld4(rp + a.cout + c) + ld4(rp + rw + c) + ld4(rp + rw + a.cout + c));
                             }
-                            if (!(DBG(8))) *reinterpret_cast<f32x4*>(yp + c) = v;
-                        } else {
+                        }
+                        f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = s1;
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) {
-                                if (c + j >= a.cout) continue;
-                                float x = v[j] + (a.bias ? a.bias[c + j] : 0.f);
-                                if (RES == 1 || RES == 3) x += rp[c + j];
-                                if (RES == 2) {
-                                    const long rw = (long)a.wo * 2 * a.cout;
-                                    x += 0.25f * (rp[c + j] + rp[a.cout + c + j] + rp[rw + c + j] + rp[rw + a.cout + c + j]);
-                                }
-                                yp[c + j] = x;
+                        for (int mt = 0; mt < MT; ++mt) {
+                            f32x4 v;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) v[j] = acc[mt][nt][gq * 4 + j];
+                            v += rv[mt];
+                            if (okm[mt]) {
+                                if (!(DBG(8))) *reinterpret_cast<f32x4*>(ypm[mt] + c) = v;
+                                s1 += v;
+                                s2 += v * v;
+                            }
+                        }
+                        if (sp) {
+                            // sum over the 32 pixel lanes of this lane half: 4 DPP steps inside a row of 16, then across rows
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) { s1[j] = half_wave_sum_hi(s1[j]); s2[j] = half_wave_sum_hi(s2[j]); }
+                            if (li == 16) {
+                                *reinterpret_cast<f32x4*>(sp + c) = s1;
+                                *reinterpret_cast<f32x4*>(sp + a.cout + c) = s2;
                             }
                         }
                     }
+                }
+            } else {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    if (!okm[mt]) continue;
+                    float* yp = ypm[mt];
+                    const float* rp = rpm[mt];
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                        for (int gq = 0; gq < 4; ++gq)
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const int c = cb + nt * 32 + gq * 8 + j;
+                                if (c >= a.cout) continue;
+                                float x = acc[mt][nt][gq * 4 + j] + (a.bias ? a.bias[c] : 0.f);
+                                if (RES == 1 || RES == 3) x += rp[c];
+                                if (RES == 2) {
+                                    const long rw = (long)a.wo * 2 * a.cout;
+                                    x += 0.25f * (rp[c] + rp[a.cout + c] + rp[rw + c] + rp[rw + a.cout + c]);
+                                }
+                                yp[c] = x;
+                            }
                 }
             }
         };
@@ -1227,22 +1294,9 @@ extern "C" int sgd_pack_weight_dgrad(const float* w_src, void* w_dst, int32_t co
     return pack_weight_impl(w_src, w_dst, cin_fwd, cout_fwd, ksize, prec, cin_p_out, cout_p_out, 1, stream);
 }
 
-extern "C" int sgd_igemm(const sgd_igemm_args* args, void* stream) {
-    SGD_CLEAR_ERR();
-    if (!args) return SGD_ERR_ARG;
-    KArgs ka;
-    ka.a = *args;
-    sgd_igemm_args& a = ka.a;
-    Geo& g = ka.g;
-    if (!a.x0 || !a.w || !a.y || a.c0 <= 0 || a.c1 < 0 || a.cout <= 0) return SGD_ERR_ARG;
-    if (a.c1 > 0 && (!a.x1 || a.c0 % KC != 0)) return SGD_ERR_ARG;
-    if (a.y_ld < a.cout) return SGD_ERR_ARG;
-    if (a.pro != SGD_PRO_NONE && (!a.pa || !a.pb)) return SGD_ERR_ARG;
-    const int cin = a.c0 + a.c1;
-    const int bn = pick_bn(a.cout);
-    if (a.cout_p % bn != 0 || a.cout_p < a.cout || a.cin_p % KC != 0 || a.cin_p < cin) return SGD_ERR_ARG;
-    const bool vec = (a.c0 % 4 == 0) && (a.c1 % 4 == 0);
-    int na;
+// tile geometry of a launch (everything that does not depend on the packed-weight dims)
+static int make_geo(const sgd_igemm_args& a, Geo& g, int bn, int& na) {
+    if (a.c0 <= 0 || a.c1 < 0 || a.cout <= 0 || a.y_ld < a.cout) return SGD_ERR_ARG;
     if (a.mode == SGD_MODE_CONV3) {
         if (a.n <= 0 || a.hi <= 0 || a.wi <= 0 || (a.stride != 1 && a.stride != 2)) return SGD_ERR_ARG;
         if (a.stride == 2 && a.resample != SGD_RS_NONE) return SGD_ERR_ARG;
@@ -1284,6 +1338,48 @@ extern "C" int sgd_igemm(const sgd_igemm_args* args, void* stream) {
     } else {
         return SGD_ERR_ARG;
     }
+    // epilogue statistics (args.stats): whole 128-row tiles of ONE image, 16-byte stores
+    g.sparts = 0;
+    const int ppt = bn == 128 ? 2 : 4;                        // M slices per tile = compute-wave rows
+    if (((a.cout | a.y_ld) & 3) == 0 && a.orows_in == 0) {
+        if (a.mode == SGD_MODE_CONV3) {
+            if (g.nb == 1 && (1 << (g.tw_l2 + g.th_l2)) == BM) g.sparts = g.tiles_x * g.tiles_y * ppt;
+        } else if (a.rows_per_n > 0 && a.rows_per_n % BM == 0 && a.m % a.rows_per_n == 0) {
+            g.sparts = a.rows_per_n / BM * ppt;
+        }
+    }
+    return SGD_OK;
+}
+
+extern "C" int sgd_igemm_stats_parts(const sgd_igemm_args* args) {
+    if (!args) return 0;
+    Geo g;
+    int na;
+    if (make_geo(*args, g, pick_bn(args->cout), na) != SGD_OK) return 0;
+    return g.sparts;
+}
+
+extern "C" int sgd_igemm(const sgd_igemm_args* args, void* stream) {
+    SGD_CLEAR_ERR();
+    if (!args) return SGD_ERR_ARG;
+    KArgs ka;
+    ka.a = *args;
+    sgd_igemm_args& a = ka.a;
+    Geo& g = ka.g;
+    if (!a.x0 || !a.w || !a.y || a.c0 <= 0 || a.c1 < 0 || a.cout <= 0) return SGD_ERR_ARG;
+    if (a.c1 > 0 && (!a.x1 || a.c0 % KC != 0)) return SGD_ERR_ARG;
+    if (a.y_ld < a.cout) return SGD_ERR_ARG;
+    if (a.pro != SGD_PRO_NONE && (!a.pa || !a.pb)) return SGD_ERR_ARG;
+    const int cin = a.c0 + a.c1;
+    const int bn = pick_bn(a.cout);
+    if (a.cout_p % bn != 0 || a.cout_p < a.cout || a.cin_p % KC != 0 || a.cin_p < cin) return SGD_ERR_ARG;
+    const bool vec = (a.c0 % 4 == 0) && (a.c1 % 4 == 0);
+    int na;
+    {
+        const int rc = make_geo(a, g, bn, na);
+        if (rc != SGD_OK) return rc;
+    }
+    if (a.stats && g.sparts == 0) return SGD_ERR_ARG;
     g.nt = a.cout_p / bn;
     {
         // epilogue uses 32-bit row indices

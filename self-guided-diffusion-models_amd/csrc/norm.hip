@@ -49,6 +49,19 @@ __global__ __launch_bounds__(256) void chan_stats_kernel(const float* __restrict
     }
 }
 
+// partial[n][parts][2][c] -> sums[n][c_total][2] at channel offset c_off (fixed order, double accumulation)
+__global__ void stats_reduce_kernel(const float* __restrict__ partial, int parts, int c, float* __restrict__ sums,
+                                    int c_total, int c_off) {
+    const int n = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;      // (k, channel)
+    if (i >= 2 * c) return;
+    const int k = i / c, ch = i - k * c;
+    const float* p = partial + (long)n * parts * 2 * c + (long)k * c + ch;
+    double t = 0;
+    for (int q = 0; q < parts; ++q) t += p[(long)q * 2 * c];
+    sums[((long)n * c_total + c_off + ch) * 2 + k] = (float)t;
+}
+
 __global__ void gn_coef_kernel(const float* __restrict__ sums, const float* __restrict__ gamma,
                                const float* __restrict__ beta, const float* __restrict__ film, int film_ld,
                                int n, int c, int groups, int hw, float eps, float* __restrict__ a,
@@ -182,6 +195,15 @@ extern "C" int sgd_chan_stats(const float* x, int32_t n, int32_t hw, int32_t c, 
     const int slabs = (c + 31) / 32;
     hipLaunchKernelGGL(chan_stats_kernel, dim3(n * slabs), dim3(256), 0, (hipStream_t)stream, x, hw, c, sums,
                        c_total, c_off);
+    return sgd_check_launch();
+}
+
+extern "C" int sgd_stats_reduce(const float* partial, int32_t n, int32_t parts, int32_t c, float* sums,
+                                int32_t c_total, int32_t c_off, void* stream) {
+    SGD_CLEAR_ERR();
+    if (!partial || !sums || n <= 0 || parts <= 0 || c <= 0 || c_off < 0 || c_off + c > c_total) return SGD_ERR_ARG;
+    hipLaunchKernelGGL(stats_reduce_kernel, dim3((2 * c + 127) / 128, n), dim3(128), 0, (hipStream_t)stream, partial,
+                       parts, c, sums, c_total, c_off);
     return sgd_check_launch();
 }
 

@@ -393,6 +393,7 @@ class _Engine:
         self.tape = []            # forward structure, walked in reverse by train.build_backward
         self.drops = []           # (igemm args, p box, seed box) of the launches that apply train-time dropout
         self.lse = {}             # attention log-sum-exp buffers (written only when present)
+        self.stats_of = {}        # tensor data_ptr -> (partial statistics buffer, parts, channels) written by its producer
         self._p_drop = 0.0
         self._build()
 
@@ -409,9 +410,12 @@ class _Engine:
 
     def igemm(self, tag, x0, c0, y, cout, pk, *, x1=None, c1=0, conv=None, m=0, rows_per_n=0,
               pro=L.PRO_NONE, silu=0, pa=None, pb=None, pc=None, bias=None, res=None, res_mode=L.RS_NONE,
-              y_ld=None, y_off=0, orows=(0, 0, 0)):
+              y_ld=None, y_off=0, orows=(0, 0, 0), stats=False):
+        """stats=True: the epilogue also writes the GroupNorm statistics of y (consumed by gn() through
+        sgd_stats_reduce instead of a sgd_chan_stats pass over the tensor)"""
         a = L.IgemmArgs()
         a.x0, a.x1, a.c0, a.c1 = x0.data_ptr(), (x1.data_ptr() if x1 is not None else 0), c0, c1
+        rows_n = conv[0] if conv is not None else (m // rows_per_n if rows_per_n else 0)
         if conv is not None:
             nimg, hi, wi, ho, wo, stride, resample = conv
             a.mode, a.n, a.hi, a.wi, a.ho, a.wo, a.stride, a.resample = L.MODE_CONV3, nimg, hi, wi, ho, wo, stride, resample
@@ -430,6 +434,12 @@ class _Engine:
         a.y_ld = y_ld if y_ld is not None else cout
         a.orows_in, a.orows_out, a.orow_off = orows
         a.prec = self.prec
+        if stats and os.environ.get("SGDM_FUSED_STATS", "1") != "0":
+            parts = self.lib.sgd_igemm_stats_parts(C.byref(a))
+            if parts > 0:
+                sbuf = self.buf(rows_n, parts, 2, cout)
+                a.stats = sbuf.data_ptr()
+                self.stats_of[y.data_ptr()] = (sbuf, parts, cout)
         self.prog.keep.append((a, pk))
         self._late.append((a, pk))                # cin_p / cout_p are known after the first pack
         # algorithmic work of this launch: 2*M*N*K flops; every input/output element moved once + weights
@@ -449,7 +459,11 @@ class _Engine:
         sums = self.buf(n, ct, 2)
         off = 0
         for t, c in srcs:
-            self.prog.add(tag + ".stats", self.lib.sgd_chan_stats, _ptr(t), n, hw, c, _ptr(sums), ct, off)
+            st = self.stats_of.get(t.data_ptr())
+            if st is not None and st[2] == c:
+                self.prog.add(tag + ".stats", self.lib.sgd_stats_reduce, _ptr(st[0]), n, st[1], c, _ptr(sums), ct, off)
+            else:
+                self.prog.add(tag + ".stats", self.lib.sgd_chan_stats, _ptr(t), n, hw, c, _ptr(sums), ct, off)
             off += c
         a, b = self.buf(n, ct), self.buf(n, ct)
         self._last_sums = sums
@@ -531,7 +545,7 @@ class _Engine:
                 (t, c, hh, ww), = srcs
                 y = self.buf(self.n, hh, ww, layer[2])
                 a = self.igemm(p, t, c, y, layer[2], self.pack([p + ".weight"], 3),
-                               conv=(self.n, hh, ww, hh, ww, 1, L.RS_NONE), bias=self.m.P(p + ".bias"))
+                               conv=(self.n, hh, ww, hh, ww, 1, L.RS_NONE), bias=self.m.P(p + ".bias"), stats=True)
                 self.tape.append(dict(kind="conv_in", p=p, x=t, y=y, a=a, cin=c, cout=layer[2], hw=(hh, ww)))
                 srcs = [(y, layer[2], hh, ww)]
             elif kind == "res":
@@ -542,14 +556,16 @@ class _Engine:
                 (t, c, hh, ww), = srcs
                 y = self.buf(self.n, hh // 2, ww // 2, c)
                 a = self.igemm(p + ".op", t, c, y, c, self.pack([p + ".op.weight"], 3),
-                               conv=(self.n, hh, ww, hh // 2, ww // 2, 2, L.RS_NONE), bias=self.m.P(p + ".op.bias"))
+                               conv=(self.n, hh, ww, hh // 2, ww // 2, 2, L.RS_NONE), bias=self.m.P(p + ".op.bias"),
+                               stats=True)
                 self.tape.append(dict(kind="down", p=p, x=t, y=y, c=c, hw_in=(hh, ww), a=a))
                 srcs = [(y, c, hh // 2, ww // 2)]
             elif kind == "up":
                 (t, c, hh, ww), = srcs
                 y = self.buf(self.n, hh * 2, ww * 2, c)
                 a = self.igemm(p + ".conv", t, c, y, c, self.pack([p + ".conv.weight"], 3),
-                               conv=(self.n, hh, ww, hh * 2, ww * 2, 1, L.RS_UP2), bias=self.m.P(p + ".conv.bias"))
+                               conv=(self.n, hh, ww, hh * 2, ww * 2, 1, L.RS_UP2), bias=self.m.P(p + ".conv.bias"),
+                               stats=True)
                 self.tape.append(dict(kind="up", p=p, x=t, y=y, c=c, hw_in=(hh, ww), a=a))
                 srcs = [(y, c, hh * 2, ww * 2)]
         return srcs[0]
@@ -569,7 +585,7 @@ class _Engine:
         h1 = self.buf(n, ho, wo, cout)
         ac1 = self.igemm(p + ".in_layers.2", t0, c0, h1, cout, self.pack([p + ".in_layers.2.weight"], 3), x1=t1,
                          c1=c1, conv=(n, hh, ww, ho, wo, 1, rs), pro=L.PRO_AFFINE_NC, silu=1, pa=a1, pb=b1,
-                         bias=P(p + ".in_layers.2.bias"))
+                         bias=P(p + ".in_layers.2.bias"), stats=True)
         film_ptr = self.film.data_ptr() + 4 * self.film_off[p]
         a2, b2 = self.gn(p + ".out_layers.0", [(h1, cout)], ho * wo, p + ".out_layers.0", film=film_ptr,
                          film_ld=self.film_ld)
@@ -588,7 +604,7 @@ class _Engine:
         y = self.buf(n, ho, wo, cout)
         ac2 = self.igemm(p + ".out_layers.3", h1, cout, y, cout, self.pack([p + ".out_layers.3.weight"], 3),
                          conv=(n, ho, wo, ho, wo, 1, L.RS_NONE), pro=L.PRO_AFFINE_NC, silu=1, pa=a2, pb=b2,
-                         bias=P(p + ".out_layers.3.bias"), res=res, res_mode=res_mode)
+                         bias=P(p + ".out_layers.3.bias"), res=res, res_mode=res_mode, stats=True)
         pbox, sbox = C.c_float(0.0), C.c_uint32(0)
         self.drops.append((ac2, pbox, sbox))                  # nn.Dropout sits in front of conv2 (openaimodel.py:272)
         self.tape.append(dict(kind="res", drop_p=pbox, drop_seed=sbox, p=p,
@@ -734,8 +750,8 @@ class UNetModel(UNetModelBase):
                      C.c_void_p(qkv.data_ptr() + 4 * d), C.c_void_p(qkv.data_ptr() + 8 * d), 3 * ch, 3 * d,
                      n, heads, T, T, d, 1.0 / math.sqrt(d), _ptr(att), ch, _ptr(lse))
         y = eng.buf(n, hh, ww, ch)
-        ap = eng.igemm(p + ".proj_out", att, ch, y, ch, eng.pack([p + ".proj_out.weight"], 1), m=n * T,
-                       bias=P(p + ".proj_out.bias"), res=t)
+        ap = eng.igemm(p + ".proj_out", att, ch, y, ch, eng.pack([p + ".proj_out.weight"], 1), m=n * T, rows_per_n=T,
+                       bias=P(p + ".proj_out.bias"), res=t, stats=True)
         eng.tape.append(dict(kind="attn", p=p, x=t, ch=ch, heads=heads, d=d, T=T, hw=(hh, ww), a=a, b=b, sums=sums,
                              qkv=qkv, att=att, lse=lse, qkv_args=aq, proj_args=ap, y=y))
         return (y, ch, hh, ww)

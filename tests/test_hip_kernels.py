@@ -291,3 +291,42 @@ def test_boundary_kernels():
     back = torch.empty(4, 7, 8, 8, device="cuda")
     L.check(lib.sgd_nhwc_to_nchw(_p(out), 4, 8, 8, 7, _p(back), _stream()), "nchw")
     assert torch.equal(back.cpu(), ref.permute(0, 3, 1, 2))
+
+
+@pytest.mark.parametrize("shape", [(3, 16, 16, 64, 128), (2, 32, 32, 32, 256), (2, 16, 16, 128, 32)])
+def test_epilogue_statistics_match_chan_stats(shape):
+    """sgd_igemm's fused GroupNorm statistics of its output + sgd_stats_reduce == sgd_chan_stats(y)"""
+    n, h, w, cin, cout = shape
+    L, lib = _lib()
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(n, h, w, cin, generator=g).cuda()
+    wt = (torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5).cuda()
+    bias = torch.randn(cout, generator=g).cuda()
+    res = torch.randn(n, h, w, cout, generator=g).cuda()
+    y = torch.empty(n, h, w, cout, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    prec = L.PREC_F32
+    buf = torch.empty(lib.sgd_packed_weight_bytes(cout, cin, 3, prec) // 4, device="cuda")
+    cp, op = C.c_int32(), C.c_int32()
+    L.check(lib.sgd_pack_weight(C.c_void_p(wt.data_ptr()), C.c_void_p(buf.data_ptr()), cout, cin, 3, prec, C.byref(cp),
+                                C.byref(op), st), "pack")
+    a = L.IgemmArgs()
+    a.x0, a.c0, a.mode, a.n, a.hi, a.wi, a.ho, a.wo, a.stride = x.data_ptr(), cin, L.MODE_CONV3, n, h, w, h, w, 1
+    a.w, a.cin_p, a.cout_p, a.bias, a.res = buf.data_ptr(), cp.value, op.value, bias.data_ptr(), res.data_ptr()
+    a.y, a.cout, a.y_ld, a.prec = y.data_ptr(), cout, cout, prec
+    parts = lib.sgd_igemm_stats_parts(C.byref(a))
+    assert parts == (h * w // 128) * (2 if cout % 128 == 0 else 4)
+    partial = torch.full((n, parts, 2, cout), float("nan"), device="cuda")
+    a.stats = partial.data_ptr()
+    L.check(lib.sgd_igemm(C.byref(a), st), "igemm")
+    sums = torch.zeros(n, cout + 8, 2, device="cuda")
+    L.check(lib.sgd_stats_reduce(C.c_void_p(partial.data_ptr()), n, parts, cout, C.c_void_p(sums.data_ptr()), cout + 8, 8, st),
+            "reduce")
+    ref = torch.zeros(n, cout + 8, 2, device="cuda")
+    L.check(lib.sgd_chan_stats(C.c_void_p(y.data_ptr()), n, h * w, cout, C.c_void_p(ref.data_ptr()), cout + 8, 8, st), "stats")
+    torch.cuda.synchronize()
+    yy = y.double().reshape(n, h * w, cout).cpu()
+    exact = torch.stack([yy.sum(1), (yy * yy).sum(1)], -1)
+    assert float((sums[:, 8:].cpu().double() - exact).abs().max() / exact.abs().max()) < 2e-6
+    assert float((ref[:, 8:].cpu().double() - exact).abs().max() / exact.abs().max()) < 2e-6
+    assert float(sums[:, :8].abs().max()) == 0.0
