@@ -25,7 +25,7 @@ constexpr int WLD = WT + 4;
 struct WArgs {
     sgd_igemm_args a;           // forward descriptor (input side)
     const float* gy;
-    int gy_ld, cout, ksplit, taps, rows, co_tiles, ci_tiles, ktiles, hc, wc;
+    int gy_ld, cout, ksplit, taps, rows, co_tiles, ci_tiles, ktiles, hc, wc, wo_l2, ho_l2;
     float* slabs;
 };
 
@@ -76,8 +76,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WArgs w) {
                 if (c < cin) {
                     if (conv) {
                         // output pixel (n, oy, ox) -> conv-input pixel (oy*s + dy, ox*s + dx)
-                        const int ox = row % a.wo, t = row / a.wo;
-                        const int oy = t % a.ho, n = t / a.ho;
+                        // ho, wo are powers of two (sgd_igemm's CONV3 contract): shifts, not divisions
+                        const int ox = row & (a.wo - 1), t = row >> w.wo_l2;
+                        const int oy = t & (a.ho - 1), n = t >> w.ho_l2;
                         const int y = oy * a.stride + dy, x = ox * a.stride + dx;
                         if (y >= 0 && y < w.hc && x >= 0 && x < w.wc) {
                             if (a.resample == SGD_RS_AVGPOOL2) {
@@ -131,6 +132,161 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WArgs w) {
                 if (co < w.cout) slab[(long)co * cin + ci] = acc[mt][nt][r];
             }
         }
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight gradient of a 3x3 stride-1 conv in split precision (f16x3 / bf16x3), all nine taps per block.
+// K tile = an 8x8 patch of output pixels of one image: the gradient tile GY[64 px][128 co] and the activated
+// input halo tile U[10x10 px][32 ci] are staged ONCE (16-bit hi / lo planes) and feed 9 taps x 4 k-steps x 3
+// products = 108 MFMAs per wave (wave = 32 co x 32 ci x 9 taps, 144 accumulator registers).  Both operands are
+// consumed K-major (a lane needs 8 consecutive pixels of ONE channel) from row-major [pixel][channel] LDS
+// planes through ds_read_b64_tr_b16, the hardware transposing read: no transpose pass, NHWC rows staged as is.
+// Row pitches: GY 320 B (4 consecutive pixels -> bank offsets 0/64/128/192), U 64 B (4 consecutive halo pixels
+// = 256 contiguous bytes): conflict-free for the 32-lane halves of the transposing read.
+// ---------------------------------------------------------------------------------------------
+constexpr int FGP = 160;        // GY plane row pitch (16-bit elements)
+constexpr int FUP = 32;         // U plane row pitch
+constexpr int FCI = 32;         // ci tile
+
+template <int PREC, bool VEC>
+__global__ __launch_bounds__(256, 2) void wgrad_conv_kernel(const WArgs w) {
+    typedef typename Split<PREC>::T T;
+    typedef T T4 __attribute__((ext_vector_type(4)));
+    typedef T T8 __attribute__((ext_vector_type(8)));
+    typedef short s4 __attribute__((ext_vector_type(4)));
+    const sgd_igemm_args& a = w.a;
+    __shared__ __attribute__((aligned(16))) T Gh[64 * FGP];
+    __shared__ __attribute__((aligned(16))) T Gl[64 * FGP];
+    __shared__ __attribute__((aligned(16))) T Uh[100 * FUP];
+    __shared__ __attribute__((aligned(16))) T Ul[100 * FUP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+
+    int bid = blockIdx.x;
+    const int ks = bid % w.ksplit; bid /= w.ksplit;
+    const int cit = bid % w.ci_tiles; bid /= w.ci_tiles;
+    const int cot = bid;
+    const int co0 = cot * WT, ci0 = cit * FCI;
+    const int cin = a.c0 + a.c1;
+    const int pw = a.wo >> 3, ppi = pw * (a.ho >> 3);         // patches per row / per image
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    // transposing-read addresses of this lane: group gidx = lane >> 4 -> (k half, 16-channel half); lane 4q+p of the group
+    // addresses pixel q of the 4-pixel block, channels 4p .. 4p+3
+    const int gidx = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+    const int kbase = 8 * (gidx >> 1) + q;                    // + 16 s + 4 rd
+    const int chl = 16 * (gidx & 1) + 4 * pp;                 // channel inside the wave's 32
+    auto trd = [&](const T* p) -> T4 {
+        s4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)p);
+        return __builtin_bit_cast(T4, v);
+    };
+
+    for (int kt = ks; kt < w.ktiles; kt += w.ksplit) {
+        const int n = kt / ppi, pr = kt - n * ppi;
+        const int y0 = (pr / pw) * 8, x0 = (pr - (pr / pw) * pw) * 8;
+        __syncthreads();
+        // ---- stage GY[64 px][128 co]
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int idx = tid + i * 256;
+            const int r = idx >> 5, qd = idx & 31;
+            const long row = ((long)n * a.ho + y0 + (r >> 3)) * a.wo + x0 + (r & 7);
+            const int co = co0 + qd * 4;
+            f32x4 gv = {0.f, 0.f, 0.f, 0.f};
+            if (co + 3 < w.cout) gv = ld4(w.gy + row * w.gy_ld + co);
+            else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) if (co + j < w.cout) gv[j] = w.gy[row * w.gy_ld + co + j];
+            }
+            T4 h, l;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { h[j] = Split<PREC>::hi(gv[j]); l[j] = Split<PREC>::hi(gv[j] - Split<PREC>::back(h[j])); }
+            *reinterpret_cast<T4*>(Gh + r * FGP + qd * 4) = h;
+            *reinterpret_cast<T4*>(Gl + r * FGP + qd * 4) = l;
+        }
+        // ---- stage the activated input halo U[10 x 10 px][32 ci] (conv-input space, zero outside the image)
+        for (int idx = tid; idx < 100 * (FCI / 4); idx += 256) {
+            const int hp = idx >> 3, qd = idx & 7;
+            const int hy = hp / 10, hx = hp - hy * 10;
+            const int y = y0 + hy - 1, x = x0 + hx - 1;
+            const int c = ci0 + qd * 4;
+            f32x4 uv = {0.f, 0.f, 0.f, 0.f};
+            if (c < cin && y >= 0 && y < w.hc && x >= 0 && x < w.wc) {
+                if (a.resample == SGD_RS_AVGPOOL2) {
+#pragma unroll
+                    for (int sy = 0; sy < 2; ++sy)
+#pragma unroll
+                        for (int sx = 0; sx < 2; ++sx) {
+                            long rr = ((long)n * a.hi + 2 * y + sy) * a.wi + 2 * x + sx;
+                            uv += apply_pro(a, load_raw<VEC>(a, rr, c), load_coef<VEC>(a, n, rr, c), c, rr);
+                        }
+                    uv = uv * 0.25f;
+                } else {
+                    long rr = a.resample == SGD_RS_UP2 ? ((long)n * a.hi + (y >> 1)) * a.wi + (x >> 1)
+                                                       : ((long)n * a.hi + y) * a.wi + x;
+                    uv = apply_pro(a, load_raw<VEC>(a, rr, c), load_coef<VEC>(a, n, rr, c), c, rr);
+                }
+            }
+            T4 h, l;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { h[j] = Split<PREC>::hi(uv[j]); l[j] = Split<PREC>::hi(uv[j] - Split<PREC>::back(h[j])); }
+            *reinterpret_cast<T4*>(Uh + hp * FUP + qd * 4) = h;
+            *reinterpret_cast<T4*>(Ul + hp * FUP + qd * 4) = l;
+        }
+        __syncthreads();
+        // ---- 4 k-steps of 16 pixels (two patch rows)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            T8 ah, al;
+            {
+                const int k0 = 16 * s + kbase;
+                const T* g0 = Gh + k0 * FGP + wave * 32 + chl;
+                const T* g1 = Gl + k0 * FGP + wave * 32 + chl;
+                const T4 h0 = trd(g0), h1 = trd(g0 + 4 * FGP), l0 = trd(g1), l1 = trd(g1 + 4 * FGP);
+                ah = T8{h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+                al = T8{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+            }
+            // halo pixel of this lane's k (read 0): patch pixel k0 -> (row 2s + (k0 >> 3 & 1), col k0 & 7)
+            const int k0 = 16 * s + kbase;
+            const int hb = ((k0 >> 3) + 1) * 10 + (k0 & 7) + 1;      // halo index of tap (0, 0); read 1 = + 4
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int off = (t / 3 - 1) * 10 + (t % 3 - 1);
+                const T* u0 = Uh + (hb + off) * FUP + chl;
+                const T* u1 = Ul + (hb + off) * FUP + chl;
+                const T4 h0 = trd(u0), h1 = trd(u0 + 4 * FUP), l0 = trd(u1), l1 = trd(u1 + 4 * FUP);
+                const T8 bh = T8{h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+                const T8 bl = T8{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+                if constexpr (PREC == SGD_PREC_F16X3) {
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[t], 0, 0, 0);
+                } else {
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[t], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // ---- slab store: D rows = co (registers), cols = ci (lanes)
+    const int ci = ci0 + li;
+    if (ci < cin) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            float* slab = w.slabs + ((long)ks * 9 + t) * w.cout * cin;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (co < w.cout) slab[(long)co * cin + ci] = acc[t][r];
+            }
+        }
+    }
 }
 
 __global__ void wgrad_reduce_kernel(const float* __restrict__ slabs, int ksplit, int taps, int cout, int cin,
@@ -401,8 +557,12 @@ extern "C" int sgd_wgrad(const sgd_igemm_args* fwd, const float* gy, int32_t gy_
         w.wc = a.resample == SGD_RS_AVGPOOL2 ? a.wi / 2 : (a.resample == SGD_RS_UP2 ? a.wi * 2 : a.wi);
         w.taps = 9;
         w.rows = a.n * a.ho * a.wo;
+        if (a.ho <= 0 || a.wo <= 0 || (a.ho & (a.ho - 1)) || (a.wo & (a.wo - 1))) return SGD_ERR_ARG;
+        w.wo_l2 = __builtin_ctz(a.wo);
+        w.ho_l2 = __builtin_ctz(a.ho);
     } else if (a.mode == SGD_MODE_FLAT) {
         w.hc = w.wc = 1;
+        w.wo_l2 = w.ho_l2 = 0;
         w.taps = 1;
         w.rows = a.m;
     } else {
@@ -416,9 +576,24 @@ extern "C" int sgd_wgrad(const sgd_igemm_args* fwd, const float* gy, int32_t gy_
     w.ksplit = ksplit > w.ktiles ? w.ktiles : ksplit;
     if (w.ksplit != ksplit) return SGD_ERR_ARG;          // caller sizes the slabs: must agree
     const bool vec = (a.c0 % 4 == 0) && (a.c1 % 4 == 0);
+    hipStream_t st = (hipStream_t)stream;
+    // split-precision, all-taps kernel: 3x3 stride 1 on whole 8x8 output patches, channel counts that fill the tiles
+    if (a.mode == SGD_MODE_CONV3 && a.stride == 1 && a.resample != SGD_RS_ZEROUP2 && a.prec != SGD_PREC_F32
+        && a.ho % 8 == 0 && a.wo % 8 == 0 && cout >= 32 && cin >= 32 && gy_ld % 4 == 0 && !getenv("SGDM_WGRAD_F32")) {
+        w.ci_tiles = (cin + FCI - 1) / FCI;
+        const long fgrid = (long)w.co_tiles * w.ci_tiles * w.ksplit;
+        if (fgrid > 0x7fffffffL) return SGD_ERR_ARG;
+        if (a.prec == SGD_PREC_F16X3) {
+            if (vec) hipLaunchKernelGGL((wgrad_conv_kernel<SGD_PREC_F16X3, true>), dim3((unsigned)fgrid), dim3(256), 0, st, w);
+            else hipLaunchKernelGGL((wgrad_conv_kernel<SGD_PREC_F16X3, false>), dim3((unsigned)fgrid), dim3(256), 0, st, w);
+        } else {
+            if (vec) hipLaunchKernelGGL((wgrad_conv_kernel<SGD_PREC_BF16X3, true>), dim3((unsigned)fgrid), dim3(256), 0, st, w);
+            else hipLaunchKernelGGL((wgrad_conv_kernel<SGD_PREC_BF16X3, false>), dim3((unsigned)fgrid), dim3(256), 0, st, w);
+        }
+        return sgd_check_launch();
+    }
     const long grid = (long)w.taps * w.co_tiles * w.ci_tiles * w.ksplit;
     if (grid > 0x7fffffffL) return SGD_ERR_ARG;
-    hipStream_t st = (hipStream_t)stream;
     if (vec) hipLaunchKernelGGL((wgrad_kernel<true>), dim3((unsigned)grid), dim3(256), 0, st, w);
     else hipLaunchKernelGGL((wgrad_kernel<false>), dim3((unsigned)grid), dim3(256), 0, st, w);
     return sgd_check_launch();

@@ -89,18 +89,6 @@ struct KArgs {
 // ---------------------------------------------------------------------------------------------
 // F32   : row = 32 floats (channel order) + 4 pad.
 // split : row = 4 groups of 8 channels; group = hi[8] (16 B) | lo[8] (16 B); + 16 B pad. Same 144 B.
-template <int PREC> struct Split;
-template <> struct Split<SGD_PREC_F16X3> {
-    typedef _Float16 T;
-    static __device__ __forceinline__ T hi(float v) { return (T)v; }
-    static __device__ __forceinline__ float back(T h) { return (float)h; }
-};
-template <> struct Split<SGD_PREC_BF16X3> {
-    typedef __bf16 T;
-    static __device__ __forceinline__ T hi(float v) { return (T)v; }
-    static __device__ __forceinline__ float back(T h) { return (float)h; }
-};
-
 template <int PREC>
 __device__ __forceinline__ void lds_store_act(float* rowp, int c4, f32x4 v) {
     if constexpr (PREC == SGD_PREC_F32) {

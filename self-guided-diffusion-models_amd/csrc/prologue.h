@@ -6,6 +6,20 @@
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 
+// 16-bit element type of the split-precision modes (fp32 x = hi + lo, both 16-bit; three MFMA products)
+template <int PREC> struct Split;
+template <> struct Split<SGD_PREC_F16X3> {
+    typedef _Float16 T;
+    static __device__ __forceinline__ T hi(float v) { return (T)v; }
+    static __device__ __forceinline__ float back(T h) { return (float)h; }
+};
+template <> struct Split<SGD_PREC_BF16X3> {
+    typedef __bf16 T;
+    static __device__ __forceinline__ T hi(float v) { return (T)v; }
+    static __device__ __forceinline__ float back(T h) { return (float)h; }
+};
+
+
 // raw input vector: 4 consecutive channels starting at c of source row `row` (virtual concat x0|x1)
 template <bool VEC>
 __device__ __forceinline__ f32x4 load_raw(const sgd_igemm_args& a, long row, int c) {
