@@ -25,7 +25,7 @@ constexpr int WLD = WT + 4;
 struct WArgs {
     sgd_igemm_args a;           // forward descriptor (input side)
     const float* gy;
-    int gy_ld, cout, ksplit, taps, rows, co_tiles, ci_tiles, ktiles, hc, wc, wo_l2, ho_l2;
+    int gy_ld, cout, ksplit, taps, rows, co_tiles, ci_tiles, ktiles, hc, wc, wo_l2, ho_l2, gvec;
     float* slabs;
 };
 
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_conv_kernel(const WArgs w) {
             const long row = ((long)n * a.ho + y0 + (r >> 3)) * a.wo + x0 + (r & 7);
             const int co = co0 + qd * 4;
             f32x4 gv = {0.f, 0.f, 0.f, 0.f};
-            if (co + 3 < w.cout) gv = ld4(w.gy + row * w.gy_ld + co);
+            if (w.gvec && co + 3 < w.cout) gv = ld4(w.gy + row * w.gy_ld + co);
             else {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) if (co + j < w.cout) gv[j] = w.gy[row * w.gy_ld + co + j];
@@ -579,7 +579,8 @@ extern "C" int sgd_wgrad(const sgd_igemm_args* fwd, const float* gy, int32_t gy_
     hipStream_t st = (hipStream_t)stream;
     // split-precision, all-taps kernel: 3x3 stride 1 on whole 8x8 output patches, channel counts that fill the tiles
     if (a.mode == SGD_MODE_CONV3 && a.stride == 1 && a.resample != SGD_RS_ZEROUP2 && a.prec != SGD_PREC_F32
-        && a.ho % 8 == 0 && a.wo % 8 == 0 && cout >= 32 && cin >= 32 && gy_ld % 4 == 0 && !getenv("SGDM_WGRAD_F32")) {
+        && a.ho % 8 == 0 && a.wo % 8 == 0 && !getenv("SGDM_WGRAD_F32")) {
+        w.gvec = gy_ld % 4 == 0;
         w.ci_tiles = (cin + FCI - 1) / FCI;
         const long fgrid = (long)w.co_tiles * w.ci_tiles * w.ksplit;
         if (fgrid > 0x7fffffffL) return SGD_ERR_ARG;
