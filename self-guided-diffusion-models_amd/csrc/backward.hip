@@ -327,14 +327,25 @@ __global__ __launch_bounds__(256) void colsum_stage1_kernel(const float* __restr
     }
 }
 
-__global__ void colsum_stage2_kernel(const float* __restrict__ work, int chunks, int c, float* __restrict__ out,
-                                     int accumulate, float scale) {
-    const int col = blockIdx.x * blockDim.x + threadIdx.x;
-    if (col >= c) return;
+// stage 2: 8 chunk lanes x 32 columns per block (independent loads in flight), fixed-order double accumulation
+__global__ __launch_bounds__(256) void colsum_stage2_kernel(const float* __restrict__ work, int chunks, int c,
+                                                            float* __restrict__ out, int accumulate, float scale) {
+    const int col = blockIdx.x * 32 + (threadIdx.x & 31), rl = threadIdx.x >> 5;
     double t = 0;
-    for (int k = 0; k < chunks; ++k) t += work[(long)k * c + col];
-    t *= scale;
-    out[col] = accumulate ? out[col] + (float)t : (float)t;
+    if (col < c) {
+#pragma unroll 4
+        for (int k = rl; k < chunks; k += 8) t += work[(long)k * c + col];
+    }
+    __shared__ double red[8][32];
+    red[rl][threadIdx.x & 31] = t;
+    __syncthreads();
+    if (threadIdx.x < 32 && col < c) {
+        double u = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) u += red[k][threadIdx.x];
+        u *= scale;
+        out[col] = accumulate ? out[col] + (float)u : (float)u;
+    }
 }
 
 // =============================================================================================
@@ -617,7 +628,7 @@ extern "C" int sgd_colsum(const float* g, int32_t rows, int32_t c, int32_t ld, f
     if (chunks > work_chunks) chunks = work_chunks;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(colsum_stage1_kernel, dim3((c + 31) / 32, chunks), dim3(256), 0, st, g, rows, c, ld, chunks, work);
-    hipLaunchKernelGGL(colsum_stage2_kernel, dim3((c + 255) / 256), dim3(256), 0, st, work, chunks, c, out, accumulate,
+    hipLaunchKernelGGL(colsum_stage2_kernel, dim3((c + 31) / 32), dim3(256), 0, st, work, chunks, c, out, accumulate,
                        scale);
     return sgd_check_launch();
 }

@@ -49,17 +49,29 @@ __global__ __launch_bounds__(256) void chan_stats_kernel(const float* __restrict
     }
 }
 
-// partial[n][parts][2][c] -> sums[n][c_total][2] at channel offset c_off (fixed order, double accumulation)
-__global__ void stats_reduce_kernel(const float* __restrict__ partial, int parts, int c, float* __restrict__ sums,
-                                    int c_total, int c_off) {
+// partial[n][parts][2][c] -> sums[n][c_total][2] at channel offset c_off.  8 part lanes x 32 (k, channel) columns per
+// block keep the loads independent (a single thread walking the parts pays one memory latency per part);
+// fixed-order double accumulation.
+__global__ __launch_bounds__(256) void stats_reduce_kernel(const float* __restrict__ partial, int parts, int c,
+                                                           float* __restrict__ sums, int c_total, int c_off) {
     const int n = blockIdx.y;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;      // (k, channel)
-    if (i >= 2 * c) return;
-    const int k = i / c, ch = i - k * c;
-    const float* p = partial + (long)n * parts * 2 * c + (long)k * c + ch;
+    const int i = blockIdx.x * 32 + (threadIdx.x & 31), pl = threadIdx.x >> 5;      // i = (k, channel)
     double t = 0;
-    for (int q = 0; q < parts; ++q) t += p[(long)q * 2 * c];
-    sums[((long)n * c_total + c_off + ch) * 2 + k] = (float)t;
+    if (i < 2 * c) {
+        const float* p = partial + (long)n * parts * 2 * c + i;
+#pragma unroll 4
+        for (int q = pl; q < parts; q += 8) t += p[(long)q * 2 * c];
+    }
+    __shared__ double red[8][32];
+    red[pl][threadIdx.x & 31] = t;
+    __syncthreads();
+    if (threadIdx.x < 32 && i < 2 * c) {
+        double u = 0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) u += red[q][threadIdx.x];
+        const int k = i / c, ch = i - k * c;
+        sums[((long)n * c_total + c_off + ch) * 2 + k] = (float)u;
+    }
 }
 
 __global__ void gn_coef_kernel(const float* __restrict__ sums, const float* __restrict__ gamma,
@@ -202,7 +214,7 @@ extern "C" int sgd_stats_reduce(const float* partial, int32_t n, int32_t parts, 
                                 int32_t c_total, int32_t c_off, void* stream) {
     SGD_CLEAR_ERR();
     if (!partial || !sums || n <= 0 || parts <= 0 || c <= 0 || c_off < 0 || c_off + c > c_total) return SGD_ERR_ARG;
-    hipLaunchKernelGGL(stats_reduce_kernel, dim3((2 * c + 127) / 128, n), dim3(128), 0, (hipStream_t)stream, partial,
+    hipLaunchKernelGGL(stats_reduce_kernel, dim3((2 * c + 31) / 32, n), dim3(256), 0, (hipStream_t)stream, partial,
                        parts, c, sums, c_total, c_off);
     return sgd_check_launch();
 }

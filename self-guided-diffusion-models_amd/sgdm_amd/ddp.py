@@ -9,8 +9,10 @@ xGMI is point-to-point (7 links x ~153 GB/s per GPU): a few LARGE buckets (defau
 => 5 collectives) keep every link busy without the fixed per-collective cost of torch DDP's 25 MB default.
 
 Unlike torch DDP nothing is broadcast per step: EMA shadows and schedule tables are rank-deterministic
-(SURVEY.md 2.3 "drop"), and parameters without a gradient are pre-zeroed in the arena so all ranks reduce
-identical byte ranges (the reference needs ``ddp_find_unused_parameters_true`` for that, README.md:90-94).
+(SURVEY.md 2.3 "drop").  The arena holds exactly the parameters the static backward program produces, in the
+same order on every rank, so all ranks reduce identical byte ranges; parameters off the path
+(``to_cond_tokens_2d.*`` of unetca_fast) are not in it and keep ``grad = None`` like in the reference
+(which needs ``ddp_find_unused_parameters_true`` for them, README.md:90-94).
 
 Device-agnostic on purpose: the same code runs on CPU tensors over gloo in tests/test_ddp_gloo.py.
 """
