@@ -944,10 +944,24 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
 
     // per-lane LDS float offsets of this wave's MFMA row tiles (row -> halo pixel of tap (0,0))
+    // Which tile pixel a lane's MFMA row stands for.  A 32-row block covers two image rows of a 16-wide tile whose halo
+    // rows are 18 pixels apart in LDS; with lane == pixel the 16 lanes ds_read_b128 serves per LDS cycle ({0-3,12-15,
+    // 20-27} / {4-11,16-19,28-31}) meet pixels that collide mod 16 -> 2-way bank conflicts on every input fragment read.
+    // The permutation gives each such lane group 16 pixels distinct mod 16 (36-float pixel pitch: bank = 9*pixel mod
+    // 16 quads).  The epilogue uses the same map, so results are unchanged.
+    int pli = li;
+    if (CONV && g.tw_l2 == 4 && s == 1) {
+        if (li < 4) pli = li;
+        else if (li < 12) pli = li + 4;
+        else if (li < 16) pli = li - 8;
+        else if (li < 20) pli = li;
+        else if (li < 28) pli = li + 2;
+        else pli = li < 30 ? li - 8 : li;
+    }
     int aoff[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-        int r = wm * WM + mt * 32 + li;
+        int r = wm * WM + mt * 32 + pli;
         int p;
         if (CONV) {
             int tx = r & (TW - 1), ty = (r >> g.tw_l2) & (TH - 1), nb = r >> (g.tw_l2 + g.th_l2);
@@ -1062,7 +1076,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
             const float* rpm[MT];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-                const int row = wm * WM + mt * 32 + li;
+                const int row = wm * WM + mt * 32 + pli;
                 int orow, n = 0, oy = 0, ox = 0;
                 if (CONV) {
                     const int tx = row & (TW - 1), ty = (row >> g.tw_l2) & (TH - 1), nb = row >> (g.tw_l2 + g.th_l2);
