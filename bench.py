@@ -138,8 +138,11 @@ def train_step_bench(model, diff, data, cond, layout, B, world, barrier, wl, ste
     dev = next(model.parameters()).device
     model.train()
     diff.train()
-    opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=0.01)      # optim/adamw.yaml, data lr/wd
+    from sgdm_amd.optim import FusedAdamWEma
     ema = LitEma(model)
+    # optim/adamw.yaml + data lr/wd; AdamW and the LitEma shadow update run as ONE launch (sgd_adamw_ema_step)
+    opt = FusedAdamWEma([p for p in model.parameters() if p.requires_grad], lr=1e-4, weight_decay=0.01, ema=ema,
+                        ema_model=model)
     x = data["image"].to(dev)
 
     def step():
@@ -147,7 +150,6 @@ def train_step_bench(model, diff, data, cond, layout, B, world, barrier, wl, ste
         opt.zero_grad(set_to_none=True)
         loss.backward()
         opt.step()
-        ema(model)
         return loss
 
     for _ in range(warmup):
@@ -165,7 +167,7 @@ def train_step_bench(model, diff, data, cond, layout, B, world, barrier, wl, ste
     diff.eval()
     return dict(ms=round(1000.0 * float(tt.item()) / steps, 2), batch_per_gpu=B, global_batch=B * world, steps=steps,
                 dropout=float(model.dropout), loss=round(float(loss.item()), 4),
-                includes="q_sample + UNet fwd/bwd + bucketed RCCL grad all-reduce (overlapped) + AdamW + EMA",
+                includes="q_sample + UNet fwd/bwd + bucketed RCCL grad all-reduce (overlapped) + fused AdamW/EMA step",
                 algorithmic_tflop=round(3 * B * wl["gflop_per_eval_img"] / 1e3, 3))
 
 

@@ -267,6 +267,27 @@ int sgd_q_sample(const float* x0, const float* noise, const int64_t* t, const fl
 int sgd_mse_loss(const float* eps_nhwc, const float* noise_nchw, int32_t b, int32_t c, int32_t hw,
                  float* per_sample, float* geps_nhwc, void* stream);
 
+/* --------------------------------------------------------------------------------------
+ * Optimizer step: AdamW (lightning_module_common.py:20-42: torch.optim.AdamW defaults, decoupled weight decay)
+ * and the LitEma shadow update (dynamic/ema.py:25-44) of every parameter in ONE launch:
+ *   p *= 1 - lr*wd;  m += (1-b1)(g-m)  [torch's lerp_];  v = b2*v + (1-b2) g*g;
+ *   p -= (lr / (1-b1^t)) * m / (sqrt(v)/sqrt(1-b2^t) + eps);      shadow -= ema_omd * (shadow - p)
+ * table: DEVICE array of `count` entries; g == NULL: the parameter got no gradient this step (AdamW skips it as
+ * torch does, its shadow still follows); m/v/ema may be NULL only together with g / when ema_omd < 0 (no EMA).
+ * chunk_start: DEVICE int32[count + 1], prefix sum of ceil(n / 4096) (block b serves the tensor that owns chunk b). */
+typedef struct {
+    float* p;
+    const float* g;
+    float* m;
+    float* v;
+    float* ema;
+    int64_t n;
+} sgd_opt_tensor;
+int sgd_adamw_ema_step(const sgd_opt_tensor* table, const int32_t* chunk_start, int32_t count, int32_t total_chunks,
+                       float lr, float one_minus_beta1, float beta2, float one_minus_beta2 /* host doubles, rounded
+                       once: 1.0f - 0.999f is off by 1.3e-5 relative */, float eps, float weight_decay,
+                       float bias_correction1, float bias_correction2, float ema_one_minus_decay, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -228,3 +228,59 @@ extern "C" int sgd_cfg_combine(const float* eps_nhwc, int32_t cfg_mode, float w,
                        cfg_mode, w, b, c, hw, out_nchw);
     return sgd_check_launch();
 }
+
+// ---------------------------------------------------------------------------------------------
+// fused AdamW + LitEma step over a table of tensors (multi-tensor apply): HBM-bound, 36 bytes per element
+// ---------------------------------------------------------------------------------------------
+namespace {
+constexpr int OPT_CHUNK = 4096;
+
+__global__ __launch_bounds__(256) void adamw_ema_kernel(const sgd_opt_tensor* __restrict__ table,
+                                                        const int32_t* __restrict__ chunk_start, int count, float lr,
+                                                        float omb1, float b2, float omb2, float eps, float wd,
+                                                        float bc1, float bc2, float omd) {
+    // the tensor that owns this chunk: last t with chunk_start[t] <= blockIdx.x
+    int lo = 0, hi = count - 1;
+    const int b = blockIdx.x;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (chunk_start[mid] <= b) lo = mid; else hi = mid - 1;
+    }
+    const sgd_opt_tensor t = table[lo];
+    const long base = (long)(b - chunk_start[lo]) * OPT_CHUNK;
+    const float step_size = lr / bc1, rs2 = 1.0f / sqrtf(bc2), decay_f = 1.0f - lr * wd;
+    for (int i = threadIdx.x; i < OPT_CHUNK; i += 256) {
+        const long e = base + i;
+        if (e >= t.n) break;
+        float p = t.p[e];
+        if (t.g) {
+            const float g = t.g[e];
+            float m = t.m[e], v = t.v[e];
+            p *= decay_f;
+            m = m + omb1 * (g - m);
+            v = b2 * v + omb2 * g * g;
+            p -= step_size * (m / (sqrtf(v) * rs2 + eps));
+            t.m[e] = m;
+            t.v[e] = v;
+            t.p[e] = p;
+        }
+        if (omd >= 0.f && t.ema) {
+            const float s = t.ema[e];
+            t.ema[e] = s - omd * (s - p);
+        }
+    }
+}
+}  // namespace
+
+extern "C" int sgd_adamw_ema_step(const sgd_opt_tensor* table, const int32_t* chunk_start, int32_t count,
+                                  int32_t total_chunks, float lr, float one_minus_beta1, float beta2,
+                                  float one_minus_beta2, float eps, float weight_decay, float bias_correction1,
+                                  float bias_correction2, float ema_one_minus_decay, void* stream) {
+    SGD_CLEAR_ERR();
+    if (!table || !chunk_start || count <= 0 || total_chunks <= 0 || bias_correction1 <= 0.f || bias_correction2 <= 0.f)
+        return SGD_ERR_ARG;
+    hipLaunchKernelGGL(adamw_ema_kernel, dim3(total_chunks), dim3(256), 0, (hipStream_t)stream, table, chunk_start,
+                       count, lr, one_minus_beta1, beta2, one_minus_beta2, eps, weight_decay, bias_correction1, bias_correction2,
+                       ema_one_minus_decay);
+    return sgd_check_launch();
+}

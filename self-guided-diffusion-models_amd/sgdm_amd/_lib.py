@@ -66,6 +66,7 @@ SIGNATURES = {
     "sgd_resample_bwd": (i32, [vp, i32, i32, i32, i32, i32, vp, i32, vp]),
     "sgd_q_sample": (i32, [vp, vp, vp, vp, vp, i32, i64, vp, vp]),
     "sgd_mse_loss": (i32, [vp, vp, i32, i32, i32, vp, vp, vp]),
+    "sgd_adamw_ema_step": (i32, [vp, vp, i32, i32, f32, f32, f32, f32, f32, f32, f32, f32, f32, vp]),
     "sgd_timestep_embedding": (i32, [vp, vp, i32, i32, i32, vp, vp]),
     "sgd_cond_select": (i32, [vp, i32, vp, vp, i32, i32, i32, vp, vp]),
     "sgd_pack_input": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp]),

@@ -167,3 +167,9 @@ def test_schedule_buffers_bit_exact():
             assert np.array_equal(ds.ddim_timesteps, v[f"ddim{S}.timesteps"])
             assert np.array_equal(np.asarray(ds.ddim_sigmas, dtype=np.float64), v[f"ddim{S}.eta{eta}.sigmas"])
             assert np.array_equal(np.asarray(ds.ddim_alphas, dtype=np.float64), v[f"ddim{S}.eta{eta}.alphas"])
+
+
+def test_optimizer_chunk_table():
+    from sgdm_amd.optim import CHUNK, chunk_table
+    assert chunk_table([1, CHUNK, CHUNK + 1, 3 * CHUNK]) == [0, 1, 2, 4, 7]
+    assert chunk_table([]) == [0]

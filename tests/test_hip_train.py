@@ -215,3 +215,51 @@ def test_train_step_with_dropout_matches_oracle_on_the_same_masks():
         e2 = m(batch["image"].cuda(), t.cuda(), cond=batch["cond"].float().cuda(), layout=batch["layout"].cuda(),
                cond_drop_prob=0.0)[0]
     assert torch.equal(e1, e2)
+
+
+def test_fused_adamw_ema_matches_torch_adamw_and_litema():
+    """sgd_adamw_ema_step (one launch) == torch.optim.AdamW + LitEma.forward, incl. a parameter without gradient"""
+    import torch.nn as nn
+    from sgdm_amd.ema import LitEma
+    from sgdm_amd.optim import FusedAdamWEma
+
+    class M(nn.Module):
+        def __init__(self):
+            super().__init__()
+            g = torch.Generator().manual_seed(3)
+            self.a = nn.Parameter(torch.randn(1, generator=g))
+            self.b = nn.Parameter(torch.randn(5, 7, generator=g))
+            self.c = nn.Parameter(torch.randn(4097, generator=g))
+            self.d = nn.Parameter(torch.randn(3, 10000, generator=g))
+            self.unused = nn.Parameter(torch.randn(33, generator=g))
+            self.frozen = nn.Parameter(torch.randn(9, generator=g), requires_grad=False)
+
+    m1, m2 = M().cuda(), M().cuda()
+    e1, e2 = LitEma(m1).cuda(), LitEma(m2).cuda()
+    o1 = torch.optim.AdamW([p for p in m1.parameters() if p.requires_grad], lr=3e-3, weight_decay=0.01)
+    o2 = FusedAdamWEma([p for p in m2.parameters() if p.requires_grad], lr=3e-3, weight_decay=0.01, ema=e2, ema_model=m2)
+    g = torch.Generator().manual_seed(4)
+    for step in range(4):
+        for (n1, p1), (n2, p2) in zip(m1.named_parameters(), m2.named_parameters()):
+            if n1 in ("unused", "frozen"):
+                continue
+            gr = torch.randn(p1.shape, generator=g).cuda() * (10.0 ** (step - 2))
+            p1.grad, p2.grad = gr.clone(), gr.clone()
+        o1.step()
+        e1(m1)
+        o2.step()
+    torch.cuda.synchronize()
+    def close(x, ref):          # 2e-6 of the value scale; parameters are O(1) and may pass near zero (cancellation)
+        return float((x.double() - ref.double()).abs().max()) <= 2e-6 * max(float(ref.abs().max()), 1.0)
+
+    for (n1, p1), (n2, p2) in zip(m1.named_parameters(), m2.named_parameters()):
+        assert close(p2.detach().cpu(), p1.detach().cpu()), n1
+    for (n1, b1), (n2, b2) in zip(e1.named_buffers(), e2.named_buffers()):
+        assert close(b2.float().cpu(), b1.float().cpu()), n1
+    assert int(e2.num_updates) == 4
+    for p1, p2 in zip(o1.param_groups[0]["params"], o2.param_groups[0]["params"]):
+        if p1.grad is None:
+            assert not o2.state[p2]
+            continue
+        assert max_rel(o2.state[p2]["exp_avg"].cpu(), o1.state[p1]["exp_avg"].cpu()) < 2e-6
+        assert max_rel(o2.state[p2]["exp_avg_sq"].cpu(), o1.state[p1]["exp_avg_sq"].cpu()) < 2e-6
