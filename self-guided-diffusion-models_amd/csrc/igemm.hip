@@ -1116,30 +1116,40 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
                 }
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
+                    // load phase: bias + residual of the four quads of this 32-channel block for both rows -- 12 independent
+                    // loads in flight (the compiler may not hoist them itself: y and res could alias), then the stores
+                    constexpr int QB = RES == 2 ? 1 : 2;      // quads per batch, bounded by the register budget (168 with 12 waves per CU)
 #pragma unroll
-                    for (int gq = 0; gq < 4; ++gq) {
+                    for (int q0 = 0; q0 < 4; q0 += QB) {
+                    f32x4 rv[4][MT];
+#pragma unroll
+                    for (int gq = q0; gq < q0 + QB; ++gq) {
                         const int c = cb + nt * 32 + gq * 8;
-                        if (c >= a.cout) continue;            // uniform within a lane half
+                        const int cl = c < a.cout ? c : 0;    // clamped: the quad is skipped below
                         f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-                        if (a.bias) bv = ld4(a.bias + c);
-                        f32x4 rv[MT];
+                        if (a.bias) bv = ld4(a.bias + cl);
 #pragma unroll
                         for (int mt = 0; mt < MT; ++mt) {
-                            rv[mt] = bv;
-                            if (RES == 1 || RES == 3) rv[mt] += ld4(rpm[mt] + c);
+                            rv[gq][mt] = bv;
+                            if (RES == 1 || RES == 3) rv[gq][mt] += ld4(rpm[mt] + cl);
                             if (RES == 2) {
                                 const long rw = (long)a.wo * 2 * a.cout;
                                 const float* rp = rpm[mt];
-                                rv[mt] += 0.25f * (ld4(rp + c) + ld4(rp + a.cout + c) + ld4(rp + rw + c) + ld4(rp + rw + a.cout + c));
+                                rv[gq][mt] += 0.25f * (ld4(rp + cl) + ld4(rp + a.cout + cl) + ld4(rp + rw + cl) + ld4(rp + rw + a.cout + cl));
                             }
                         }
+                    }
+#pragma unroll
+                    for (int gq = q0; gq < q0 + QB; ++gq) {
+                        const int c = cb + nt * 32 + gq * 8;
+                        if (c >= a.cout) continue;            // uniform within a lane half
                         f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = s1;
 #pragma unroll
                         for (int mt = 0; mt < MT; ++mt) {
                             f32x4 v;
 #pragma unroll
                             for (int j = 0; j < 4; ++j) v[j] = acc[mt][nt][gq * 4 + j];
-                            v += rv[mt];
+                            v += rv[gq][mt];
                             if (okm[mt]) {
                                 if (!(DBG(8))) *reinterpret_cast<f32x4*>(ypm[mt] + c) = v;
                                 s1 += v;
@@ -1155,6 +1165,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
                                 *reinterpret_cast<f32x4*>(sp + a.cout + c) = s2;
                             }
                         }
+                    }
                     }
                 }
             } else {
