@@ -178,6 +178,53 @@ def ddim_sample(sched, eps_fn, x_T, noises, num_steps, eta=0.0, log_num_per_prog
     return img, torch.cat(pred, 0), torch.cat(inter, 0), visited
 
 
+def plms_combine(e_t, old_eps):
+    """Adams-Bashforth combination of the current and up to three previous eps (ddim_plms_sampler.py:447-459);
+    with no history the caller forms the pseudo improved-Euler average itself."""
+    n = len(old_eps)
+    if n == 1:
+        return (3 * e_t - old_eps[-1]) / 2
+    if n == 2:
+        return (23 * e_t - 16 * old_eps[-1] + 5 * old_eps[-2]) / 12
+    return (55 * e_t - 59 * old_eps[-1] + 37 * old_eps[-2] - 9 * old_eps[-3]) / 24
+
+
+def plms_sample(sched, eps_fn, x_T, noises, num_steps, log_num_per_prog=10, clip_denoised=True, dtp=1.0,
+                num_ddpm_timesteps=1000):
+    """DDIMSampler.sample/plms_sampling (ddim_plms_sampler.py:38-46,84-97,394-482): eta forced to 0, the first step
+    evaluates the UNet twice.  ``noises(j)`` is the j-th p_sample_plms noise draw (num_steps + 1 draws in all)."""
+    steps = make_ddim_timesteps(num_steps, num_ddpm_timesteps)
+    tabs = make_ddim_tables(sched["alphas_cumprod"], steps, 0.0)
+    total = steps.shape[0]
+    snaps = snapshot_indices(total, log_num_per_prog)
+    time_range = np.flip(steps)
+    img = x_T
+    B = x_T.shape[0]
+    old_eps, pred, inter, visited = [], [], [], []
+    draw = 0
+    for i, step in enumerate(time_range):
+        index = total - i - 1
+        ts = torch.full((B,), int(step), dtype=torch.long)
+        ts_next = torch.full((B,), int(time_range[min(i + 1, len(time_range) - 1)]), dtype=torch.long)
+        e_t = eps_fn(img, ts)
+        if len(old_eps) == 0:
+            x_prev, _ = ddim_step(tabs, index, img, e_t, noises(draw), clip_denoised, dtp)
+            draw += 1
+            e_t_prime = (e_t + eps_fn(x_prev, ts_next)) / 2
+        else:
+            e_t_prime = plms_combine(e_t, old_eps)
+        img, x0 = ddim_step(tabs, index, img, e_t_prime, noises(draw), clip_denoised, dtp)
+        draw += 1
+        old_eps.append(e_t)
+        if len(old_eps) >= 4:
+            old_eps.pop(0)
+        visited.append((index, int(step)))
+        if index in snaps:
+            inter.append(img.unsqueeze(0))
+            pred.append(x0.unsqueeze(0))
+    return img, torch.cat(pred, 0), torch.cat(inter, 0), visited
+
+
 # --------------------------------------------------------------------------
 # EMA / LR
 # --------------------------------------------------------------------------

@@ -244,7 +244,7 @@ class Schedule_DDPM(nn.Module):
 
 
 class DDIMSampler(object):
-    """ddim_plms_sampler.py:25-391 (sampler_type='ddim'; 'plms' is a 'next' row)"""
+    """ddim_plms_sampler.py:25-525 (sampler_type 'ddim' | 'plms')"""
 
     def __init__(self, ddpm_num_timesteps, device, sampler_type):
         self.ddpm_num_timesteps = ddpm_num_timesteps
@@ -253,6 +253,8 @@ class DDIMSampler(object):
 
     def make_schedule(self, sampling_kwargs, ddim_discretize="uniform", **kwargs):
         S, eta = sampling_kwargs["num_timesteps"], sampling_kwargs["ddim_eta"]
+        if eta != 0 and self.sampler_type == "plms":
+            eta = 0                                               # ddim_plms_sampler.py:41-45 (warns and resets)
         ac = sampling_kwargs["alphas_cumprod"]
         self.ddim_timesteps = make_ddim_timesteps(ddim_discretize, S, self.ddpm_num_timesteps)
         assert ac.shape[0] == self.ddpm_num_timesteps, "alphas have to be defined for each timestep"
@@ -262,10 +264,87 @@ class DDIMSampler(object):
 
     @torch.no_grad()
     def sample(self, shape, sampling_kwargs=None, **kwargs):
-        if self.sampler_type != "ddim":
-            raise NotImplementedError("PLMS is a 'next' row (SURVEY 8(f) rank 2)")
         self.make_schedule(sampling_kwargs=sampling_kwargs)
-        return self.ddim_sampling(shape, sampling_kwargs=sampling_kwargs, **kwargs)
+        if self.sampler_type == "ddim":
+            return self.ddim_sampling(shape, sampling_kwargs=sampling_kwargs, **kwargs)
+        if self.sampler_type == "plms":
+            return self.plms_sampling(shape, sampling_kwargs=sampling_kwargs, **kwargs)
+        raise NotImplementedError
+
+    @torch.no_grad()
+    def plms_sampling(self, shape, sampling_kwargs, denoise_sample_fn_kwargs=None, denoise_sample_fn=None, **kwargs):
+        """ddim_plms_sampler.py:394-482: pseudo linear multistep.  Per step ONE UNet evaluation at 2B (two on the
+        first step), the guided eps kept as a [B,3,H,W] tensor for the Adams-Bashforth history, and the same fused
+        update kernel as DDIM (p_sample_plms == p_sample_ddim with a given eps, ddim_plms_sampler.py:484-525).
+        RNG order of the reference: x_T, then one randn per p_sample_plms call (num_steps + 1 draws)."""
+        sk = sampling_kwargs
+        if sk.get("dtp", 1) < 1.0:
+            raise NotImplementedError("dynamic thresholding (dtp < 1) is not on the fused step path yet")
+        dev = torch.device(self.device)
+        B, Cc = shape[0], shape[1]
+        hw = int(np.prod(shape[2:]))
+        x_T = kwargs.get("x_T")
+        img = torch.randn(shape, device=dev) if x_T is None else x_T.to(dev).float().contiguous()
+        noise_fn = kwargs.get("noise_fn")
+        timesteps = self.ddim_timesteps
+        total = timesteps.shape[0]
+        time_range = np.flip(timesteps)
+        snaps = torch.linspace(0, total, sk["log_num_per_prog"], dtype=torch.int).cpu().numpy().tolist()
+        runner = _StepRunner(denoise_sample_fn, denoise_sample_fn_kwargs or {})
+        lib = runner.lib
+        clip = 1 if sk["clip_denoised"] else 0
+        coef = (C.c_float * 4)()
+        draws = [0]
+
+        def guided(x, ts):
+            eps, mode, w, bb, cc = runner.eps(x, ts)
+            if mode == 0:
+                return eps.reshape(shape).clone()
+            out = torch.empty(shape, device=dev)
+            L.check(lib.sgd_cfg_combine(_ptr(eps), mode, w, bb, cc, hw, _ptr(out), _stream()), "sgd_cfg_combine")
+            return out
+
+        def update(x, e, index, want_x0):
+            z = torch.randn(shape, device=dev) if noise_fn is None else noise_fn(draws[0]).to(dev)
+            draws[0] += 1
+            if sk["noise_dropout"] > 0.0:
+                z = torch.nn.functional.dropout(z, p=sk["noise_dropout"])
+            coef[0] = float(self.ddim_sqrt_one_minus_alphas[index])
+            coef[1] = float(self.ddim_alphas[index])
+            coef[2] = float(self.ddim_alphas_prev[index])
+            coef[3] = float(self.ddim_sigmas[index])
+            nxt = torch.empty_like(x)
+            x0 = torch.empty_like(x) if want_x0 else None
+            e = e.contiguous()
+            # a guided NCHW eps is "NHWC with one channel" over B*C planes
+            L.check(lib.sgd_ddim_step(_ptr(x), _ptr(e), _ptr(z), 0, 0.0, coef, float(sk["temperature"]), clip,
+                                      B * Cc, 1, hw, _ptr(nxt), _ptr(x0), _stream()), "sgd_ddim_step")
+            return nxt, x0
+
+        old_eps, pred, inter = [], [], []
+        for i, step in enumerate(time_range):
+            index = total - i - 1
+            ts = torch.full((B,), int(step), device=dev, dtype=torch.long)
+            e_t = guided(img, ts)
+            if len(old_eps) == 0:
+                ts_next = torch.full((B,), int(time_range[min(i + 1, len(time_range) - 1)]), device=dev, dtype=torch.long)
+                x_prev, _ = update(img, e_t, index, False)
+                e_t_prime = (e_t + guided(x_prev, ts_next)) / 2
+            elif len(old_eps) == 1:
+                e_t_prime = (3 * e_t - old_eps[-1]) / 2
+            elif len(old_eps) == 2:
+                e_t_prime = (23 * e_t - 16 * old_eps[-1] + 5 * old_eps[-2]) / 12
+            else:
+                e_t_prime = (55 * e_t - 59 * old_eps[-1] + 37 * old_eps[-2] - 9 * old_eps[-3]) / 24
+            want = index in snaps
+            img, x0 = update(img, e_t_prime, index, want)
+            old_eps.append(e_t)
+            if len(old_eps) >= 4:
+                old_eps.pop(0)
+            if want:
+                inter.append(img.unsqueeze(0))
+                pred.append(x0.unsqueeze(0))
+        return img, dict(x_inter=torch.cat(inter, 0), pred_x0=torch.cat(pred, 0))
 
     @torch.no_grad()
     def ddim_sampling(self, shape, sampling_kwargs, denoise_sample_fn_kwargs=None, denoise_sample_fn=None, **kwargs):

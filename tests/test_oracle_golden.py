@@ -279,3 +279,16 @@ def test_train_step_loss_and_grads(name):
             assert max_rel(sd[pname].grad, v[key]) < 5e-5, pname
     assert sorted(v[tag + ".loss_keys"].tolist()) == ["train/ddpm_loss", "train/epoch_stats_x",
                                                       "train/epoch_stats_y", "train/loss"]
+
+
+def test_plms10_trajectory():
+    """PLMS (ddim_plms_sampler.py:394-525): double UNet evaluation on the first step, Adams-Bashforth history"""
+    v = load_npz("plms.npz")
+    z = torch.from_numpy(v["plms10.z"])
+    img, pred, inter, visited = D.plms_sample(D.make_schedule(), _tiny_label_model(), torch.from_numpy(v["plms10.x_T"]),
+                                              lambda j: z[j], 10)
+    assert [s for _, s in visited] == [901, 801, 701, 601, 501, 401, 301, 201, 101, 1]
+    assert pred.shape[0] == 9
+    assert rel_l2(inter, v["plms10.x_inter"]) < 1e-3
+    assert (D.to_uint8(img).int() - torch.from_numpy(v["plms10.samples_u8"]).int()).abs().max() <= 1
+    assert (D.to_uint8(pred).int() - torch.from_numpy(v["plms10.pred_x0_u8"]).int()).abs().max() <= 1
