@@ -145,20 +145,27 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WArgs w) {
 // = 256 contiguous bytes): conflict-free for the 32-lane halves of the transposing read.
 // ---------------------------------------------------------------------------------------------
 constexpr int FGP = 160;        // GY plane row pitch (16-bit elements)
-constexpr int FUP = 32;         // U plane row pitch
-constexpr int FCI = 32;         // ci tile
 
-template <int PREC, bool VEC>
+// TAPS == 9: 3x3 stride-1 conv as described above (U = 10x10 halo x 32 ci, pitch 64 B, accumulators = taps).
+// TAPS == 1: 1x1 conv / linear: K tile = 64 consecutive rows, U = [64 rows][128 ci] at the GY pitch, the four
+//            accumulators are the four 32-channel ci sub-blocks (same transposing reads, no halo).
+template <int PREC, bool VEC, int TAPS>
 __global__ __launch_bounds__(256, 2) void wgrad_conv_kernel(const WArgs w) {
     typedef typename Split<PREC>::T T;
     typedef T T4 __attribute__((ext_vector_type(4)));
     typedef T T8 __attribute__((ext_vector_type(8)));
     typedef short s4 __attribute__((ext_vector_type(4)));
+    constexpr bool CONV = TAPS == 9;
+    constexpr int NACC = CONV ? 9 : 4;
+    constexpr int UROWS = CONV ? 100 : 64;
+    constexpr int UPITCH = CONV ? 32 : FGP;
+    constexpr int CIT = CONV ? 32 : 128;              // ci tile of a block
     const sgd_igemm_args& a = w.a;
-    __shared__ __attribute__((aligned(16))) T Gh[64 * FGP];
-    __shared__ __attribute__((aligned(16))) T Gl[64 * FGP];
-    __shared__ __attribute__((aligned(16))) T Uh[100 * FUP];
-    __shared__ __attribute__((aligned(16))) T Ul[100 * FUP];
+    extern __shared__ __attribute__((aligned(16))) unsigned char wsm[];
+    T* Gh = reinterpret_cast<T*>(wsm);
+    T* Gl = Gh + 64 * FGP;
+    T* Uh = Gl + 64 * FGP;
+    T* Ul = Uh + UROWS * UPITCH;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
 
@@ -166,13 +173,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_conv_kernel(const WArgs w) {
     const int ks = bid % w.ksplit; bid /= w.ksplit;
     const int cit = bid % w.ci_tiles; bid /= w.ci_tiles;
     const int cot = bid;
-    const int co0 = cot * WT, ci0 = cit * FCI;
+    const int co0 = cot * WT, ci0 = cit * CIT;
     const int cin = a.c0 + a.c1;
-    const int pw = a.wo >> 3, ppi = pw * (a.ho >> 3);         // patches per row / per image
+    const int pw = CONV ? a.wo >> 3 : 1, ppi = CONV ? pw * (a.ho >> 3) : 1;   // patches per row / per image
 
-    f32x16 acc[9];
+    f32x16 acc[NACC];
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+    for (int t = 0; t < NACC; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
@@ -180,86 +187,103 @@ __global__ __launch_bounds__(256, 2) void wgrad_conv_kernel(const WArgs w) {
     // addresses pixel q of the 4-pixel block, channels 4p .. 4p+3
     const int gidx = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
     const int kbase = 8 * (gidx >> 1) + q;                    // + 16 s + 4 rd
-    const int chl = 16 * (gidx & 1) + 4 * pp;                 // channel inside the wave's 32
+    const int chl = 16 * (gidx & 1) + 4 * pp;                 // channel inside a 32-channel block
     auto trd = [&](const T* p) -> T4 {
         s4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)p);
         return __builtin_bit_cast(T4, v);
     };
+    auto split_store = [&](T* hp, T* lp, f32x4 v) {
+        T4 h, l;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { h[j] = Split<PREC>::hi(v[j]); l[j] = Split<PREC>::hi(v[j] - Split<PREC>::back(h[j])); }
+        *reinterpret_cast<T4*>(hp) = h;
+        *reinterpret_cast<T4*>(lp) = l;
+    };
 
     for (int kt = ks; kt < w.ktiles; kt += w.ksplit) {
-        const int n = kt / ppi, pr = kt - n * ppi;
-        const int y0 = (pr / pw) * 8, x0 = (pr - (pr / pw) * pw) * 8;
+        const int n = CONV ? kt / ppi : 0, pr = kt - n * ppi;
+        const int y0 = CONV ? (pr / pw) * 8 : 0, x0 = CONV ? (pr - (pr / pw) * pw) * 8 : 0;
         __syncthreads();
-        // ---- stage GY[64 px][128 co]
+        // ---- stage GY[64 rows][128 co]
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int idx = tid + i * 256;
             const int r = idx >> 5, qd = idx & 31;
-            const long row = ((long)n * a.ho + y0 + (r >> 3)) * a.wo + x0 + (r & 7);
+            const long row = CONV ? ((long)n * a.ho + y0 + (r >> 3)) * a.wo + x0 + (r & 7) : (long)kt * 64 + r;
             const int co = co0 + qd * 4;
             f32x4 gv = {0.f, 0.f, 0.f, 0.f};
-            if (w.gvec && co + 3 < w.cout) gv = ld4(w.gy + row * w.gy_ld + co);
-            else {
+            if (row < w.rows) {
+                if (w.gvec && co + 3 < w.cout) gv = ld4(w.gy + row * w.gy_ld + co);
+                else {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) if (co + j < w.cout) gv[j] = w.gy[row * w.gy_ld + co + j];
-            }
-            T4 h, l;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { h[j] = Split<PREC>::hi(gv[j]); l[j] = Split<PREC>::hi(gv[j] - Split<PREC>::back(h[j])); }
-            *reinterpret_cast<T4*>(Gh + r * FGP + qd * 4) = h;
-            *reinterpret_cast<T4*>(Gl + r * FGP + qd * 4) = l;
-        }
-        // ---- stage the activated input halo U[10 x 10 px][32 ci] (conv-input space, zero outside the image)
-        for (int idx = tid; idx < 100 * (FCI / 4); idx += 256) {
-            const int hp = idx >> 3, qd = idx & 7;
-            const int hy = hp / 10, hx = hp - hy * 10;
-            const int y = y0 + hy - 1, x = x0 + hx - 1;
-            const int c = ci0 + qd * 4;
-            f32x4 uv = {0.f, 0.f, 0.f, 0.f};
-            if (c < cin && y >= 0 && y < w.hc && x >= 0 && x < w.wc) {
-                if (a.resample == SGD_RS_AVGPOOL2) {
-#pragma unroll
-                    for (int sy = 0; sy < 2; ++sy)
-#pragma unroll
-                        for (int sx = 0; sx < 2; ++sx) {
-                            long rr = ((long)n * a.hi + 2 * y + sy) * a.wi + 2 * x + sx;
-                            uv += apply_pro(a, load_raw<VEC>(a, rr, c), load_coef<VEC>(a, n, rr, c), c, rr);
-                        }
-                    uv = uv * 0.25f;
-                } else {
-                    long rr = a.resample == SGD_RS_UP2 ? ((long)n * a.hi + (y >> 1)) * a.wi + (x >> 1)
-                                                       : ((long)n * a.hi + y) * a.wi + x;
-                    uv = apply_pro(a, load_raw<VEC>(a, rr, c), load_coef<VEC>(a, n, rr, c), c, rr);
+                    for (int j = 0; j < 4; ++j) if (co + j < w.cout) gv[j] = w.gy[row * w.gy_ld + co + j];
                 }
             }
-            T4 h, l;
+            split_store(Gh + r * FGP + qd * 4, Gl + r * FGP + qd * 4, gv);
+        }
+        // ---- stage the activated input
+        if constexpr (CONV) {
+            // halo U[10 x 10 px][32 ci] (conv-input space, zero outside the image)
+            for (int idx = tid; idx < 100 * (CIT / 4); idx += 256) {
+                const int hp = idx >> 3, qd = idx & 7;
+                const int hy = hp / 10, hx = hp - hy * 10;
+                const int y = y0 + hy - 1, x = x0 + hx - 1;
+                const int c = ci0 + qd * 4;
+                f32x4 uv = {0.f, 0.f, 0.f, 0.f};
+                if (c < cin && y >= 0 && y < w.hc && x >= 0 && x < w.wc) {
+                    if (a.resample == SGD_RS_AVGPOOL2) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { h[j] = Split<PREC>::hi(uv[j]); l[j] = Split<PREC>::hi(uv[j] - Split<PREC>::back(h[j])); }
-            *reinterpret_cast<T4*>(Uh + hp * FUP + qd * 4) = h;
-            *reinterpret_cast<T4*>(Ul + hp * FUP + qd * 4) = l;
+                        for (int sy = 0; sy < 2; ++sy)
+#pragma unroll
+                            for (int sx = 0; sx < 2; ++sx) {
+                                long rr = ((long)n * a.hi + 2 * y + sy) * a.wi + 2 * x + sx;
+                                uv += apply_pro(a, load_raw<VEC>(a, rr, c), load_coef<VEC>(a, n, rr, c), c, rr);
+                            }
+                        uv = uv * 0.25f;
+                    } else {
+                        long rr = a.resample == SGD_RS_UP2 ? ((long)n * a.hi + (y >> 1)) * a.wi + (x >> 1)
+                                                           : ((long)n * a.hi + y) * a.wi + x;
+                        uv = apply_pro(a, load_raw<VEC>(a, rr, c), load_coef<VEC>(a, n, rr, c), c, rr);
+                    }
+                }
+                split_store(Uh + hp * UPITCH + qd * 4, Ul + hp * UPITCH + qd * 4, uv);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int idx = tid + i * 256;
+                const int r = idx >> 5, qd = idx & 31;
+                const long row = (long)kt * 64 + r;
+                const int c = ci0 + qd * 4;
+                f32x4 uv = {0.f, 0.f, 0.f, 0.f};
+                if (row < w.rows && c < cin) {
+                    const int ni = a.pro == SGD_PRO_AFFINE_NC ? (int)(row / a.rows_per_n) : 0;
+                    uv = apply_pro(a, load_raw<VEC>(a, row, c), load_coef<VEC>(a, ni, row, c), c, row);
+                }
+                split_store(Uh + r * UPITCH + qd * 4, Ul + r * UPITCH + qd * 4, uv);
+            }
         }
         __syncthreads();
-        // ---- 4 k-steps of 16 pixels (two patch rows)
+        // ---- 4 k-steps of 16 rows
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
+            const int k0 = 16 * s + kbase;
             T8 ah, al;
             {
-                const int k0 = 16 * s + kbase;
                 const T* g0 = Gh + k0 * FGP + wave * 32 + chl;
                 const T* g1 = Gl + k0 * FGP + wave * 32 + chl;
                 const T4 h0 = trd(g0), h1 = trd(g0 + 4 * FGP), l0 = trd(g1), l1 = trd(g1 + 4 * FGP);
                 ah = T8{h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
                 al = T8{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
             }
-            // halo pixel of this lane's k (read 0): patch pixel k0 -> (row 2s + (k0 >> 3 & 1), col k0 & 7)
-            const int k0 = 16 * s + kbase;
-            const int hb = ((k0 >> 3) + 1) * 10 + (k0 & 7) + 1;      // halo index of tap (0, 0); read 1 = + 4
+            // CONV: halo pixel of tap (0, 0) for this lane's k (patch row k0 >> 3, col k0 & 7); read 1 = 4 pixels on
+            const int hb = CONV ? ((k0 >> 3) + 1) * 10 + (k0 & 7) + 1 : k0;
 #pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const int off = (t / 3 - 1) * 10 + (t % 3 - 1);
-                const T* u0 = Uh + (hb + off) * FUP + chl;
-                const T* u1 = Ul + (hb + off) * FUP + chl;
-                const T4 h0 = trd(u0), h1 = trd(u0 + 4 * FUP), l0 = trd(u1), l1 = trd(u1 + 4 * FUP);
+            for (int t = 0; t < NACC; ++t) {
+                const int off = CONV ? ((t / 3 - 1) * 10 + (t % 3 - 1)) * UPITCH : t * 32;
+                const T* u0 = Uh + hb * UPITCH + off + chl;
+                const T* u1 = Ul + hb * UPITCH + off + chl;
+                const T4 h0 = trd(u0), h1 = trd(u0 + 4 * UPITCH), l0 = trd(u1), l1 = trd(u1 + 4 * UPITCH);
                 const T8 bh = T8{h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
                 const T8 bl = T8{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
                 if constexpr (PREC == SGD_PREC_F16X3) {
@@ -275,18 +299,29 @@ __global__ __launch_bounds__(256, 2) void wgrad_conv_kernel(const WArgs w) {
         }
     }
     // ---- slab store: D rows = co (registers), cols = ci (lanes)
-    const int ci = ci0 + li;
-    if (ci < cin) {
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            float* slab = w.slabs + ((long)ks * 9 + t) * w.cout * cin;
+    for (int t = 0; t < NACC; ++t) {
+        const int ci = ci0 + (CONV ? 0 : t * 32) + li;
+        if (ci >= cin) continue;
+        float* slab = w.slabs + ((long)ks * TAPS + (CONV ? t : 0)) * w.cout * cin;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int co = co0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (co < w.cout) slab[(long)co * cin + ci] = acc[t][r];
-            }
+        for (int r = 0; r < 16; ++r) {
+            const int co = co0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (co < w.cout) slab[(long)co * cin + ci] = acc[t][r];
         }
     }
+}
+
+template <int PREC, bool VEC, int TAPS>
+static void launch_wgrad_fast(const WArgs& w, long grid, hipStream_t st) {
+    constexpr size_t smem = (2 * 64 * FGP + 2 * (TAPS == 9 ? 100 * 32 : 64 * FGP)) * 2;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)wgrad_conv_kernel<PREC, VEC, TAPS>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)smem);
+        attr = true;
+    }
+    hipLaunchKernelGGL((wgrad_conv_kernel<PREC, VEC, TAPS>), dim3((unsigned)grid), dim3(256), smem, st, w);
 }
 
 __global__ void wgrad_reduce_kernel(const float* __restrict__ slabs, int ksplit, int taps, int cout, int cin,
@@ -588,20 +623,20 @@ extern "C" int sgd_wgrad(const sgd_igemm_args* fwd, const float* gy, int32_t gy_
     if (w.ksplit != ksplit) return SGD_ERR_ARG;          // caller sizes the slabs: must agree
     const bool vec = (a.c0 % 4 == 0) && (a.c1 % 4 == 0);
     hipStream_t st = (hipStream_t)stream;
-    // split-precision, all-taps kernel: 3x3 stride 1 on whole 8x8 output patches, channel counts that fill the tiles
-    if (a.mode == SGD_MODE_CONV3 && a.stride == 1 && a.resample != SGD_RS_ZEROUP2 && a.prec != SGD_PREC_F32
-        && a.ho % 8 == 0 && a.wo % 8 == 0 && !getenv("SGDM_WGRAD_F32")) {
+    // split-precision kernels: 3x3 stride 1 on whole 8x8 output patches (all taps per block), and 1x1 / linear
+    const bool fast_conv = a.mode == SGD_MODE_CONV3 && a.stride == 1 && a.resample != SGD_RS_ZEROUP2 && a.ho % 8 == 0
+                           && a.wo % 8 == 0;
+    const bool fast_flat = a.mode == SGD_MODE_FLAT && a.pro != SGD_PRO_LN_ROW && cout >= 32 && cin >= 32;
+    if ((fast_conv || fast_flat) && a.prec != SGD_PREC_F32 && !getenv("SGDM_WGRAD_F32")) {
         w.gvec = gy_ld % 4 == 0;
-        w.ci_tiles = (cin + FCI - 1) / FCI;
+        if (fast_conv) w.ci_tiles = (cin + 31) / 32;
         const long fgrid = (long)w.co_tiles * w.ci_tiles * w.ksplit;
         if (fgrid > 0x7fffffffL) return SGD_ERR_ARG;
-        if (a.prec == SGD_PREC_F16X3) {
-            if (vec) hipLaunchKernelGGL((wgrad_conv_kernel<SGD_PREC_F16X3, true>), dim3((unsigned)fgrid), dim3(256), 0, st, w);
-            else hipLaunchKernelGGL((wgrad_conv_kernel<SGD_PREC_F16X3, false>), dim3((unsigned)fgrid), dim3(256), 0, st, w);
-        } else {
-            if (vec) hipLaunchKernelGGL((wgrad_conv_kernel<SGD_PREC_BF16X3, true>), dim3((unsigned)fgrid), dim3(256), 0, st, w);
-            else hipLaunchKernelGGL((wgrad_conv_kernel<SGD_PREC_BF16X3, false>), dim3((unsigned)fgrid), dim3(256), 0, st, w);
-        }
+#define SGD_WG(P, V)                                                             \
+        do { if (fast_conv) launch_wgrad_fast<P, V, 9>(w, fgrid, st); else launch_wgrad_fast<P, V, 1>(w, fgrid, st); } while (0)
+        if (a.prec == SGD_PREC_F16X3) { if (vec) SGD_WG(SGD_PREC_F16X3, true); else SGD_WG(SGD_PREC_F16X3, false); }
+        else { if (vec) SGD_WG(SGD_PREC_BF16X3, true); else SGD_WG(SGD_PREC_BF16X3, false); }
+#undef SGD_WG
         return sgd_check_launch();
     }
     const long grid = (long)w.taps * w.co_tiles * w.ci_tiles * w.ksplit;
