@@ -457,7 +457,8 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
             // boundaries (rows_per_n % 128 == 0), so the coefficients of a tile are one (n, channel quad) vector.
             // =================================================================================
             const bool tile_uni = a.pro == SGD_PRO_AFFINE_NC && a.rows_per_n % BM == 0;
-            const bool leanf = VEC && (a.pro == SGD_PRO_NONE || tile_uni) && a.drop_p == 0.f && cin % KC == 0
+            const bool ln = a.pro == SGD_PRO_LN_ROW;              // per-row (mean, rstd) + per-channel gamma / beta
+            const bool leanf = VEC && (a.pro == SGD_PRO_NONE || tile_uni || ln) && a.drop_p == 0.f && cin % KC == 0
                                && (a.c1 == 0 || a.c0 % KC == 0) && !DBG(3);
             if (leanf) {
                 constexpr int AI = BM * 8 / (NTHREADS - 256);             // input quads per thread per step (2)
@@ -471,14 +472,17 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
                 typedef std::integral_constant<int, 2> R2;
                 f32x4 araw[NB_RING][AI], breg[NB_RING][BI];
                 Coef kq[NB_RING];
+                float2 rst[NB_RING][AI];                                  // LayerNorm row statistics of the items
                 struct Cur { int k, chunk; int m0; const float* wt; const float* ka; const float* kb; };
                 auto open_tile = [&](Cur& c) {                           // per-tile scalars
                     const Tile T = tile_at(g, lin_of(c.k), BN, TW, TH);
                     c.m0 = (int)T.m0;
                     c.wt = reinterpret_cast<const float*>(a.w) + (size_t)(T.n0c + brow) * a.cin_p + c4 * 4;
                     const long ko = tile_uni ? (long)(c.m0 / a.rows_per_n) * cin : 0;
-                    c.ka = tile_uni ? a.pa + ko + c4 * 4 : a.x0;          // no prologue: harmless bytes, no branch
-                    c.kb = tile_uni ? a.pb + ko + c4 * 4 : a.x0;
+                    // coefficient quads of a chunk: GroupNorm a / b of the tile's image, or LayerNorm gamma / beta;
+                    // no prologue (or no beta): harmless bytes of the input instead of a branch around the load
+                    c.ka = tile_uni ? a.pa + ko + c4 * 4 : (ln ? a.pb + c4 * 4 : a.x0);
+                    c.kb = tile_uni ? a.pb + ko + c4 * 4 : ((ln && a.pc) ? a.pc + c4 * 4 : a.x0);
                 };
                 auto advance = [&](Cur& c) {
                     if (++c.chunk == nchunks) {
@@ -498,13 +502,14 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
                     else { src = a.x1 + (ch - a.c0); stride = a.c1; }
 #pragma unroll
                     for (int it = 0; it < BI; ++it) breg[R][it] = ld4(ci.wt + ch + (size_t)(it * 64) * a.cin_p);
-                    kq[R].p = ld4(ci.ka + (tile_uni ? ch : 0));
-                    kq[R].q = ld4(ci.kb + (tile_uni ? ch : 0));
+                    kq[R].p = ld4(ci.ka + ((tile_uni || ln) ? ch : 0));
+                    kq[R].q = ld4(ci.kb + ((tile_uni || (ln && a.pc)) ? ch : 0));
 #pragma unroll
                     for (int j = 0; j < AI; ++j) {
                         int row = ci.m0 + arow + j * 64;
                         row = row < M ? row : M - 1;
                         araw[R][j] = ld4(src + (long)row * stride + c4 * 4);
+                        rst[R][j] = *reinterpret_cast<const float2*>(ln ? a.pa + (long)row * 2 : a.x0);
                     }
                     advance(ci);
                 };
@@ -517,6 +522,10 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
                     for (int j = 0; j < AI; ++j) {
                         f32x4 v = araw[R][j];
                         if (tile_uni) v = v * kq[R].p + kq[R].q;
+                        if (ln) {
+                            v = (v - rst[R][j].x) * rst[R][j].y * kq[R].p;
+                            if (a.pc) v += kq[R].q;
+                        }
                         if (a.pro_silu) {
 #pragma unroll
                             for (int e = 0; e < 4; ++e) v[e] = sgd_silu(v[e]);
