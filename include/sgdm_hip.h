@@ -101,6 +101,13 @@ int64_t sgd_packed_weight_bytes(int32_t cout, int32_t cin, int32_t ksize, int32_
 int sgd_pack_weight(const float* w_src, void* w_dst, int32_t cout, int32_t cin, int32_t ksize,
                     int32_t prec, int32_t* cin_p, int32_t* cout_p /* HOST out */, void* stream);
 
+/* Skinny linear with a long reduction (mlp_cond.0 of the cluster-k5000 config, openaimodel.py:597-607: [2B, 5000] x
+ * [256, 5000]^T): exact fp32 FMA, the K range split over `ksplit` blocks per 64-column tile, partial sums in
+ * work[ksplit, m, n] folded in fixed order (deterministic).  w is the nn.Linear weight as stored ([n, k], no packing).
+ *   y[m, n] = x[m, :k] . w[n, :k] + bias[n]                                (bias may be NULL) */
+int sgd_linear_splitk(const float* x, int32_t x_ld, const float* w, const float* bias, int32_t m, int32_t n, int32_t k,
+                      float* work, int32_t ksplit, float* y, int32_t y_ld, void* stream);
+
 /* --------------------------------------------------------------------------------------
  * GroupNorm(32) as statistics + per-(n,c) affine coefficients consumed by sgd_igemm's
  * prologue (util.py:199-216; openaimodel.py:246-247,270-271,312-316,348,831-832).

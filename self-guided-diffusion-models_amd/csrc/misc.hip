@@ -284,3 +284,81 @@ extern "C" int sgd_adamw_ema_step(const sgd_opt_tensor* table, const int32_t* ch
                        ema_one_minus_decay);
     return sgd_check_launch();
 }
+
+// ---------------------------------------------------------------------------------------------
+// skinny split-K linear (few rows, thousands of input features): the tiled conv kernel would walk the whole K range
+// with 4 blocks; here (n / 64) x ksplit blocks each own a K slice
+// ---------------------------------------------------------------------------------------------
+namespace {
+constexpr int LS_MMAX = 256;     // rows handled by one launch (8 per thread x 4 thread rows x up to 8 row tiles)
+
+__global__ __launch_bounds__(256) void linear_splitk_kernel(const float* __restrict__ x, int x_ld,
+                                                            const float* __restrict__ w, int m, int n, int k,
+                                                            int ksplit, float* __restrict__ work) {
+    __shared__ float ws[64][33];
+    __shared__ float xs[32][33];
+    const int tn = threadIdx.x & 63, tm = threadIdx.x >> 6;       // column of the tile, row group (8 rows of a 32-row tile)
+    const int n0 = blockIdx.x * 64, ks = blockIdx.y;
+    const int kper = ((k + ksplit - 1) / ksplit + 31) / 32 * 32;
+    const int kb = ks * kper, ke = (kb + kper < k) ? kb + kper : k;
+    float acc[LS_MMAX / 32][8];
+#pragma unroll
+    for (int i = 0; i < LS_MMAX / 32; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = 0.f;
+    for (int k0 = kb; k0 < ke; k0 += 32) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < 64 * 32; i += 256) {
+            const int r = i >> 5, c = i & 31;
+            ws[r][c] = (n0 + r < n && k0 + c < ke) ? w[(long)(n0 + r) * k + k0 + c] : 0.f;
+        }
+#pragma unroll
+        for (int mt = 0; mt < LS_MMAX / 32; ++mt) {
+            if (mt * 32 >= m) break;
+            __syncthreads();
+            for (int i = threadIdx.x; i < 32 * 32; i += 256) {
+                const int r = i >> 5, c = i & 31;
+                xs[r][c] = (mt * 32 + r < m && k0 + c < ke) ? x[(long)(mt * 32 + r) * x_ld + k0 + c] : 0.f;
+            }
+            __syncthreads();
+#pragma unroll 8
+            for (int c = 0; c < 32; ++c) {
+                const float wv = ws[tn][c];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[mt][j] = fmaf(xs[tm * 8 + j][c], wv, acc[mt][j]);
+            }
+        }
+    }
+    if (n0 + tn < n) {
+#pragma unroll
+        for (int mt = 0; mt < LS_MMAX / 32; ++mt)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int row = mt * 32 + tm * 8 + j;
+                if (row < m) work[((long)ks * m + row) * n + n0 + tn] = acc[mt][j];
+            }
+    }
+}
+
+__global__ void linear_splitk_fold_kernel(const float* __restrict__ work, const float* __restrict__ bias, int m, int n,
+                                          int ksplit, float* __restrict__ y, int y_ld) {
+    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (i >= (long)m * n) return;
+    const int row = (int)(i / n), col = (int)(i - (long)row * n);
+    float s = 0.f;
+    for (int q = 0; q < ksplit; ++q) s += work[(long)q * m * n + i];
+    y[(long)row * y_ld + col] = s + (bias ? bias[col] : 0.f);
+}
+}  // namespace
+
+extern "C" int sgd_linear_splitk(const float* x, int32_t x_ld, const float* w, const float* bias, int32_t m, int32_t n,
+                                 int32_t k, float* work, int32_t ksplit, float* y, int32_t y_ld, void* stream) {
+    SGD_CLEAR_ERR();
+    if (!x || !w || !work || !y || m <= 0 || m > LS_MMAX || n <= 0 || k <= 0 || ksplit <= 0 || x_ld < k || y_ld < n)
+        return SGD_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(linear_splitk_kernel, dim3((n + 63) / 64, ksplit), dim3(256), 0, st, x, x_ld, w, m, n, k, ksplit, work);
+    hipLaunchKernelGGL(linear_splitk_fold_kernel, dim3((unsigned)(((long)m * n + 255) / 256)), dim3(256), 0, st, work, bias,
+                       m, n, ksplit, y, y_ld);
+    return sgd_check_launch();
+}

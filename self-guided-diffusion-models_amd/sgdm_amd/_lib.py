@@ -46,6 +46,7 @@ SIGNATURES = {
     "sgd_stats_reduce": (i32, [vp, i32, i32, i32, vp, i32, i32, vp]),
     "sgd_packed_weight_bytes": (i64, [i32, i32, i32, i32]),
     "sgd_pack_weight": (i32, [vp, vp, i32, i32, i32, i32, C.POINTER(i32), C.POINTER(i32), vp]),
+    "sgd_linear_splitk": (i32, [vp, i32, vp, vp, i32, i32, i32, vp, i32, vp, i32, vp]),
     "sgd_chan_stats": (i32, [vp, i32, i32, i32, vp, i32, i32, vp]),
     "sgd_gn_coef": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, vp, vp, vp]),
     "sgd_ln_stats": (i32, [vp, i32, i32, f32, vp, vp]),

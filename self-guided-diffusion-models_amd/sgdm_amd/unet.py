@@ -410,7 +410,7 @@ class _Engine:
 
     def igemm(self, tag, x0, c0, y, cout, pk, *, x1=None, c1=0, conv=None, m=0, rows_per_n=0,
               pro=L.PRO_NONE, silu=0, pa=None, pb=None, pc=None, bias=None, res=None, res_mode=L.RS_NONE,
-              y_ld=None, y_off=0, orows=(0, 0, 0), stats=False):
+              y_ld=None, y_off=0, orows=(0, 0, 0), stats=False, launch=True):
         """stats=True: the epilogue also writes the GroupNorm statistics of y (consumed by gn() through
         sgd_stats_reduce instead of a sgd_chan_stats pass over the tensor)"""
         a = L.IgemmArgs()
@@ -449,7 +449,8 @@ class _Engine:
         cin = c0 + c1
         flops = 2.0 * rows * cout * taps * cin
         nbytes = 4.0 * (rows_in * cin + rows * cout * (2 if res is not None else 1) + taps * cin * cout)
-        self.prog.add(tag, self.lib.sgd_igemm, C.byref(a), flops=flops, nbytes=nbytes)
+        if launch:          # launch=False: descriptor only (the backward's weight gradient reads it)
+            self.prog.add(tag, self.lib.sgd_igemm, C.byref(a), flops=flops, nbytes=nbytes)
         return a
 
     def gn(self, tag, srcs, hw, gname, film=None, film_ld=0):
@@ -725,8 +726,18 @@ class UNetModel(UNetModelBase):
         P = self.P
         c1 = eng.buf(eng.n, ted // 2)
         eng.emb_c = eng.buf(eng.n, ted // 2)                                      # emb = cat(time, cond), :942
+        skinny = self.cond_dim >= 1024 and eng.n <= 256          # cluster k = 5000: split the long reduction over blocks
         a0 = eng.igemm("mlp_cond.0", eng.cond_m, self.cond_dim, c1, ted // 2, eng.pack(["mlp_cond.0.weight"], 1),
-                       m=eng.n, bias=P("mlp_cond.0.bias"))
+                       m=eng.n, bias=P("mlp_cond.0.bias"), launch=not skinny)
+        if skinny:
+            ksplit = max(1, min(64, self.cond_dim // 128))
+            work = eng.buf(ksplit, eng.n, ted // 2)
+            wt, bs = P("mlp_cond.0.weight"), P("mlp_cond.0.bias")
+            eng.prog.add("mlp_cond.0", eng.lib.sgd_linear_splitk, _ptr(eng.cond_m), self.cond_dim, _ptr(wt), _ptr(bs),
+                         eng.n, ted // 2, self.cond_dim, _ptr(work), ksplit, _ptr(c1), ted // 2,
+                         flops=2.0 * eng.n * self.cond_dim * (ted // 2),
+                         nbytes=4.0 * (eng.n * self.cond_dim + self.cond_dim * (ted // 2) + eng.n * (ted // 2)))
+            eng.prog.keep.append((wt, bs))
         a2 = eng.igemm("mlp_cond.2", c1, ted // 2, eng.emb_c, ted // 2, eng.pack(["mlp_cond.2.weight"], 1), m=eng.n,
                        silu=1, bias=P("mlp_cond.2.bias"))
         eng.tape.append(dict(kind="mlp2", name="mlp_cond", x=eng.cond_m, h=c1, y=eng.emb_c, a0=a0, a2=a2,
