@@ -173,3 +173,22 @@ def test_optimizer_chunk_table():
     from sgdm_amd.optim import CHUNK, chunk_table
     assert chunk_table([1, CHUNK, CHUNK + 1, 3 * CHUNK]) == [0, 1, 2, 4, 7]
     assert chunk_table([]) == [0]
+
+
+def test_committed_bench_line_has_the_contract_fields():
+    """the bench line committed under profiles/ (produced by bench.py on the MI355X) carries every field of the contract"""
+    import json
+    line = json.loads(open(os.path.join(ROOT, "profiles", "r1_bench_c2_f16x3.json")).read().strip().splitlines()[-1])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "train_step"):
+        assert k in line, k
+    assert line["higher_is_better"] is True and line["scaling"] == "weak" and line["data"] == "synthetic"
+    assert "workload" in line["config"] and "model" not in line["config"]
+    r = line["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    c = line["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] in ("reference", "port")
