@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define SGD_ABI_VERSION 3
+#define SGD_ABI_VERSION 4
 int sgd_abi_version(void);
 
 /* --------------------------------------------------------------------------------------
@@ -204,10 +204,16 @@ int sgd_pack_weight_dgrad(const float* w_src, void* w_dst, int32_t cout_fwd, int
  * -------------------------------------------------------------------------------------- */
 /* weight gradient of a fused conv / linear:  dW[co, ci, tap] = sum_rows gy[row, co] * act(x)[row shifted by tap, ci]
  * `fwd` describes the FORWARD launch (its input side: x0/x1, prologue, resample, geometry are re-used to recompute the
- * activated input; its w/bias/res/y fields are ignored).  Exact-fp32 MFMA.  Partial sums of `ksplit` row slices are
- * written to `slabs` [ksplit][taps][cout][cin] and folded by sgd_wgrad_reduce into the reference layout. */
+ * activated input; its w/bias/res/y fields are ignored).  Arithmetic follows fwd->prec: exact-fp32 MFMA, or the
+ * three-product 16-bit split (3x3 stride-1 and 1x1 / linear; other geometries fall back to exact fp32).  Partial sums
+ * of `ksplit` row slices are written to `slabs` [ksplit][taps][cout][cin] and folded by sgd_wgrad_reduce into the
+ * reference layout.  bias_slabs (optional, [ksplit][cout]): partial column sums of gy = the bias gradient, taken from
+ * the gy rows the kernel stages anyway; fold with sgd_colsum_fold. */
 int sgd_wgrad(const sgd_igemm_args* fwd /* HOST */, const float* gy, int32_t gy_ld, int32_t cout,
-              float* slabs, int32_t ksplit, void* stream);
+              float* slabs, int32_t ksplit, float* bias_slabs, void* stream);
+/* out[c] (+)= scale * sum_k partial[k, c]   (fixed order, double accumulation) */
+int sgd_colsum_fold(const float* partial, int32_t chunks, int32_t c, float* out, int32_t accumulate, float scale,
+                    void* stream);
 /* dw[co, ci, tap] (OIHW / [cout, cin]) = (accumulate ? dw : 0) + scale * sum_k slabs[k][tap][co][ci]
  * (`scale` undoes the power-of-two gradient scaling that keeps the split-f16 dgrad operands in range) */
 int sgd_wgrad_reduce(const float* slabs, int32_t ksplit, int32_t taps, int32_t cout, int32_t cin,

@@ -27,6 +27,7 @@ struct WArgs {
     const float* gy;
     int gy_ld, cout, ksplit, taps, rows, co_tiles, ci_tiles, ktiles, hc, wc, wo_l2, ho_l2, gvec;
     float* slabs;
+    float* bslab;               // [ksplit][cout] partial column sums of gy (bias gradient), or NULL
 };
 
 template <bool VEC>
@@ -200,6 +201,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_conv_kernel(const WArgs w) {
         *reinterpret_cast<T4*>(lp) = l;
     };
 
+    f32x4 bsum = {0.f, 0.f, 0.f, 0.f};                   // bias gradient: column sums of the staged gy rows
     for (int kt = ks; kt < w.ktiles; kt += w.ksplit) {
         const int n = CONV ? kt / ppi : 0, pr = kt - n * ppi;
         const int y0 = CONV ? (pr / pw) * 8 : 0, x0 = CONV ? (pr - (pr / pw) * pw) * 8 : 0;
@@ -220,6 +222,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_conv_kernel(const WArgs w) {
                 }
             }
             split_store(Gh + r * FGP + qd * 4, Gl + r * FGP + qd * 4, gv);
+            bsum += gv;                                   // this thread's co quad (idx & 31) is the same for all its items
         }
         // ---- stage the activated input
         if constexpr (CONV) {
@@ -296,6 +299,19 @@ __global__ __launch_bounds__(256, 2) void wgrad_conv_kernel(const WArgs w) {
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[t], 0, 0, 0);
                 }
             }
+        }
+    }
+    if (w.bslab && cit == 0) {
+        // fold the 8 row lanes of every co quad through LDS (the planes are free after the last MFMA phase)
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(wsm);       // [8][128]
+        *reinterpret_cast<f32x4*>(red + (tid >> 5) * 128 + (tid & 31) * 4) = bsum;
+        __syncthreads();
+        if (tid < 128) {
+            float t = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t += red[k * 128 + tid];
+            if (co0 + tid < w.cout) w.bslab[(long)ks * w.cout + co0 + tid] = t;
         }
     }
     // ---- slab store: D rows = co (registers), cols = ci (lanes)
@@ -588,7 +604,7 @@ inline unsigned nblk(long total, int cap = 1 << 20) {
 }  // namespace
 
 extern "C" int sgd_wgrad(const sgd_igemm_args* fwd, const float* gy, int32_t gy_ld, int32_t cout, float* slabs,
-                         int32_t ksplit, void* stream) {
+                         int32_t ksplit, float* bias_slabs, void* stream) {
     SGD_CLEAR_ERR();
     if (!fwd || !gy || !slabs || cout <= 0 || ksplit <= 0 || gy_ld < cout) return SGD_ERR_ARG;
     WArgs w;
@@ -615,7 +631,7 @@ extern "C" int sgd_wgrad(const sgd_igemm_args* fwd, const float* gy, int32_t gy_
         return SGD_ERR_ARG;
     }
     if (w.rows <= 0) return SGD_ERR_ARG;
-    w.gy = gy; w.gy_ld = gy_ld; w.cout = cout; w.slabs = slabs;
+    w.gy = gy; w.gy_ld = gy_ld; w.cout = cout; w.slabs = slabs; w.bslab = bias_slabs;
     w.co_tiles = (cout + WT - 1) / WT;
     w.ci_tiles = (cin + WT - 1) / WT;
     w.ktiles = (w.rows + WK - 1) / WK;
@@ -639,6 +655,9 @@ extern "C" int sgd_wgrad(const sgd_igemm_args* fwd, const float* gy, int32_t gy_
 #undef SGD_WG
         return sgd_check_launch();
     }
+    if (bias_slabs)          // exact-f32 / strided fallback: the same [ksplit][cout] partial column sums, by the colsum kernel
+        hipLaunchKernelGGL(colsum_stage1_kernel, dim3((cout + 31) / 32, w.ksplit), dim3(256), 0, st, gy, w.rows, cout, gy_ld,
+                           w.ksplit, bias_slabs);
     const long grid = (long)w.taps * w.co_tiles * w.ci_tiles * w.ksplit;
     if (grid > 0x7fffffffL) return SGD_ERR_ARG;
     if (vec) hipLaunchKernelGGL((wgrad_kernel<true>), dim3((unsigned)grid), dim3(256), 0, st, w);
@@ -665,6 +684,15 @@ extern "C" int sgd_colsum(const float* g, int32_t rows, int32_t c, int32_t ld, f
     hipLaunchKernelGGL(colsum_stage1_kernel, dim3((c + 31) / 32, chunks), dim3(256), 0, st, g, rows, c, ld, chunks, work);
     hipLaunchKernelGGL(colsum_stage2_kernel, dim3((c + 31) / 32), dim3(256), 0, st, work, chunks, c, out, accumulate,
                        scale);
+    return sgd_check_launch();
+}
+
+extern "C" int sgd_colsum_fold(const float* partial, int32_t chunks, int32_t c, float* out, int32_t accumulate,
+                               float scale, void* stream) {
+    SGD_CLEAR_ERR();
+    if (!partial || !out || chunks <= 0 || c <= 0) return SGD_ERR_ARG;
+    hipLaunchKernelGGL(colsum_stage2_kernel, dim3((c + 31) / 32), dim3(256), 0, (hipStream_t)stream, partial, chunks, c, out,
+                       accumulate, scale);
     return sgd_check_launch();
 }
 

@@ -149,15 +149,18 @@ class Backward:
         ktiles = (rows + 63) // 64
         ksplit = max(1, min(ktiles, 1024 // base))
         slabs = self.buf(ksplit, taps, cout, cin)
-        self.prog.add(tag + ".wgrad", self.lib.sgd_wgrad, C.byref(fwd_args), _ptr(gy), gy_ld, cout, _ptr(slabs), ksplit)
+        # the bias gradient (column sums of gy) comes out of the same launch: the kernel stages the gy rows anyway
+        bslab = self.buf(ksplit, cout) if bias_name is not None else None
+        self.prog.add(tag + ".wgrad", self.lib.sgd_wgrad, C.byref(fwd_args), _ptr(gy), gy_ld, cout, _ptr(slabs), ksplit,
+                      _ptr(bslab) if bslab is not None else None)
         dw = dw_view if dw_view is not None else self.pg(wname)
         self.prog.add(tag + ".wred", self.lib.sgd_wgrad_reduce, _ptr(slabs), ksplit, taps, cout, cin, _ptr(dw), 0,
                       self.unscale)
         if dw_view is None:
             self.wrote(wname)
         if bias_name is not None:
-            self.prog.add(tag + ".bias", self.lib.sgd_colsum, _ptr(gy), rows, cout, gy_ld, _ptr(self.pg(bias_name)), 0,
-                          self.unscale, _ptr(self.cwork), self.CW)
+            self.prog.add(tag + ".bias", self.lib.sgd_colsum_fold, _ptr(bslab), ksplit, cout, _ptr(self.pg(bias_name)), 0,
+                          self.unscale)
             self.wrote(bias_name)
 
     def colsum(self, tag, g_ptr, rows, c, ld, pname):

@@ -53,7 +53,13 @@ def test_conv_dgrad_is_forward_kernel_on_adjoint_weights(shape, prec, tol):
 
 def _wgrad(L, lib, fwd, gy, cout, cin, taps, ksplit):
     slabs = torch.full((ksplit, taps, cout, cin), float("nan"), device="cuda")
-    L.check(lib.sgd_wgrad(C.byref(fwd), _p(gy), gy.shape[-1], cout, _p(slabs), ksplit, _stream()), "wgrad")
+    bsl = torch.full((ksplit, cout), float("nan"), device="cuda")
+    L.check(lib.sgd_wgrad(C.byref(fwd), _p(gy), gy.shape[-1], cout, _p(slabs), ksplit, _p(bsl), _stream()), "wgrad")
+    # the bias gradient rides along: partial column sums of gy, folded like sgd_colsum's second stage
+    db = torch.full((cout,), float("nan"), device="cuda")
+    L.check(lib.sgd_colsum_fold(_p(bsl), ksplit, cout, _p(db), 0, 1.0, _stream()), "fold")
+    ref_db = gy.reshape(-1, gy.shape[-1])[:, :cout].double().sum(0).float()
+    assert max_rel(db.cpu(), ref_db.cpu()) < 2e-6
     dw = torch.full((cout, cin, taps), float("nan"), device="cuda")
     L.check(lib.sgd_wgrad_reduce(_p(slabs), ksplit, taps, cout, cin, _p(dw), 0, 1.0, _stream()), "reduce")
     L.check(lib.sgd_wgrad_reduce(_p(slabs), ksplit, taps, cout, cin, _p(dw), 1, 1.0, _stream()), "reduce+")     # accumulate
