@@ -306,8 +306,9 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
                 const int lt = tid - 256;
                 const int c4 = lt & 7;                                   // channel quad (inputs and weights alike)
                 const int items = g.pix * 8;
-                auto go = [&](auto latec) {
+                auto go = [&](auto latec, auto poolc) {
                     constexpr bool LATE = decltype(latec)::value;
+                    constexpr int NS = decltype(poolc)::value ? 4 : 1;   // source pixels per item (fused 2x2 average pool)
                     constexpr int T0 = LATE ? 5 : 1;
                     typedef std::integral_constant<int, 0> R0;
                     typedef std::integral_constant<int, 1> R1;
@@ -377,7 +378,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
                         fill(c);
                         return c;
                     };
-                    f32x4 araw[AJ];
+                    f32x4 araw[AJ][NS];
                     Coef kq;
                     auto transform = [&](f32x4 v, bool ok) {
                         if (uni) v = v * kq.p + kq.q;
@@ -388,12 +389,24 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
                         if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
                         return v;
                     };
-                    auto issue_item = [&](const S& c, int j) { araw[j] = ld4(c.src + (long)rows2[j] * c.stride + c4 * 4); };
+                    auto issue_item = [&](const S& c, int j) {
+                        const float* p0 = c.src + (long)rows2[j] * c.stride + c4 * 4;
+                        araw[j][0] = ld4(p0);
+                        if constexpr (NS == 4) {            // ResBlock(down): the conv reads avg_pool2d(SiLU(GN(x))) (openaimodel.py:301-306)
+                            araw[j][1] = ld4(p0 + c.stride);
+                            araw[j][2] = ld4(p0 + (long)a.wi * c.stride);
+                            araw[j][3] = ld4(p0 + (long)(a.wi + 1) * c.stride);
+                        }
+                    };
                     auto issue_coef = [&](const S& c) { kq.p = ld4(c.ka + c4 * 4); kq.q = ld4(c.kb + c4 * 4); };
                     auto finish = [&](int slot, int j) {
-                        if (live[j])
-                            lds_store_act<PREC>(As + (size_t)(slot % NA) * a_floats + (size_t)pixj[j] * LDA, c4,
-                                                transform(araw[j], (valid1 >> j) & 1u));
+                        if (live[j]) {
+                            const bool ok = (valid1 >> j) & 1u;
+                            f32x4 v = transform(araw[j][0], ok);
+                            if constexpr (NS == 4)
+                                v = 0.25f * (v + transform(araw[j][1], ok) + transform(araw[j][2], ok) + transform(araw[j][3], ok));
+                            lds_store_act<PREC>(As + (size_t)(slot % NA) * a_floats + (size_t)pixj[j] * LDA, c4, v);
+                        }
                     };
                     // ---- prologue: weight slices 0..4 in flight / staged, chunk 0 staged synchronously, chunk 1 requested
                     load_next(R0());
@@ -443,8 +456,13 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
                         }
                     }
                 };
-                if (wave >= 8) go(std::true_type());
-                else go(std::false_type());
+                if (a.resample == SGD_RS_AVGPOOL2) {
+                    if (wave >= 8) go(std::true_type(), std::true_type());
+                    else go(std::false_type(), std::true_type());
+                } else {
+                    if (wave >= 8) go(std::true_type(), std::false_type());
+                    else go(std::false_type(), std::false_type());
+                }
                 PROBE_END(1);
                 return;
             }
@@ -713,7 +731,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
                 for (int q = 0; q < Q; ++q)
 #pragma unroll
                     for (int t = 0; t < 9; ++t) SYNC();
-            } else if (g.fast_a) {
+            } else if (g.fast_a && a.resample != SGD_RS_AVGPOOL2) {
                 // Split-phase staging, one item per K step: at tap t (1..AJ) a thread transforms the raw row quad it
                 // requested NINE steps earlier (chunk q+1) into LDS and re-uses the register for the same item of chunk
                 // q+2.  Every tap carries the same small amount of loader work (the per-step barrier makes the slowest
@@ -1346,7 +1364,7 @@ static int make_geo(const sgd_igemm_args& a, Geo& g, int bn, int& na) {
         g.tiles_x = a.wo / tw; g.tiles_y = a.ho / th;
         g.pix = nb * g.hh * g.hw;
         g.mt = ((a.n + nb - 1) / nb) * g.tiles_x * g.tiles_y;
-        g.fast_a = (a.resample != SGD_RS_AVGPOOL2 && g.pix <= FAST_PIX) ? 1 : 0;
+        g.fast_a = g.pix <= FAST_PIX ? 1 : 0;
         na = 2;
     } else if (a.mode == SGD_MODE_FLAT) {
         if (a.m <= 0) return SGD_ERR_ARG;
