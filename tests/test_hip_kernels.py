@@ -330,3 +330,21 @@ def test_epilogue_statistics_match_chan_stats(shape):
     assert float((sums[:, 8:].cpu().double() - exact).abs().max() / exact.abs().max()) < 2e-6
     assert float((ref[:, 8:].cpu().double() - exact).abs().max() / exact.abs().max()) < 2e-6
     assert float(sums[:, :8].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("m,n,k,ksplit", [(7, 100, 1234, 5), (160, 256, 5000, 39), (256, 64, 33, 1)])
+def test_linear_splitk(m, n, k, ksplit):
+    """skinny split-K linear (mlp_cond.0 at K = 5000) vs float64; ragged m / n / k and a padded x row stride"""
+    L, lib = _lib()
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(m, k + 3, generator=g)
+    w = torch.randn(n, k, generator=g) / k ** 0.5
+    b = torch.randn(n, generator=g)
+    xd, wd, bd = x.cuda(), w.cuda(), b.cuda()
+    work = torch.full((ksplit, m, n), float("nan"), device="cuda")
+    y = torch.full((m, n + 2), float("nan"), device="cuda")
+    L.check(lib.sgd_linear_splitk(_p(xd), k + 3, _p(wd), _p(bd), m, n, k, _p(work), ksplit, _p(y), n + 2, _stream()), "lin")
+    ref = (x[:, :k].double() @ w.double().t() + b.double()).float()
+    assert max_rel(y[:, :n].cpu(), ref) < 2e-6
+    assert torch.isnan(y[:, n:]).all()
+    assert lib.sgd_linear_splitk(_p(xd), k + 3, _p(wd), _p(bd), 257, n, k, _p(work), ksplit, _p(y), n + 2, _stream()) == 1
