@@ -32,12 +32,13 @@ def _step(name, prec):
     return m, v, tag, loss, ld
 
 
-@pytest.mark.parametrize("prec,tol", [("f32", 5e-5), ("f16x3", 1e-4)])
+@pytest.mark.parametrize("prec,tol", [("f32", 5e-5), ("f16x3", 1e-4), ("bf16x3", 5e-4)])
 def test_train_step_unet_fast_vs_reference(prec, tol):
     m, v, tag, loss, ld = _step("uf_clusterlayout_c32_s16", prec)
     ref = float(v[tag + ".loss"])
-    assert abs(loss.item() - ref) < 2e-5 * abs(ref)
-    assert max_rel(ld["train/epoch_stats_y"].cpu(), v[tag + ".per_sample"]) < 2e-5
+    ltol = 2e-4 if prec == "bf16x3" else 2e-5          # bf16 halves carry 16 significand bits together, f16 halves 22
+    assert abs(loss.item() - ref) < ltol * abs(ref)
+    assert max_rel(ld["train/epoch_stats_y"].cpu(), v[tag + ".per_sample"]) < ltol
     assert sorted(ld.keys()) == sorted(v[tag + ".loss_keys"].tolist())
     grads = {k: p.grad for k, p in m.named_parameters()}
     assert sorted(k for k, p in m.named_parameters() if p.requires_grad and p.grad is None) == list(v[tag + ".unused_params"])
