@@ -192,7 +192,10 @@ def main():
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        # "nccl" is RCCL on ROCm.  SGDM_DIST_BACKEND=gloo lets several ranks share ONE GPU to exercise this path on a
+        # single-GPU box (tests only: the ranks then time-slice the device)
+        dist.init_process_group(os.environ.get("SGDM_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
+    local_rank %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
