@@ -119,6 +119,12 @@ int sgd_chan_stats(const float* x, int32_t n, int32_t hw, int32_t c,
 /* sums[n, c_off + c, 2] = sum over parts of partial[n, parts, 2, c] (partials written by sgd_igemm's epilogue) */
 int sgd_stats_reduce(const float* partial, int32_t n, int32_t parts, int32_t c,
                      float* sums /* [n, c_total, 2] */, int32_t c_total, int32_t c_off, void* stream);
+/* sgd_stats_reduce of up to two concatenated sources (c = c0 + c1; partsX == 0: that source's sums are already in
+ * `sums`, written by sgd_chan_stats) followed by sgd_gn_coef, in one launch.  `sums` is written for the sources with
+ * partials (the training backward reads it); the coefficients are bit-identical to the two-launch route. */
+int sgd_gn_coef_parts(const float* partial0, int32_t parts0, int32_t c0, const float* partial1, int32_t parts1, int32_t c1,
+                      float* sums, const float* gamma, const float* beta, const float* film, int32_t film_ld,
+                      int32_t n, int32_t groups, int32_t hw, float eps, float* a, float* b, void* stream);
 int sgd_gn_coef(const float* sums, const float* gamma, const float* beta,
                 const float* film /* [n, film_ld] scale at +0, shift at +c; or NULL */, int32_t film_ld,
                 int32_t n, int32_t c, int32_t groups, int32_t hw, float eps,

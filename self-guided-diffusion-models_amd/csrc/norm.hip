@@ -102,6 +102,61 @@ __global__ void gn_coef_kernel(const float* __restrict__ sums, const float* __re
     b[i] = (float)be;
 }
 
+// sgd_stats_reduce (for up to two concatenated sources) + sgd_gn_coef in ONE launch: one block per image.
+// Phase 1 folds the producers' partial statistics into sums[n, c, 2] (kept: the training backward reads them; a source
+// with parts == 0 already has its sums there, written by sgd_chan_stats); phase 2 is gn_coef_kernel's arithmetic on the
+// float-rounded sums, so both routes give bit-identical coefficients.
+__global__ __launch_bounds__(256) void gn_coef_parts_kernel(const float* __restrict__ p0, int parts0, int c0,
+                                                            const float* __restrict__ p1, int parts1, int c1,
+                                                            float* __restrict__ sums, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, const float* __restrict__ film,
+                                                            int film_ld, int groups, int hw, float eps,
+                                                            float* __restrict__ a, float* __restrict__ b) {
+    extern __shared__ float sh[];                     // [c][2]
+    const int nn = blockIdx.x, c = c0 + c1;
+    for (int ch = threadIdx.x; ch < c; ch += blockDim.x) {
+        const bool first = ch < c0;
+        const float* p = first ? p0 : p1;
+        const int parts = first ? parts0 : parts1, cs = first ? c0 : c1, cl = first ? ch : ch - c0;
+        float s, ss;
+        if (parts > 0) {
+            const float* q = p + (long)nn * parts * 2 * cs + cl;
+            double t0 = 0, t1 = 0;
+#pragma unroll 4
+            for (int k = 0; k < parts; ++k) { t0 += q[(long)k * 2 * cs]; t1 += q[(long)k * 2 * cs + cs]; }
+            s = (float)t0;
+            ss = (float)t1;
+            sums[((long)nn * c + ch) * 2] = s;
+            sums[((long)nn * c + ch) * 2 + 1] = ss;
+        } else {
+            s = sums[((long)nn * c + ch) * 2];
+            ss = sums[((long)nn * c + ch) * 2 + 1];
+        }
+        sh[ch * 2] = s;
+        sh[ch * 2 + 1] = ss;
+    }
+    __syncthreads();
+    const int cpg = c / groups;
+    for (int cc = threadIdx.x; cc < c; cc += blockDim.x) {
+        const int g0 = (cc / cpg) * cpg;
+        double s = 0, ss = 0;
+        for (int k = 0; k < cpg; ++k) { s += sh[(g0 + k) * 2]; ss += sh[(g0 + k) * 2 + 1]; }
+        const double cnt = (double)cpg * hw;
+        const double mean = s / cnt;
+        double var = ss / cnt - mean * mean;
+        if (var < 0) var = 0;
+        const double rstd = 1.0 / sqrt(var + (double)eps);
+        double ga = gamma[cc] * rstd, be = beta[cc] - mean * ga;
+        if (film) {
+            const double sc = 1.0 + film[(long)nn * film_ld + cc], shf = film[(long)nn * film_ld + c + cc];
+            ga *= sc;
+            be = be * sc + shf;
+        }
+        a[(long)nn * c + cc] = (float)ga;
+        b[(long)nn * c + cc] = (float)be;
+    }
+}
+
 // one wave per row, row held in registers (c <= 1024)
 template <bool APPLY>
 __global__ __launch_bounds__(256) void ln_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
@@ -229,6 +284,20 @@ extern "C" int sgd_gn_coef(const float* sums, const float* gamma, const float* b
     const long total = (long)n * c;
     hipLaunchKernelGGL(gn_coef_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        sums, gamma, beta, film, film_ld, n, c, groups, hw, eps, a, b);
+    return sgd_check_launch();
+}
+
+extern "C" int sgd_gn_coef_parts(const float* p0, int32_t parts0, int32_t c0, const float* p1, int32_t parts1, int32_t c1,
+                                 float* sums, const float* gamma, const float* beta, const float* film, int32_t film_ld,
+                                 int32_t n, int32_t groups, int32_t hw, float eps, float* a, float* b, void* stream) {
+    SGD_CLEAR_ERR();
+    const int c = c0 + c1;
+    if (!sums || !gamma || !beta || !a || !b || n <= 0 || c0 <= 0 || c1 < 0 || groups <= 0 || c % groups != 0 || hw <= 0 ||
+        parts0 < 0 || parts1 < 0 || (parts0 > 0 && !p0) || (c1 > 0 && parts1 > 0 && !p1) || c > 8192)
+        return SGD_ERR_ARG;
+    if (film && film_ld < 2 * c) return SGD_ERR_ARG;
+    hipLaunchKernelGGL(gn_coef_parts_kernel, dim3(n), dim3(256), (size_t)c * 2 * sizeof(float), (hipStream_t)stream, p0,
+                       parts0, c0, p1, parts1, c1, sums, gamma, beta, film, film_ld, groups, hw, eps, a, b);
     return sgd_check_launch();
 }
 

@@ -48,6 +48,7 @@ SIGNATURES = {
     "sgd_pack_weight": (i32, [vp, vp, i32, i32, i32, i32, C.POINTER(i32), C.POINTER(i32), vp]),
     "sgd_linear_splitk": (i32, [vp, i32, vp, vp, i32, i32, i32, vp, i32, vp, i32, vp]),
     "sgd_chan_stats": (i32, [vp, i32, i32, i32, vp, i32, i32, vp]),
+    "sgd_gn_coef_parts": (i32, [vp, i32, i32, vp, i32, i32, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp, vp, vp]),
     "sgd_gn_coef": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, vp, vp, vp]),
     "sgd_ln_stats": (i32, [vp, i32, i32, f32, vp, vp]),
     "sgd_ln_apply": (i32, [vp, vp, vp, vp, i32, i32, f32, vp, vp]),

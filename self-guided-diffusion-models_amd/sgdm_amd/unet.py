@@ -459,18 +459,27 @@ class _Engine:
         ct = sum(c for _, c in srcs)
         sums = self.buf(n, ct, 2)
         off = 0
+        parts = []
         for t, c in srcs:
             st = self.stats_of.get(t.data_ptr())
             if st is not None and st[2] == c:
-                self.prog.add(tag + ".stats", self.lib.sgd_stats_reduce, _ptr(st[0]), n, st[1], c, _ptr(sums), ct, off)
+                parts.append((st[0], st[1], c))           # partial statistics written by the producer's epilogue
             else:
                 self.prog.add(tag + ".stats", self.lib.sgd_chan_stats, _ptr(t), n, hw, c, _ptr(sums), ct, off)
+                parts.append((None, 0, c))
             off += c
         a, b = self.buf(n, ct), self.buf(n, ct)
         self._last_sums = sums
-        self.prog.add(tag + ".coef", self.lib.sgd_gn_coef, _ptr(sums), _ptr(self.m.P(gname + ".weight")),
-                      _ptr(self.m.P(gname + ".bias")), C.c_void_p(film or 0), film_ld, n, ct, GN_GROUPS, hw,
-                      GN_EPS, _ptr(a), _ptr(b))
+        gw, gb = self.m.P(gname + ".weight"), self.m.P(gname + ".bias")
+        if len(parts) <= 2 and any(p[1] > 0 for p in parts):
+            # fold the partials and form the coefficients in one launch
+            (p0, n0, c0), (p1, n1, c1) = parts[0], (parts[1] if len(parts) == 2 else (None, 0, 0))
+            self.prog.add(tag + ".coef", self.lib.sgd_gn_coef_parts, _ptr(p0) if p0 is not None else None, n0, c0,
+                          _ptr(p1) if p1 is not None else None, n1, c1, _ptr(sums), _ptr(gw), _ptr(gb),
+                          C.c_void_p(film or 0), film_ld, n, GN_GROUPS, hw, GN_EPS, _ptr(a), _ptr(b))
+        else:
+            self.prog.add(tag + ".coef", self.lib.sgd_gn_coef, _ptr(sums), _ptr(gw), _ptr(gb), C.c_void_p(film or 0),
+                          film_ld, n, ct, GN_GROUPS, hw, GN_EPS, _ptr(a), _ptr(b))
         return a, b
 
     # ---- program construction
