@@ -228,10 +228,11 @@ def main():
         torch.cuda.synchronize()
 
     with torch.no_grad():
-        x = run_steps(x, list(range(999, 999 - args.warmup, -1)))            # W untimed warm-up steps
+        # step i of the run is timestep 999 - i (wrapping past 0 so any --steps / --warmup is valid)
+        x = run_steps(x, [(999 - i) % 1000 for i in range(args.warmup)])     # W untimed warm-up steps
         barrier()
         t0 = time.perf_counter()
-        x = run_steps(x, list(range(999 - args.warmup, 999 - args.warmup - args.steps, -1)))   # EXACTLY K steps
+        x = run_steps(x, [(999 - i) % 1000 for i in range(args.warmup, args.warmup + args.steps)])   # EXACTLY K steps
         barrier()
         elapsed = time.perf_counter() - t0
     tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
