@@ -101,7 +101,7 @@ class _StepRunner:
             w = self.kwargs.get("cond_scale")
             cond, layout = self.kwargs.get("cond"), self.kwargs.get("layout")
             fast_int = isinstance(w, int) if m.KIND == "unetca_fast" else isinstance(w, (int, float))
-            if isinstance(w, (int, float)) and not (fast_int and w in (0, 1)):
+            if isinstance(w, (int, float)) and not (fast_int and w in (0, 1)) and self.kwargs.get("p0") is None:
                 # batch-doubled evaluation, guided score formed inside the step kernel
                 has_mask = (m._cond_width > 0) or (m._in_ch_total > m.in_channels)
                 p = torch.cat((torch.full((B,), 0.0, device=x.device), torch.full((B,), 1.0, device=x.device)))
@@ -349,15 +349,41 @@ class DDIMSampler(object):
     @torch.no_grad()
     def ddim_sampling(self, shape, sampling_kwargs, denoise_sample_fn_kwargs=None, denoise_sample_fn=None, **kwargs):
         sk = sampling_kwargs
-        if sk.get("vis") is not None and any(getattr(sk["vis"], k, None) for k in ("condscale_c", "chainvis", "interp")):
-            raise NotImplementedError("vis/exp sampling variants are a 'next' row (SURVEY 8(f) rank 2)")
         if sk.get("dtp", 1) < 1.0:
             raise NotImplementedError("dynamic thresholding (dtp < 1) is not on the fused step path yet")
         dev = torch.device(self.device)
-        B, Cc = shape[0], shape[1]
-        hw = int(np.prod(shape[2:]))
         x_T = kwargs.get("x_T")
         img = torch.randn(shape, device=dev) if x_T is None else x_T.to(dev).float().contiguous()
+        dkw = dict(denoise_sample_fn_kwargs or {})
+        vis = sk.get("vis")
+
+        def should_vis(name):                                   # eval/test_exps/common_stuff.py:35-36
+            return vis is not None and hasattr(vis, name) and bool(getattr(vis, name))
+
+        if should_vis("interp") or should_vis("scoremix_vis"):
+            raise NotImplementedError("the interp / scoremix vis variants need the reference's eval helpers")
+        if should_vis("condscale"):
+            # guidance-weight sweep (ddim_plms_sampler.py:107-140): `samples` start noises x 8 weights 0, 3/8, .. 21/8,
+            # per-sample tensor cond_scale; only the `layout` entry of the kwargs is re-batched, as in the reference
+            ns, nw = vis.condscale_c.samples, 8
+            scales = [i * 3.0 / nw for i in range(nw)]
+            cs = torch.tensor(scales * ns, device=dev).reshape(-1, 1, 1, 1)
+            img = torch.randn([ns] + list(shape[1:]), device=dev).repeat_interleave(nw, 0)
+            assert len(dkw["layout"]) >= ns
+            dkw["layout"] = dkw["layout"][:ns].repeat_interleave(nw, 0)
+            assert len(cs) == len(img) == len(dkw["layout"])
+            dkw["cond_scale"] = cs
+        if should_vis("chainvis"):
+            # conditional / unconditional chain pairs from the same start noise (ddim_plms_sampler.py:157-175)
+            ns = vis.chainvis_c.samples
+            img = torch.randn([ns] + list(shape[1:]), device=dev).repeat_interleave(2, 0)
+            dkw["cond"] = dkw["cond"][:ns].repeat_interleave(2, 0)
+            assert len(dkw["cond"]) == len(img)
+            dkw["p0"] = torch.tensor([1, 0], device=dev, dtype=torch.float32).repeat(ns)
+        denoise_sample_fn_kwargs = dkw
+        shape = tuple(img.shape)
+        B, Cc = shape[0], shape[1]
+        hw = int(np.prod(shape[2:]))
         noise_fn = kwargs.get("noise_fn")
         timesteps = self.ddim_timesteps
         total = timesteps.shape[0]

@@ -996,9 +996,14 @@ def _cfg_eval(model, x, t, cond_scale, cond, layout, probs):
     B = x.shape[0]
     has_mask = (model._cond_width > 0) or (model._in_ch_total > model.in_channels)
     mask = model._draw_mask(2 * B, probs, x.device) if has_mask else None
-    if not isinstance(cond_scale, (int, float)):
-        raise NotImplementedError("tensor cond_scale (vis sweeps, ddim_plms_sampler.py:117-142) is a 'next' row")
     eng = model._run(x, t, cond, layout, mask, 2 * B)
+    if torch.is_tensor(cond_scale):
+        # per-sample guidance weights [B,1,1,1] (cond-scale sweeps, ddim_plms_sampler.py:117-142): plain broadcasting on
+        # the two NCHW halves, exactly get_guided_score (openaimodel.py:853-859)
+        eps_c, eps_u = torch.chunk(model._to_nchw(eng), 2, dim=0)
+        return model.get_guided_score(eps_u, eps_c, cond_scale.to(eps_c.device))
+    if not isinstance(cond_scale, (int, float)):
+        raise TypeError(f"cond_scale must be a number or a tensor, got {type(cond_scale)}")
     return model._cfg_combine(eng, cond_scale, B)
 
 

@@ -7,7 +7,7 @@ forcing.  Native DDPM trajectories are well conditioned and are compared on uint
 import pytest
 import torch
 
-from conftest import load_npz, rel_l2
+from conftest import load_npz, max_rel, rel_l2
 from test_hip_unet import build_model
 
 pytestmark = pytest.mark.gpu
@@ -156,3 +156,36 @@ def test_plms10_trajectory_vs_reference():
     print("plms free-running: rel_l2", r, "u8 max", int(d1.max()), int(d2.max()), "u8 >1 frac", float((d1 > 1).float().mean()))
     assert r < 5e-3
     assert d1.max() <= 1 and d2.max() <= 1
+
+
+def test_tensor_cond_scale_matches_per_sample_numbers():
+    """forward_with_cond_scale with a [B,1,1,1] tensor of guidance weights == one evaluation per weight"""
+    m, _ = build_model("uf_label_c32_s16", "f32")
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 3, 16, 16, generator=g).cuda()
+    t = torch.tensor([700, 20]).cuda()
+    w = torch.tensor([0.375, 2.25]).reshape(2, 1, 1, 1).cuda()
+    with torch.no_grad():
+        got = m.forward_with_cond_scale(x, t, cond_scale=w, cond=_cond(), layout=None)
+        for i in range(2):
+            ref = m.forward_with_cond_scale(x, t, cond_scale=float(w[i]), cond=_cond(), layout=None)
+            assert max_rel(got[i].cpu(), ref[i].cpu()) < 2e-6
+
+
+def test_ddim_chainvis_pairs_share_their_start_noise():
+    """vis.chainvis (ddim_plms_sampler.py:157-175): (conditional, unconditional) chains from the same x_T"""
+    class V:
+        chainvis = True
+
+        class chainvis_c:
+            samples = 2
+    m, _ = build_model("uf_label_c32_s16", "f32")
+    d = _diffusion(m)
+    skw = dict(_skw("ddim", 4, 0.0), vis=V())
+    torch.manual_seed(5)
+    samples, inter = d.p_sample_loop("ddim", (2, 3, 16, 16), skw,
+                                     denoise_sample_fn_kwargs=dict(cond=_cond(), layout=None, cond_scale=2.0),
+                                     condition_kwargs={})
+    assert tuple(samples.shape) == (4, 3, 16, 16)
+    # rows 1 and 3 are unconditional (p0 = 0 keeps... the mask convention: p = 1 drops) -> differ from their partners
+    assert (samples[0].int() - samples[1].int()).abs().max() > 0
