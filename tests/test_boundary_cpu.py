@@ -192,3 +192,12 @@ def test_committed_bench_line_has_the_contract_fields():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
     assert c["kind"] in ("reference", "port")
+
+
+def test_library_exports_nothing_undeclared():
+    """every `sgd_*` function the shared library exports is declared in include/sgdm_hip.h (no hidden entry points)"""
+    import subprocess
+    from sgdm_amd import _lib as L
+    out = subprocess.run(["nm", "-D", "--defined-only", L.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if " T sgd_" in ln}
+    assert exported == set(L.SIGNATURES), exported ^ set(L.SIGNATURES)
