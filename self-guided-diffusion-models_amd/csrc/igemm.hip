@@ -1020,15 +1020,16 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
             if (!(DBG(4))) fr[ks & 1].mma(acc);
             // The four MFMA waves reach this point together (barrier-synchronised), so a burst of 8 ds_read_b128 per
             // wave fills the LDS queue and the in-order wave cannot issue its MFMAs until its reads are accepted
-            // (measured: LDS phase and MFMA phase fully serialised).  Interleave: one MFMA, two reads, ... then the
-            // rest of the MFMAs cover the latency of the last reads.
+            // (measured: LDS phase and MFMA phase fully serialised).  Interleave: one MFMA, ONE read, ... (8 gaps; two reads
+            // per gap over 4 gaps measured 2-3 % slower: it saturates the LDS port while it lasts), then the rest of the
+            // MFMAs cover the latency of the last reads.
             if (!(DBG(32))) {
 #pragma unroll
-                for (int i = 0; i < FragT::NREADS / 2; ++i) {
+                for (int i = 0; i < FragT::NREADS; ++i) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                 }
-                __builtin_amdgcn_sched_group_barrier(0x008, FragT::NMMA - FragT::NREADS / 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, FragT::NMMA - FragT::NREADS, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
         }

@@ -13,7 +13,7 @@ import os
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libsgdm_hip.so")
+LIB_PATH = os.environ.get("SGDM_LIB_PATH") or os.path.join(_HERE, "lib", "libsgdm_hip.so")   # override: A/B builds (tools)
 
 MODE_FLAT, MODE_CONV3 = 0, 1
 RS_NONE, RS_AVGPOOL2, RS_UP2, RS_ZEROUP2 = 0, 1, 2, 3
