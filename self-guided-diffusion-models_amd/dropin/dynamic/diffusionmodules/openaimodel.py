@@ -1,2 +1,6 @@
-"""`dynamic=unet_fast` target (config/dynamic/unet_fast.yaml:1) -> MI355X HIP implementation."""
+"""`dynamic=unet_fast` target (config/dynamic/unet_fast.yaml:1) -> MI355X HIP implementation.
+Other names of the reference module (openaimodel.py: EncoderUNetModel, ResBlock, ...) resolve lazily in the checkout."""
+from sgdm_amd._overlay import reference_fallback
 from sgdm_amd.unet import UNetModel  # noqa: F401
+
+__getattr__ = reference_fallback(__name__, __file__)

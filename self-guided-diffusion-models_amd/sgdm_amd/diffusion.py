@@ -192,6 +192,13 @@ class Schedule_DDPM(nn.Module):
         return (mean, self._ext(self.posterior_variance, t, x_t.shape),
                 self._ext(self.posterior_log_variance_clipped, t, x_t.shape))
 
+    def vis_schedule(self):
+        try:
+            from diffusion_utils.taokit.wandb_utils import vis_schedule_ddpm     # the reference's wandb helper
+        except Exception:
+            return {}
+        return vis_schedule_ddpm(_betas=self.betas.cpu(), _alphas_cumprod=self.alphas_cumprod.cpu(), _snr_derivative=None)
+
     @torch.no_grad()
     def sample(self, shape, sampling_kwargs=None, denoise_sample_fn=None, denoise_sample_fn_kwargs=None, **kwargs):
         """ancestral DDPM loop (ddpm_sampler.py:194-238); ``x_T`` / ``noise_fn(i)`` may be injected for tests"""
@@ -203,6 +210,9 @@ class Schedule_DDPM(nn.Module):
                                linear_start=h.linear_start, linear_end=h.linear_end, cosine_s=h.cosine_s)
         if sk.get("dtp", 1) < 1.0:
             raise NotImplementedError("dynamic thresholding (dtp < 1) is not on the fused step path yet")
+        if h.parameterization not in ("eps", "x0"):
+            raise NotImplementedError()                                        # ddpm_sampler.py:162-163
+        x0_param = h.parameterization == "x0"
         dev = self.betas.device
         B, Cc = shape[0], shape[1]
         hw = int(np.prod(shape[2:]))
@@ -229,6 +239,8 @@ class Schedule_DDPM(nn.Module):
                 z = torch.nn.functional.dropout(z, p=noise_dropout)
             row = self._step_tab[i]
             coef[0], coef[1], coef[2], coef[3] = row[0], row[1], row[2], row[3]
+            if x0_param:
+                coef[0], coef[1] = 0.0, -1.0        # x_recon = model_out (ddpm_sampler.py:160-161): 0*x - (-1)*out, exact
             coef[4] = (float(row[4]) * float(temperature[i])) if i != 0 else 0.0      # no noise when t == 0
             want = i in snaps
             x0 = torch.empty_like(img) if want else None
@@ -474,4 +486,8 @@ class LatentDiffusion(nn.Module):
         return samples, inter
 
     def vis_schedule(self):
-        raise NotImplementedError("wandb schedule plots are out of scope (SURVEY 2 row 22)")
+        """ddpm.py:124-126 -> ddpm_sampler.py:240-243: a dict of wandb line plots of the schedule, logged once on the
+        first training batch (lightning_module.py:116-122).  The plotting helper is the reference's own
+        (diffusion_utils/taokit/wandb_utils.py:44-79, needs wandb); it is used when the checkout is importable, otherwise
+        there is nothing to log and the caller's ``logger.experiment.log({})`` is a no-op."""
+        return self.sampler.vis_schedule()

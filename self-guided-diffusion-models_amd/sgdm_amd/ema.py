@@ -45,15 +45,17 @@ class LitEma(nn.Module):
     def copy_to(self, model):
         m_param = dict(model.named_parameters())
         shadow = dict(self.named_buffers())
-        for key in m_param:
-            if m_param[key].requires_grad:
-                m_param[key].data.copy_(shadow[self.m_name2s_name[key]].data)
-            else:
-                assert key not in self.m_name2s_name
+        with torch.no_grad():
+            for key in m_param:
+                if m_param[key].requires_grad:
+                    m_param[key].copy_(shadow[self.m_name2s_name[key]])
+                else:
+                    assert key not in self.m_name2s_name
 
     def store(self, parameters):
         self.collected_params = [param.clone() for param in parameters]
 
     def restore(self, parameters):
-        for c_param, param in zip(self.collected_params, parameters):
-            param.data.copy_(c_param.data)
+        with torch.no_grad():
+            for c_param, param in zip(self.collected_params, parameters):
+                param.copy_(c_param)

@@ -61,7 +61,7 @@ class FusedAdamWEma(torch.optim.Optimizer):
             dev = ps[0].device
             if dev.type != "cuda":
                 raise RuntimeError("FusedAdamWEma runs on the GPU only (there is no CPU fallback)")
-            rows, step_t = [], None
+            rows, step_t, keep, touched = [], None, [], []
             for p in ps:
                 if p.dtype != torch.float32 or not p.is_contiguous():
                     raise RuntimeError("FusedAdamWEma expects contiguous fp32 parameters")
@@ -77,7 +77,9 @@ class FusedAdamWEma(torch.optim.Optimizer):
                         raise RuntimeError("FusedAdamWEma: parameters of one group must share their step count")
                     step_t = float(st["step"])
                     g = g if g.is_contiguous() else g.contiguous()
-                    st["_g"] = g                                  # keep alive until the launch has consumed it
+                    keep.append(g)                                # alive until the launch has consumed it; NOT optimizer
+                                                                  # state (state_dict stays torch.optim.AdamW's format)
+                    touched.append(p)
                 sh = self._shadow_of.get(id(p))
                 rows.append((p.data_ptr(), g.data_ptr() if g is not None else 0,
                              st["exp_avg"].data_ptr() if g is not None else 0,
@@ -97,5 +99,9 @@ class FusedAdamWEma(torch.optim.Optimizer):
                                            float(group["lr"]), 1.0 - b1, b2, 1.0 - b2, group["eps"], group["weight_decay"],
                                            1.0 - b1 ** t, 1.0 - b2 ** t, omd,
                                            torch.cuda.current_stream().cuda_stream), "sgd_adamw_ema_step")
-            self._table_keep = table
+            self._table_keep = (table, keep)
+            # The kernel writes the parameters through raw pointers, which autograd's version counters do not see.
+            # Consumers that cache derived copies keyed on (data_ptr, _version) -- the UNet's igemm-packed forward and
+            # adjoint weights (unet._Packed, train._PackedAdj) and the FiLM bias concat -- must observe the update.
+            torch._C._increment_version(touched)
         return loss

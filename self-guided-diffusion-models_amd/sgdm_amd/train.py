@@ -17,8 +17,13 @@ walking the forward tape in reverse:
 
 ``loss.backward()`` works because the UNet evaluation is a ``torch.autograd.Function`` whose inputs are the
 trainable parameters; it returns one gradient tensor per parameter in the reference layout.
-Implemented for ``unet_fast``; ``unetca_fast`` (LayerNorm / multi-query attention / strided-conv adjoints)
-raises NotImplementedError -- next rows.
+Both operators are covered: ``unet_fast`` and ``unetca_fast`` (LayerNorm, multi-query attention with context / null
+keys, strided-conv Downsample and nearest+conv Upsample adjoints).
+
+One engine (workspace + tape) exists per (UNet batch, H, W, precision), so the activations a backward reads are those of
+the LAST forward on that engine: ``_UNetTrainFn.backward`` checks a forward-generation counter and raises if another
+forward ran in between (two losses on one model need two backward-before-next-forward passes, as here, or two batches
+of different size).
 """
 import ctypes as C
 import math
@@ -498,13 +503,18 @@ class _UNetTrainFn(torch.autograd.Function):
     def forward(ctx, model, eng, args, *params):
         x, t, cond, layout, mask = args
         eng.run(x, t, cond, layout, mask, train=True)
-        ctx.model, ctx.eng = model, eng
+        eng.generation = getattr(eng, "generation", 0) + 1
+        ctx.model, ctx.eng, ctx.generation = model, eng, eng.generation
         ctx.names = [n for n, p in model.named_parameters() if p.requires_grad]
         return model._to_nchw(eng)
 
     @staticmethod
     def backward(ctx, geps):
         eng = ctx.eng
+        if eng.generation != ctx.generation:
+            raise RuntimeError("sgdm_amd: backward through a stale forward -- another training forward ran on this "
+                               "model (same batch/resolution) after the one being differentiated and overwrote its "
+                               "activations; call backward() before the next forward")
         if getattr(eng, "backward", None) is None:
             eng.backward = make_backward(eng)
         grads = eng.backward.run(geps)
@@ -586,6 +596,8 @@ def p_losses_hip(diff, x_start, t, noise=None, *args, **kwargs):
         loss = _MSEFn.apply(model_output, target)
     elif h.loss_type == "l1":
         loss = (target - model_output).abs().reshape(len(target), -1).mean(1)
+    elif h.loss_type == "huber":                                              # ddpm.py:99-103
+        loss = torch.nn.functional.smooth_l1_loss(target, model_output, reduction="none").reshape(len(target), -1).mean(1)
     else:
         raise NotImplementedError(f"unknown loss type '{h.loss_type}'")
     if prefix == "train":

@@ -218,8 +218,11 @@ class UNetModelBase(nn.Module):
         self.hip_precision = default_precision()
         self._engines = {}
 
-    def _heads_for(self, ch):
-        return self.num_heads if self.num_head_channels == -1 else ch // self.num_head_channels
+    def _heads_for(self, ch, up=False):
+        """input/middle blocks use num_heads, output blocks num_heads_upsample (openaimodel.py:664-668,778-782)"""
+        if self.num_head_channels == -1:
+            return self.num_heads_upsample if up else self.num_heads
+        return ch // self.num_head_channels
 
     def _walk(self):
         """block plan; mirrors openaimodel.py:634-835 / openaimodel_ca.py:645-836"""
@@ -247,7 +250,7 @@ class UNetModelBase(nn.Module):
                 layers = [("res", ch + ich, mc * mult, None)]
                 ch = mc * mult
                 if ds in self.attention_resolutions:
-                    layers.append(("attn", ch, self._heads_for(ch)))
+                    layers.append(("attn", ch, self._heads_for(ch, up=True)))
                 if level and i == nrb:
                     layers.append(("res", ch, ch, "up") if self.resblock_updown else ("up", ch))
                     ds //= 2

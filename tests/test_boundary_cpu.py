@@ -42,7 +42,7 @@ def _build(name):
         cond[kw["condition_method"]] = AD(layout_dim=entry["layout_dim"])
     target = ("dynamic.diffusionmodules.openaimodel.UNetModel" if entry["kind"] == "unet_fast"
               else "dynamic.diffusionmodules.openaimodel_ca.UNetModel")      # config/dynamic/*.yaml:1
-    from diffusion_utils.util import instantiate_from_config
+    from sgdm_amd.util import instantiate_from_config
     return instantiate_from_config(dict(target=target, params=dict(condition=cond, **kw))), entry
 
 
@@ -142,7 +142,7 @@ def test_litema_matches_reference():
 
 
 def test_lr_lambda_matches_reference():
-    from diffusion_utils.lr_scheduler import LambdaLinearScheduler
+    from sgdm_amd.util import LambdaLinearScheduler
     v = load_npz("diffusion.npz")
     sch = LambdaLinearScheduler(warm_up_steps=[500], cycle_lengths=[10000000000000], f_start=[1.e-6], f_max=[1.],
                                 f_min=[1.])

@@ -1,0 +1,218 @@
+"""The drop-in module tree really drops in: with ``dropin/`` ahead of the reference checkout on ``sys.path`` the
+reference's OWN, unedited ``lightning_module.py`` imports, constructs ``TaoDiffusion`` (operator + EMA + diffusion
+process through the Hydra ``target:`` strings), builds its optimizer / LR lambda and runs the first-batch hook's
+``vis_schedule()``.  Build container only (needs /root/reference); runs in a subprocess so the stub modules and the
+merged namespace packages do not leak into the rest of the suite.  CPU only: ctor + wiring, no forward.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "self-guided-diffusion-models_amd")
+REF = "/root/reference"
+
+pytestmark = pytest.mark.skipif(not os.path.isdir(REF), reason="needs the reference checkout (build container only)")
+
+HARNESS = r'''
+import importlib, importlib.abc, importlib.machinery, json, os, sys, types
+from unittest.mock import MagicMock
+import torch
+from torch import nn
+
+REF, DROPIN, PKG = sys.argv[1:4]
+sys.dont_write_bytecode = True
+sys.path[:0] = [DROPIN, PKG, REF]          # INTEGRATION.md section 1: dropin ahead of the checkout
+
+FIRST_PARTY = {"dynamic", "diffusion", "diffusion_utils", "dynamic_input", "eval", "dataset", "callbacks", "clustering",
+               "lightning_module", "lightning_module_common", "pl_datamodule", "self_sl", "side_repo", "sgdm_amd"}
+# third-party packages the reference imports that this image lacks (SURVEY.md 8(c)); anything else must import for real
+ABSENT = {"wandb", "torchvision", "omegaconf", "hydra", "h5py", "cleanfid", "torch_fidelity", "pytorch_fid", "faiss",
+          "timm", "seaborn", "distinctipy", "cv2", "pycocotools", "kornia", "lpips", "prdc", "clip", "blobfile", "ipdb",
+          "sklearn_extra", "dotmap", "albumentations", "imageio", "skimage", "scikit_image", "pytorch_lightning"}
+stubbed = []
+
+
+class _Logger:
+    def __getattr__(self, _):
+        return lambda *a, **k: None
+
+
+def _lightning():
+    pl = types.ModuleType("pytorch_lightning")
+
+    class AD(dict):
+        __getattr__ = dict.__getitem__
+
+    def wrap(v):
+        return AD({k: wrap(x) for k, x in v.items()}) if isinstance(v, dict) else v
+
+    class LightningModule(nn.Module):
+        global_rank = 0
+        current_epoch = 0
+        global_step = 0
+
+        def save_hyperparameters(self):
+            import inspect
+            frame = inspect.currentframe().f_back
+            self.hparams = wrap(dict(frame.f_locals["kwargs"]))
+
+    pl.LightningModule = LightningModule
+    pl.Callback = type("Callback", (), {})
+    util = types.ModuleType("pytorch_lightning.utilities")
+    util.rank_zero_only = lambda f: f
+    cbs = types.ModuleType("pytorch_lightning.callbacks")
+    cbs.Callback = pl.Callback
+    pl.utilities, pl.callbacks = util, cbs
+    sys.modules.update({"pytorch_lightning": pl, "pytorch_lightning.utilities": util,
+                        "pytorch_lightning.callbacks": cbs})
+    tm = types.ModuleType("torchmetrics")
+
+    class Metric(nn.Module):
+        def __init__(self, **kw):
+            super().__init__()
+
+        def add_state(self, name, default, dist_reduce_fx=None):
+            self.register_buffer(name, default)
+
+    tm.Metric = Metric
+    sys.modules["torchmetrics"] = tm
+    return AD
+
+
+class _StubAbsentThirdParty(importlib.abc.MetaPathFinder, importlib.abc.Loader):
+    """last on sys.meta_path: a module nothing else could find becomes a MagicMock -- unless it is first-party
+    (reference or drop-in): those must resolve to real files, that is what this test is about"""
+
+    def find_spec(self, name, path=None, target=None):
+        if name.split(".")[0] in FIRST_PARTY or name.split(".")[0] not in ABSENT:
+            return None
+        return importlib.machinery.ModuleSpec(name, self, is_package=True)
+
+    def create_module(self, spec):
+        m = MagicMock(name=spec.name)
+        m.__path__ = []
+        m.__spec__ = spec
+        m.__name__ = spec.name
+        stubbed.append(spec.name)
+        return m
+
+    def exec_module(self, module):
+        pass
+
+
+import einops
+loguru = types.ModuleType("loguru"); loguru.logger = _Logger(); sys.modules["loguru"] = loguru
+ee = types.ModuleType("einops_exts")
+ee.rearrange_many = lambda ts, p, **kw: tuple(einops.rearrange(t, p, **kw) for t in ts)
+ee.repeat_many = lambda ts, p, **kw: tuple(einops.repeat(t, p, **kw) for t in ts)
+ee.check_shape = lambda *a, **k: None
+ee.__path__ = []
+eet = types.ModuleType("einops_exts.torch")
+eet.EinopsToAndFrom = type("EinopsToAndFrom", (nn.Module,), {})
+ee.torch = eet
+sys.modules["einops_exts"] = ee
+sys.modules["einops_exts.torch"] = eet
+AD = _lightning()
+sys.meta_path.append(_StubAbsentThirdParty())
+
+out = {}
+import lightning_module                                   # lightning_module.py:1-52, unedited
+import dynamic.ema, dynamic.diffusionmodules.openaimodel, dynamic.diffusionmodules.openaimodel_ca, diffusion.ddpm
+import dynamic_input.condition, dynamic_input.misc, dynamic_input.clustering, dynamic_input.feat, dynamic_input.image
+import diffusion_utils.util, diffusion_utils.lr_scheduler, diffusion_utils.taokit.pl_utils
+import dynamic.diffusionmodules.util
+import sgdm_amd.unet, sgdm_amd.ema, sgdm_amd.diffusion, sgdm_amd.plugin
+from dynamic.attention_ldm import log                     # dataset/voc12.py:25
+import dataset.voc12                                      # noqa
+import callbacks.my_callbacks                             # callbacks/my_callbacks.py:19-24
+from eval.test_exps.common_stuff import sampling_cond_str  # noqa  (common_stuff.py:9 imports clip_unnormalize_...)
+
+
+def where(mod):
+    f = os.path.abspath(mod.__file__)
+    return "dropin" if f.startswith(DROPIN) else ("reference" if f.startswith(REF) else f)
+
+
+out["where"] = {m.__name__: where(m) for m in (
+    dynamic.ema, dynamic.diffusionmodules.openaimodel, dynamic.diffusionmodules.openaimodel_ca, diffusion.ddpm,
+    dynamic_input.condition, dynamic_input.misc, dynamic_input.clustering, diffusion_utils.util,
+    diffusion_utils.lr_scheduler, diffusion_utils.taokit.pl_utils, dataset.voc12, callbacks.my_callbacks,
+    sys.modules["dynamic.attention_ldm"], sys.modules["dynamic.diffusionmodules.util"])}
+out["targets"] = dict(
+    unet=dynamic.diffusionmodules.openaimodel.UNetModel is sgdm_amd.unet.UNetModel,
+    unet_ca=dynamic.diffusionmodules.openaimodel_ca.UNetModel is sgdm_amd.unet.UNetModelCA,
+    ddpm=diffusion.ddpm.LatentDiffusion is sgdm_amd.diffusion.LatentDiffusion,
+    ema=dynamic.ema.LitEma is sgdm_amd.ema.LitEma and lightning_module.LitEma is sgdm_amd.ema.LitEma,
+    plugin=lightning_module.prepare_denoise_fn_kwargs_4sampling is sgdm_amd.plugin.prepare_denoise_fn_kwargs_4sampling)
+# a name the drop-in module does not define is served from the reference's file of the same module path
+from dynamic.diffusionmodules.openaimodel import EncoderUNetModel        # diffusion/classifier.py:13
+out["fallback"] = os.path.abspath(sys.modules[EncoderUNetModel.__module__].__file__).startswith(REF)
+from diffusion.ddpm import clip_unnormalize_to_zero_to_255               # re-exported by the reference's ddpm.py:12
+out["fallback2"] = callable(clip_unnormalize_to_zero_to_255)
+
+MODEL = dict(num_timesteps=1000, beta_schedule="linear", loss_type="l2", linear_start=1e-4, linear_end=2e-2, cosine_s=8e-3,
+             given_betas=None, v_posterior=0.0, parameterization="eps", learn_logvar=False, logvar_init=0.0)
+for kind, target, extra in (
+        ("unet_fast", "dynamic.diffusionmodules.openaimodel.UNetModel", dict(cond_dim=10, condition_method="label")),
+        ("unetca_fast", "dynamic.diffusionmodules.openaimodel_ca.UNetModel",
+         dict(cond_dim=27, condition_method="stegoclusterlayout", use_ca_block=True, legacy=False, cond_token_num=1,
+              context_dim=32, use_cls_token_as_pooled=True))):
+    cond = AD(scale_type="imagen", stegoclusterlayout=AD(layout_dim=27))
+    dyn = dict(target=target, params=dict(image_size=16, in_channels=3, out_channels=3, model_channels=32,
+                                          num_res_blocks=2, channel_mult=[1, 2, 4], attention_resolutions=[4],
+                                          num_heads=8, use_scale_shift_norm=True, dropout=0.1, condition=cond, **extra))
+    hp = dict(dynamic=dyn, diffusion_model=dict(target="diffusion.ddpm.LatentDiffusion", params=dict(MODEL, device="cpu")),
+              device="cpu", use_ema=True, parameterization="eps", condition_method=extra["condition_method"],
+              cond_dim=extra["cond_dim"], cond_scale=2.0, cond_drop_prob=0.1, data=dict(h5_file=None), condition=cond,
+              optim=dict(name="adamw", params=dict(lr=1e-4, wd=0.01), scheduler_config=dict(
+                  target="diffusion_utils.lr_scheduler.LambdaLinearScheduler",
+                  params=dict(warm_up_steps=[500], cycle_lengths=[10000000000000], f_start=[1.e-6], f_max=[1.], f_min=[1.]))))
+    m = lightning_module.TaoDiffusion(**hp)               # lightning_module.py:57-80
+    opts, scheds = m.configure_optimizers()               # lightning_module_common.py:20-42
+    n_train = sum(1 for p in m.model.parameters() if p.requires_grad)
+    vis = m.diffusion.vis_schedule()                      # lightning_module.py:116-122 (first training batch)
+    with m.ema_scope():                                   # lightning_module.py:91-101
+        pass
+    out[kind] = dict(model=type(m.model).__module__, diffusion=type(m.diffusion).__module__,
+                     ema=type(m.model_ema).__module__, ema_buffers=len(list(m.model_ema.buffers())), n_train=n_train,
+                     opt=type(opts[0]).__name__, n_opt=len(opts[0].param_groups[0]["params"]),
+                     lr0=scheds[0]["scheduler"].get_last_lr()[0], vis_is_dict=isinstance(vis, dict),
+                     bound=m.diffusion.denoise_fn.__self__ is m.model)
+out["stubbed"] = sorted(set(s.split(".")[0] for s in stubbed))
+print("RESULT " + json.dumps(out))
+'''
+
+
+def test_reference_lightning_module_runs_on_the_dropin(tmp_path):
+    script = tmp_path / "harness.py"
+    script.write_text(HARNESS)
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")
+    env.pop("PYTHONPATH", None)
+    r = subprocess.run([sys.executable, str(script), REF, os.path.join(PKG, "dropin"), PKG], capture_output=True,
+                       text=True, cwd=str(tmp_path), env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-4000:]
+    res = json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+    w = res["where"]
+    for name in ("dynamic.ema", "dynamic.diffusionmodules.openaimodel", "dynamic.diffusionmodules.openaimodel_ca",
+                 "diffusion.ddpm", "dynamic_input.condition"):
+        assert w[name] == "dropin", (name, w[name])
+    for name in ("dynamic_input.misc", "dynamic_input.clustering", "diffusion_utils.util", "diffusion_utils.lr_scheduler",
+                 "diffusion_utils.taokit.pl_utils", "dataset.voc12", "callbacks.my_callbacks", "dynamic.attention_ldm",
+                 "dynamic.diffusionmodules.util"):
+        assert w[name] == "reference", (name, w[name])
+    assert all(res["targets"].values()), res["targets"]
+    assert res["fallback"] and res["fallback2"]
+    for kind in ("unet_fast", "unetca_fast"):
+        k = res[kind]
+        assert k["model"] == "sgdm_amd.unet" and k["diffusion"] == "sgdm_amd.diffusion" and k["ema"] == "sgdm_amd.ema"
+        assert k["ema_buffers"] == k["n_train"] + 2            # one shadow per trainable parameter + decay + num_updates
+        assert k["opt"] == "AdamW" and k["n_opt"] >= k["n_train"]
+        assert abs(k["lr0"] - 1e-4 * 1e-6) < 1e-15            # LambdaLinearScheduler warm-up start (lr_scheduler.py:81-98)
+        assert k["vis_is_dict"] and k["bound"]
+    # only genuinely absent third-party packages were stubbed
+    assert not (set(res["stubbed"]) & {"dynamic", "diffusion", "diffusion_utils", "dynamic_input", "eval", "dataset",
+                                       "callbacks", "sgdm_amd"})

@@ -264,3 +264,149 @@ def test_fused_adamw_ema_matches_torch_adamw_and_litema():
             continue
         assert max_rel(o2.state[p2]["exp_avg"].cpu(), o1.state[p1]["exp_avg"].cpu()) < 2e-6
         assert max_rel(o2.state[p2]["exp_avg_sq"].cpu(), o1.state[p1]["exp_avg_sq"].cpu()) < 2e-6
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# the training LOOP (forward -> backward -> optimizer -> next forward): parameters updated through raw pointers by the
+# fused optimizer, or swapped by LitEma, must reach the igemm-packed copies the next forward / backward use
+# ------------------------------------------------------------------------------------------------------------------
+def _loop_inputs(entry, step):
+    from sgdm_amd.synth import synth_batch
+    kw = entry["ctor"]
+    batch = synth_batch(kw["condition_method"], 4, 16, kw["cond_dim"], entry["layout_dim"], seed=200 + step)
+    g = torch.Generator().manual_seed(300 + step)
+    t = torch.randint(0, 1000, (4,), generator=g)
+    noise = torch.randn(4, 3, 16, 16, generator=g)
+    mask = torch.rand(4, generator=g) < 0.5
+    return batch, t, noise, mask
+
+
+def _run_loop(name, prec, kind, steps=3, lr=1e-3):
+    """kind: 'fused' (FusedAdamWEma, one launch) | 'torch' (torch.optim.AdamW + LitEma.forward)"""
+    import bench
+    from sgdm_amd.diffusion import LatentDiffusion
+    from sgdm_amd.ema import LitEma
+    from sgdm_amd.optim import FusedAdamWEma
+    m, entry = build_model(name, prec)
+    m.dropout = 0.0
+    m.train()
+    d = LatentDiffusion(device="cuda", **bench.MODEL_PARAMS).train()
+    d.set_denoise_fn(m.forward, m.forward_with_cond_scale)
+    ema = LitEma(m).cuda()
+    params = [p for p in m.parameters() if p.requires_grad]
+    if kind == "fused":
+        opt = FusedAdamWEma(params, lr=lr, weight_decay=0.01, ema=ema, ema_model=m)
+    else:
+        opt = torch.optim.AdamW(params, lr=lr, weight_decay=0.01)
+    losses = []
+    for step in range(steps):
+        batch, t, noise, mask = _loop_inputs(entry, step)
+        loss, _ = d.p_losses(batch["image"].cuda(), t.cuda(), noise.cuda(), cond=batch["cond"].float().cuda(),
+                             layout=batch["layout"].cuda() if "layout" in batch else None, cond_drop_prob=0.5,
+                             cond_drop_mask=mask.cuda())
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+        if kind == "torch":
+            ema(m)
+        losses.append(loss.item())
+    # evaluation input (never trained on)
+    batch, t, noise, mask = _loop_inputs(entry, 99)
+    m.eval()
+
+    def ev():
+        with torch.no_grad():
+            return m(batch["image"].cuda(), t.cuda(), cond=batch["cond"].float().cuda(),
+                     layout=batch["layout"].cuda() if "layout" in batch else None, cond_drop_prob=0.0,
+                     cond_drop_mask=mask.cuda())[0].cpu()
+    eps = ev()
+    ema.store(m.parameters())                     # ema_scope (reference lightning_module.py:91-101)
+    ema.copy_to(m)
+    eps_ema = ev()
+    ema.restore(m.parameters())
+    eps_back = ev()
+    shadows = {k: dict(ema.named_buffers())[s].detach().cpu() for k, s in ema.m_name2s_name.items()}
+    return dict(losses=losses, eps=eps, eps_ema=eps_ema, eps_back=eps_back, entry=entry, shadows=shadows,
+                params={k: p.detach().cpu() for k, p in m.named_parameters()}, state_keys=sorted(
+                    {k for st in opt.state.values() for k in st}))
+
+
+def _oracle_loop(entry, steps=3, lr=1e-3):
+    from conftest import cfg_from_index
+    from oracle import diffusion_ref as D
+    from oracle import unet_ref as U
+    from sgdm_amd.synth import weights_from_seed
+    cfg = cfg_from_index(entry)
+    sd = {k: tt.clone().requires_grad_(kind == "param")
+          for (k, _, kind), tt in zip(entry["manifest"], weights_from_seed(entry["manifest"], entry["seed"]).values())}
+    train = [v for v in sd.values() if v.requires_grad]
+    opt = torch.optim.AdamW(train, lr=lr, weight_decay=0.01)
+    shadow = {k: v.detach().clone() for k, v in sd.items() if v.requires_grad}
+    sched = D.make_schedule()
+    losses = []
+    for step in range(steps):
+        batch, t, noise, mask = _loop_inputs(entry, step)
+        fn = lambda xn, tt: U.unet_forward(cfg, sd, xn, tt, batch["cond"].float(), batch.get("layout"), mask)
+        loss, _, _, _ = D.p_losses(sched, fn, batch["image"], t, noise)
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+        n = step + 1
+        decay = min(0.9999, (1 + n) / (10 + n))                     # LitEma.forward (dynamic/ema.py:25-44)
+        with torch.no_grad():
+            for k in shadow:
+                shadow[k].sub_((1.0 - decay) * (shadow[k] - sd[k]))
+        losses.append(loss.item())
+    batch, t, noise, mask = _loop_inputs(entry, 99)
+    with torch.no_grad():
+        run = lambda w: U.unet_forward(cfg, w, batch["image"], t, batch["cond"].float(), batch.get("layout"), mask)
+        eps = run(sd)
+        eps_ema = run({**sd, **shadow})
+    return dict(losses=losses, eps=eps, eps_ema=eps_ema)
+
+
+@pytest.mark.parametrize("name,prec", [("uf_clusterlayout_c32_s16", "f32"), ("uf_clusterlayout_c32_s16", "f16x3"),
+                                       ("ca_stego_c32_s16", "f16x3")])
+def test_training_loop_fused_optimizer_updates_the_packed_weights(name, prec):
+    """3 optimizer steps: FusedAdamWEma == torch AdamW + LitEma on the same HIP UNet (loss sequence, step-3 eps,
+    eps under the EMA weights, parameters, shadows), and both follow the CPU oracle trained with torch AdamW."""
+    a = _run_loop(name, prec, "fused")
+    b = _run_loop(name, prec, "torch")
+    for la, lb in zip(a["losses"], b["losses"]):
+        assert abs(la - lb) <= 1e-5 * abs(lb), (a["losses"], b["losses"])
+    assert max_rel(a["eps"], b["eps"]) < 1e-5
+    assert max_rel(a["eps_ema"], b["eps_ema"]) < 1e-5
+    assert torch.equal(a["eps_back"], a["eps"]) and torch.equal(b["eps_back"], b["eps"])      # restore() re-packs too
+    for k in a["params"]:
+        assert float((a["params"][k] - b["params"][k]).abs().max()) <= 2e-6 * max(1.0, float(b["params"][k].abs().max())), k
+    for k in a["shadows"]:
+        assert float((a["shadows"][k] - b["shadows"][k]).abs().max()) <= 2e-6 * max(1.0, float(b["shadows"][k].abs().max())), k
+    assert a["state_keys"] == b["state_keys"] == ["exp_avg", "exp_avg_sq", "step"]            # torch.optim.AdamW's format
+    # the loop really trains: Adam's first steps move every weight by ~lr, the evaluation output moves with them
+    o = _oracle_loop(a["entry"])
+    for la, lo in zip(a["losses"], o["losses"]):
+        assert abs(la - lo) <= 2e-4 * abs(lo), (a["losses"], o["losses"])
+    assert abs(o["losses"][0] - o["losses"][2]) > 1e-3 * abs(o["losses"][0])
+    # Adam normalises the step by |g|: elements whose gradient is rounding noise move differently on the two
+    # implementations, so the comparison after 3 steps is looser than a single evaluation's 1e-4
+    assert max_rel(a["eps"], o["eps"]) < 2e-3, max_rel(a["eps"], o["eps"])
+    assert max_rel(a["eps_ema"], o["eps_ema"]) < 2e-3
+    assert max_rel(a["eps_ema"], a["eps"]) > 1e-3          # the two weight sets are distinguishable at all
+
+
+def test_stale_forward_raises_in_backward():
+    """one workspace per (batch, resolution): backward after a second training forward must not silently use the
+    second forward's activations"""
+    import bench
+    from sgdm_amd.diffusion import LatentDiffusion
+    m, entry = build_model("uf_clusterlayout_c32_s16", "f32")
+    m.train()
+    d = LatentDiffusion(device="cuda", **bench.MODEL_PARAMS).train()
+    d.set_denoise_fn(m.forward, m.forward_with_cond_scale)
+    batch, t, noise, mask = _loop_inputs(entry, 0)
+    kw = dict(cond=batch["cond"].float().cuda(), layout=batch["layout"].cuda(), cond_drop_prob=0.5, cond_drop_mask=mask.cuda())
+    l1, _ = d.p_losses(batch["image"].cuda(), t.cuda(), noise.cuda(), **kw)
+    l2, _ = d.p_losses(batch["image"].cuda(), t.cuda(), noise.cuda(), **kw)
+    l2.backward()
+    with pytest.raises(RuntimeError, match="stale forward"):
+        l1.backward()
