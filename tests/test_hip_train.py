@@ -310,6 +310,9 @@ def _run_loop(name, prec, kind, steps=3, lr=1e-3):
         if kind == "torch":
             ema(m)
         losses.append(loss.item())
+        if step == 0:
+            params1 = {k: p.detach().cpu().clone() for k, p in m.named_parameters()}
+            shadows1 = {k: dict(ema.named_buffers())[s].detach().cpu().clone() for k, s in ema.m_name2s_name.items()}
     # evaluation input (never trained on)
     batch, t, noise, mask = _loop_inputs(entry, 99)
     m.eval()
@@ -325,10 +328,8 @@ def _run_loop(name, prec, kind, steps=3, lr=1e-3):
     eps_ema = ev()
     ema.restore(m.parameters())
     eps_back = ev()
-    shadows = {k: dict(ema.named_buffers())[s].detach().cpu() for k, s in ema.m_name2s_name.items()}
-    return dict(losses=losses, eps=eps, eps_ema=eps_ema, eps_back=eps_back, entry=entry, shadows=shadows,
-                params={k: p.detach().cpu() for k, p in m.named_parameters()}, state_keys=sorted(
-                    {k for st in opt.state.values() for k in st}))
+    return dict(losses=losses, eps=eps, eps_ema=eps_ema, eps_back=eps_back, entry=entry, shadows=shadows1,
+                params=params1, state_keys=sorted({k for st in opt.state.values() for k in st}))
 
 
 def _oracle_loop(entry, steps=3, lr=1e-3):
@@ -377,6 +378,10 @@ def test_training_loop_fused_optimizer_updates_the_packed_weights(name, prec):
     assert max_rel(a["eps"], b["eps"]) < 1e-5
     assert max_rel(a["eps_ema"], b["eps_ema"]) < 1e-5
     assert torch.equal(a["eps_back"], a["eps"]) and torch.equal(b["eps_back"], b["eps"])      # restore() re-packs too
+    # parameters / shadows after the FIRST step (identical gradients in, one optimizer step out).  Later steps are
+    # compared through loss and eps only: parameters whose true gradient is zero (a conv bias in front of a GroupNorm
+    # with one channel per group) receive rounding noise, which Adam normalises to +-lr per step -- they random-walk
+    # without touching the output, differently for any two implementations
     for k in a["params"]:
         assert float((a["params"][k] - b["params"][k]).abs().max()) <= 2e-6 * max(1.0, float(b["params"][k].abs().max())), k
     for k in a["shadows"]:
