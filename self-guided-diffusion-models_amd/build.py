@@ -62,6 +62,25 @@ def build_probe():
     return out
 
 
+def build_ablation(mask):
+    """production kernels with one compile-time ablation mask (csrc/igemm.hip: SGDM_ABL), tools/ only"""
+    os.makedirs(OBJ, exist_ok=True)
+    out = os.path.join(LIBDIR, f"libsgdm_hip_abl{mask}.so")
+    objs = []
+    for src in _sources():
+        if src == "igemm.hip":
+            obj = os.path.join(OBJ, f"igemm.abl{mask}.o")
+            r = subprocess.run([HIPCC, *FLAGS, f"-DSGDM_ABL={mask}", "-c", os.path.join(CSRC, src), "-o", obj],
+                               capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError(r.stderr)
+        else:
+            obj = _compile(src, False)
+        objs.append(obj)
+    subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out, *objs], check=True)
+    return out
+
+
 def build_lib(force=False):
     os.makedirs(OBJ, exist_ok=True)
     os.makedirs(LIBDIR, exist_ok=True)
@@ -78,4 +97,7 @@ def build_lib(force=False):
 
 
 if __name__ == "__main__":
-    print(build_probe() if "--probe" in sys.argv else build_lib(force="--force" in sys.argv))
+    if "--abl" in sys.argv:
+        print(build_ablation(int(sys.argv[sys.argv.index("--abl") + 1])))
+    else:
+        print(build_probe() if "--probe" in sys.argv else build_lib(force="--force" in sys.argv))

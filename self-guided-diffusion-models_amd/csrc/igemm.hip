@@ -4,15 +4,19 @@
 //   Tile 128 rows x BN cols, K step = one tap x 32 input channels.
 //
 // Wave-specialised block (512 threads = 8 waves, 1 block per CU, 2 waves per SIMD):
-//   waves 0-3  "compute": only ds_read_b128 fragment reads + MFMA (+ the epilogue).  Each owns a
-//              64x64 (BN=128) or 32x32 (BN=32) output sub-tile; fragments of the next K step are
-//              read BEFORE the step barrier so the matrix pipe never waits on LDS latency.
-//   waves 4-7  "loader": global -> registers -> LDS.  The activated input tile (GroupNorm apply +
-//              SiLU / LayerNorm, avg-pool / nearest-upsample, channel concat, 16-bit hi/lo split) is
-//              staged ONCE per 32-channel chunk as a halo tile and re-read by the 9 taps; the per-tap
-//              weight slice [BN x 32] runs two steps ahead in a 3-deep LDS ring.  The loaders' VALU
-//              work (exp, rcp, cvt) executes on the SIMDs' vector pipe while the compute wave of the
-//              same SIMD keeps the matrix pipe busy.
+//   waves 0-3  "compute": MFMA (+ the epilogue).  Each owns a 64x64 (BN=128) or 32x32 (BN=32) output sub-tile.
+//              INPUT fragments are ds_read_b128 reads of the LDS tile (those of the next K step are read BEFORE the
+//              step barrier so the matrix pipe never waits on LDS latency); WEIGHT fragments never touch LDS: the
+//              weights are packed in MFMA fragment order (pack_weight_kernel), so a wave's slice of one K step is
+//              eight fully coalesced 1 KiB global loads straight into the operand registers, requested one K step
+//              ahead (L2-resident: every CU of an N tile streams the same slices).  Measured reason: with the weight
+//              slices staged through LDS (18 KB of ds_write_b128 per step next to 64 KB of fragment reads) the LDS
+//              array was ~80 % busy per MFMA-bound step and every ds_read between two MFMAs stalled its wave; the
+//              matrix pipe and the LDS phase ran back to back instead of overlapped (profiles/r2_ablation.txt).
+//   waves 4-7  "loader": global -> registers -> LDS, inputs only.  The activated input tile (GroupNorm apply +
+//              SiLU / LayerNorm, avg-pool / nearest-upsample, channel concat, 16-bit hi/lo split) is staged ONCE per
+//              32-channel chunk as a halo tile and re-read by the 9 taps.  The loaders' VALU work (exp, rcp, cvt)
+//              executes on the SIMDs' vector pipe while the compute wave of the same SIMD keeps the matrix pipe busy.
 //   One s_barrier per K step; A tile double-buffered (triple for 1x1) so no extra barrier at chunk seams.
 //
 // Arithmetic: PREC_F32 uses v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32 accumulate).
@@ -33,10 +37,10 @@ namespace {
 constexpr int KC = 32;        // input channels per K chunk
 constexpr int LDA = KC + 4;   // LDS row stride in floats (144 B): conflict-free b128 fragment reads
 constexpr int BM = 128;
-constexpr int NB_RING = 3;    // weight-slice ring depth
-constexpr int NTHREADS = 768;  // 4 compute waves + 6 input-tile loader waves + 2 weight loader waves
-constexpr int A_THREADS = 384;
-constexpr int B_THREADS = 128;
+constexpr int NB_RING = 3;    // register ring depth of the 1x1 loaders (input rows requested 3 steps ahead)
+constexpr int NTHREADS = 512;  // 4 compute waves + 4 input-tile loader waves
+constexpr int A_THREADS = NTHREADS - 256;
+constexpr int WUNIT = 4096;   // bytes of one packed weight unit: 32 output x 32 input channels of one tap, fragment order
 constexpr int FAST_PIX = 192;  // halo tiles up to this many pixels (16x8 outputs + halo = 180) use the split-phase A loader
 
 struct Geo {
@@ -50,7 +54,7 @@ struct Geo {
     int sparts;               // statistics slots per image (args.stats), 0: unsupported geometry
     int fast_a;               // 1: split-phase A loader (stride 1, no avg-pool, pix*8 <= JMAX*256)
 #ifdef SGDM_PROBE
-    int dbg;                  // SGDM_DBG bits: 1 skip A staging, 2 skip B staging, 4 skip MFMA, 8 skip stores
+    int dbg;                  // SGDM_DBG bits: 1 skip A staging, 2 skip B staging, 4 skip MFMA, 8 skip stores, 16 skip the epilogue, 256 skip its statistics
     unsigned long long* stamp;   // [block][wave][4]: total cycles, cycles inside barriers, barriers, epilogue cycles
     unsigned long long* trace;   // [16 blocks][wave][512 barriers][2]: arrival / release time of every barrier
 #endif
@@ -77,6 +81,23 @@ struct Geo {
 #define PROBE_BEGIN()
 #define PROBE_END(role)
 #define PROBE_EPI(expr) expr
+#endif
+
+// Compile-time ablations (build.py --abl MASK -> libsgdm_hip_abl<MASK>.so, tools/ only): unlike the run-time DBG knobs of the
+// probe build they cost nothing themselves, so the time of a phase is the difference between two such libraries.
+//   1 no output stores   2 no residual / bias loads   4 no epilogue statistics   8 no epilogue at all   16 no MFMA
+//   32 no weight-fragment loads   64 no input-fragment LDS reads   128 no per-step barrier in the compute/loader loops (WRONG results)
+#ifdef SGDM_ABL
+#define ABL(bit) (((SGDM_ABL) & (bit)) != 0)
+#else
+#define ABL(bit) false
+#endif
+
+// keep a value live without using it (ablation builds); the "v" constraint exists in the device pass only
+#if defined(__HIP_DEVICE_COMPILE__)
+#define KEEP_LIVE(x) asm volatile("" :: "v"(x))
+#else
+#define KEEP_LIVE(x) (void)(x)
 #endif
 
 struct KArgs {
@@ -109,63 +130,80 @@ __device__ __forceinline__ void lds_store_act(float* rowp, int c4, f32x4 v) {
     }
 }
 
-// MFMA operand fragments of one K sub-step of one wave tile
+// MFMA operand fragments of one K sub-step of one wave tile.  A: the input side (pixels), read from the LDS tile;
+// B: the weight side, loaded from the fragment-ordered packed weights in global memory (`p` already carries lane * 16).
 template <int PREC, int MT, int NT> struct Frag {
     typedef typename Split<PREC>::T T;
     typedef T T8 __attribute__((ext_vector_type(8)));
     static constexpr int NKS = KC / 16;           // 16 channels per sub-step
-    static constexpr int NREADS = 2 * (MT + NT);  // ds_read_b128 per sub-step
+    static constexpr int NREADS = 2 * MT;         // ds_read_b128 per sub-step
+    static constexpr int NWLOADS = 2 * NT;        // 16-byte global loads per sub-step
     static constexpr int NMMA = 3 * MT * NT;      // MFMAs per sub-step
-    T8 ah[MT], al[MT], bh[NT], bl[NT];
-    __device__ __forceinline__ void load(const float* const* ap, const float* bp, int ks, int lh) {
-        const int goff = (ks * 2 + lh) * 8;       // float offset of this lane-half's 8-channel group
+    struct A {
+        T8 h[MT], l[MT];
+        __device__ __forceinline__ void load(const float* const* ap, int ks, int lh) {
+            const int goff = (ks * 2 + lh) * 8;   // float offset of this lane-half's 8-channel group
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            ah[mt] = *reinterpret_cast<const T8*>(ap[mt] + goff);
-            al[mt] = *reinterpret_cast<const T8*>(ap[mt] + goff + 4);
+            for (int mt = 0; mt < MT; ++mt) {
+                h[mt] = *reinterpret_cast<const T8*>(ap[mt] + goff);
+                l[mt] = *reinterpret_cast<const T8*>(ap[mt] + goff + 4);
+            }
         }
+    };
+    struct B {
+        T8 h[NT], l[NT];
+        __device__ __forceinline__ void load(const char* p, int ks) {
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            bh[nt] = *reinterpret_cast<const T8*>(bp + nt * 32 * LDA + goff);
-            bl[nt] = *reinterpret_cast<const T8*>(bp + nt * 32 * LDA + goff + 4);
+            for (int nt = 0; nt < NT; ++nt) {
+                h[nt] = *reinterpret_cast<const T8*>(p + nt * WUNIT + ks * 2048);
+                l[nt] = *reinterpret_cast<const T8*>(p + nt * WUNIT + ks * 2048 + 1024);
+            }
         }
-    }
-    __device__ __forceinline__ void mma(f32x16 (&acc)[MT][NT]) const {
+    };
+    static __device__ __forceinline__ void mma(f32x16 (&acc)[MT][NT], const A& a, const B& b) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 if constexpr (PREC == SGD_PREC_F16X3) {
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[nt], al[mt], acc[mt][nt], 0, 0, 0);
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[nt], ah[mt], acc[mt][nt], 0, 0, 0);
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[nt], ah[mt], acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b.h[nt], a.l[mt], acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b.l[nt], a.h[mt], acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b.h[nt], a.h[mt], acc[mt][nt], 0, 0, 0);
                 } else {
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[nt], al[mt], acc[mt][nt], 0, 0, 0);
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl[nt], ah[mt], acc[mt][nt], 0, 0, 0);
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[nt], ah[mt], acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b.h[nt], a.l[mt], acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b.l[nt], a.h[mt], acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b.h[nt], a.h[mt], acc[mt][nt], 0, 0, 0);
                 }
             }
     }
 };
 template <int MT, int NT> struct Frag<SGD_PREC_F32, MT, NT> {
     static constexpr int NKS = KC / 8;            // 8 channels per sub-step (4 MFMA k-pairs)
-    static constexpr int NREADS = MT + NT;
+    static constexpr int NREADS = MT;
+    static constexpr int NWLOADS = NT;
     static constexpr int NMMA = 4 * MT * NT;
-    f32x4 a[MT], b[NT];
-    __device__ __forceinline__ void load(const float* const* ap, const float* bp, int ks, int lh) {
+    struct A {
+        f32x4 v[MT];
+        __device__ __forceinline__ void load(const float* const* ap, int ks, int lh) {
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) a[mt] = *reinterpret_cast<const f32x4*>(ap[mt] + ks * 8 + lh * 4);
+            for (int mt = 0; mt < MT; ++mt) v[mt] = *reinterpret_cast<const f32x4*>(ap[mt] + ks * 8 + lh * 4);
+        }
+    };
+    struct B {
+        f32x4 v[NT];
+        __device__ __forceinline__ void load(const char* p, int ks) {
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) b[nt] = *reinterpret_cast<const f32x4*>(bp + nt * 32 * LDA + ks * 8 + lh * 4);
-    }
-    __device__ __forceinline__ void mma(f32x16 (&acc)[MT][NT]) const {
+            for (int nt = 0; nt < NT; ++nt) v[nt] = *reinterpret_cast<const f32x4*>(p + nt * WUNIT + ks * 1024);
+        }
+    };
+    static __device__ __forceinline__ void mma(f32x16 (&acc)[MT][NT], const A& a, const B& b) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[nt][j], a[mt][j], acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(b.v[nt][j], a.v[mt][j], acc[mt][nt], 0, 0, 0);
     }
 };
 
@@ -222,8 +260,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int a_floats = g.pix * LDA;
     float* As = smem;                                       // [NA][pix][LDA]
-    float* Bs = smem + (size_t)NA * a_floats;               // [NB_RING][BN][LDA]
-    int2* pixtab = reinterpret_cast<int2*>(Bs + NB_RING * BN * LDA);   // [3][pix] (source row or -1, image n)
+    int2* pixtab = reinterpret_cast<int2*>(smem + (size_t)NA * a_floats);   // [3][pix] (source row or -1, image n)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
@@ -287,22 +324,18 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
     if (tid >= 256) {
         if constexpr (CONV) {
             // =================================================================================
-            // unified loader (the sampler's ResBlock convs: stride 1, per-image GroupNorm affine (+SiLU) or no prologue,
-            // whole 32-channel chunks from one source, no dropout).  All eight loader waves do the same thing every K step:
-            //   weights: 1/8 of slice B(step+2) registers -> LDS, request 1/8 of B(step+5)      (2 x 16 B per thread)
-            //   inputs : at this wave's taps (waves 4-7: 1..3, waves 8-11: 5..7) transform ONE raw row quad requested
-            //            nine steps earlier into LDS and request the same item of the next chunk
-            // Spreading the weight slice over all loader waves matters because a wave's global loads issue serially
-            // (~50-120 cycles each with every CU streaming): two dedicated waves needed ~950 cycles per step for their
-            // 8 loads each and paced the block.  Everything is branch-free so the in-order vmcnt waits stay exact.
+            // lean loader (the sampler's ResBlock convs: stride 1, per-image GroupNorm affine (+SiLU) or no prologue,
+            // whole 32-channel chunks from one source, no dropout).  At taps 1..6 of a chunk every loader thread transforms
+            // ONE raw row quad requested nine steps earlier into LDS and requests the same item of the next chunk; the
+            // per-tile work (source rows, padding flags) is hoisted, chunk pointers are wave-uniform scalars.  Everything is
+            // branch-free so the in-order vmcnt waits stay exact.
             // =================================================================================
             const bool uni = VEC && g.nb == 1 && a.pro == SGD_PRO_AFFINE_NC;
             const bool lean2 = g.fast_a && VEC && (uni || a.pro == SGD_PRO_NONE) && a.drop_p == 0.f && cin % KC == 0
                                && (a.c1 == 0 || a.c0 % KC == 0) && !DBG(3);
             if (lean2) {
-                constexpr int LT = NTHREADS - 256;                       // 512 loader threads
-                constexpr int AJ = (FAST_PIX * 8 + LT - 1) / LT;         // input items per thread per chunk (3)
-                constexpr int BI = BN == 128 ? 2 : 1;                    // weight quads per thread per slice
+                constexpr int LT = NTHREADS - 256;                       // 256 loader threads
+                constexpr int AJ = (FAST_PIX * 8 + LT - 1) / LT;         // input items per thread per chunk (6)
                 const int lt = tid - 256;
                 const int c4 = lt & 7;                                   // channel quad (inputs and weights alike)
                 const int items = g.pix * 8;
@@ -313,34 +346,6 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
                     typedef std::integral_constant<int, 0> R0;
                     typedef std::integral_constant<int, 1> R1;
                     typedef std::integral_constant<int, 2> R2;
-                    // ---- weights
-                    const int brow = BN == 128 ? (lt >> 3) : ((lt & 255) >> 3);   // BN = 32: the upper half duplicates
-                    f32x4 breg[NB_RING][BI];
-                    const float* wthr = reinterpret_cast<const float*>(a.w) + (size_t)brow * a.cin_p + c4 * 4;
-                    const size_t tap_stride = (size_t)a.cout_p * a.cin_p;
-                    int ck = 0, ctap = 0, cchunk = 0;
-                    const float* wtile = wthr + (size_t)tile_at(g, lin_of(0), BN, TW, TH).n0c * a.cin_p;
-                    auto load_next = [&](auto rc) {
-                        constexpr int R = decltype(rc)::value;
-                        const float* wp = wtile + (size_t)ctap * tap_stride + cchunk * KC;
-#pragma unroll
-                        for (int it = 0; it < BI; ++it) breg[R][it] = ld4(wp + (size_t)(it * 64) * a.cin_p);
-                        if (++ctap == TAPS) {
-                            ctap = 0;
-                            if (++cchunk == nchunks) {
-                                cchunk = 0;
-                                if (++ck == ntiles) { ck = ntiles - 1; cchunk = nchunks - 1; ctap = TAPS - 1; }
-                                else wtile = wthr + (size_t)tile_at(g, lin_of(ck), BN, TW, TH).n0c * a.cin_p;
-                            }
-                        }
-                    };
-                    float* const bdst = Bs + brow * LDA + c4 * 4;
-                    auto store_B = [&](int slot, auto rc) {
-                        constexpr int R = decltype(rc)::value;
-#pragma unroll
-                        for (int it = 0; it < BI; ++it)
-                            *reinterpret_cast<f32x4*>(bdst + (size_t)slot * BN * LDA + it * 64 * LDA) = breg[R][it];
-                    };
                     // ---- inputs
                     int pixj[AJ], rows2[AJ];
                     bool live[AJ];
@@ -408,9 +413,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
                             lds_store_act<PREC>(As + (size_t)(slot % NA) * a_floats + (size_t)pixj[j] * LDA, c4, v);
                         }
                     };
-                    // ---- prologue: weight slices 0..4 in flight / staged, chunk 0 staged synchronously, chunk 1 requested
-                    load_next(R0());
-                    load_next(R1());
+                    // ---- prologue: chunk 0 staged synchronously, chunk 1 requested
                     S s1, s2;
                     s2.k = 0; s2.chunk = 0; fill(s2);
                     load_rows(0);
@@ -420,11 +423,6 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
                     for (int j = 0; j < AJ; ++j) issue_item(s2, j);
 #pragma unroll
                     for (int j = 0; j < AJ; ++j) finish(0, j);
-                    store_B(0, R0());
-                    store_B(1, R1());
-                    load_next(R2());
-                    load_next(R0());
-                    load_next(R1());
                     s2 = advance(s2);                                   // chunk 1
                     if (s2.k != 0) load_rows(s2.k);
 #pragma unroll
@@ -433,8 +431,6 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
                     SYNC();
                     for (int q = 0; q < Q; ++q) {
                         // tap 0: chunk q+1 becomes the one being transformed, chunk q+2 the one being requested
-                        store_B(2, R2());
-                        load_next(R2());
                         s1 = s2;
                         valid1 = valid2;
                         s2 = advance(s2);
@@ -443,9 +439,6 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
                         SYNC();
 #pragma unroll
                         for (int t = 1; t < 9; ++t) {                                              // taps 1..8
-                            if (t % 3 == 1) { store_B(0, R0()); load_next(R0()); }
-                            else if (t % 3 == 2) { store_B(1, R1()); load_next(R1()); }
-                            else { store_B(2, R2()); load_next(R2()); }
                             if (t >= T0 && t < T0 + AJ) {
                                 finish(q + 1, t - T0);
                                 issue_item(s2, t - T0);
@@ -456,21 +449,16 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
                         }
                     }
                 };
-                if (a.resample == SGD_RS_AVGPOOL2) {
-                    if (wave >= 8) go(std::true_type(), std::true_type());
-                    else go(std::false_type(), std::true_type());
-                } else {
-                    if (wave >= 8) go(std::true_type(), std::false_type());
-                    else go(std::false_type(), std::false_type());
-                }
+                if (a.resample == SGD_RS_AVGPOOL2) go(std::false_type(), std::true_type());
+                else go(std::false_type(), std::false_type());
                 PROBE_END(1);
                 return;
             }
         } else {
             // =================================================================================
-            // unified loader, 1x1 convs / linears (skip connections, attention qkv / proj_out): every K step needs a
-            // fresh 128 x 32 input tile AND a fresh weight slice, so each of the 512 loader threads moves two input quads
-            // and two weight quads per step through a 3-deep register ring (requested 3 steps before they are staged).
+            // lean loader, 1x1 convs / linears (skip connections, attention qkv / proj_out): every K step needs a fresh
+            // 128 x 32 input tile, so each of the 256 loader threads moves four input quads per step through a 3-deep
+            // register ring (requested 3 steps before they are staged).
             // Lean cases only: no prologue, or a per-image GroupNorm affine whose image boundaries fall on tile
             // boundaries (rows_per_n % 128 == 0), so the coefficients of a tile are one (n, channel quad) vector.
             // =================================================================================
@@ -479,23 +467,21 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
             const bool leanf = VEC && (a.pro == SGD_PRO_NONE || tile_uni || ln) && a.drop_p == 0.f && cin % KC == 0
                                && (a.c1 == 0 || a.c0 % KC == 0) && !DBG(3);
             if (leanf) {
-                constexpr int AI = BM * 8 / (NTHREADS - 256);             // input quads per thread per step (2)
-                constexpr int BI = BN == 128 ? 2 : 1;
+                constexpr int AI = BM * 8 / (NTHREADS - 256);             // input quads per thread per step (4)
+                constexpr int AROWS = (NTHREADS - 256) / 8;               // rows covered by one pass of the loader threads (32)
                 const int lt = tid - 256;
                 const int c4 = lt & 7;
-                const int arow = lt >> 3;                                 // + 64 j
-                const int brow = BN == 128 ? (lt >> 3) : ((lt & 255) >> 3);
+                const int arow = lt >> 3;                                 // + AROWS * j
                 typedef std::integral_constant<int, 0> R0;
                 typedef std::integral_constant<int, 1> R1;
                 typedef std::integral_constant<int, 2> R2;
-                f32x4 araw[NB_RING][AI], breg[NB_RING][BI];
+                f32x4 araw[NB_RING][AI];
                 Coef kq[NB_RING];
                 float2 rst[NB_RING][AI];                                  // LayerNorm row statistics of the items
-                struct Cur { int k, chunk; int m0; const float* wt; const float* ka; const float* kb; };
+                struct Cur { int k, chunk; int m0; const float* ka; const float* kb; };
                 auto open_tile = [&](Cur& c) {                           // per-tile scalars
                     const Tile T = tile_at(g, lin_of(c.k), BN, TW, TH);
                     c.m0 = (int)T.m0;
-                    c.wt = reinterpret_cast<const float*>(a.w) + (size_t)(T.n0c + brow) * a.cin_p + c4 * 4;
                     const long ko = tile_uni ? (long)(c.m0 / a.rows_per_n) * cin : 0;
                     // coefficient quads of a chunk: GroupNorm a / b of the tile's image, or LayerNorm gamma / beta;
                     // no prologue (or no beta): harmless bytes of the input instead of a branch around the load
@@ -518,13 +504,11 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
                     int stride;
                     if (ch < a.c0) { src = a.x0 + ch; stride = a.c0; }
                     else { src = a.x1 + (ch - a.c0); stride = a.c1; }
-#pragma unroll
-                    for (int it = 0; it < BI; ++it) breg[R][it] = ld4(ci.wt + ch + (size_t)(it * 64) * a.cin_p);
                     kq[R].p = ld4(ci.ka + ((tile_uni || ln) ? ch : 0));
                     kq[R].q = ld4(ci.kb + ((tile_uni || (ln && a.pc)) ? ch : 0));
 #pragma unroll
                     for (int j = 0; j < AI; ++j) {
-                        int row = ci.m0 + arow + j * 64;
+                        int row = ci.m0 + arow + j * AROWS;
                         row = row < M ? row : M - 1;
                         araw[R][j] = ld4(src + (long)row * stride + c4 * 4);
                         rst[R][j] = *reinterpret_cast<const float2*>(ln ? a.pa + (long)row * 2 : a.x0);
@@ -533,9 +517,6 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
                 };
                 auto finish = [&](int slot, auto rc) {                   // stage the chunk under the finish cursor
                     constexpr int R = decltype(rc)::value;
-#pragma unroll
-                    for (int it = 0; it < BI; ++it)
-                        *reinterpret_cast<f32x4*>(Bs + (size_t)slot * BN * LDA + (brow + it * 64) * LDA + c4 * 4) = breg[R][it];
 #pragma unroll
                     for (int j = 0; j < AI; ++j) {
                         f32x4 v = araw[R][j];
@@ -548,8 +529,8 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
 #pragma unroll
                             for (int e = 0; e < 4; ++e) v[e] = sgd_silu(v[e]);
                         }
-                        if (cf.m0 + arow + j * 64 >= M) v = f32x4{0.f, 0.f, 0.f, 0.f};
-                        lds_store_act<PREC>(As + (size_t)slot * a_floats + (size_t)(arow + j * 64) * LDA, c4, v);
+                        if (cf.m0 + arow + j * AROWS >= M) v = f32x4{0.f, 0.f, 0.f, 0.f};
+                        lds_store_act<PREC>(As + (size_t)slot * a_floats + (size_t)(arow + j * AROWS) * LDA, c4, v);
                     }
                     advance(cf);
                 };
@@ -581,80 +562,12 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
             }
         }
         // =====================================================================================
-        // loader roles.  Each wave runs ONE kind of global load in a branch-free steady state so the
-        // compiler's in-order vmcnt bookkeeping stays exact (a conditional load anywhere degrades every
-        // later wait to vmcnt(0) == full memory latency per K step):
-        //   waves 10-11  weight slices: B(step+2) registers -> LDS, then issue B(step+5)
-        //   waves 4-9    input tile:    raw loads of chunk q+1 at tap 0, transform + LDS write at taps 1..7
-        // Out-of-range prefetches are clamped to the last valid step/chunk (harmless duplicates written
-        // to ring slots nobody reads any more) instead of being branched around.
+        // general input-tile loader (strided / big-halo / partial-chunk / dropout cases).  Branch-free steady state so
+        // the compiler's in-order vmcnt bookkeeping stays exact (a conditional load anywhere degrades every later wait
+        // to vmcnt(0) == full memory latency per K step): raw loads of chunk q+1 requested at the taps of chunk q,
+        // transformed and written to LDS one chunk later.  Out-of-range prefetches are clamped to the last valid chunk
+        // (harmless duplicates written to ring slots nobody reads any more) instead of being branched around.
         // =====================================================================================
-        if (tid >= 256 + A_THREADS) {
-            // ---------------------------------------------------------------- B loader
-            const int lt = tid - 256 - A_THREADS;
-            constexpr int BITEMS = BN * 8 / B_THREADS;    // float4 per thread per weight slice (8 or 2)
-            f32x4 breg[NB_RING][BITEMS];                  // B(step) lives in breg[step % 3]
-            typedef std::integral_constant<int, 0> R0;
-            typedef std::integral_constant<int, 1> R1;
-            typedef std::integral_constant<int, 2> R2;
-            const float* wthr = reinterpret_cast<const float*>(a.w) + (size_t)(lt >> 3) * a.cin_p + (lt & 7) * 4;
-            const size_t tap_stride = (size_t)a.cout_p * a.cin_p;
-            // prefetch cursor (walks the stream in order)
-            int ck = 0, ctap = 0, cchunk = 0;
-            const float* wtile = wthr + (size_t)tile_at(g, lin_of(0), BN, TW, TH).n0c * a.cin_p;
-            auto load_next = [&](auto rc) {
-                constexpr int R = decltype(rc)::value;
-                const float* wp = wtile + (size_t)ctap * tap_stride + cchunk * KC;
-                if (!(DBG(2))) {
-#pragma unroll
-                for (int it = 0; it < BITEMS; ++it) breg[R][it] = ld4(wp + (size_t)(it * 16) * a.cin_p);
-                }
-                // advance, clamping at the last step of the stream
-                if (++ctap == TAPS) {
-                    ctap = 0;
-                    if (++cchunk == nchunks) {
-                        cchunk = 0;
-                        if (++ck == ntiles) { ck = ntiles - 1; cchunk = nchunks - 1; ctap = TAPS - 1; }
-                        else wtile = wthr + (size_t)tile_at(g, lin_of(ck), BN, TW, TH).n0c * a.cin_p;
-                    }
-                }
-            };
-            auto store_B = [&](int step, auto rc) {
-                constexpr int R = decltype(rc)::value;
-                float* bp = Bs + (size_t)(step % NB_RING) * BN * LDA + (lt >> 3) * LDA + (lt & 7) * 4;
-                if (!(DBG(2))) {
-#pragma unroll
-                for (int it = 0; it < BITEMS; ++it) *reinterpret_cast<f32x4*>(bp + it * 16 * LDA) = breg[R][it];
-                }
-            };
-            load_next(R0());
-            load_next(R1());
-            store_B(0, R0());
-            store_B(1, R1());
-            load_next(R2());
-            load_next(R0());
-            load_next(R1());
-            SYNC();
-            // steady state without any conditional around the loads/stores (S % 3 == 0 for CONV3: 9 taps per chunk),
-            // so the waits in front of the LDS stores stay at vmcnt(16+): only the slice loaded three steps ago
-            auto body = [&](int step, auto rc) {
-                PROBE_EPI(store_B(step + 2, rc));
-                load_next(rc);
-                SYNC();
-            };
-            int step = 0;
-            for (; step + 3 <= S; step += 3) {
-                body(step, R2());
-                body(step + 1, R0());
-                body(step + 2, R1());
-            }
-            if (step < S) {
-                body(step, R2());
-                if (step + 1 < S) body(step + 1, R0());
-            }
-            PROBE_END(2);
-            return;
-        }
         // -------------------------------------------------------------------- A loader
         const int lt = tid - 256;
         const int c4 = lt & 7;                        // this thread's channel quad inside every chunk
@@ -797,13 +710,9 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
                         SYNC();
                     }
                 };
-                // The common case (the sampler's ResBlock convs: per-image GroupNorm affine (+SiLU) or no prologue, whole
-                // 32-channel chunks from one source, no dropout) gets its own loop with the per-tile work hoisted: source rows
-                // and padding flags are read from the tile table once per tile, the chunk's source pointer / stride /
-                // coefficient pointer are wave-uniform scalars.  ~45 vector instructions per item: next to a saturated
-                // matrix pipe a SIMD issues only ~4 other vector instructions per MFMA, so loader VALU count is what
-                // paces a K step.  The second input-tile wave of a SIMD (waves 8, 9) works at taps 5..8, the first
-                // (waves 4..7) at taps 1..4, so the two never stack on one step.
+                // Shared-coefficient case that missed the lean loader above only through its geometry (e.g. dropout off but a
+                // partial last chunk): per-tile work hoisted, source rows and padding flags read from the tile table once
+                // per tile, the chunk's source pointer / stride / coefficient pointer wave-uniform scalars.
                 auto run_lean = [&](auto latec) {
                     constexpr bool LATE = decltype(latec)::value;
                     constexpr int T0 = LATE ? 5 : 1;
@@ -893,8 +802,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
                 };
                 const bool lean2 = lean && cin % KC == 0 && (a.c1 == 0 || a.c0 % KC == 0);
                 if (lean2) {
-                    if (wave >= 8) run_lean(std::true_type());
-                    else run_lean(std::false_type());
+                    run_lean(std::false_type());
                 } else {
                     run();
                 }
@@ -998,55 +906,68 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
         }
         aoff[mt] = p * LDA;
     }
-    const int boff = (wn * WN + li) * LDA;
+    // weight fragments: wave (wm, wn) needs N blocks wn*NT .. wn*NT+NT-1 of its tile; consecutive K steps of the stream
+    // [chunk][tap] are `wstep` bytes apart (all N blocks of the layer for that step)
+    const size_t wstep = (size_t)(a.cout_p >> 5) * WUNIT;
+    const char* const wlane = reinterpret_cast<const char*>(a.w) + (size_t)(wn * NT) * WUNIT + lane * 16;
+    auto wtile_of = [&](int k) { return wlane + (size_t)(tile_at(g, lin_of(k), BN, TW, TH).n0c >> 5) * WUNIT; };
 
     f32x16 acc[MT][NT];
 
-    // One K step: [wait frags(cur)] [issue reads(next)] [MFMA block(cur)] per sub-step.  Strict
-    // alternation keeps at most ONE batch of LDS reads outstanding (they were issued one whole MFMA
-    // block earlier, so the explicit lgkmcnt(0) never stalls); the last sub-step's reads belong to the
-    // NEXT step and are issued before this step's barrier.
-    FragT fr[2];
-    auto do_step = [&](const float* const* ap, const float* bp, const float* const* nap, const float* nbp, bool more) {
+    // One K step, per sub-step: [wait input frags(cur)] [issue LDS reads(next)] [MFMA block(cur)] [request the weight
+    // frags of the SAME sub-step of the next K step].  Strict alternation keeps at most ONE batch of LDS reads
+    // outstanding (they were issued one whole MFMA block earlier, so the explicit lgkmcnt(0) never stalls); the last
+    // sub-step's reads belong to the NEXT step and are issued before this step's barrier.  The weight loads have a whole
+    // K step (>= 768 matrix-pipe cycles) to return from L2; their vmcnt waits are the compiler's (plain loads).
+    typename FragT::A fa[2];
+    typename FragT::B fb[NKS];
+    auto do_step = [&](const float* const* ap, const float* const* nap, const char* wnext) {
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) {
             __builtin_amdgcn_s_waitcnt(0xC07F);                        // lgkmcnt(0) only
             __builtin_amdgcn_sched_barrier(0);
-            if (!(DBG(128))) {
-            if (ks + 1 < NKS) fr[(ks + 1) & 1].load(ap, bp, ks + 1, lh);
-            else fr[(ks + 1) & 1].load(nap, nbp, 0, lh);
+            if (!(DBG(128)) && !ABL(64)) {
+            if (ks + 1 < NKS) fa[(ks + 1) & 1].load(ap, ks + 1, lh);
+            else fa[(ks + 1) & 1].load(nap, 0, lh);
             }   // unconditional (a branch here would block the interleave); past the
                                                             // last step it reads a valid ring slot nobody needs
-            if (!(DBG(4))) fr[ks & 1].mma(acc);
-            // The four MFMA waves reach this point together (barrier-synchronised), so a burst of 8 ds_read_b128 per
-            // wave fills the LDS queue and the in-order wave cannot issue its MFMAs until its reads are accepted
-            // (measured: LDS phase and MFMA phase fully serialised).  Interleave: one MFMA, ONE read, ... (8 gaps; two reads
-            // per gap over 4 gaps measured 2-3 % slower: it saturates the LDS port while it lasts), then the rest of the
-            // MFMAs cover the latency of the last reads.
+            if (!(DBG(4)) && !ABL(16)) FragT::mma(acc, fa[ks & 1], fb[ks]);
+            if (!(DBG(2)) && !ABL(32)) fb[ks].load(wnext, ks);
+            // Interleave: one MFMA, ONE LDS read, ... then one MFMA, ONE weight load, ...; the rest of the MFMAs cover
+            // the latency of the last reads (a burst of reads in front of the MFMAs fills the LDS queue and the in-order
+            // wave cannot issue its MFMAs until they are accepted).
             if (!(DBG(32))) {
+                constexpr int P1 = FragT::NREADS < FragT::NMMA ? FragT::NREADS : FragT::NMMA;
+                constexpr int P2 = FragT::NWLOADS < FragT::NMMA - P1 ? FragT::NWLOADS : FragT::NMMA - P1;
 #pragma unroll
-                for (int i = 0; i < FragT::NREADS; ++i) {
+                for (int i = 0; i < P1; ++i) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                 }
-                __builtin_amdgcn_sched_group_barrier(0x008, FragT::NMMA - FragT::NREADS, 0);
+#pragma unroll
+                for (int i = 0; i < P2; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                }
+                if constexpr (FragT::NMMA - P1 - P2 > 0) __builtin_amdgcn_sched_group_barrier(0x008, FragT::NMMA - P1 - P2, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
         SYNC();
     };
     const int rowstep = g.hw * LDA;                // LDS floats between halo rows
-    const int bslot_floats = BN * LDA;
 
+    const char* wp = wtile_of(0);                  // weight fragments of the CURRENT step
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) fb[ks].load(wp, ks);
     SYNC();                               // pairs with the loaders' prologue barrier
     {
         const float* ap0[MT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) ap0[mt] = As + aoff[mt];
-        fr[0].load(ap0, Bs + boff, 0, lh);
+        fa[0].load(ap0, 0, lh);
     }
-    int sstep = 0;
-    int aslot = 0, bslot = 0;                      // ring positions of the current chunk / step
+    int aslot = 0;                                 // ring position of the current chunk
     for (int k = 0; k < ntiles; ++k) {
 #pragma unroll
         for (int i = 0; i < MT; ++i)
@@ -1054,13 +975,15 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
             for (int j = 0; j < NT; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        const char* const wseam = k + 1 < ntiles ? wtile_of(k + 1) : nullptr;    // first step of the next tile
         for (int chunk = 0; chunk < nchunks; ++chunk) {
             const int naslot = aslot + 1 == NA ? 0 : aslot + 1;
             const float* acur = As + (size_t)aslot * a_floats;
             const float* anext = As + (size_t)naslot * a_floats;
+            // step after this chunk's last one: next chunk, next tile, or (end of the stream) the same slice again
+            const bool last_chunk = chunk + 1 == nchunks;
             if (CONV) {
-                // 9 taps fully unrolled: tap offsets and weight-ring slots (9 % 3 == 0: every chunk starts
-                // at ring slot 0) are compile-time, so no scalar index math sits between the MFMA blocks.
+                // 9 taps fully unrolled: tap offsets are compile-time, so no scalar index math sits between the MFMA blocks.
 #pragma unroll
                 for (int tap = 0; tap < TAPS; ++tap) {
                     const float* ap[MT];
@@ -1071,20 +994,20 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
                     const float* nab = tap + 1 == TAPS ? anext : acur;
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt) { ap[mt] = acur + toff + aoff[mt]; nap[mt] = nab + ntoff + aoff[mt]; }
-                    const float* bp = Bs + (tap % 3) * bslot_floats + boff;
-                    const float* nbp = Bs + (ntap % 3) * bslot_floats + boff;
-                    do_step(ap, bp, nap, nbp, sstep + 1 < S);
-                    ++sstep;
+                    const char* wnext = wp + wstep;
+                    if (tap + 1 == TAPS && last_chunk) wnext = wseam ? wseam : wp;
+                    do_step(ap, nap, wnext);
+                    wp = wnext;
                 }
             } else {
-                const int nbslot = bslot + 1 == NB_RING ? 0 : bslot + 1;
                 const float* ap[MT];
                 const float* nap[MT];
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) { ap[mt] = acur + aoff[mt]; nap[mt] = anext + aoff[mt]; }
-                do_step(ap, Bs + bslot * bslot_floats + boff, nap, Bs + nbslot * bslot_floats + boff, sstep + 1 < S);
-                ++sstep;
-                bslot = nbslot;
+                const char* wnext = wp + wstep;
+                if (last_chunk) wnext = wseam ? wseam : wp;
+                do_step(ap, nap, wnext);
+                wp = wnext;
             }
             aslot = naslot;
         }
@@ -1155,12 +1078,12 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
                         const int c = cb + nt * 32 + gq * 8;
                         const int cl = c < a.cout ? c : 0;    // clamped: the quad is skipped below
                         f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-                        if (a.bias) bv = ld4(a.bias + cl);
+                        if (a.bias && !ABL(2)) bv = ld4(a.bias + cl);
 #pragma unroll
                         for (int mt = 0; mt < MT; ++mt) {
                             rv[gq][mt] = bv;
-                            if (RES == 1 || RES == 3) rv[gq][mt] += ld4(rpm[mt] + cl);
-                            if (RES == 2) {
+                            if ((RES == 1 || RES == 3) && !ABL(2)) rv[gq][mt] += ld4(rpm[mt] + cl);
+                            if (RES == 2 && !ABL(2)) {
                                 const long rw = (long)a.wo * 2 * a.cout;
                                 const float* rp = rpm[mt];
                                 rv[gq][mt] += 0.25f * (ld4(rp + cl) + ld4(rp + a.cout + cl) + ld4(rp + rw + cl) + ld4(rp + rw + a.cout + cl));
@@ -1179,12 +1102,13 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
                             for (int j = 0; j < 4; ++j) v[j] = acc[mt][nt][gq * 4 + j];
                             v += rv[gq][mt];
                             if (okm[mt]) {
-                                if (!(DBG(8))) *reinterpret_cast<f32x4*>(ypm[mt] + c) = v;
+                                if (!(DBG(8)) && !ABL(1)) *reinterpret_cast<f32x4*>(ypm[mt] + c) = v;
+                                else KEEP_LIVE(v);
                                 s1 += v;
                                 s2 += v * v;
                             }
                         }
-                        if (sp) {
+                        if (sp && !DBG(256) && !ABL(4)) {
                             // sum over the 32 pixel lanes of this lane half: 4 DPP steps inside a row of 16, then across rows
 #pragma unroll
                             for (int j = 0; j < 4; ++j) { s1[j] = half_wave_sum_hi(s1[j]); s2[j] = half_wave_sum_hi(s2[j]); }
@@ -1221,8 +1145,15 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
                 }
             }
         };
+        auto keep_acc = [&]() {                     // ablation builds: the accumulators stay live without an epilogue
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) KEEP_LIVE(acc[i][j]);
+        };
         PROBE_EPI(
-        if (!a.res) epilogue(std::integral_constant<int, 0>());
+        if (DBG(16) || ABL(8)) keep_acc();
+        else if (!a.res) epilogue(std::integral_constant<int, 0>());
         else if (a.res_mode == SGD_RS_NONE) epilogue(std::integral_constant<int, 1>());
         else if (a.res_mode == SGD_RS_AVGPOOL2) epilogue(std::integral_constant<int, 2>());
         else epilogue(std::integral_constant<int, 3>()));
@@ -1231,35 +1162,60 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// weight packing:  OIHW [cout, cin, k, k]  ->  [tap][cout_p][cin_p] 4-byte elements
+// weight packing:  OIHW [cout, cin, k, k]  ->  MFMA fragment order, so that the compute waves load their operands
+// straight from global memory with fully coalesced 16-byte-per-lane loads (no LDS staging of weights).
+//
+//   unit(chunk, tap, nb) = 4 KiB holding the 32 output channels nb*32.. x 32 input channels chunk*32.. of one tap,
+//   units ordered [chunk][tap][nb] (nb over ALL cout_p / 32 blocks: a K step of the stream is contiguous).
+//   split modes: unit = [ks 0..1][hi | lo][lane 0..63][8 x 16-bit]   lane = lh*32 + li holds W[nb*32+li][chunk*32+ks*16+lh*8 .. +7]
+//   f32        : unit = [ks 0..3][lane 0..63][4 x f32]               lane = lh*32 + li holds W[nb*32+li][chunk*32+ks*8+lh*4 .. +3]
+//   (exactly the A-operand lane map of v_mfma_f32_32x32x16_f16 / four v_mfma_f32_32x32x2_f32 k-pairs).
+// One thread produces one lane's 16 bytes (f32) or its hi AND lo 16 bytes (split) of one sub-step.
 // ---------------------------------------------------------------------------------------------
 template <int PREC>
 __global__ void pack_weight_kernel(const float* __restrict__ src, float* __restrict__ dst, int cout, int cin,
                                    int ks, int cout_p, int cin_p, int transpose) {
-    const long total = (long)ks * ks * cout_p * cin_p;
+    constexpr int NKS = PREC == SGD_PREC_F32 ? 4 : 2;         // sub-steps per unit
+    constexpr int CPL = PREC == SGD_PREC_F32 ? 4 : 8;         // input channels per lane per sub-step
+    const int kk = ks * ks, nblk = cout_p >> 5;
+    const long total = (long)(cin_p >> 5) * kk * nblk * NKS * 64;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        int ci = i % cin_p;
-        long t = i / cin_p;
-        int co = t % cout_p;
-        int tap = t / cout_p;
-        float v = 0.f;
-        if (ci < cin && co < cout) {
-            // forward: dst[tap][co][ci] = W[co][ci][tap].  dgrad (adjoint conv): the packed "output" index co
-            // walks W's input channels, "input" index ci walks W's output channels, taps are flipped.
-            if (!transpose) v = src[((long)co * cin + ci) * ks * ks + tap];
-            else v = src[((long)ci * cout + co) * ks * ks + (ks * ks - 1 - tap)];
+        const int lane = i & 63;
+        long t = i >> 6;
+        const int sub = t % NKS; t /= NKS;
+        const long unit = t;
+        const int nb = t % nblk; t /= nblk;
+        const int tap = t % kk;
+        const int chunk = t / kk;
+        const int co = nb * 32 + (lane & 31);
+        const int ci0 = chunk * 32 + sub * (2 * CPL) + (lane >> 5) * CPL;
+        float v[CPL];
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) {
+            const int ci = ci0 + j;
+            float x = 0.f;
+            if (ci < cin && co < cout) {
+                // forward: W[co][ci][tap].  dgrad (adjoint conv): the packed "output" index co walks W's input channels,
+                // "input" index ci walks W's output channels, taps are flipped.
+                if (!transpose) x = src[((long)co * cin + ci) * kk + tap];
+                else x = src[((long)ci * cout + co) * kk + (kk - 1 - tap)];
+            }
+            v[j] = x;
         }
         if constexpr (PREC == SGD_PREC_F32) {
-            dst[i] = v;
+            *reinterpret_cast<f32x4*>(dst + unit * 1024 + sub * 256 + lane * 4) = f32x4{v[0], v[1], v[2], v[3]};
         } else {
             typedef typename Split<PREC>::T T;
-            T h = Split<PREC>::hi(v);
-            T l = Split<PREC>::hi(v - Split<PREC>::back(h));
-            // same layout as the LDS rows: 8-channel groups, hi[8] | lo[8]
-            T* row = reinterpret_cast<T*>(dst + (i - ci));
-            int gidx = ci >> 3, p = ci & 7;
-            row[gidx * 16 + p] = h;
-            row[gidx * 16 + 8 + p] = l;
+            typedef T T8 __attribute__((ext_vector_type(8)));
+            T8 h, l;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                h[j] = Split<PREC>::hi(v[j]);
+                l[j] = Split<PREC>::hi(v[j] - Split<PREC>::back(h[j]));
+            }
+            T* up = reinterpret_cast<T*>(dst + unit * 1024) + sub * 1024 + lane * 8;
+            *reinterpret_cast<T8*>(up) = h;
+            *reinterpret_cast<T8*>(up + 512) = l;
         }
     }
 }
@@ -1311,7 +1267,7 @@ static int pack_weight_impl(const float* w_src, void* w_dst, int32_t cout, int32
     const int cin_p = ((cin + KC - 1) / KC) * KC;
     if (cin_p_out) *cin_p_out = cin_p;
     if (cout_p_out) *cout_p_out = cout_p;
-    const long total = (long)ksize * ksize * cout_p * cin_p;
+    const long total = (long)ksize * ksize * cout_p * cin_p / (prec == SGD_PREC_F32 ? 4 : 8);     // 16-byte vectors
     int grid = (int)((total + 255) / 256);
     if (grid > 4096) grid = 4096;
     hipStream_t st = (hipStream_t)stream;
@@ -1357,9 +1313,9 @@ static int make_geo(const sgd_igemm_args& a, Geo& g, int bn, int& na) {
         int nb = BM / (th * tw);
         g.hh = a.stride == 2 ? 2 * th + 1 : th + 2;
         g.hw = a.stride == 2 ? 2 * tw + 1 : tw + 2;
-        // the double-buffered halo tile must fit LDS next to the weight ring; rows of images beyond nb
-        // are computed on don't-care data and masked in the epilogue
-        while (nb > 1 && (2 * (size_t)nb * g.hh * g.hw * LDA + (size_t)NB_RING * bn * LDA) * 4 + (size_t)nb * g.hh * g.hw * 16 > 150 * 1024)
+        // the double-buffered halo tile must fit LDS; rows of images beyond nb are computed on don't-care data and
+        // masked in the epilogue
+        while (nb > 1 && 2 * (size_t)nb * g.hh * g.hw * LDA * 4 + (size_t)nb * g.hh * g.hw * 24 > 150 * 1024)
             nb >>= 1;
         g.tw_l2 = ilog2(tw); g.th_l2 = ilog2(th); g.nb = nb;
         g.tiles_x = a.wo / tw; g.tiles_y = a.ho / th;
@@ -1438,7 +1394,7 @@ extern "C" int sgd_igemm(const sgd_igemm_args* args, void* stream) {
         g.trace = tp ? reinterpret_cast<unsigned long long*>(strtoull(tp, nullptr, 0)) : nullptr;
     }
 #endif
-    const size_t smem = ((size_t)na * g.pix * LDA + (size_t)NB_RING * bn * LDA) * sizeof(float) + (size_t)g.pix * 24;
+    const size_t smem = (size_t)na * g.pix * LDA * sizeof(float) + (size_t)g.pix * 24;
     if (smem > 160 * 1024) return SGD_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     const bool conv = a.mode == SGD_MODE_CONV3;
