@@ -53,7 +53,8 @@ def build_probe():
     objs = []
     for src in _sources():
         obj = os.path.join(OBJ, src[:-4] + ".probe.o")
-        r = subprocess.run([HIPCC, *FLAGS, "-DSGDM_PROBE", "-c", os.path.join(CSRC, src), "-o", obj],
+        r = subprocess.run([HIPCC, *FLAGS, "-DSGDM_PROBE", *os.environ.get("SGDM_PROBE_FLAGS", "").split(), "-c",
+                            os.path.join(CSRC, src), "-o", obj],
                            capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(r.stderr)

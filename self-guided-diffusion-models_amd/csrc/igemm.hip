@@ -63,7 +63,7 @@ struct Geo {
 // Diagnostic build only (build.py --probe -> libsgdm_hip_probe.so, never loaded by the product path): ablation knobs
 // and per-wave cycle accounting.  In the shipped library the knobs fold to constants and no stamp executes.
 #ifdef SGDM_PROBE
-#define DBG(bit) (g.dbg & (bit))
+#define DBG(bit) 0          /* run-time knobs retired: they perturbed the MFMA/LDS interleave; use build.py --abl */
 #define SYNC() do { if (g.stamp) { const unsigned long long t0_ = __builtin_amdgcn_s_memtime(); __syncthreads(); \
                     const unsigned long long t1_ = __builtin_amdgcn_s_memtime(); \
                     if (g.trace && blockIdx.x < 16 && pr_nbar < 512 && (threadIdx.x & 63) == 0) { \
@@ -86,7 +86,8 @@ struct Geo {
 // Compile-time ablations (build.py --abl MASK -> libsgdm_hip_abl<MASK>.so, tools/ only): unlike the run-time DBG knobs of the
 // probe build they cost nothing themselves, so the time of a phase is the difference between two such libraries.
 //   1 no output stores   2 no residual / bias loads   4 no epilogue statistics   8 no epilogue at all   16 no MFMA
-//   32 no weight-fragment loads   64 no input-fragment LDS reads   128 no per-step barrier in the compute/loader loops (WRONG results)
+//   32 no weight-fragment loads   64 no input-fragment LDS reads   256 lean conv loader: no transform math   512: no global loads
+//   1024: no LDS stores (split + ds_write)   128 no per-step barrier in the compute/loader loops (WRONG results)
 #ifdef SGDM_ABL
 #define ABL(bit) (((SGDM_ABL) & (bit)) != 0)
 #else
@@ -249,9 +250,13 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
     const sgd_igemm_args& a = ka.a;
     const Geo& g = ka.g;
     constexpr bool CONV = TAPS == 9;
-    constexpr int NA = CONV ? 2 : 3;              // A tile ring depth
-    constexpr int WM = (BN == 128) ? 64 : 32;     // wave tile rows
-    constexpr int WN = (BN == 128) ? 64 : 32;     // wave tile cols
+    constexpr int NA = 3;                         // A tile ring depth (CONV: chunks, loaders two ahead; FLAT: K steps)
+    // wave tile: BN = 128 -> every MFMA wave owns ALL 128 rows x its own 32 columns, so the four waves of a block load
+    // disjoint weight fragments (a 64 x 64 split made two waves fetch the same 8 KB per step: the per-CU vector memory
+    // pipe was > 50 % busy and its full queue stalled the in-order MFMA waves at their loads); the input fragments they
+    // share come from LDS, which has the bandwidth to spare now.  BN = 32: four 32 x 32 waves stacked along M.
+    constexpr int WM = (BN == 128) ? 128 : 32;    // wave tile rows
+    constexpr int WN = 32;                        // wave tile cols
     constexpr int MT = WM / 32, NT = WN / 32;
     constexpr int WAVES_N = BN / WN;
     typedef Frag<PREC, MT, NT> FragT;
@@ -260,7 +265,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int a_floats = g.pix * LDA;
     float* As = smem;                                       // [NA][pix][LDA]
-    int2* pixtab = reinterpret_cast<int2*>(smem + (size_t)NA * a_floats);   // [3][pix] (source row or -1, image n)
+    int2* pixtab = reinterpret_cast<int2*>(smem + (size_t)NA * a_floats);   // [4][pix] (source row or -1, image n)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
@@ -289,7 +294,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
     auto build_pixtab = [&](int k, int t0, int nthr) {
         if (k >= ntiles) return;
         const Tile T = tile_at(g, lin_of(k), BN, TW, TH);
-        int2* tab = pixtab + (size_t)(k % 3) * g.pix;
+        int2* tab = pixtab + (size_t)(k & 3) * g.pix;
         for (int pix = t0; pix < g.pix; pix += nthr) {
             int2 e;
             e.x = -1;
@@ -318,10 +323,19 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
     build_pixtab(0, tid, NTHREADS);
     build_pixtab(1, tid, NTHREADS);
     build_pixtab(2, tid, NTHREADS);
+    build_pixtab(3, tid, NTHREADS);
     __syncthreads();
     PROBE_BEGIN();
 
     if (tid >= 256) {
+        // The loader shares its SIMD's vector issue with an MFMA wave that always has an instruction waiting; at equal
+        // priority the older (MFMA) wave wins every arbitration and the loader got ~1 issue slot per MFMA (measured: ~460
+        // vector instructions per chunk took 10k cycles and the compute waves waited 27 % of the time at the chunk
+        // barrier).  An MFMA needs one issue slot per 32 cycles, so handing the loader the priority costs the matrix
+        // pipe nothing as long as the loader's own stream has dependency gaps.
+#ifndef SGDM_NO_LOADER_PRIO
+        __builtin_amdgcn_s_setprio(2);
+#endif
         if constexpr (CONV) {
             // =================================================================================
             // lean loader (the sampler's ResBlock convs: stride 1, per-image GroupNorm affine (+SiLU) or no prologue,
@@ -357,27 +371,30 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
                     }
                     unsigned valid1 = 0, valid2 = 0;
                     auto load_rows = [&](int k) {
-                        const int2* tab = pixtab + (size_t)(k % 3) * g.pix;
+                        const int2* tab = pixtab + (size_t)(k & 3) * g.pix;
                         valid2 = 0;
 #pragma unroll
                         for (int j = 0; j < AJ; ++j) {
                             const int ex = tab[pixj[j]].x;
                             rows2[j] = ex < 0 ? 0 : ex;
-                            if (ex >= 0 && live[j]) valid2 |= 1u << j;
+                            if (ex >= 0) valid2 |= 1u << j;
                         }
                     };
-                    struct S { int k, chunk; const float* src; int stride; const float* ka; const float* kb; };
+                    struct S { int k, chunk, img0; const float* src; int stride; const float* ka; const float* kb; };
                     auto fill = [&](S& c) {
                         const int ch = c.chunk * KC;
                         if (ch < a.c0) { c.src = a.x0 + ch; c.stride = a.c0; }
                         else { c.src = a.x1 + (ch - a.c0); c.stride = a.c1; }
-                        const long ko = (long)tile_at(g, lin_of(c.k), BN, TW, TH).img0 * cin + ch;
+                        const long ko = (long)c.img0 * cin + ch;
                         c.ka = uni ? a.pa + ko : a.x0;   // no prologue: 32 harmless bytes instead of a branch around the load
                         c.kb = uni ? a.pb + ko : a.x0;
                     };
                     auto advance = [&](S c) {
                         if (++c.chunk == nchunks) {
-                            if (c.k + 1 < ntiles) { c.chunk = 0; ++c.k; }
+                            if (c.k + 1 < ntiles) {      // tile index math (integer divisions) once per tile, not per chunk
+                                c.chunk = 0; ++c.k;
+                                c.img0 = tile_at(g, lin_of(c.k), BN, TW, TH).img0;
+                            }
                             else c.chunk = nchunks - 1;
                         }
                         fill(c);
@@ -386,6 +403,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
                     f32x4 araw[AJ][NS];
                     Coef kq;
                     auto transform = [&](f32x4 v, bool ok) {
+                        if (ABL(256)) return v;
                         if (uni) v = v * kq.p + kq.q;
                         if (a.pro_silu) {
 #pragma unroll
@@ -396,6 +414,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
                     };
                     auto issue_item = [&](const S& c, int j) {
                         const float* p0 = c.src + (long)rows2[j] * c.stride + c4 * 4;
+                        if (ABL(512)) { KEEP_LIVE(p0); return; }
                         araw[j][0] = ld4(p0);
                         if constexpr (NS == 4) {            // ResBlock(down): the conv reads avg_pool2d(SiLU(GN(x))) (openaimodel.py:301-306)
                             araw[j][1] = ld4(p0 + c.stride);
@@ -404,49 +423,54 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
                         }
                     };
                     auto issue_coef = [&](const S& c) { kq.p = ld4(c.ka + c4 * 4); kq.q = ld4(c.kb + c4 * 4); };
+                    // Branch-free: an item slot past the end of the tile is a DUPLICATE of the tile's last pixel (same source
+                    // row, same channel quad as the thread that owns it, hence the same bytes to the same LDS address).  A
+                    // branch per item made six separate basic blocks: the six dependency chains (affine -> exp -> rcp -> split)
+                    // ran one after the other, and next to an MFMA wave a single serial chain gets ~2 issue slots per MFMA
+                    // (measured 7.9k cycles for ~400 instructions per chunk -- the loaders paced the whole block).
                     auto finish = [&](int slot, int j) {
-                        if (live[j]) {
-                            const bool ok = (valid1 >> j) & 1u;
-                            f32x4 v = transform(araw[j][0], ok);
-                            if constexpr (NS == 4)
-                                v = 0.25f * (v + transform(araw[j][1], ok) + transform(araw[j][2], ok) + transform(araw[j][3], ok));
-                            lds_store_act<PREC>(As + (size_t)(slot % NA) * a_floats + (size_t)pixj[j] * LDA, c4, v);
-                        }
+                        const bool ok = (valid1 >> j) & 1u;
+                        f32x4 v = transform(araw[j][0], ok);
+                        if constexpr (NS == 4)
+                            v = 0.25f * (v + transform(araw[j][1], ok) + transform(araw[j][2], ok) + transform(araw[j][3], ok));
+                        if (!ABL(1024)) lds_store_act<PREC>(As + (size_t)(slot % NA) * a_floats + (size_t)pixj[j] * LDA, c4, v);
+                        else KEEP_LIVE(v);
                     };
-                    // ---- prologue: chunk 0 staged synchronously, chunk 1 requested
-                    S s1, s2;
-                    s2.k = 0; s2.chunk = 0; fill(s2);
+                    // ---- ONE barrier per chunk; the loaders run two chunks ahead of the compute waves in LDS (ring of 3)
+                    // and three ahead in global memory: in period q they transform chunk q+2 (requested in period q-1) into
+                    // slot (q+2) % 3 and request chunk q+3.  Prologue: chunk 0 staged synchronously; period 0 additionally
+                    // stages chunk 1 (the compute waves read it only after barrier 1).
+                    S s2;                                               // chunk whose raw rows are in flight / in registers
+                    auto stage = [&](int slot) {                        // transform the chunk under s2, request the next one
+                        valid1 = valid2;
+                        auto finish_all = [&]() {
+#pragma unroll
+                            for (int j = 0; j < AJ; ++j) finish(slot, j);
+                        };
+#ifdef SGDM_PROBE_DRAIN
+                        __builtin_amdgcn_s_waitcnt(0x0F70);             // vmcnt(0): exclude the load wait from the phase time
+#endif
+                        PROBE_EPI(finish_all());                        // probe build: cycles of the transform phase
+                        const int kprev = s2.k;
+                        s2 = advance(s2);
+                        if (s2.k != kprev) load_rows(s2.k);
+                        issue_coef(s2);
+#pragma unroll
+                        for (int j = 0; j < AJ; ++j) issue_item(s2, j);
+                    };
+                    s2.k = 0; s2.chunk = 0; s2.img0 = tile_at(g, lin_of(0), BN, TW, TH).img0; fill(s2);
                     load_rows(0);
-                    valid1 = valid2;
                     issue_coef(s2);
 #pragma unroll
                     for (int j = 0; j < AJ; ++j) issue_item(s2, j);
-#pragma unroll
-                    for (int j = 0; j < AJ; ++j) finish(0, j);
-                    s2 = advance(s2);                                   // chunk 1
-                    if (s2.k != 0) load_rows(s2.k);
-#pragma unroll
-                    for (int j = 0; j < AJ; ++j) issue_item(s2, j);
-                    if (!LATE) issue_coef(s2);
-                    SYNC();
+                    stage(0);                                           // chunk 0 -> slot 0, request chunk 1
+                    SYNC();                                             // barrier 0
+                    stage(1);                                           // period 0: chunk 1 -> slot 1, request chunk 2
                     for (int q = 0; q < Q; ++q) {
-                        // tap 0: chunk q+1 becomes the one being transformed, chunk q+2 the one being requested
-                        s1 = s2;
-                        valid1 = valid2;
-                        s2 = advance(s2);
-                        if (s2.k != s1.k) load_rows(s2.k);
-                        if (LATE) issue_coef(s1);
-                        SYNC();
-#pragma unroll
-                        for (int t = 1; t < 9; ++t) {                                              // taps 1..8
-                            if (t >= T0 && t < T0 + AJ) {
-                                finish(q + 1, t - T0);
-                                issue_item(s2, t - T0);
-                            }
-                            if (!LATE && t == 7) issue_coef(s2);
-                            if (t == 8 && q + 3 < Q && (q + 3) % nchunks == 0) build_pixtab((q + 3) / nchunks, lt, LT);
-                            SYNC();
-                        }
+                        stage((q + 2) % NA);                            // chunk q+2 -> slot (q+2) % 3, request chunk q+3
+                        // table of the tile that chunk q+4 opens (read by load_rows one period later)
+                        if (q + 4 < Q && (q + 4) % nchunks == 0) build_pixtab((q + 4) / nchunks, lt, LT);
+                        SYNC();                                         // barrier q+1
                     }
                 };
                 if (a.resample == SGD_RS_AVGPOOL2) go(std::false_type(), std::true_type());
@@ -576,7 +600,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
         struct TabRef { const int2* tab; long m0; };
         auto tabref = [&](int k) {
             TabRef t;
-            t.tab = pixtab + (size_t)(k % 3) * g.pix;
+            t.tab = pixtab + (size_t)(k & 3) * g.pix;
             t.m0 = CONV ? 0 : tile_at(g, lin_of(k), BN, TW, TH).m0;
             return t;
         };
@@ -637,22 +661,17 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
         };
 
         if (CONV) {
+            // ONE barrier per chunk, loaders two chunks ahead in LDS (see the lean loader above)
             constexpr int AJ = (FAST_PIX * 8 + A_THREADS - 1) / A_THREADS;   // item slots per thread (6)
             stage_A_sync(0, 0);
             if (DBG(1)) {
-                SYNC();
-                for (int q = 0; q < Q; ++q)
-#pragma unroll
-                    for (int t = 0; t < 9; ++t) SYNC();
+                for (int q = 0; q <= Q; ++q) SYNC();
             } else if (g.fast_a && a.resample != SGD_RS_AVGPOOL2) {
-                // Split-phase staging, one item per K step: at tap t (1..AJ) a thread transforms the raw row quad it
-                // requested NINE steps earlier (chunk q+1) into LDS and re-uses the register for the same item of chunk
-                // q+2.  Every tap carries the same small amount of loader work (the per-step barrier makes the slowest
-                // wave of a step the pace of the block), no load is consumed sooner than 3 steps after its issue and
-                // none sits behind a branch (the in-order vmcnt stays exact).
+                // Split-phase staging: the raw row quads of chunk q+3 are requested in period q and transformed into LDS
+                // in period q+1, so no load is consumed sooner than a whole chunk (9 K steps) after its issue and none
+                // sits behind a branch (the in-order vmcnt stays exact).
                 const bool uni = VEC && g.nb == 1 && a.pro == SGD_PRO_AFFINE_NC;
                 const bool kshared = uni || a.pro == SGD_PRO_NONE;
-                const bool lean = VEC && kshared && a.drop_p == 0.f;       // the ResBlock convs of the sampler
                 f32x4 araw[AJ];
                 Coef kq;
                 struct Ctx { const int2* tab; int c; int chunk; long ko; };
@@ -661,159 +680,47 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
                     Ctx cx;
                     const int k = q / nchunks;
                     cx.chunk = q - k * nchunks;
-                    cx.tab = pixtab + (size_t)(k % 3) * g.pix;
+                    cx.tab = pixtab + (size_t)(k & 3) * g.pix;
                     cx.c = cx.chunk * KC + c4 * 4;
                     // per-image GroupNorm coefficients of this thread's channel quad (tile = one image)
                     cx.ko = (long)tile_at(g, lin_of(k), BN, TW, TH).img0 * cin + (cx.c < cin ? cx.c : 0);
                     return cx;
                 };
-                auto issue_item = [&](const Ctx& cx, int j) {
+                Ctx cx = ctx_of(1);
+                auto request = [&]() {
                     TabRef tr;
                     tr.tab = cx.tab;
                     tr.m0 = 0;
-                    araw[j] = raw_item(tr, lt + j * A_THREADS, cx.c);
-                };
-                auto issue_coef = [&](const Ctx& cx) {
                     // other prologues read 32 harmless bytes of the input instead of branching around the loads
                     kq.p = ld4(uni ? a.pa + cx.ko : a.x0);
                     kq.q = ld4(uni ? a.pb + cx.ko : a.x0);
+#pragma unroll
+                    for (int j = 0; j < AJ; ++j) araw[j] = raw_item(tr, lt + j * A_THREADS, cx.c);
                 };
-                auto finish = [&](int slot, const Ctx& cx, int j) {
+                auto stage = [&](int slot, int qnext) {
                     TabRef tr;
                     tr.tab = cx.tab;
                     tr.m0 = 0;
-                    finish_item(slot, tr, cx.chunk, lt + j * A_THREADS, araw[j], kshared ? &kq : nullptr);
-                };
-                auto run = [&]() {
-                    Ctx cx1 = ctx_of(1), cx2 = ctx_of(2);
 #pragma unroll
-                    for (int j = 0; j < AJ; ++j) issue_item(cx1, j);
-                    issue_coef(cx1);
+                    for (int j = 0; j < AJ; ++j)
+                        finish_item(slot, tr, cx.chunk, lt + j * A_THREADS, araw[j], kshared ? &kq : nullptr);
+                    cx = ctx_of(qnext);
+                    request();
+                };
+                request();
+                SYNC();                                                  // barrier 0
+                stage(1, 2);
+                for (int q = 0; q < Q; ++q) {
+                    stage(q + 2, q + 3);
+                    if (q + 4 < Q && (q + 4) % nchunks == 0) build_pixtab((q + 4) / nchunks, lt, A_THREADS);
                     SYNC();
-                    for (int q = 0; q < Q; ++q) {
-                        SYNC();                                                                    // tap 0
-#pragma unroll
-                        for (int t = 1; t < 8; ++t) {                                              // taps 1..7
-                            if (t <= AJ) {
-                                finish(q + 1, cx1, t - 1);
-                                issue_item(cx2, t - 1);
-                            }
-                            if (t == 7) {
-                                cx1 = cx2;
-                                cx2 = ctx_of(q + 3);
-                                issue_coef(cx1);
-                            }
-                            SYNC();
-                        }
-                        // tap 8: table of the tile that chunk q+3 opens (its rows are requested from tap 1 of chunk q+1 on)
-                        if (q + 3 < Q && (q + 3) % nchunks == 0) build_pixtab((q + 3) / nchunks, lt, A_THREADS);
-                        SYNC();
-                    }
-                };
-                // Shared-coefficient case that missed the lean loader above only through its geometry (e.g. dropout off but a
-                // partial last chunk): per-tile work hoisted, source rows and padding flags read from the tile table once
-                // per tile, the chunk's source pointer / stride / coefficient pointer wave-uniform scalars.
-                auto run_lean = [&](auto latec) {
-                    constexpr bool LATE = decltype(latec)::value;
-                    constexpr int T0 = LATE ? 5 : 1;
-                    int pixj[AJ], rows2[AJ];
-                    bool live[AJ];
-#pragma unroll
-                    for (int j = 0; j < AJ; ++j) {
-                        const int idx = lt + j * A_THREADS;
-                        live[j] = idx < items;
-                        pixj[j] = (live[j] ? idx : items - 1) >> 3;
-                    }
-                    unsigned valid1 = 0, valid2 = 0;
-                    auto load_rows = [&](int k) {
-                        const int2* tab = pixtab + (size_t)(k % 3) * g.pix;
-                        valid2 = 0;
-#pragma unroll
-                        for (int j = 0; j < AJ; ++j) {
-                            const int ex = tab[pixj[j]].x;
-                            rows2[j] = ex < 0 ? 0 : ex;
-                            if (ex >= 0 && live[j]) valid2 |= 1u << j;
-                        }
-                    };
-                    struct S { int k, chunk; const float* src; int stride; const float* ka; const float* kb; };
-                    auto fill = [&](S& c) {              // derived fields of (k, chunk)
-                        const int ch = c.chunk * KC;
-                        if (ch < a.c0) { c.src = a.x0 + ch; c.stride = a.c0; }
-                        else { c.src = a.x1 + (ch - a.c0); c.stride = a.c1; }
-                        const long ko = (long)tile_at(g, lin_of(c.k), BN, TW, TH).img0 * cin + ch;
-                        c.ka = uni ? a.pa + ko : a.x0;   // no prologue: 32 harmless bytes instead of a branch around the load
-                        c.kb = uni ? a.pb + ko : a.x0;
-                    };
-                    auto advance = [&](S c) {            // next chunk of the stream, clamped at its end
-                        if (++c.chunk == nchunks) {
-                            if (c.k + 1 < ntiles) { c.chunk = 0; ++c.k; }
-                            else c.chunk = nchunks - 1;
-                        }
-                        fill(c);
-                        return c;
-                    };
-                    auto issue_item = [&](const S& c, int j) { araw[j] = ld4(c.src + (long)rows2[j] * c.stride + c4 * 4); };
-                    auto issue_coef = [&](const S& c) { kq.p = ld4(c.ka + c4 * 4); kq.q = ld4(c.kb + c4 * 4); };
-                    auto finish = [&](int slot, int j) {
-                        if (live[j]) {
-                            f32x4 v = araw[j];
-                            if (uni) v = v * kq.p + kq.q;
-                            if (a.pro_silu) {
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) v[e] = sgd_silu(v[e]);
-                            }
-                            if (!((valid1 >> j) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};
-                            lds_store_act<PREC>(As + (size_t)(slot % NA) * a_floats + (size_t)pixj[j] * LDA, c4, v);
-                        }
-                    };
-                    S s1, s2;
-                    s2.k = 0; s2.chunk = 0; fill(s2);
-                    s2 = advance(s2);                                   // chunk 1
-                    s1 = s2;
-                    load_rows(s2.k);
-#pragma unroll
-                    for (int j = 0; j < AJ; ++j) issue_item(s2, j);
-                    if (!LATE) issue_coef(s2);
-                    SYNC();
-                    for (int q = 0; q < Q; ++q) {
-                        // tap 0: chunk q+1 becomes the one being transformed, chunk q+2 the one being requested
-                        s1 = s2;
-                        valid1 = valid2;
-                        s2 = advance(s2);
-                        if (s2.k != s1.k) load_rows(s2.k);
-                        if (LATE) issue_coef(s1);
-                        SYNC();
-#pragma unroll
-                        for (int t = 1; t < 8; ++t) {                                              // taps 1..7
-                            if (t >= T0 && t < T0 + AJ) {
-                                finish(q + 1, t - T0);
-                                issue_item(s2, t - T0);
-                            }
-                            if (!LATE && t == 7) issue_coef(s2);
-                            SYNC();
-                        }
-                        if (LATE) {                                                                // tap 8
-                            finish(q + 1, 8 - T0);
-                            issue_item(s2, 8 - T0);
-                        }
-                        if (q + 3 < Q && (q + 3) % nchunks == 0) build_pixtab((q + 3) / nchunks, lt, A_THREADS);
-                        SYNC();
-                    }
-                };
-                const bool lean2 = lean && cin % KC == 0 && (a.c1 == 0 || a.c0 % KC == 0);
-                if (lean2) {
-                    run_lean(std::false_type());
-                } else {
-                    run();
                 }
             } else {
-                SYNC();
+                SYNC();                                                  // barrier 0
+                stage_A_sync(1, 1);
                 for (int q = 0; q < Q; ++q) {
-                    SYNC();                                                                        // tap 0
-                    stage_A_sync(q + 1, q + 1);                                                    // tap 1
-#pragma unroll
-                    for (int t = 1; t < 8; ++t) SYNC();
-                    if (q + 3 < Q && (q + 3) % nchunks == 0) build_pixtab((q + 3) / nchunks, lt, A_THREADS);
+                    stage_A_sync(q + 2, q + 2);
+                    if (q + 4 < Q && (q + 4) % nchunks == 0) build_pixtab((q + 4) / nchunks, lt, A_THREADS);
                     SYNC();
                 }
             }
@@ -921,7 +828,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
     // K step (>= 768 matrix-pipe cycles) to return from L2; their vmcnt waits are the compiler's (plain loads).
     typename FragT::A fa[2];
     typename FragT::B fb[NKS];
-    auto do_step = [&](const float* const* ap, const float* const* nap, const char* wnext) {
+    auto do_step = [&](const float* const* ap, const float* const* nap, const char* wnext, auto barrier_after) {
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) {
             __builtin_amdgcn_s_waitcnt(0xC07F);                        // lgkmcnt(0) only
@@ -953,7 +860,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        SYNC();
+        if constexpr (decltype(barrier_after)::value) SYNC();
     };
     const int rowstep = g.hw * LDA;                // LDS floats between halo rows
 
@@ -968,6 +875,12 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
         fa[0].load(ap0, 0, lh);
     }
     int aslot = 0;                                 // ring position of the current chunk
+    // CONV: ONE barrier per 32-channel chunk (9 K steps).  The weights never pass through LDS and the input tile of a
+    // chunk is immutable while its 9 taps run, so nothing inside a chunk needs the loaders: period q (between barriers
+    // q and q+1) computes chunk q from ring slot q % 3 and, at its end, prefetches the first fragments of chunk q+1
+    // (slot complete since barrier q), while the loaders fill slot (q+2) % 3 (last read in period q-1).  Only the very
+    // first period is different: chunk 1 is still being written during it, so its fragments are read after barrier 1.
+    bool first_period = CONV;
     for (int k = 0; k < ntiles; ++k) {
 #pragma unroll
         for (int i = 0; i < MT; ++i)
@@ -995,8 +908,23 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt) { ap[mt] = acur + toff + aoff[mt]; nap[mt] = nab + ntoff + aoff[mt]; }
                     const char* wnext = wp + wstep;
-                    if (tap + 1 == TAPS && last_chunk) wnext = wseam ? wseam : wp;
-                    do_step(ap, nap, wnext);
+                    if (tap + 1 == TAPS) {
+                        if (last_chunk) wnext = wseam ? wseam : wp;
+                        if (first_period) {
+#pragma unroll
+                            for (int mt = 0; mt < MT; ++mt) nap[mt] = acur + aoff[mt];      // harmless: re-read below
+                        }
+                        do_step(ap, nap, wnext, std::true_type());
+                        if (first_period) {
+                            const float* rp[MT];
+#pragma unroll
+                            for (int mt = 0; mt < MT; ++mt) rp[mt] = anext + aoff[mt];
+                            fa[0].load(rp, 0, lh);                 // NKS is even: the next sub-step uses fa[0]
+                            first_period = false;
+                        }
+                    } else {
+                        do_step(ap, nap, wnext, std::false_type());
+                    }
                     wp = wnext;
                 }
             } else {
@@ -1006,7 +934,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
                 for (int mt = 0; mt < MT; ++mt) { ap[mt] = acur + aoff[mt]; nap[mt] = anext + aoff[mt]; }
                 const char* wnext = wp + wstep;
                 if (last_chunk) wnext = wseam ? wseam : wp;
-                do_step(ap, nap, wnext);
+                do_step(ap, nap, wnext, std::true_type());
                 wp = wnext;
             }
             aslot = naslot;
@@ -1315,14 +1243,14 @@ static int make_geo(const sgd_igemm_args& a, Geo& g, int bn, int& na) {
         g.hw = a.stride == 2 ? 2 * tw + 1 : tw + 2;
         // the double-buffered halo tile must fit LDS; rows of images beyond nb are computed on don't-care data and
         // masked in the epilogue
-        while (nb > 1 && 2 * (size_t)nb * g.hh * g.hw * LDA * 4 + (size_t)nb * g.hh * g.hw * 24 > 150 * 1024)
+        while (nb > 1 && 3 * (size_t)nb * g.hh * g.hw * LDA * 4 + (size_t)nb * g.hh * g.hw * 32 > 150 * 1024)
             nb >>= 1;
         g.tw_l2 = ilog2(tw); g.th_l2 = ilog2(th); g.nb = nb;
         g.tiles_x = a.wo / tw; g.tiles_y = a.ho / th;
         g.pix = nb * g.hh * g.hw;
         g.mt = ((a.n + nb - 1) / nb) * g.tiles_x * g.tiles_y;
         g.fast_a = g.pix <= FAST_PIX ? 1 : 0;
-        na = 2;
+        na = 3;
     } else if (a.mode == SGD_MODE_FLAT) {
         if (a.m <= 0) return SGD_ERR_ARG;
         if (a.pro == SGD_PRO_AFFINE_NC && a.rows_per_n <= 0) return SGD_ERR_ARG;
@@ -1337,7 +1265,7 @@ static int make_geo(const sgd_igemm_args& a, Geo& g, int bn, int& na) {
     }
     // epilogue statistics (args.stats): whole 128-row tiles of ONE image, 16-byte stores
     g.sparts = 0;
-    const int ppt = bn == 128 ? 2 : 4;                        // M slices per tile = compute-wave rows
+    const int ppt = bn == 128 ? 1 : 4;                        // M slices per tile = compute-wave rows
     if (((a.cout | a.y_ld) & 3) == 0 && a.orows_in == 0) {
         if (a.mode == SGD_MODE_CONV3) {
             if (g.nb == 1 && (1 << (g.tw_l2 + g.th_l2)) == BM) g.sparts = g.tiles_x * g.tiles_y * ppt;
@@ -1394,7 +1322,7 @@ extern "C" int sgd_igemm(const sgd_igemm_args* args, void* stream) {
         g.trace = tp ? reinterpret_cast<unsigned long long*>(strtoull(tp, nullptr, 0)) : nullptr;
     }
 #endif
-    const size_t smem = (size_t)na * g.pix * LDA * sizeof(float) + (size_t)g.pix * 24;
+    const size_t smem = (size_t)na * g.pix * LDA * sizeof(float) + (size_t)g.pix * 32;
     if (smem > 160 * 1024) return SGD_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     const bool conv = a.mode == SGD_MODE_CONV3;

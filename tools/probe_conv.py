@@ -41,9 +41,10 @@ if not a.plain:
 g.w, g.cin_p, g.cout_p, g.bias = buf.data_ptr(), cp.value, op.value, bias.data_ptr()
 g.y, g.cout, g.y_ld, g.prec = y.data_ptr(), cout, cout, prec
 for _ in range(20): L.check(lib.sgd_igemm(C.byref(g), st), "igemm")
-stamps = torch.zeros(8192 * 12 * 4, dtype=torch.int64, device=dev)
+NW = 8                                     # waves per block (4 MFMA + 4 input loaders)
+stamps = torch.zeros(8192 * NW * 4, dtype=torch.int64, device=dev)
 os.environ["SGDM_STAMP_PTR"] = hex(stamps.data_ptr())
-trace = torch.zeros(16 * 12 * 512 * 2, dtype=torch.int64, device=dev)
+trace = torch.zeros(16 * NW * 512 * 2, dtype=torch.int64, device=dev)
 if a.trace:
     os.environ["SGDM_TRACE_PTR"] = hex(trace.data_ptr())
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -51,21 +52,21 @@ torch.cuda.synchronize(); e0.record()
 L.check(lib.sgd_igemm(C.byref(g), st), "igemm")
 e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1)
-s = stamps.cpu().view(-1, 12, 4)
+s = stamps.cpu().view(-1, NW, 4)
 s = s[s[:, 0, 0] > 0]                      # blocks that ran
 fl = 2.0 * n * hw * hw * cout * cin * a.ks * a.ks
 print(f"cin={cin} cout={cout} hw={hw} ks={a.ks} prec={a.prec} dbg={a.dbg}: {ms:.4f} ms {fl/ms/1e9:.1f} TF  blocks={len(s)}")
-for role, name, waves in ((0, "compute", slice(0, 4)), (1, "A loader", slice(4, 10)), (2, "B loader", slice(10, 12))):
+for role, name, waves in ((0, "compute", slice(0, 4)), (1, "loader", slice(4, 8))):
     r = s[:, waves, :].double()
     tot, bar, nb = r[..., 0].mean(), r[..., 1].mean(), r[..., 2].mean()
     print(f"  {name:9s}: total {tot:9.0f} cyc  barriers {nb:6.0f}  per-barrier-interval {tot/nb:7.0f} cyc  in-barrier {bar/nb:7.0f} cyc ({100*bar/tot:4.1f}%)  work {(tot-bar)/nb:7.0f}  epilogue total {r[..., 3].mean():8.0f} ({100*r[..., 3].mean()/tot:4.1f}%)")
 
 r = s.double()
-print("  per-wave work/step:", " ".join(f"{((r[:, w, 0] - r[:, w, 1]) / r[:, w, 2]).mean():6.0f}" for w in range(12)))
-print("  per-wave in-barrier:", " ".join(f"{(r[:, w, 1] / r[:, w, 2]).mean():6.0f}" for w in range(12)))
+print("  per-wave work/step:", " ".join(f"{((r[:, w, 0] - r[:, w, 1]) / r[:, w, 2]).mean():6.0f}" for w in range(NW)))
+print("  per-wave in-barrier:", " ".join(f"{(r[:, w, 1] / r[:, w, 2]).mean():6.0f}" for w in range(NW)))
 
 if a.trace:
-    tr = trace.cpu().view(16, 12, 512, 2).double()
+    tr = trace.cpu().view(16, NW, 512, 2).double()
     nb = int(s[0, 0, 2])
     # work of wave w in interval i = arrival(i) - release(i-1); step phase = (i - 1) % 9 for the conv stream
     work = tr[:, :, 1:nb, 0] - tr[:, :, 0:nb - 1, 1]           # [blk, wave, nb-1]
@@ -73,7 +74,7 @@ if a.trace:
     span = tr[:, :, 1:nb, 1] - tr[:, :, 0:nb - 1, 1]
     ph = torch.arange(nb - 1) % 9
     print("  phase (tap):        " + " ".join(f"{p:6d}" for p in range(9)))
-    for w in range(12):
+    for w in range(NW):
         print(f"  wave {w:2d} work      : " + " ".join(f"{work[:, w, ph == p].mean():6.0f}" for p in range(9)))
     print("  step span (wave 0): " + " ".join(f"{span[:, 0, ph == p].mean():6.0f}" for p in range(9)))
     print("  min wait over waves:" + " ".join(f"{wait[:, :, ph == p].min(dim=1).values.mean():6.0f}" for p in range(9)))
