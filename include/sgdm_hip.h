@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define SGD_ABI_VERSION 4
+#define SGD_ABI_VERSION 5
 int sgd_abi_version(void);
 
 /* --------------------------------------------------------------------------------------
@@ -61,7 +61,8 @@ typedef struct sgd_igemm_args {
     const float* pa;       /* AFFINE_NC: a[n, C]      LN_ROW: stats[row, 2] = (mean, rstd) */
     const float* pb;       /* AFFINE_NC: b[n, C]      LN_ROW: gamma[C] */
     const float* pc;       /*                         LN_ROW: beta[C] or NULL */
-    /* weights packed by sgd_pack_weight: [taps][cout_p][cin_p] (precision-specific element) */
+    /* weights packed by sgd_pack_weight: MFMA fragment order, 4 KiB units [cin_p/32][taps][cout_p/32] of
+       32 output x 32 input channels (csrc/igemm.hip: pack_weight_kernel); opaque to the caller */
     const void* w;
     int32_t cin_p, cout_p;
     const float* bias;     /* [cout] or NULL */
@@ -191,6 +192,17 @@ int sgd_ddpm_step(const float* x, const float* eps_nhwc, const float* z, int32_t
 int sgd_ddim_step(const float* x, const float* eps_nhwc, const float* z, int32_t cfg_mode, float w,
                   const float* coef /* HOST [4]: sqrt_one_minus_at, a_t, a_prev, sigma_t */, float temperature,
                   int32_t clip, int32_t b, int32_t c, int32_t hw, float* x_out, float* x0_out, void* stream);
+/* The same two steps with the per-step coefficients read from DEVICE memory (coef_dev[5] / coef_dev[4], same meaning as
+ * above) and x updated IN PLACE (x_out == x allowed: the update is elementwise).  With the UNet inputs (x, t) and these
+ * coefficients in fixed device buffers, one sampling step = UNet program + this launch has no by-value argument that
+ * changes between steps, so it can be captured into a hipGraph once per trajectory and replayed
+ * (sgdm_amd/diffusion.py: _GraphedStep; reference loop: ddpm_sampler.py:194-238, ddim_plms_sampler.py:302-344). */
+int sgd_ddpm_step_dev(const float* x, const float* eps_nhwc, const float* z, int32_t cfg_mode, float w,
+                      const float* coef_dev, int32_t clip, int32_t b, int32_t c, int32_t hw,
+                      float* x_out, float* x0_out, void* stream);
+int sgd_ddim_step_dev(const float* x, const float* eps_nhwc, const float* z, int32_t cfg_mode, float w,
+                      const float* coef_dev, float temperature, int32_t clip, int32_t b, int32_t c, int32_t hw,
+                      float* x_out, float* x0_out, void* stream);
 /* ((x+1)*127.5).clamp(0,255).to(uint8)  (diffusion_utils/util.py:99-100) */
 int sgd_to_uint8(const float* x, int64_t count, uint8_t* out, void* stream);
 /* guided eps only (forward_with_cond_scale return value): eps_nhwc [2b,h,w,c] -> NCHW [b,c,h,w] */

@@ -81,11 +81,16 @@ __device__ __forceinline__ float guided(const float* __restrict__ eps, int cfg_m
 
 struct Coef5 { float v[5]; };
 
-__global__ void ddpm_step_kernel(const float* __restrict__ x, const float* __restrict__ eps,
-                                 const float* __restrict__ z, int cfg_mode, float w, Coef5 k, int clip, int b, int c,
-                                 int hw, float* __restrict__ x_out, float* __restrict__ x0_out) {
+// x / x_out carry no __restrict__: the graph-replayed form updates x in place
+__global__ void ddpm_step_kernel(const float* x, const float* __restrict__ eps,
+                                 const float* __restrict__ z, int cfg_mode, float w, Coef5 k, const float* kdev, int clip,
+                                 int b, int c, int hw, float* x_out, float* __restrict__ x0_out) {
     const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
     if (i >= (long)b * c * hw) return;
+    if (kdev) {
+#pragma unroll
+        for (int j = 0; j < 5; ++j) k.v[j] = kdev[j];
+    }
     const int p = i % hw;
     const long t = i / hw;
     const int cc = t % c, n = t / c;
@@ -98,12 +103,16 @@ __global__ void ddpm_step_kernel(const float* __restrict__ x, const float* __res
     if (x0_out) x0_out[i] = x0;
 }
 
-__global__ void ddim_step_kernel(const float* __restrict__ x, const float* __restrict__ eps,
-                                 const float* __restrict__ z, int cfg_mode, float w, Coef5 k, float temperature,
-                                 int clip, int b, int c, int hw, float* __restrict__ x_out,
+__global__ void ddim_step_kernel(const float* x, const float* __restrict__ eps,
+                                 const float* __restrict__ z, int cfg_mode, float w, Coef5 k, const float* kdev,
+                                 float temperature, int clip, int b, int c, int hw, float* x_out,
                                  float* __restrict__ x0_out) {
     const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
     if (i >= (long)b * c * hw) return;
+    if (kdev) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) k.v[j] = kdev[j];
+    }
     const int p = i % hw;
     const long t = i / hw;
     const int cc = t % c, n = t / c;
@@ -195,7 +204,19 @@ extern "C" int sgd_ddpm_step(const float* x, const float* eps_nhwc, const float*
     Coef5 k;
     for (int i = 0; i < 5; ++i) k.v[i] = coef[i];
     hipLaunchKernelGGL(ddpm_step_kernel, dim3(nblk((long)b * c * hw)), dim3(256), 0, (hipStream_t)stream, x, eps_nhwc,
-                       z, cfg_mode, w, k, clip, b, c, hw, x_out, x0_out);
+                       z, cfg_mode, w, k, (const float*)nullptr, clip, b, c, hw, x_out, x0_out);
+    return sgd_check_launch();
+}
+
+extern "C" int sgd_ddpm_step_dev(const float* x, const float* eps_nhwc, const float* z, int32_t cfg_mode, float w,
+                                 const float* coef_dev, int32_t clip, int32_t b, int32_t c, int32_t hw, float* x_out,
+                                 float* x0_out, void* stream) {
+    SGD_CLEAR_ERR();
+    if (!x || !eps_nhwc || !z || !coef_dev || !x_out || b <= 0 || c <= 0 || hw <= 0 || cfg_mode < 0 || cfg_mode > 2)
+        return SGD_ERR_ARG;
+    Coef5 k = {};
+    hipLaunchKernelGGL(ddpm_step_kernel, dim3(nblk((long)b * c * hw)), dim3(256), 0, (hipStream_t)stream, x, eps_nhwc,
+                       z, cfg_mode, w, k, coef_dev, clip, b, c, hw, x_out, x0_out);
     return sgd_check_launch();
 }
 
@@ -209,7 +230,19 @@ extern "C" int sgd_ddim_step(const float* x, const float* eps_nhwc, const float*
     for (int i = 0; i < 4; ++i) k.v[i] = coef[i];
     k.v[4] = 0.f;
     hipLaunchKernelGGL(ddim_step_kernel, dim3(nblk((long)b * c * hw)), dim3(256), 0, (hipStream_t)stream, x, eps_nhwc,
-                       z, cfg_mode, w, k, temperature, clip, b, c, hw, x_out, x0_out);
+                       z, cfg_mode, w, k, (const float*)nullptr, temperature, clip, b, c, hw, x_out, x0_out);
+    return sgd_check_launch();
+}
+
+extern "C" int sgd_ddim_step_dev(const float* x, const float* eps_nhwc, const float* z, int32_t cfg_mode, float w,
+                                 const float* coef_dev, float temperature, int32_t clip, int32_t b, int32_t c, int32_t hw,
+                                 float* x_out, float* x0_out, void* stream) {
+    SGD_CLEAR_ERR();
+    if (!x || !eps_nhwc || !z || !coef_dev || !x_out || b <= 0 || c <= 0 || hw <= 0 || cfg_mode < 0 || cfg_mode > 2)
+        return SGD_ERR_ARG;
+    Coef5 k = {};
+    hipLaunchKernelGGL(ddim_step_kernel, dim3(nblk((long)b * c * hw)), dim3(256), 0, (hipStream_t)stream, x, eps_nhwc,
+                       z, cfg_mode, w, k, coef_dev, temperature, clip, b, c, hw, x_out, x0_out);
     return sgd_check_launch();
 }
 

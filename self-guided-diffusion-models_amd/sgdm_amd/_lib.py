@@ -20,7 +20,7 @@ RS_NONE, RS_AVGPOOL2, RS_UP2, RS_ZEROUP2 = 0, 1, 2, 3
 PRO_NONE, PRO_AFFINE_NC, PRO_LN_ROW = 0, 1, 2
 PREC_F32, PREC_F16X3, PREC_BF16X3 = 0, 1, 2
 PREC_BY_NAME = {"f32": PREC_F32, "f16x3": PREC_F16X3, "bf16x3": PREC_BF16X3}
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
@@ -77,6 +77,8 @@ SIGNATURES = {
     "sgd_fill_null_kv": (i32, [vp, i32, i32, i32, i32, vp, vp]),
     "sgd_ddpm_step": (i32, [vp, vp, vp, i32, f32, C.POINTER(f32), i32, i32, i32, i32, vp, vp, vp]),
     "sgd_ddim_step": (i32, [vp, vp, vp, i32, f32, C.POINTER(f32), f32, i32, i32, i32, i32, vp, vp, vp]),
+    "sgd_ddpm_step_dev": (i32, [vp, vp, vp, i32, f32, vp, i32, i32, i32, i32, vp, vp, vp]),
+    "sgd_ddim_step_dev": (i32, [vp, vp, vp, i32, f32, vp, f32, i32, i32, i32, i32, vp, vp, vp]),
     "sgd_to_uint8": (i32, [vp, i64, vp, vp]),
     "sgd_cfg_combine": (i32, [vp, i32, f32, i32, i32, i32, vp, vp]),
 }

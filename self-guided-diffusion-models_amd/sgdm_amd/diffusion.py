@@ -13,6 +13,7 @@ per-step mask uniform_ and z) are kept in the reference's order so seeded runs l
 """
 import copy
 import ctypes as C
+import os
 from functools import partial
 
 import numpy as np
@@ -110,6 +111,85 @@ class _StepRunner:
                 return eng.eps_nhwc, m._scale_mode(), float(w), B, Cc
         e = self.fn(x, t, **self.kwargs)            # generic path: guided eps, NCHW
         return e.contiguous(), 0, 0.0, B * Cc, 1
+
+
+class _GraphedStep:
+    """One CFG sampling step -- UNet at 2B (~135 launches) + the fused update -- captured ONCE per trajectory into a
+    hipGraph (``torch.cuda.CUDAGraph`` capture of the stream the C-ABI launchers are given) and replayed per step.
+
+    Everything a step varies lives in fixed device buffers the captured kernels read: ``img`` (updated in place by
+    ``sgd_*_step_dev``), ``t`` [B], ``coef`` (row of the per-step table), ``z`` and the cond-drop mask.  The RNG draws
+    (``z``, the mask's ``uniform_``) stay OUTSIDE the graph, in the reference's order, so seeded trajectories are the
+    same with and without the graph.  Host work per step: 5 tiny torch ops + one graph launch instead of ~140 ctypes
+    launches -- irrelevant at UNet batch 80 (21 ms of GPU work per step) and the difference between host-bound and
+    device-bound at C1 size (ch=64, 32x32, bs=8).  Reference loops: ddpm_sampler.py:194-238, ddim_plms_sampler.py:302-344.
+    """
+
+    def __init__(self, runner, img, kind, clip, temperature=1.0):
+        m = runner.model
+        self.m, self.lib, self.kind = m, runner.lib, kind
+        B, Cc = img.shape[0], img.shape[1]
+        hw = int(np.prod(img.shape[2:]))
+        dev = img.device
+        self.img = img
+        self.t = torch.zeros(B, dtype=torch.long, device=dev)
+        self.coef = torch.zeros(5, dtype=torch.float32, device=dev)
+        self.z = torch.empty_like(img)
+        kw = runner.kwargs
+        self.has_mask = (m._cond_width > 0) or (m._in_ch_total > m.in_channels)
+        self.u = torch.zeros(2 * B, device=dev)
+        self.p = torch.cat((torch.full((B,), 0.0, device=dev), torch.full((B,), 1.0, device=dev)))
+        self.mask = torch.zeros(2 * B, dtype=torch.bool, device=dev)
+        prec = L.PREC_BY_NAME[m.hip_precision]
+        eng = m._engine(2 * B, img.shape[2], img.shape[3], prec)
+        self.eng = eng
+        eng.prepare(img, self.t, kw.get("cond"), kw.get("layout"), self.mask if self.has_mask else None)
+        self._inputs = eng._keep_inputs                 # the captured launches read these buffers on every replay
+        w, mode = float(kw["cond_scale"]), m._scale_mode()
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            if not getattr(eng, "ran", False):
+                eng.launch(side.cuda_stream)            # one-time function attributes are set outside the capture
+            side.synchronize()
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph, stream=side):
+                st = torch.cuda.current_stream(dev).cuda_stream
+                eng.launch(st)
+                if kind == "ddpm":
+                    L.check(self.lib.sgd_ddpm_step_dev(_ptr(img), _ptr(eng.eps_nhwc), _ptr(self.z), mode, w, _ptr(self.coef),
+                                                       clip, B, Cc, hw, _ptr(img), None, st), "sgd_ddpm_step_dev")
+                else:
+                    L.check(self.lib.sgd_ddim_step_dev(_ptr(img), _ptr(eng.eps_nhwc), _ptr(self.z), mode, w, _ptr(self.coef),
+                                                       float(temperature), clip, B, Cc, hw, _ptr(img), None, st),
+                            "sgd_ddim_step_dev")
+        torch.cuda.current_stream(dev).wait_stream(side)
+
+    def step(self, t_row, coef_row, noise=None):
+        """t_row: [B] long device tensor; coef_row: device tensor [5]; draws the mask uniform and z like the eager path"""
+        if self.has_mask:
+            self.u.uniform_(0, 1)                       # prob_mask_like (openaimodel.py:462-463): same RNG consumption
+            torch.lt(self.u, self.p, out=self.mask)
+        self.t.copy_(t_row)
+        if noise is None:
+            self.z.normal_()                            # == torch.randn(shape) (noise_like, util.py:264-267)
+        else:
+            self.z.copy_(noise)
+        self.coef.copy_(coef_row)
+        self.graph.replay()
+
+
+def _graph_ok(runner, sk, kwargs):
+    """the captured step covers the common case only: fused CFG evaluation on the drop-in UNet, a numeric guidance weight,
+    no noise dropout, no dynamic thresholding; ``hip_graph=False`` in the sampling kwargs turns it off"""
+    m = runner.model
+    w = runner.kwargs.get("cond_scale")
+    if m is None or not sk.get("hip_graph", True) or os.environ.get("SGDM_HIP_GRAPH", "1") == "0":
+        return False
+    fast_int = isinstance(w, int) if m.KIND == "unetca_fast" else isinstance(w, (int, float))
+    if not isinstance(w, (int, float)) or (fast_int and w in (0, 1)) or runner.kwargs.get("p0") is not None:
+        return False
+    return sk.get("noise_dropout", 0) == 0 and sk.get("dtp", 1) >= 1.0
 
 
 class Schedule_DDPM(nn.Module):
@@ -230,9 +310,23 @@ class Schedule_DDPM(nn.Module):
         coef = (C.c_float * 5)()
         nxt = torch.empty_like(img)
         order = kwargs.get("step_indices")          # bench / teacher-forced tests: visit only these steps
-        order = reversed(range(0, timesteps)) if order is None else list(order)
+        order = list(reversed(range(0, timesteps))) if order is None else list(order)
+        gstep, coef_dev = None, None
+        if _graph_ok(runner, sk, kwargs):
+            tab = self._step_tab.double()                                       # same double product -> fp32 as below
+            if x0_param:
+                tab[:, 0], tab[:, 1] = 0.0, -1.0
+            tab[:, 4] *= torch.tensor([float(v) for v in temperature], dtype=torch.float64)
+            tab[0, 4] = 0.0                                                     # no noise when t == 0
+            coef_dev = tab.float().to(dev)
+            img = img.clone() if x_T is not None else img                       # updated in place: never the caller's x_T
+            gstep = _GraphedStep(runner, img, "ddpm", clip)
         for i in order:
             ts = ts_tab[i]
+            want = i in snaps
+            if gstep is not None and not want:
+                gstep.step(ts, coef_dev[i], None if noise_fn is None else noise_fn(i).to(dev))
+                continue
             eps, mode, w, bb, cc = runner.eps(img, ts)
             z = torch.randn(shape, device=dev) if noise_fn is None else noise_fn(i).to(dev)
             if noise_dropout > 0.:
@@ -242,11 +336,13 @@ class Schedule_DDPM(nn.Module):
             if x0_param:
                 coef[0], coef[1] = 0.0, -1.0        # x_recon = model_out (ddpm_sampler.py:160-161): 0*x - (-1)*out, exact
             coef[4] = (float(row[4]) * float(temperature[i])) if i != 0 else 0.0      # no noise when t == 0
-            want = i in snaps
             x0 = torch.empty_like(img) if want else None
             L.check(lib.sgd_ddpm_step(_ptr(img), _ptr(eps), _ptr(z), mode, w, coef, clip, bb, cc, hw,
                                       _ptr(nxt), _ptr(x0), _stream()), "sgd_ddpm_step")
-            img, nxt = nxt, img
+            if gstep is not None:
+                img.copy_(nxt)                      # the captured step owns `img`
+            else:
+                img, nxt = nxt, img
             if want:
                 pred.append(x0.unsqueeze(0))
                 inter.append(img.clone().unsqueeze(0))
@@ -406,8 +502,20 @@ class DDIMSampler(object):
         clip = 1 if sk["clip_denoised"] else 0
         coef = (C.c_float * 4)()
         nxt = torch.empty_like(img)
+        gstep, coef_dev = None, None
+        if _graph_ok(runner, sk, kwargs):
+            tab = np.stack([self.ddim_sqrt_one_minus_alphas, self.ddim_alphas, self.ddim_alphas_prev, self.ddim_sigmas,
+                            np.zeros_like(self.ddim_sigmas)], 1)
+            coef_dev = torch.tensor(tab, dtype=torch.float64).float().to(dev)   # float(table[index]) -> fp32, as below
+            img = img.clone() if x_T is not None else img
+            gstep = _GraphedStep(runner, img, "ddim", clip, temperature=float(sk["temperature"]))
+            ts_dev = torch.tensor(np.ascontiguousarray(timesteps), dtype=torch.long, device=dev).view(-1, 1).expand(total, B).contiguous()
         for i, step in enumerate(np.flip(timesteps)):
             index = total - i - 1
+            want = index in snaps
+            if gstep is not None and not want:
+                gstep.step(ts_dev[index], coef_dev[index], None if noise_fn is None else noise_fn(i).to(dev))
+                continue
             ts = torch.full((B,), int(step), device=dev, dtype=torch.long)
             eps, mode, w, bb, cc = runner.eps(img, ts)
             z = torch.randn(shape, device=dev) if noise_fn is None else noise_fn(i).to(dev)    # drawn even at eta=0
@@ -418,11 +526,13 @@ class DDIMSampler(object):
             coef[1] = float(self.ddim_alphas[index])
             coef[2] = float(self.ddim_alphas_prev[index])
             coef[3] = float(self.ddim_sigmas[index])
-            want = index in snaps
             x0 = torch.empty_like(img) if want else None
             L.check(lib.sgd_ddim_step(_ptr(img), _ptr(eps), _ptr(z), mode, w, coef, float(sk["temperature"]), clip,
                                       bb, cc, hw, _ptr(nxt), _ptr(x0), _stream()), "sgd_ddim_step")
-            img, nxt = nxt, img
+            if gstep is not None:
+                img.copy_(nxt)                      # the captured step owns `img`
+            else:
+                img, nxt = nxt, img
             if want:
                 inter.append(img.detach().cpu().unsqueeze(0))
                 pred.append(x0.detach().cpu().unsqueeze(0))
@@ -431,7 +541,7 @@ class DDIMSampler(object):
 
 def to_uint8(x):
     """clip_unnormalize_to_zero_to_255 (diffusion_utils/util.py:99-100)"""
-    if x.device.type != "cuda":
+    if x.device.type != "cuda" or x.numel() == 0:
         return ((x + 1) * 127.5).clamp(0, 255).to(torch.uint8)         # snapshots the DDIM path moved to host
     x = x.contiguous().float()
     out = torch.empty(x.shape, dtype=torch.uint8, device=x.device)

@@ -639,7 +639,15 @@ class _Engine:
             self._film_sig = sig
 
     def run(self, x, t, cond, layout, mask, train=False):
-        m, n, lib = self.m, self.n, self.lib
+        stream = torch.cuda.current_stream().cuda_stream
+        self.prepare(x, t, cond, layout, mask, train=train)
+        self.launch(stream)
+
+    def prepare(self, x, t, cond, layout, mask, train=False):
+        """host side of one evaluation: weight-pack refresh, dropout seeds, input validation / dtype normalisation.
+        The tensors are kept (``_keep_inputs``) and read by ``launch`` -- a captured launch sequence (hipGraph) re-reads
+        the SAME buffers on every replay, so a caller that replays must update them in place."""
+        m, n = self.m, self.n
         stream = torch.cuda.current_stream().cuda_stream
         self.refresh(stream)
         p_drop = float(m.dropout) if (train and m.dropout) else 0.0      # (grad mode is off inside autograd.Function)
@@ -654,17 +662,13 @@ class _Engine:
         x = x.contiguous().float()
         t = t.contiguous().to(torch.int64)
         mask_u8 = mask.contiguous().view(torch.uint8) if mask is not None else None
-        L.check(lib.sgd_timestep_embedding(_ptr(t), _ptr(self.freqs), B, n, m.model_channels, _ptr(self.temb),
-                                           stream), "temb")
         cl = m._in_ch_total - m.in_channels
         if cl:
             if layout is None:
                 raise ValueError(f"condition_method={m.condition_method} needs `layout`")
             layout = layout.contiguous().float()
             assert layout.shape == (B, cl, self.h, self.w), (layout.shape, (B, cl, self.h, self.w))
-        L.check(lib.sgd_pack_input(_ptr(x), _ptr(layout) if cl else C.c_void_p(0), _ptr(mask_u8),
-                                   _ptr(m.null_layout_emb) if cl else C.c_void_p(0), B, n, m.in_channels, cl,
-                                   self.h, self.w, _ptr(self.x_in), stream), "pack_input")
+        is_i64 = False
         if m._cond_width:
             if cond is None:
                 raise ValueError(f"condition_method={m.condition_method} needs `cond`")
@@ -673,10 +677,23 @@ class _Engine:
             if not is_i64:
                 cond = cond.float()
             assert cond.numel() == B * m._cond_width, (cond.shape, m._cond_width)
+        self._keep_inputs = (x, t, cond, layout, mask_u8, B, is_i64)
+
+    def launch(self, stream):
+        """device side: boundary kernels + the static launch program (no allocation, no sync: graph-capturable)"""
+        m, n, lib = self.m, self.n, self.lib
+        x, t, cond, layout, mask_u8, B, is_i64 = self._keep_inputs
+        cl = m._in_ch_total - m.in_channels
+        L.check(lib.sgd_timestep_embedding(_ptr(t), _ptr(self.freqs), B, n, m.model_channels, _ptr(self.temb),
+                                           stream), "temb")
+        L.check(lib.sgd_pack_input(_ptr(x), _ptr(layout) if cl else C.c_void_p(0), _ptr(mask_u8),
+                                   _ptr(m.null_layout_emb) if cl else C.c_void_p(0), B, n, m.in_channels, cl,
+                                   self.h, self.w, _ptr(self.x_in), stream), "pack_input")
+        if m._cond_width:
             L.check(lib.sgd_cond_select(_ptr(cond), int(is_i64), _ptr(mask_u8), _ptr(m.null_cond_emb), B, n,
                                         m._cond_width, _ptr(self.cond_m), stream), "cond_select")
-        self._keep_inputs = (x, t, cond, layout, mask_u8)
         self.prog.run(stream)
+        self.ran = True
 
 
 # ------------------------------------------------------------------------------------------------

@@ -189,3 +189,46 @@ def test_ddim_chainvis_pairs_share_their_start_noise():
     assert tuple(samples.shape) == (4, 3, 16, 16)
     # rows 1 and 3 are unconditional (p0 = 0 keeps... the mask convention: p = 1 drops) -> differ from their partners
     assert (samples[0].int() - samples[1].int()).abs().max() > 0
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# hipGraph-captured sampling step (sgdm_amd/diffusion.py: _GraphedStep): same kernels, same buffers' contents, same RNG
+# draws in the same order -> the trajectory must be IDENTICAL to the eager launch sequence, bit for bit
+# ------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name,method,steps", [("uf_label_c32_s16", "native", 40), ("uf_label_c32_s16", "ddim", 20),
+                                               ("ca_stego_c32_s16", "native", 30)])
+def test_graph_captured_step_equals_eager(name, method, steps):
+    from test_hip_unet import INDEX
+    from sgdm_amd.synth import synth_batch
+    m, entry = build_model(name, "f16x3")
+    d = _diffusion(m)
+    kw = entry["ctor"]
+    batch = synth_batch(kw["condition_method"], 2, 16, kw["cond_dim"], entry["layout_dim"], seed=23)
+    cond = batch["cond"].cuda() if entry["kind"] == "unet_fast" else batch["cond"].float().cuda()
+    dkw = dict(cond=cond, layout=batch["layout"].cuda() if "layout" in batch else None, cond_scale=2.0)
+    if method == "native":
+        skw, extra = _skw("native", 1000), dict(step_indices=list(range(steps - 1, -1, -1)))
+        # snapshots at i in linspace(0, 1000, 10): only i = 0 falls into the visited range -> exercises the eager fallback
+    else:
+        skw, extra = _skw("ddim", steps, 1.0), {}
+    out = {}
+    for graph in (False, True):
+        torch.manual_seed(1234)                                   # z and the mask uniform come from the global generator
+        samples, inter = d.p_sample_loop(method, (2, 3, 16, 16), dict(skw, hip_graph=graph),
+                                         denoise_sample_fn_kwargs=dict(dkw), condition_kwargs={}, **extra)
+        out[graph] = (samples.cpu(), inter["pred_x0"].cpu(), inter["x_inter"].cpu())
+    assert torch.equal(out[False][0], out[True][0])
+    assert torch.equal(out[False][1], out[True][1])
+    assert torch.equal(out[False][2], out[True][2])
+    assert out[True][1].shape[0] >= 1                             # at least one snapshot step ran next to the replays
+
+
+def test_graph_step_does_not_touch_the_callers_x_T():
+    m, _ = build_model("uf_label_c32_s16", "f32")
+    d = _diffusion(m)
+    x_T = torch.randn(2, 3, 16, 16, device="cuda")
+    keep = x_T.clone()
+    d.p_sample_loop("native", (2, 3, 16, 16), dict(_skw("native", 1000), hip_graph=True),
+                    denoise_sample_fn_kwargs=dict(cond=_cond(), layout=None, cond_scale=2.0), condition_kwargs={},
+                    x_T=x_T, step_indices=[999, 998, 997])
+    assert torch.equal(x_T, keep)
