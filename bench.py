@@ -13,7 +13,14 @@ metric value = images/s of a full 1000-step trajectory = (N * B) / (1000 * t_ste
 
 One JSON line on rank 0 with `roofline` (dominant kernel: the fused implicit-GEMM conv, timed with HIP
 events around every launch in an instrumented pass) and `cpu_baseline` (the CPU oracle -- the
-restatement of the reference's UNet -- timed on this box's host cores on a bounded sample).
+restatement of the reference's UNet -- timed on this box's host cores on a bounded sample), plus sub-records of
+the same run: `train_step` (metric's second half), `f32_exact` (the headline workload in exact-fp32 MFMA
+arithmetic), `c5` (BASELINE.json configs[4], unetca_fast bs=80) and `c1` (configs[0] at its true shape on the GPU,
+eager launches vs the hipGraph-captured step).
+
+Multi-GPU: the driver launches one rank per GPU through torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE in the
+environment).  Run by hand as `python bench.py --gpus N` it launches the N ranks ITSELF -- as child processes, before
+this process has touched the GPU -- over RCCL on 127.0.0.1 and relays rank 0's JSON line.
 """
 import argparse
 import json
@@ -48,12 +55,38 @@ MODEL_PARAMS = dict(given_betas=None, beta_schedule="linear", linear_start=0.000
                     parameterization="eps", log_num_per_prog=10, loss_type="l2", sampling="native",
                     num_timesteps=1000)
 PEAK_TFLOPS = {"f32": 157.3, "f16x3": 2500.0 / 3, "bf16x3": 2500.0 / 3}     # MI355X_MICROARCH.md chip table
+# BASELINE.json configs[0] (C1): cifar10 unet_fast ch=64 label K=10, 32x32, 10-step DDIM eta=0, w=2, bs=8
+C1 = dict(kind="unet_fast", batch=8, image=32, cond_dim=10, method="label", layout_dim=0, model_channels=64, ddim_steps=10,
+          desc="cifar10 unet_fast ch64 label-k10 32x32 cond_scale=2 bs=8, 10-step DDIM eta=0", gflop_per_eval_img=4.94)
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as children (this process has not initialised
+    the GPU -- device_count() does not) and relay rank 0's stdout; exit code = worst child."""
+    import socket
+    import subprocess
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out)
+    sys.stdout.flush()
+    return max(abs(rc) for rc in rcs)
 
 
 def build_model(wl, device, prec, batch=None):
     from sgdm_amd.synth import synth_batch, weights_from_seed
     from sgdm_amd.unet import UNetModel, UNetModelCA
-    common = dict(image_size=wl["image"], in_channels=3, out_channels=3, model_channels=128, num_res_blocks=2,
+    common = dict(image_size=wl["image"], in_channels=3, out_channels=3, model_channels=wl.get("model_channels", 128),
+                  num_res_blocks=2,
                   channel_mult=[1, 2, 4], attention_resolutions=[4], num_heads=8, use_scale_shift_norm=True,
                   cond_dim=wl["cond_dim"], condition_method=wl["method"])
     cond = AD(scale_type="imagen")
@@ -113,10 +146,30 @@ def cpu_baseline(wl, sd, seconds_budget=25.0):
             U.forward_with_cond_scale(cfg, sd, x, t, 2.0, cond, data.get("layout"))
             times.append(time.time() - t0)
     per_step = min(times)
-    return dict(value=B / (1000.0 * per_step), unit="images/s", cores=cores, kind="port",
-                sample=f"{len(times)} CFG UNet steps at bs={B} (UNet batch {2 * B}) of the same model on the host "
-                       f"cores, best {per_step:.2f} s/step, extrapolated linearly to 1000 steps",
-                s_per_step_bs8=per_step)
+    out = dict(value=B / (1000.0 * per_step), unit="images/s", cores=cores, kind="port",
+               sample=f"{len(times)} CFG UNet steps at bs={B} (UNet batch {2 * B}) of the same model on the host "
+                      f"cores, best {per_step:.2f} s/step, extrapolated linearly to 1000 steps",
+               s_per_step_bs8=round(per_step, 3))
+    # config C1 in full on the CPU path (10-step DDIM, bs=8, ch=64, 32x32)
+    from oracle import diffusion_ref as D
+    from sgdm_amd.synth import weights_from_seed
+    from sgdm_amd.unet import UNetModel
+    c1cfg = U.make_cfg("unet_fast", C1["image"], model_channels=C1["model_channels"], cond_dim=C1["cond_dim"],
+                       condition_method="label", resblock_updown=True)
+    man = [(k, tuple(v)) for k, v, _ in U.param_manifest(c1cfg)]
+    sd1 = weights_from_seed(man, 23)
+    d1 = synth_batch("label", C1["batch"], C1["image"], C1["cond_dim"], 0, seed=23)
+    g = torch.Generator().manual_seed(3)
+    xT = torch.randn(C1["batch"], 3, C1["image"], C1["image"], generator=g)
+    zs = torch.randn(C1["ddim_steps"], C1["batch"], 3, C1["image"], C1["image"], generator=g)
+    with torch.no_grad():
+        t0 = time.time()
+        D.ddim_sample(D.make_schedule(), lambda x_, t_: U.forward_with_cond_scale(c1cfg, sd1, x_, t_, 2.0, d1["cond"], None),
+                      xT, lambda i: zs[i], C1["ddim_steps"], eta=0.0)
+        c1_s = time.time() - t0
+    out["c1_full"] = dict(seconds=round(c1_s, 2), images=C1["batch"], images_per_s=round(C1["batch"] / c1_s, 3),
+                          workload=C1["desc"])
+    return out
 
 
 def pmc_traffic(args, B):
@@ -124,11 +177,18 @@ def pmc_traffic(args, B):
     WRITE_SIZE in separate rocprofv3 --pmc runs of this same bench command, gfx950 FETCH_SIZE x2 correction).
     PMC collection needs the profiler around the process, so it cannot be taken live inside this run; null when no
     committed pass matches the workload/precision/batch being benchmarked."""
-    path = os.path.join(ROOT, "profiles", f"r1_pmc_hbm_{args.workload}.json")
-    if not os.path.exists(path) or args.prec != "f16x3" or B != WORKLOADS[args.workload]["batch"]:
-        return None
+    for rnd in ("r2", "r1"):
+        path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_hbm_{args.workload}.json")
+        if os.path.exists(path):
+            break
+    else:
+        return None, None
+    if args.prec != "f16x3" or B != WORKLOADS[args.workload]["batch"]:
+        return None, None
     k = json.load(open(path))["kernels"].get("igemm_kernel")
-    return round(k["hbm_bytes_per_launch"]) if k else None
+    return (round(k["hbm_bytes_per_launch"]) if k else None,
+            f"replayed from {os.path.relpath(path, ROOT)} (separate rocprofv3 --pmc passes of this command: FETCH_SIZE x2 + "
+            "WRITE_SIZE; counters cannot be read from inside the process)")
 
 
 def train_step_bench(model, diff, data, cond, layout, B, world, barrier, wl, steps=4, warmup=2):
@@ -183,8 +243,12 @@ def main():
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-train", action="store_true")
     ap.add_argument("--train-batch", type=int, default=80, help="per-GPU batch of the train-step leg (metric: bs=80)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the f32_exact / c5 / c1 sub-records")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of the hipGraph-captured step")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(self_launch(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -212,7 +276,8 @@ def main():
     layout = data["layout"].to(dev) if "layout" in data else None
     dkw = dict(cond=cond, layout=layout, cond_scale=2.0)
     skw = dict(sampling_method="native", num_timesteps=1000, ddim_eta=0.0, log_num_per_prog=10, clip_denoised=True,
-               dtp=1, temperature=1.0, noise_dropout=0, random_sample_condition=False, return_inter_dict=True)
+               dtp=1, temperature=1.0, noise_dropout=0, random_sample_condition=False, return_inter_dict=True,
+               hip_graph=not args.no_graph)
     torch.manual_seed(23 + rank)
     x = torch.randn(B, 3, S, S, device=dev)
 
@@ -259,6 +324,71 @@ def main():
         tlayout = tdata["layout"].to(dev) if "layout" in tdata else None
         train = train_step_bench(model, diff, tdata, tcond, tlayout, TB, world, barrier, wl)
 
+    def time_sampling(mdl, dif, bsz, size, kw, steps, warm, skw_):
+        """ms per CFG sampling step of `mdl` (setup outside, W untimed + K timed steps, barrier + sync around)"""
+        xx = torch.randn(bsz, 3, size, size, device=dev)
+
+        def go(x_, idx):
+            return dif.sampler.sample((bsz, 3, size, size), sampling_kwargs=skw_, denoise_sample_fn=dif.denoise_sample_fn,
+                                      denoise_sample_fn_kwargs=kw, x_T=x_, step_indices=idx)[0]
+        with torch.no_grad():
+            go(xx.clone(), [999])
+            xx = go(xx, [(999 - i) % 1000 for i in range(warm)])
+            barrier()
+            t0_ = time.perf_counter()
+            go(xx, [(999 - i) % 1000 for i in range(warm, warm + steps)])
+            barrier()
+            return 1000.0 * (time.perf_counter() - t0_) / steps
+
+    extra = {}
+    if not args.no_extra and args.workload == "c2" and world == 1:
+        # ---- the headline workload in exact-fp32 MFMA arithmetic (v_mfma_f32_32x32x2_f32: bit-for-bit an fp32 FMA chain)
+        if args.prec != "f32":
+            model.hip_precision = "f32"
+            ms32 = time_sampling(model, diff, B, S, dkw, 3, 1, skw)
+            tfl = 2 * B * wl["gflop_per_eval_img"] / ms32
+            extra["f32_exact"] = dict(ms_per_step=round(ms32, 3), value=round(B / ms32, 4), unit="images/s",
+                                      tflops_per_s=round(tfl, 1), frac_of_fp32_mfma_peak=round(tfl / PEAK_TFLOPS["f32"], 4),
+                                      peak=PEAK_TFLOPS["f32"], steps=3, warmup=1)
+            model.hip_precision = args.prec
+        # ---- BASELINE.json configs[4] (C5): unetca_fast stegoclusterlayout bs=80 -- sampling step + train step
+        w5 = WORKLOADS["c5"]
+        m5, _, d5 = build_model(w5, dev, args.prec, w5["batch"])
+        diff5 = LatentDiffusion(device=str(dev), **MODEL_PARAMS)
+        diff5.set_denoise_fn(m5.forward, m5.forward_with_cond_scale)
+        k5 = dict(cond=d5["cond"].float().to(dev), layout=d5["layout"].to(dev), cond_scale=2.0)
+        ms5 = time_sampling(m5, diff5, w5["batch"], S, k5, 5, 2, skw)
+        extra["c5"] = dict(workload=w5["desc"], ms_per_step=round(ms5, 3), value=round(w5["batch"] / ms5, 4), unit="images/s",
+                           tflops_per_s=round(2 * w5["batch"] * w5["gflop_per_eval_img"] / ms5, 1), steps=5, warmup=2)
+        if not args.no_train:
+            extra["c5"]["train_step"] = train_step_bench(m5, diff5, d5, k5["cond"], k5["layout"], w5["batch"], world, barrier, w5)
+        del m5, diff5
+        # ---- BASELINE.json configs[0] (C1) at its true shape on the GPU: 10-step DDIM, bs=8 -- ~140 small launches per
+        # step, so the host launch path matters: eager ctypes launches vs the hipGraph-captured step
+        m1, _, d1 = build_model(C1, dev, args.prec, C1["batch"])
+        diff1 = LatentDiffusion(device=str(dev), **MODEL_PARAMS)
+        diff1.set_denoise_fn(m1.forward, m1.forward_with_cond_scale)
+        k1 = dict(cond=d1["cond"].to(dev), layout=None, cond_scale=2.0)
+        sk1 = dict(skw, sampling_method="ddim", num_timesteps=C1["ddim_steps"])
+        c1 = {}
+        with torch.no_grad():
+            for name, g_on in (("eager", False), ("graph", True)):
+                kw_ = dict(sk1, hip_graph=g_on)
+                shape1 = (C1["batch"], 3, C1["image"], C1["image"])
+                run1 = lambda: diff1.p_sample_loop("ddim", shape1, kw_, denoise_sample_fn_kwargs=dict(k1), condition_kwargs={})
+                run1()
+                barrier()
+                t0_ = time.perf_counter()
+                for _ in range(5):
+                    run1()
+                barrier()
+                c1[name + "_ms_per_trajectory"] = round(1000.0 * (time.perf_counter() - t0_) / 5, 3)
+        c1.update(workload=C1["desc"], images_per_s=round(C1["batch"] / (c1["graph_ms_per_trajectory"] * 1e-3), 1),
+                  graph_speedup=round(c1["eager_ms_per_trajectory"] / c1["graph_ms_per_trajectory"], 2),
+                  note="whole p_sample_loop (10 steps, all of them snapshot steps, uint8 conversion); the captured step is cached on the model, capture cost excluded by the warm-up call")
+        extra["c1"] = c1
+        del m1, diff1
+
     out = None
     if rank == 0:
         # ---- instrumented pass: HIP events around every launch of the UNet program (same stream)
@@ -277,9 +407,10 @@ def main():
             ig_ms, ig_fl, ig_nb, ig_n = ig[0] / reps, ig[1] / reps, ig[2] / reps, ig[3] // reps
             peak = PEAK_TFLOPS[args.prec]
             ach = ig_fl / (ig_ms * 1e-3) / 1e12
+            traffic, traffic_src = pmc_traffic(args, B)
             roof = dict(bound="mfma", kernel="igemm_kernel (fused implicit-GEMM conv/linear, all launches of one UNet eval)",
                         achieved=round(ach, 2), peak=round(peak, 1), unit="TFLOP/s", frac=round(ach / peak, 4),
-                        traffic=pmc_traffic(args, B), launches_per_step=ig_n,
+                        traffic=traffic, traffic_source=traffic_src, launches_per_step=ig_n,
                         algorithmic_bytes_per_launch=round(ig_nb / ig_n), avg_launch_ms=round(ig_ms / ig_n, 4),
                         igemm_ms_per_step=round(ig_ms, 3), all_kernels_ms_per_step=round(tot_ms, 3),
                         algorithmic_gflop_per_step=round(ig_fl / 1e9, 1),
@@ -298,9 +429,11 @@ def main():
                       "bf16x3": "f32 as 3xbf16 split MFMA products, f32 accumulate"}[args.prec],
             "data": "synthetic",
             "config": {"workload": wl["desc"], "batch_per_gpu": B, "unet_batch": 2 * B, "precision_mode": args.prec,
-                       "algorithmic_tflop_per_step": round(2 * B * wl["gflop_per_eval_img"] / 1e3, 3)},
+                       "algorithmic_tflop_per_step": round(2 * B * wl["gflop_per_eval_img"] / 1e3, 3),
+                       "launch": "eager" if args.no_graph else "hipGraph-captured step"},
             "roofline": roof, "cpu_baseline": cpu, "train_step": train,
         }
+        out.update(extra)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -114,8 +114,9 @@ class _StepRunner:
 
 
 class _GraphedStep:
-    """One CFG sampling step -- UNet at 2B (~135 launches) + the fused update -- captured ONCE per trajectory into a
-    hipGraph (``torch.cuda.CUDAGraph`` capture of the stream the C-ABI launchers are given) and replayed per step.
+    """One CFG sampling step -- UNet at 2B (~135 launches) + the fused update -- captured into a hipGraph
+    (``torch.cuda.CUDAGraph`` capture of the stream the C-ABI launchers are given), cached on the model per
+    (batch, resolution, precision, guidance, sampler) and replayed per step.
 
     Everything a step varies lives in fixed device buffers the captured kernels read: ``img`` (updated in place by
     ``sgd_*_step_dev``), ``t`` [B], ``coef`` (row of the per-step table), ``z`` and the cond-drop mask.  The RNG draws
@@ -125,26 +126,49 @@ class _GraphedStep:
     device-bound at C1 size (ch=64, 32x32, bs=8).  Reference loops: ddpm_sampler.py:194-238, ddim_plms_sampler.py:302-344.
     """
 
-    def __init__(self, runner, img, kind, clip, temperature=1.0):
+    @classmethod
+    def get(cls, runner, img, kind, clip, temperature=1.0):
+        """the captured step for this (model, batch, resolution, precision, guidance, sampler) -- built on first use and
+        kept on the model, so later trajectories of the same configuration only refresh the static input buffers"""
+        m, kw = runner.model, runner.kwargs
+        cond, layout = kw.get("cond"), kw.get("layout")
+        sig = lambda t: None if t is None else (tuple(t.shape), t.dtype)
+        prec = L.PREC_BY_NAME[m.hip_precision]
+        eng = m._engine(2 * img.shape[0], img.shape[2], img.shape[3], prec)
+        key = (id(eng), tuple(img.shape), kind, clip, float(temperature), float(kw["cond_scale"]), m._scale_mode(),
+               sig(cond), sig(layout))
+        cache = m.__dict__.setdefault("_hip_graph_steps", {})
+        g = cache.get(key)
+        if g is None:
+            for k in [k for k in cache if k[0] != id(eng)]:
+                del cache[k]                                # graphs of a replaced engine (parameters re-allocated)
+            g = cache[key] = cls(runner, eng, img, kind, clip, temperature)
+        g.begin(img, cond, layout)
+        return g
+
+    def __init__(self, runner, eng, img, kind, clip, temperature=1.0):
         m = runner.model
-        self.m, self.lib, self.kind = m, runner.lib, kind
+        self.m, self.lib, self.kind, self.eng = m, runner.lib, kind, eng
         B, Cc = img.shape[0], img.shape[1]
         hw = int(np.prod(img.shape[2:]))
         dev = img.device
-        self.img = img
+        self.img = torch.empty_like(img)
         self.t = torch.zeros(B, dtype=torch.long, device=dev)
         self.coef = torch.zeros(5, dtype=torch.float32, device=dev)
         self.z = torch.empty_like(img)
+        self.x0 = torch.empty_like(img)                 # clipped x0 prediction of the step (snapshot steps clone it)
         kw = runner.kwargs
+        # static copies in exactly the dtypes the boundary kernels read (prepare() must not re-allocate them)
+        c0, l0 = kw.get("cond"), kw.get("layout")
+        self.cond = None if c0 is None else (c0.detach().clone() if c0.dtype == torch.int64 else c0.detach().float().clone()).contiguous()
+        self.layout = None if l0 is None else l0.detach().float().clone().contiguous()
         self.has_mask = (m._cond_width > 0) or (m._in_ch_total > m.in_channels)
         self.u = torch.zeros(2 * B, device=dev)
         self.p = torch.cat((torch.full((B,), 0.0, device=dev), torch.full((B,), 1.0, device=dev)))
         self.mask = torch.zeros(2 * B, dtype=torch.bool, device=dev)
-        prec = L.PREC_BY_NAME[m.hip_precision]
-        eng = m._engine(2 * B, img.shape[2], img.shape[3], prec)
-        self.eng = eng
-        eng.prepare(img, self.t, kw.get("cond"), kw.get("layout"), self.mask if self.has_mask else None)
+        eng.prepare(self.img, self.t, self.cond, self.layout, self.mask if self.has_mask else None)
         self._inputs = eng._keep_inputs                 # the captured launches read these buffers on every replay
+        img = self.img
         w, mode = float(kw["cond_scale"]), m._scale_mode()
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
@@ -158,12 +182,21 @@ class _GraphedStep:
                 eng.launch(st)
                 if kind == "ddpm":
                     L.check(self.lib.sgd_ddpm_step_dev(_ptr(img), _ptr(eng.eps_nhwc), _ptr(self.z), mode, w, _ptr(self.coef),
-                                                       clip, B, Cc, hw, _ptr(img), None, st), "sgd_ddpm_step_dev")
+                                                       clip, B, Cc, hw, _ptr(img), _ptr(self.x0), st), "sgd_ddpm_step_dev")
                 else:
                     L.check(self.lib.sgd_ddim_step_dev(_ptr(img), _ptr(eng.eps_nhwc), _ptr(self.z), mode, w, _ptr(self.coef),
-                                                       float(temperature), clip, B, Cc, hw, _ptr(img), None, st),
+                                                       float(temperature), clip, B, Cc, hw, _ptr(img), _ptr(self.x0), st),
                             "sgd_ddim_step_dev")
         torch.cuda.current_stream(dev).wait_stream(side)
+
+    def begin(self, img, cond, layout):
+        """start of a trajectory: x_T and the guidance tensors into the static buffers; packed weights re-checked"""
+        self.eng.refresh(torch.cuda.current_stream().cuda_stream)
+        self.img.copy_(img)
+        if self.cond is not None:
+            self.cond.copy_(cond)
+        if self.layout is not None:
+            self.layout.copy_(layout)
 
     def step(self, t_row, coef_row, noise=None):
         """t_row: [B] long device tensor; coef_row: device tensor [5]; draws the mask uniform and z like the eager path"""
@@ -319,13 +352,16 @@ class Schedule_DDPM(nn.Module):
             tab[:, 4] *= torch.tensor([float(v) for v in temperature], dtype=torch.float64)
             tab[0, 4] = 0.0                                                     # no noise when t == 0
             coef_dev = tab.float().to(dev)
-            img = img.clone() if x_T is not None else img                       # updated in place: never the caller's x_T
-            gstep = _GraphedStep(runner, img, "ddpm", clip)
+            gstep = _GraphedStep.get(runner, img, "ddpm", clip)
+            img = gstep.img                                                     # updated in place by the replays
         for i in order:
             ts = ts_tab[i]
             want = i in snaps
-            if gstep is not None and not want:
+            if gstep is not None:
                 gstep.step(ts, coef_dev[i], None if noise_fn is None else noise_fn(i).to(dev))
+                if want:
+                    pred.append(gstep.x0.clone().unsqueeze(0))
+                    inter.append(img.clone().unsqueeze(0))
                 continue
             eps, mode, w, bb, cc = runner.eps(img, ts)
             z = torch.randn(shape, device=dev) if noise_fn is None else noise_fn(i).to(dev)
@@ -339,13 +375,12 @@ class Schedule_DDPM(nn.Module):
             x0 = torch.empty_like(img) if want else None
             L.check(lib.sgd_ddpm_step(_ptr(img), _ptr(eps), _ptr(z), mode, w, coef, clip, bb, cc, hw,
                                       _ptr(nxt), _ptr(x0), _stream()), "sgd_ddpm_step")
-            if gstep is not None:
-                img.copy_(nxt)                      # the captured step owns `img`
-            else:
-                img, nxt = nxt, img
+            img, nxt = nxt, img
             if want:
                 pred.append(x0.unsqueeze(0))
                 inter.append(img.clone().unsqueeze(0))
+        if gstep is not None:
+            img = img.clone()                       # the static buffer belongs to the cached graph
         if not pred:
             return img, dict(pred_x0=img.new_zeros((0,) + tuple(shape)), x_inter=img.new_zeros((0,) + tuple(shape)))
         return img, dict(pred_x0=torch.cat(pred, 0), x_inter=torch.cat(inter, 0))
@@ -507,14 +542,17 @@ class DDIMSampler(object):
             tab = np.stack([self.ddim_sqrt_one_minus_alphas, self.ddim_alphas, self.ddim_alphas_prev, self.ddim_sigmas,
                             np.zeros_like(self.ddim_sigmas)], 1)
             coef_dev = torch.tensor(tab, dtype=torch.float64).float().to(dev)   # float(table[index]) -> fp32, as below
-            img = img.clone() if x_T is not None else img
-            gstep = _GraphedStep(runner, img, "ddim", clip, temperature=float(sk["temperature"]))
+            gstep = _GraphedStep.get(runner, img, "ddim", clip, temperature=float(sk["temperature"]))
+            img = gstep.img
             ts_dev = torch.tensor(np.ascontiguousarray(timesteps), dtype=torch.long, device=dev).view(-1, 1).expand(total, B).contiguous()
         for i, step in enumerate(np.flip(timesteps)):
             index = total - i - 1
             want = index in snaps
-            if gstep is not None and not want:
+            if gstep is not None:
                 gstep.step(ts_dev[index], coef_dev[index], None if noise_fn is None else noise_fn(i).to(dev))
+                if want:
+                    inter.append(img.detach().cpu().unsqueeze(0))
+                    pred.append(gstep.x0.detach().cpu().unsqueeze(0))
                 continue
             ts = torch.full((B,), int(step), device=dev, dtype=torch.long)
             eps, mode, w, bb, cc = runner.eps(img, ts)
@@ -529,13 +567,12 @@ class DDIMSampler(object):
             x0 = torch.empty_like(img) if want else None
             L.check(lib.sgd_ddim_step(_ptr(img), _ptr(eps), _ptr(z), mode, w, coef, float(sk["temperature"]), clip,
                                       bb, cc, hw, _ptr(nxt), _ptr(x0), _stream()), "sgd_ddim_step")
-            if gstep is not None:
-                img.copy_(nxt)                      # the captured step owns `img`
-            else:
-                img, nxt = nxt, img
+            img, nxt = nxt, img
             if want:
                 inter.append(img.detach().cpu().unsqueeze(0))
                 pred.append(x0.detach().cpu().unsqueeze(0))
+        if gstep is not None:
+            img = img.clone()                       # the static buffer belongs to the cached graph
         return img, dict(x_inter=torch.cat(inter, 0), pred_x0=torch.cat(pred, 0))
 
 

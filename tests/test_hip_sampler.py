@@ -208,7 +208,7 @@ def test_graph_captured_step_equals_eager(name, method, steps):
     dkw = dict(cond=cond, layout=batch["layout"].cuda() if "layout" in batch else None, cond_scale=2.0)
     if method == "native":
         skw, extra = _skw("native", 1000), dict(step_indices=list(range(steps - 1, -1, -1)))
-        # snapshots at i in linspace(0, 1000, 10): only i = 0 falls into the visited range -> exercises the eager fallback
+        # snapshots at i in linspace(0, 1000, 10): only i = 0 falls into the visited range
     else:
         skw, extra = _skw("ddim", steps, 1.0), {}
     out = {}
@@ -220,7 +220,7 @@ def test_graph_captured_step_equals_eager(name, method, steps):
     assert torch.equal(out[False][0], out[True][0])
     assert torch.equal(out[False][1], out[True][1])
     assert torch.equal(out[False][2], out[True][2])
-    assert out[True][1].shape[0] >= 1                             # at least one snapshot step ran next to the replays
+    assert out[True][1].shape[0] >= 1                             # at least one snapshot was taken from a replayed step
 
 
 def test_graph_step_does_not_touch_the_callers_x_T():
