@@ -101,6 +101,57 @@ def test_conv_wgrad(mode):
     assert max_rel(dw.reshape(cout, cin, 3, 3), w.grad) < 5e-6
 
 
+def _train_ksplit(taps, cout, cin, rows):
+    """the split the training program uses (sgdm_amd/train.py: Backward.wgrad)"""
+    base = taps * ((cout + 127) // 128) * ((cin + 127) // 128)
+    return max(1, min((rows + 63) // 64, 1024 // base))
+
+
+@pytest.mark.parametrize("prec,tol", [("f32", 5e-6), ("f16x3", 3e-5), ("bf16x3", 3e-4)])
+@pytest.mark.parametrize("shape", [(20, 128, 128, 64), (80, 1024, 512, 16), (40, 384, 128, 32)])
+def test_conv_wgrad_split_precision_at_production_shapes(shape, prec, tol):
+    """the weight-gradient kernel in the arithmetic mode and at the shapes / K splits the bs=80 train step runs it in
+    (wgrad_conv_kernel<split, all taps>: 128->128 @64x64, the 1024->512 concat conv @16x16, a 384->128 concat @32x32),
+    GroupNorm-affine + SiLU recomputed in its loader; reference = float64 autograd"""
+    L, lib = _lib()
+    n, cin, cout, h = shape
+    g = torch.Generator().manual_seed(21)
+    c0 = cin // 2 if cin > 128 else cin                       # the big ones are skip-concat convs (two sources)
+    c1 = cin - c0
+    x0 = torch.randn(n, c0, h, h, generator=g)
+    x1 = torch.randn(n, c1, h, h, generator=g) if c1 else None
+    pa, pb = 1 + 0.3 * torch.randn(n, cin, generator=g), 0.3 * torch.randn(n, cin, generator=g)
+    gy = torch.randn(n, cout, h, h, generator=g) / (n * h * h) ** 0.5
+    w = (torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(cin * 9)).double().requires_grad_(True)
+    xin = (torch.cat([x0, x1], 1) if c1 else x0).double()
+    u = F.silu(xin * pa.double()[:, :, None, None] + pb.double()[:, :, None, None])
+    F.conv2d(u, w, padding=1).backward(gy.double())
+    x0d, x1d = _nhwc(x0).cuda(), (_nhwc(x1).cuda() if c1 else None)
+    pad, pbd = pa.cuda(), pb.cuda()
+    fwd = _igemm_args(L, x0d, x1d, conv=(n, h, h, h, h), pa=pad, pb=pbd, silu=1)
+    fwd.prec = L.PREC_BY_NAME[prec]
+    dw = _wgrad(L, lib, fwd, _nhwc(gy).cuda(), cout, cin, 9, _train_ksplit(9, cout, cin, n * h * h))
+    err = max_rel(dw.reshape(cout, cin, 3, 3), w.grad.float())
+    assert err < tol, err
+
+
+@pytest.mark.parametrize("prec,tol", [("f16x3", 3e-5), ("bf16x3", 3e-4)])
+def test_linear_wgrad_split_precision_at_production_shapes(prec, tol):
+    """1x1 / linear weight gradient in split precision: attention qkv (512 -> 1536 over 80*256 rows)"""
+    L, lib = _lib()
+    g = torch.Generator().manual_seed(22)
+    m, k, nout = 80 * 256, 512, 1536
+    x = torch.randn(m, k, generator=g)
+    w = (torch.randn(nout, k, generator=g) / math.sqrt(k)).double().requires_grad_(True)
+    gy = torch.randn(m, nout, generator=g) / m ** 0.5
+    F.linear(x.double(), w).backward(gy.double())
+    fwd = _igemm_args(L, x.cuda(), m=m)
+    fwd.prec = L.PREC_BY_NAME[prec]
+    dw = _wgrad(L, lib, fwd, gy.cuda(), nout, k, 1, _train_ksplit(1, nout, k, m))
+    err = max_rel(dw.reshape(nout, k), w.grad.float())
+    assert err < tol, err
+
+
 def test_linear_wgrad_and_bias():
     L, lib = _lib()
     g = torch.Generator().manual_seed(13)

@@ -415,3 +415,52 @@ def test_stale_forward_raises_in_backward():
     l2.backward()
     with pytest.raises(RuntimeError, match="stale forward"):
         l1.backward()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# full-width training step (ch=128, 64x64 -- the width / resolution of BASELINE.json configs[1] and [4]) against
+# gradients recorded from the reference (tests/golden/train_full.npz, make_golden_train_full.py)
+# ------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name,prec,tol", [("uf_cluster5000_c128_s64", "f32", 5e-5), ("uf_cluster5000_c128_s64", "f16x3", 1e-4),
+                                           ("ca_stego_c128_s64", "f16x3", 1e-4)])
+def test_full_width_train_step_vs_reference(name, prec, tol):
+    import bench
+    from sgdm_amd.diffusion import LatentDiffusion
+    from sgdm_amd.synth import synth_batch
+    v = load_npz("train_full.npz")
+    tag = f"train.{name}"
+    m, entry = build_model(name, prec)
+    m.dropout = 0.0
+    m.train()
+    d = LatentDiffusion(device="cuda", **bench.MODEL_PARAMS).train()
+    d.set_denoise_fn(m.forward, m.forward_with_cond_scale)
+    kw = entry["ctor"]
+    batch = synth_batch(kw["condition_method"], 2, 64, kw["cond_dim"], entry["layout_dim"], seed=23 + 4)
+    cond = batch["cond"].cuda() if entry["kind"] == "unet_fast" else batch["cond"].float().cuda()
+    loss, ld = d.p_losses(batch["image"].cuda(), torch.from_numpy(v[tag + ".t"]).cuda(), torch.from_numpy(v[tag + ".noise"]).cuda(),
+                          cond=cond, layout=batch["layout"].cuda() if "layout" in batch else None, cond_drop_prob=0.5,
+                          cond_drop_mask=torch.from_numpy(v[tag + ".drop_mask"]).cuda())
+    loss.backward()
+    ref = float(v[tag + ".loss"])
+    assert abs(loss.item() - ref) < 2e-5 * abs(ref)
+    assert max_rel(ld["train/epoch_stats_y"].cpu(), v[tag + ".per_sample"]) < 2e-5
+    grads = {k: p.grad for k, p in m.named_parameters()}
+    assert sorted(k for k, p in m.named_parameters() if p.requires_grad and p.grad is None) == list(v[tag + ".unused_params"])
+    checked = 0
+    for key in v:
+        if key.startswith(tag + ".grad."):
+            pname = key[len(tag + ".grad."):]
+            got, want = grads[pname].cpu(), torch.from_numpy(v[key])
+        elif key.startswith(tag + ".gsample."):
+            pname = key[len(tag + ".gsample."):]
+            got = grads[pname].cpu().reshape(-1)[::int(v[f"{tag}.gstride.{pname}"])]
+            want = torch.from_numpy(v[key])
+        else:
+            continue
+        scale = float(v[f"{tag}.gmax.{pname}"])                 # max |g| of the WHOLE reference tensor
+        err = float((got.double() - want.double()).abs().max()) / max(scale, 1e-30)
+        assert err < tol, (pname, err)
+        checked += 1
+    assert checked >= 20
+    sq = sum(float((g.double() ** 2).sum()) for g in grads.values() if g is not None)
+    assert abs(sq - float(v[tag + ".grad_sqnorm"])) < 1e-3 * float(v[tag + ".grad_sqnorm"])
