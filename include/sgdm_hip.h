@@ -204,6 +204,10 @@ int sgd_ddim_step_dev(const float* x, const float* eps_nhwc, const float* z, int
                       const float* coef_dev, float temperature, int32_t clip, int32_t b, int32_t c, int32_t hw,
                       float* x_out, float* x0_out, void* stream);
 /* ((x+1)*127.5).clamp(0,255).to(uint8)  (diffusion_utils/util.py:99-100) */
+/* GEGLU gate of the SpatialTransformer feed-forward (reference dynamic/attention.py:38-45, GEGLU.forward):
+ * in [rows, 2*inner] = Linear(x) -> out[r, c] = in[r, c] * gelu(in[r, inner + c]), exact erf GELU; inner % 4 == 0 */
+int sgd_geglu(const float* in, int64_t rows, int32_t inner, float* out, void* stream);
+
 int sgd_to_uint8(const float* x, int64_t count, uint8_t* out, void* stream);
 /* guided eps only (forward_with_cond_scale return value): eps_nhwc [2b,h,w,c] -> NCHW [b,c,h,w] */
 int sgd_cfg_combine(const float* eps_nhwc, int32_t cfg_mode, float w, int32_t b, int32_t c, int32_t hw,

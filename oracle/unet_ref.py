@@ -32,7 +32,8 @@ def make_cfg(kind, image_size, in_channels=3, out_channels=3, model_channels=128
              num_heads=8, num_head_channels=-1, use_scale_shift_norm=True,
              resblock_updown=None, conv_resample=True, dropout=0.0,
              cond_dim=0, condition_method=None, layout_dim=0, scale_type="imagen",
-             cond_token_num=0, context_dim=None, use_cls_token_as_pooled=True):
+             cond_token_num=0, context_dim=None, use_cls_token_as_pooled=True,
+             use_spatial_transformer=False, transformer_depth=1):
     """Collect the reference ctor kwargs (config/dynamic/unet_fast.yaml:3-19,
     config/dynamic/unetca_fast.yaml:6-31).  ``layout_dim`` stands for
     ``condition.<condition_method>.layout_dim`` (config/condition/default.yaml)."""
@@ -49,7 +50,8 @@ def make_cfg(kind, image_size, in_channels=3, out_channels=3, model_channels=128
                 conv_resample=conv_resample, dropout=dropout, cond_dim=cond_dim or 0,
                 condition_method=condition_method, layout_dim=layout_dim,
                 scale_type=scale_type, cond_token_num=cond_token_num,
-                context_dim=context_dim, use_cls_token_as_pooled=use_cls_token_as_pooled)
+                context_dim=context_dim, use_cls_token_as_pooled=use_cls_token_as_pooled,
+                use_spatial_transformer=use_spatial_transformer, transformer_depth=transformer_depth)
 
 
 def _layout_channels(cfg):
@@ -148,6 +150,21 @@ def _layer_manifest(cfg, prefix, layer, emb_ch):
         return r
     if kind == "attn":
         _, ch, heads = layer
+        if not ca and cfg.get("use_spatial_transformer"):
+            # SpatialTransformer(ch, num_heads, ch // num_heads, depth, context_dim): registration order of
+            # dynamic/attention.py:246-258 (norm, proj_in, transformer_blocks, proj_out) and :198-215 (attn1, ff, attn2, norms)
+            inner = heads * (ch // heads)
+            r = _norm(prefix + ".norm", ch) + _conv(prefix + ".proj_in", ch, inner, 1)
+            for i in range(cfg["transformer_depth"]):
+                b = f"{prefix}.transformer_blocks.{i}"
+                for att, kdim in ((".attn1", inner), (".attn2", cfg["context_dim"])):
+                    blk = (_lin(b + att + ".to_q", inner, inner, bias=False) + _lin(b + att + ".to_k", kdim, inner, bias=False)
+                           + _lin(b + att + ".to_v", kdim, inner, bias=False) + _lin(b + att + ".to_out.0", inner, inner))
+                    if att == ".attn1":
+                        blk += _lin(b + ".ff.net.0.proj", inner, 8 * inner) + _lin(b + ".ff.net.2", 4 * inner, inner)
+                    r += blk
+                r += _norm(b + ".norm1", inner) + _norm(b + ".norm2", inner) + _norm(b + ".norm3", inner)
+            return r + _conv(prefix + ".proj_out", inner, ch, 1)
         if not ca:
             return (_norm(prefix + ".norm", ch) + _conv(prefix + ".qkv", ch, 3 * ch, 1, dims=1)
                     + _conv(prefix + ".proj_out", ch, ch, 1, dims=1))
@@ -287,6 +304,38 @@ def attention_block(sd, p, x, heads):
     return (xf + h).reshape(b, c, hh, ww)
 
 
+def _cross_attention(sd, p, x, context, heads):
+    """CrossAttention.forward (dynamic/attention.py:153-194), mask=None"""
+    q = F.linear(x, sd[p + ".to_q.weight"])
+    ctx = x if context is None else context
+    k, v = F.linear(ctx, sd[p + ".to_k.weight"]), F.linear(ctx, sd[p + ".to_v.weight"])
+    b, n, _ = q.shape
+    d = q.shape[-1] // heads
+    split = lambda t: t.reshape(b, t.shape[1], heads, d).permute(0, 2, 1, 3).reshape(b * heads, t.shape[1], d)
+    q, k, v = split(q), split(k), split(v)
+    attn = (torch.einsum("bid,bjd->bij", q, k) * d ** -0.5).softmax(dim=-1)
+    out = torch.einsum("bij,bjd->bid", attn, v).reshape(b, heads, n, d).permute(0, 2, 1, 3).reshape(b, n, heads * d)
+    return F.linear(out, sd[p + ".to_out.0.weight"], sd[p + ".to_out.0.bias"])
+
+
+def spatial_transformer(cfg, sd, p, x, heads, context=None):
+    """SpatialTransformer.forward -> BasicTransformerBlock._forward -> GEGLU feed-forward
+    (dynamic/attention.py:260-270, :217-221, :38-65); GroupNorm eps 1e-6 (:77-78)"""
+    b, c, hh, ww = x.shape
+    ln = lambda q, t: F.layer_norm(t, (t.shape[-1],), sd[q + ".weight"], sd[q + ".bias"], 1e-5)
+    h = F.group_norm(x, 32, sd[p + ".norm.weight"], sd[p + ".norm.bias"], 1e-6)
+    h = F.conv2d(h, sd[p + ".proj_in.weight"], sd[p + ".proj_in.bias"])
+    h = h.reshape(b, h.shape[1], hh * ww).permute(0, 2, 1)
+    for i in range(cfg["transformer_depth"]):
+        k = f"{p}.transformer_blocks.{i}"
+        h = _cross_attention(sd, k + ".attn1", ln(k + ".norm1", h), None, heads) + h
+        h = _cross_attention(sd, k + ".attn2", ln(k + ".norm2", h), context, heads) + h
+        a, gate = F.linear(ln(k + ".norm3", h), sd[k + ".ff.net.0.proj.weight"], sd[k + ".ff.net.0.proj.bias"]).chunk(2, dim=-1)
+        h = F.linear(a * F.gelu(gate), sd[k + ".ff.net.2.weight"], sd[k + ".ff.net.2.bias"]) + h
+    h = h.permute(0, 2, 1).reshape(b, -1, hh, ww)
+    return F.conv2d(h, sd[p + ".proj_out.weight"], sd[p + ".proj_out.bias"]) + x
+
+
 def attention_lr(sd, p, x, context, heads):
     """Attention_LR.forward (crossattetion_lr.py:81-142): multi-query attention
     over [context tokens | null kv | self tokens]."""
@@ -328,7 +377,12 @@ def _run_block(cfg, sd, prefix, blk, h, emb, context, dropout_masks):
             dm = None if dropout_masks is None else dropout_masks.get(p)
             h = res_block(cfg, sd, p, h, emb, layer[3], dm)
         elif kind == "attn":
-            h = attention_lr(sd, p, h, context, layer[2]) if ca else attention_block(sd, p, h, layer[2])
+            if ca:
+                h = attention_lr(sd, p, h, context, layer[2])
+            elif cfg.get("use_spatial_transformer"):
+                h = spatial_transformer(cfg, sd, p, h, layer[2])              # openaimodel.py:915: context is always None
+            else:
+                h = attention_block(sd, p, h, layer[2])
         elif kind == "down":
             if layer[2]:                                    # conv stride 2 (openaimodel_ca.py:167-174)
                 h = F.conv2d(h, sd[p + ".op.weight"], sd[p + ".op.bias"], stride=2, padding=1)

@@ -144,6 +144,23 @@ __global__ void cfg_combine_kernel(const float* __restrict__ eps, int cfg_mode, 
     out[i] = guided(eps, cfg_mode, w, b, n, c, hw, cc, p);
 }
 
+// GEGLU gate of the LDM transformer feed-forward (reference dynamic/attention.py:38-45): out = a * gelu(g), exact (erf) GELU
+__global__ void geglu_kernel(const float* __restrict__ in, long rows, int inner, float* __restrict__ out) {
+    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;      // one thread = 4 consecutive channels
+    const int q = inner >> 2;
+    if (i >= rows * q) return;
+    const long r = i / q;
+    const int c = (int)(i - r * q) * 4;
+    const float4 a = *reinterpret_cast<const float4*>(in + r * 2 * inner + c);
+    const float4 g = *reinterpret_cast<const float4*>(in + r * 2 * inner + inner + c);
+    float4 o;
+    o.x = a.x * (0.5f * g.x * (1.0f + erff(g.x * 0.70710678118654752f)));
+    o.y = a.y * (0.5f * g.y * (1.0f + erff(g.y * 0.70710678118654752f)));
+    o.z = a.z * (0.5f * g.z * (1.0f + erff(g.z * 0.70710678118654752f)));
+    o.w = a.w * (0.5f * g.w * (1.0f + erff(g.w * 0.70710678118654752f)));
+    *reinterpret_cast<float4*>(out + r * inner + c) = o;
+}
+
 inline unsigned nblk(long total) { return (unsigned)((total + 255) / 256); }
 
 }  // namespace
@@ -243,6 +260,14 @@ extern "C" int sgd_ddim_step_dev(const float* x, const float* eps_nhwc, const fl
     Coef5 k = {};
     hipLaunchKernelGGL(ddim_step_kernel, dim3(nblk((long)b * c * hw)), dim3(256), 0, (hipStream_t)stream, x, eps_nhwc,
                        z, cfg_mode, w, k, coef_dev, temperature, clip, b, c, hw, x_out, x0_out);
+    return sgd_check_launch();
+}
+
+extern "C" int sgd_geglu(const float* in, int64_t rows, int32_t inner, float* out, void* stream) {
+    SGD_CLEAR_ERR();
+    if (!in || !out || rows <= 0 || inner <= 0 || (inner & 3)) return SGD_ERR_ARG;
+    hipLaunchKernelGGL(geglu_kernel, dim3(nblk(rows * (inner >> 2))), dim3(256), 0, (hipStream_t)stream, in, (long)rows,
+                       inner, out);
     return sgd_check_launch();
 }
 

@@ -543,6 +543,9 @@ def make_backward(eng):
 def forward_train(model, x, t, cond, layout, mask, n):
     """autograd-capable UNet evaluation (called from UNetModelBase._run when grads are required)"""
     B, cx, H, W = x.shape
+    if getattr(model, "use_spatial_transformer", False):
+        raise NotImplementedError("training through the SpatialTransformer path is not built (inference only; no shipped "
+                                  "config sets use_spatial_transformer)")
     prec = L.PREC_BY_NAME[model.hip_precision]
     eng = model._engine(n, H, W, prec)
     params = [p for p in model.parameters() if p.requires_grad]

@@ -456,7 +456,7 @@ class _Engine:
             self.prog.add(tag, self.lib.sgd_igemm, C.byref(a), flops=flops, nbytes=nbytes)
         return a
 
-    def gn(self, tag, srcs, hw, gname, film=None, film_ld=0):
+    def gn(self, tag, srcs, hw, gname, film=None, film_ld=0, eps=GN_EPS):
         """srcs: list of (tensor, channels) forming a virtual concat -> (a, b) coefficient buffers"""
         n = self.n
         ct = sum(c for _, c in srcs)
@@ -479,10 +479,10 @@ class _Engine:
             (p0, n0, c0), (p1, n1, c1) = parts[0], (parts[1] if len(parts) == 2 else (None, 0, 0))
             self.prog.add(tag + ".coef", self.lib.sgd_gn_coef_parts, _ptr(p0) if p0 is not None else None, n0, c0,
                           _ptr(p1) if p1 is not None else None, n1, c1, _ptr(sums), _ptr(gw), _ptr(gb),
-                          C.c_void_p(film or 0), film_ld, n, GN_GROUPS, hw, GN_EPS, _ptr(a), _ptr(b))
+                          C.c_void_p(film or 0), film_ld, n, GN_GROUPS, hw, eps, _ptr(a), _ptr(b))
         else:
             self.prog.add(tag + ".coef", self.lib.sgd_gn_coef, _ptr(sums), _ptr(gw), _ptr(gb), C.c_void_p(film or 0),
-                          film_ld, n, ct, GN_GROUPS, hw, GN_EPS, _ptr(a), _ptr(b))
+                          film_ld, n, ct, GN_GROUPS, hw, eps, _ptr(a), _ptr(b))
         return a, b
 
     # ---- program construction
@@ -710,8 +710,14 @@ class UNetModel(UNetModelBase):
                  use_new_attention_order=False, use_spatial_transformer=False, transformer_depth=1,
                  context_dim=None, legacy=True, cond_dim=None, condition=None, condition_method=None):
         super().__init__()
-        if use_spatial_transformer or context_dim is not None:
-            raise NotImplementedError("SpatialTransformer path (SURVEY 8(a) A22) is not built yet")
+        if use_spatial_transformer:
+            assert context_dim is not None, "Fool!! You forgot to include the dimension of your cross-attention conditioning..."
+        if context_dim is not None:                                             # openaimodel.py:527-537
+            assert use_spatial_transformer, "Fool!! You forgot to use the spatial transformer for your cross-attention conditioning..."
+            context_dim = list(context_dim) if not isinstance(context_dim, int) else context_dim
+        self.use_spatial_transformer = use_spatial_transformer
+        self.transformer_depth = transformer_depth
+        self.context_dim = context_dim
         if use_new_attention_order:
             raise NotImplementedError("use_new_attention_order=True is not used by any shipped config")
         if condition_method == "cluster_lookup":
@@ -740,10 +746,93 @@ class UNetModel(UNetModelBase):
             sp.linear("mlp_cond.2", ted // 2, ted // 2)
         self._register_all(sp)
 
+    def _heads_for(self, ch, up=False):
+        if self.use_spatial_transformer and self.num_head_channels == -1:
+            return self.num_heads                   # SpatialTransformer(ch, num_heads, ...) in every position (openaimodel.py:683,803)
+        return super()._heads_for(ch, up)
+
     def _attn_spec(self, sp, p, ch, heads):
+        if self.use_spatial_transformer:
+            return self._st_spec(sp, p, ch, heads)
         sp.norm(p + ".norm", ch)
         sp.conv(p + ".qkv", ch, 3 * ch, 1, dims=1)
         sp.conv(p + ".proj_out", ch, ch, 1, dims=1, zero=True)                  # openaimodel.py:357
+
+    # ---- SpatialTransformer (dynamic/attention.py:238-270; registration order of the reference modules)
+    def _st_spec(self, sp, p, ch, heads):
+        d = ch // heads
+        inner = heads * d
+        cd = self.context_dim
+        sp.norm(p + ".norm", ch)
+        sp.conv(p + ".proj_in", ch, inner, 1)
+        for i in range(self.transformer_depth):
+            b = f"{p}.transformer_blocks.{i}"
+            for att, kdim in ((".attn1", inner), (".ff", None), (".attn2", cd)):
+                if att == ".ff":
+                    sp.linear(b + ".ff.net.0.proj", inner, inner * 8)           # GEGLU(dim, 4*dim): Linear(dim, 8*dim)
+                    sp.linear(b + ".ff.net.2", inner * 4, inner)
+                    continue
+                sp.linear(b + att + ".to_q", inner, inner, bias=False)
+                sp.linear(b + att + ".to_k", kdim, inner, bias=False)
+                sp.linear(b + att + ".to_v", kdim, inner, bias=False)
+                sp.linear(b + att + ".to_out.0", inner, inner)
+            for nm in (".norm1", ".norm2", ".norm3"):
+                sp.norm(b + nm, inner)
+        sp.conv(p + ".proj_out", inner, ch, 1, zero=True)                        # zero_module (attention.py:254-258)
+
+    def _build_st(self, eng, p, layer, src):
+        """SpatialTransformer.forward with context=None (openaimodel.py:915 never builds one: both attentions of a block
+        are self-attentions, which requires context_dim == inner_dim exactly as in the reference).  Per block:
+        GroupNorm(eps 1e-6) -> 1x1 proj_in -> depth x [LN -> MHA -> +x ; LN -> MHA -> +x ; LN -> GEGLU FF -> +x] -> 1x1
+        proj_out -> + x_in, on the existing kernels: GN / LN folded into the GEMM loaders, q|k|v as ONE GEMM, the MFMA
+        attention core, bias + residual in the GEMM epilogues, one elementwise launch for the GEGLU gate."""
+        _, ch, heads = layer
+        t, c, hh, ww = src
+        n, T, P, lib = eng.n, hh * ww, self.P, eng.lib
+        d = ch // heads
+        inner = heads * d
+        if self.context_dim != inner:
+            raise ValueError(f"use_spatial_transformer with context=None needs context_dim == {inner} (to_k / to_v are applied "
+                             f"to the {inner}-wide hidden states, openaimodel.py:915, attention.py:174-176)")
+        rows = n * T
+        a, b = eng.gn(p + ".norm", [(t, c)], T, p + ".norm", eps=1e-6)
+        x = eng.buf(n, T, inner)
+        eng.igemm(p + ".proj_in", t, c, x, inner, eng.pack([p + ".proj_in.weight"], 1), m=rows, rows_per_n=T,
+                  pro=L.PRO_AFFINE_NC, pa=a, pb=b, bias=P(p + ".proj_in.bias"))
+        for i in range(self.transformer_depth):
+            blk = f"{p}.transformer_blocks.{i}"
+            for att, nrm in ((".attn1", ".norm1"), (".attn2", ".norm2")):
+                st = eng.buf(rows, 2)
+                eng.prog.add(blk + nrm, lib.sgd_ln_stats, _ptr(x), rows, inner, LN_EPS, _ptr(st))
+                qkv = eng.buf(n, T, 3 * inner)
+                eng.igemm(blk + att + ".qkv", x, inner, qkv, 3 * inner,
+                          eng.pack([blk + att + ".to_q.weight", blk + att + ".to_k.weight", blk + att + ".to_v.weight"], 1),
+                          m=rows, pro=L.PRO_LN_ROW, pa=st, pb=P(blk + nrm + ".weight"), pc=P(blk + nrm + ".bias"))
+                o = eng.buf(n, T, inner)
+                lse = eng.buf(n, heads, T)
+                eng.prog.add(blk + att + ".attn", lib.sgd_attention, _ptr(qkv), 3 * inner, d,
+                             C.c_void_p(qkv.data_ptr() + 4 * inner), C.c_void_p(qkv.data_ptr() + 8 * inner), 3 * inner, d,
+                             n, heads, T, T, d, d ** -0.5, _ptr(o), inner, _ptr(lse))
+                xn = eng.buf(n, T, inner)
+                eng.igemm(blk + att + ".to_out.0", o, inner, xn, inner, eng.pack([blk + att + ".to_out.0.weight"], 1), m=rows,
+                          bias=P(blk + att + ".to_out.0.bias"), res=x)
+                x = xn
+            st = eng.buf(rows, 2)
+            eng.prog.add(blk + ".norm3", lib.sgd_ln_stats, _ptr(x), rows, inner, LN_EPS, _ptr(st))
+            hid = eng.buf(rows, 8 * inner)
+            eng.igemm(blk + ".ff.net.0.proj", x, inner, hid, 8 * inner, eng.pack([blk + ".ff.net.0.proj.weight"], 1), m=rows,
+                      pro=L.PRO_LN_ROW, pa=st, pb=P(blk + ".norm3.weight"), pc=P(blk + ".norm3.bias"),
+                      bias=P(blk + ".ff.net.0.proj.bias"))
+            gated = eng.buf(rows, 4 * inner)
+            eng.prog.add(blk + ".ff.geglu", lib.sgd_geglu, _ptr(hid), rows, 4 * inner, _ptr(gated))
+            xn = eng.buf(n, T, inner)
+            eng.igemm(blk + ".ff.net.2", gated, 4 * inner, xn, inner, eng.pack([blk + ".ff.net.2.weight"], 1), m=rows,
+                      bias=P(blk + ".ff.net.2.bias"), res=x)
+            x = xn
+        y = eng.buf(n, hh, ww, ch)
+        eng.igemm(p + ".proj_out", x, inner, y, ch, eng.pack([p + ".proj_out.weight"], 1), m=rows, rows_per_n=T,
+                  bias=P(p + ".proj_out.bias"), res=t, stats=True)
+        return (y, ch, hh, ww)
 
     def _res_prefixes(self):
         return _res_prefixes(self._plan)
@@ -774,6 +863,8 @@ class UNetModel(UNetModelBase):
 
     def _build_attn(self, eng, p, layer, src):
         """AttentionBlock + QKVAttentionLegacy (openaimodel.py:365-371, 403-420)"""
+        if self.use_spatial_transformer:
+            return self._build_st(eng, p, layer, src)
         _, ch, heads = layer
         t, c, hh, ww = src
         n, T, P = eng.n, hh * ww, self.P

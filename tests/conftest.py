@@ -62,4 +62,6 @@ def cfg_from_index(entry):
                     cond_dim=kw["cond_dim"], condition_method=kw["condition_method"],
                     layout_dim=entry["layout_dim"], cond_token_num=kw.get("cond_token_num", 0),
                     context_dim=kw.get("context_dim"),
-                    use_cls_token_as_pooled=kw.get("use_cls_token_as_pooled", True))
+                    use_cls_token_as_pooled=kw.get("use_cls_token_as_pooled", True),
+                    use_spatial_transformer=kw.get("use_spatial_transformer", False),
+                    transformer_depth=kw.get("transformer_depth", 1))
