@@ -160,7 +160,10 @@ int sgd_attention(const float* q, int32_t q_ld, int32_t q_hs,
 int sgd_timestep_embedding(const int64_t* t, const float* freqs, int32_t n_src, int32_t n, int32_t dim,
                            float* out, void* stream);
 /* cond select (openaimodel.py:929-931): out[r,:] = mask[r] ? null_row : cond[r % n_src,:]; cond is
- * float32 (is_i64 = 0) or int64 one-hot (is_i64 = 1, cast as openaimodel.py:911) */
+ * float32 (is_i64 = 0), int64 one-hot (is_i64 = 1, cast as openaimodel.py:911) or -- is_i64 = 2 -- the int64 class /
+ * cluster IDS [n_src] themselves, expanded to the one-hot row here (F.one_hot of dataset/ds_utils/
+ * unsupervised_cluster.py:33-46, supervised_label.py:31-40 moved onto the device: 8 bytes per sample cross PCIe
+ * instead of 8*k) */
 int sgd_cond_select(const void* cond, int32_t is_i64, const uint8_t* mask, const float* null_row,
                     int32_t n_src, int32_t n, int32_t k, float* out, void* stream);
 /* x NCHW [n_src,cx,h,w] (+ layout NCHW [n_src,cl,h,w] masked by mask -> null_layout[h*w]) -> NHWC
@@ -169,6 +172,24 @@ int sgd_pack_input(const float* x, const float* layout, const uint8_t* mask, con
                    int32_t n_src, int32_t n, int32_t cx, int32_t cl, int32_t h, int32_t w,
                    float* out, void* stream);
 /* NHWC [n,h,w,c] -> NCHW [n,c,h,w] */
+/* The same with the layout in its compact on-disk form, expanded on the device exactly as the reference's data
+ * workers expand it on the CPU (dataset/transforms/complex_ds_common_util.py):
+ *   layout_fmt 1: uint8 label map [n_src,h,w] -> one-hot over cl channels, label 255 -> class 0 (stego_to_onehotmask :118-123)
+ *   layout_fmt 2: int32 boxes [n_src,4] = (x0,y0,x1,y1) in the h x w frame -> mask[y0:y1, x0:x1] = 1, cl == 1
+ *                 (get_lostbboxmask :151-162) */
+int sgd_pack_input_compact(const float* x, const void* layout, int32_t layout_fmt, const uint8_t* mask,
+                           const float* null_layout, int32_t n_src, int32_t n, int32_t cx, int32_t cl, int32_t h,
+                           int32_t w, float* out, void* stream);
+/* n-hot attribute vector of a label map (stegomask_to_attr_nhot, complex_ds_common_util.py:126-133): out[b, j] = 1 if
+ * label j occurs in labels[b, :], k <= 256 */
+int sgd_labelmap_nhot(const uint8_t* labels, int32_t b, int32_t hw, int32_t k, float* out, void* stream);
+/* y[r, c] = mask[r] ? nullproj[c] : w[c, ids[r % n_src]] + bias[c] -- the first Linear of mlp_cond (openaimodel.py:
+ * 597-607) on a one-hot input as a column gather; bit-identical to the dense product (the other k-1 terms are exact
+ * zeros).  w is the nn.Linear weight as stored [nout, k]; nullproj = w . null_cond_emb + bias (computed by the caller
+ * with sgd_linear_splitk when the weights change) */
+int sgd_linear_gather(const int64_t* ids, const uint8_t* mask, const float* w, const float* bias, const float* nullproj,
+                      int32_t n_src, int32_t n, int32_t nout, int32_t k, float* out, int32_t ldo, void* stream);
+
 int sgd_nhwc_to_nchw(const float* x, int32_t n, int32_t h, int32_t w, int32_t c, float* out, void* stream);
 /* broadcast null_kv rows into the shared K/V buffer (crossattetion_lr.py:95-97):
  * kv[b, row, 0:d] = null_kv[0], kv[b, row, d:2d] = null_kv[1] */

@@ -30,6 +30,7 @@ __global__ void cond_select_kernel(const void* __restrict__ cond, int is_i64, co
     const int r = i / k, j = i % k;
     float v;
     if (mask && mask[r]) v = null_row[j];
+    else if (is_i64 == 2) v = reinterpret_cast<const int64_t*>(cond)[r % n_src] == j ? 1.f : 0.f;   // class / cluster id -> one-hot
     else if (is_i64) v = (float)reinterpret_cast<const int64_t*>(cond)[(long)(r % n_src) * k + j];
     else v = reinterpret_cast<const float*>(cond)[(long)(r % n_src) * k + j];
     out[i] = v;
@@ -51,6 +52,64 @@ __global__ void pack_input_kernel(const float* __restrict__ x, const float* __re
     else if (mask && mask[r]) v = null_layout[p];          // null_layout_emb is [1,1,H,W]: broadcast over channels
     else v = layout[((long)rs * cl + (c - cx)) * hw + p];
     out[i] = v;
+}
+
+// the same with the layout given in its compact on-disk form and expanded here (bit-exact restatement of the
+// reference's CPU-side expansion, dataset/transforms/complex_ds_common_util.py:118-123 stego_to_onehotmask and :151-162
+// get_lostbboxmask): fmt 1 = uint8 label map [n_src, h, w] (255 -> class 0) one-hot over cl channels,
+// fmt 2 = int32 boxes [n_src, 4] = (x0, y0, x1, y1), mask[y0:y1, x0:x1] = 1 (cl == 1)
+__global__ void pack_input_compact_kernel(const float* __restrict__ x, const void* __restrict__ layout, int fmt,
+                                          const uint8_t* __restrict__ mask, const float* __restrict__ null_layout,
+                                          int n_src, int n, int cx, int cl, int h, int w, float* __restrict__ out) {
+    const int ct = cx + cl, hw = h * w;
+    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (i >= (long)n * hw * ct) return;
+    const int c = i % ct;
+    const long t = i / ct;
+    const int p = t % hw, r = t / hw;
+    const int rs = r % n_src;
+    float v;
+    if (c < cx) v = x[((long)rs * cx + c) * hw + p];
+    else if (mask && mask[r]) v = null_layout[p];
+    else if (fmt == 1) {
+        int lab = reinterpret_cast<const uint8_t*>(layout)[(long)rs * hw + p];
+        if (lab == 255) lab = 0;
+        v = lab == c - cx ? 1.f : 0.f;
+    } else {
+        const int* b = reinterpret_cast<const int*>(layout) + (long)rs * 4;
+        const int px = p % w, py = p / w;
+        v = (px >= b[0] && px < b[2] && py >= b[1] && py < b[3]) ? 1.f : 0.f;
+    }
+    out[i] = v;
+}
+
+// n-hot vector of the labels present in a label map (stegomask_to_attr_nhot, complex_ds_common_util.py:126-133):
+// one block per image, presence flags in LDS
+__global__ void labelmap_nhot_kernel(const uint8_t* __restrict__ labels, int hw, int k, float* __restrict__ out) {
+    __shared__ int present[256];
+    for (int j = threadIdx.x; j < 256; j += blockDim.x) present[j] = 0;
+    __syncthreads();
+    const uint8_t* lp = labels + (long)blockIdx.x * hw;
+    for (int p = threadIdx.x; p < hw; p += blockDim.x) present[lp[p]] = 1;
+    __syncthreads();
+    for (int j = threadIdx.x; j < k; j += blockDim.x) out[(long)blockIdx.x * k + j] = present[j] ? 1.f : 0.f;
+}
+
+// first Linear of mlp_cond on a one-hot input = one weight column per row (openaimodel.py:597-607 at cluster k = 5000:
+// 2*n*k*nout flops and a k-wide input row per sample replaced by a gather).  x . w[c, :] with x one-hot at id is
+// exactly w[c, id] (adding exact zeros), so out = w[c, id] + bias[c] is bit-identical to the dense product; rows whose
+// cond is dropped take the precomputed projection of the null embedding.
+__global__ void linear_gather_kernel(const int64_t* __restrict__ ids, const uint8_t* __restrict__ mask,
+                                     const float* __restrict__ w, const float* __restrict__ bias,
+                                     const float* __restrict__ nullproj, int n_src, int n, int nout, int k,
+                                     float* __restrict__ out, int ldo) {
+    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (i >= (long)n * nout) return;
+    const int r = i / nout, c = i % nout;
+    float v;
+    if (mask && mask[r]) v = nullproj[c];
+    else v = w[(long)c * k + ids[r % n_src]] + (bias ? bias[c] : 0.f);
+    out[(long)r * ldo + c] = v;
 }
 
 __global__ void nhwc_to_nchw_kernel(const float* __restrict__ x, int n, int hw, int c, float* __restrict__ out) {
@@ -191,6 +250,35 @@ extern "C" int sgd_pack_input(const float* x, const float* layout, const uint8_t
     if (cl > 0 && (!layout || (mask && !null_layout))) return SGD_ERR_ARG;
     hipLaunchKernelGGL(pack_input_kernel, dim3(nblk((long)n * h * w * (cx + cl))), dim3(256), 0, (hipStream_t)stream,
                        x, layout, mask, null_layout, n_src, n, cx, cl, h * w, out);
+    return sgd_check_launch();
+}
+
+extern "C" int sgd_pack_input_compact(const float* x, const void* layout, int32_t layout_fmt, const uint8_t* mask,
+                                      const float* null_layout, int32_t n_src, int32_t n, int32_t cx, int32_t cl, int32_t h,
+                                      int32_t w, float* out, void* stream) {
+    SGD_CLEAR_ERR();
+    if (!x || !out || !layout || n_src <= 0 || n <= 0 || cx <= 0 || cl <= 0 || h <= 0 || w <= 0) return SGD_ERR_ARG;
+    if ((layout_fmt != 1 && layout_fmt != 2) || (layout_fmt == 2 && cl != 1) || (layout_fmt == 1 && cl > 255)) return SGD_ERR_ARG;
+    if (mask && !null_layout) return SGD_ERR_ARG;
+    hipLaunchKernelGGL(pack_input_compact_kernel, dim3(nblk((long)n * h * w * (cx + cl))), dim3(256), 0, (hipStream_t)stream,
+                       x, layout, layout_fmt, mask, null_layout, n_src, n, cx, cl, h, w, out);
+    return sgd_check_launch();
+}
+
+extern "C" int sgd_labelmap_nhot(const uint8_t* labels, int32_t b, int32_t hw, int32_t k, float* out, void* stream) {
+    SGD_CLEAR_ERR();
+    if (!labels || !out || b <= 0 || hw <= 0 || k <= 0 || k > 256) return SGD_ERR_ARG;
+    hipLaunchKernelGGL(labelmap_nhot_kernel, dim3(b), dim3(256), 0, (hipStream_t)stream, labels, hw, k, out);
+    return sgd_check_launch();
+}
+
+extern "C" int sgd_linear_gather(const int64_t* ids, const uint8_t* mask, const float* w, const float* bias,
+                                 const float* nullproj, int32_t n_src, int32_t n, int32_t nout, int32_t k, float* out,
+                                 int32_t ldo, void* stream) {
+    SGD_CLEAR_ERR();
+    if (!ids || !w || !out || n_src <= 0 || n <= 0 || nout <= 0 || k <= 0 || ldo < nout || (mask && !nullproj)) return SGD_ERR_ARG;
+    hipLaunchKernelGGL(linear_gather_kernel, dim3(nblk((long)n * nout)), dim3(256), 0, (hipStream_t)stream, ids, mask, w,
+                       bias, nullproj, n_src, n, nout, k, out, ldo);
     return sgd_check_launch();
 }
 

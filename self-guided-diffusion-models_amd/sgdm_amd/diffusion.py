@@ -161,7 +161,8 @@ class _GraphedStep:
         # static copies in exactly the dtypes the boundary kernels read (prepare() must not re-allocate them)
         c0, l0 = kw.get("cond"), kw.get("layout")
         self.cond = None if c0 is None else (c0.detach().clone() if c0.dtype == torch.int64 else c0.detach().float().clone()).contiguous()
-        self.layout = None if l0 is None else l0.detach().float().clone().contiguous()
+        self.layout = None if l0 is None else (l0.detach().clone() if l0.dtype in (torch.uint8, torch.int32, torch.int64)
+                                               else l0.detach().float().clone()).contiguous()
         self.has_mask = (m._cond_width > 0) or (m._in_ch_total > m.in_channels)
         self.u = torch.zeros(2 * B, device=dev)
         self.p = torch.cat((torch.full((B,), 0.0, device=dev), torch.full((B,), 1.0, device=dev)))

@@ -663,35 +663,58 @@ class _Engine:
         t = t.contiguous().to(torch.int64)
         mask_u8 = mask.contiguous().view(torch.uint8) if mask is not None else None
         cl = m._in_ch_total - m.in_channels
+        lfmt = 0
         if cl:
             if layout is None:
                 raise ValueError(f"condition_method={m.condition_method} needs `layout`")
-            layout = layout.contiguous().float()
-            assert layout.shape == (B, cl, self.h, self.w), (layout.shape, (B, cl, self.h, self.w))
-        is_i64 = False
+            # compact guidance, expanded on the device (sgdm_amd/guidance.py): a uint8 label map [B,H,W] / [B,1,H,W]
+            # instead of the one-hot mask [B,L,H,W], or int box corners [B,4] instead of the box mask [B,1,H,W]
+            if layout.dtype == torch.uint8 and layout.numel() == B * self.h * self.w:
+                layout, lfmt = layout.contiguous(), 1
+            elif layout.dtype in (torch.int32, torch.int64) and tuple(layout.shape) == (B, 4):
+                if cl != 1:
+                    raise ValueError("box-corner layouts need layout_dim == 1")
+                layout, lfmt = layout.to(torch.int32).contiguous(), 2
+            else:
+                layout = layout.contiguous().float()
+                assert layout.shape == (B, cl, self.h, self.w), (layout.shape, (B, cl, self.h, self.w))
+        is_i64 = 0
         if m._cond_width:
             if cond is None:
                 raise ValueError(f"condition_method={m.condition_method} needs `cond`")
             cond = cond.contiguous()
-            is_i64 = cond.dtype == torch.int64
-            if not is_i64:
-                cond = cond.float()
-            assert cond.numel() == B * m._cond_width, (cond.shape, m._cond_width)
-        self._keep_inputs = (x, t, cond, layout, mask_u8, B, is_i64)
+            if cond.dtype == torch.int64 and cond.numel() == B and m._cond_width > 1:
+                is_i64 = 2                                   # class / cluster ids: one-hot expanded on the device
+                cond = cond.reshape(B)
+            else:
+                is_i64 = int(cond.dtype == torch.int64)
+                if not is_i64:
+                    cond = cond.float()
+                assert cond.numel() == B * m._cond_width, (cond.shape, m._cond_width)
+        self._keep_inputs = (x, t, cond, layout, mask_u8, B, is_i64, lfmt)
+        self._train_mode = bool(train)               # the weight gradient of mlp_cond.0 reads the expanded rows
 
     def launch(self, stream):
         """device side: boundary kernels + the static launch program (no allocation, no sync: graph-capturable)"""
         m, n, lib = self.m, self.n, self.lib
-        x, t, cond, layout, mask_u8, B, is_i64 = self._keep_inputs
+        x, t, cond, layout, mask_u8, B, is_i64, lfmt = self._keep_inputs
         cl = m._in_ch_total - m.in_channels
         L.check(lib.sgd_timestep_embedding(_ptr(t), _ptr(self.freqs), B, n, m.model_channels, _ptr(self.temb),
                                            stream), "temb")
-        L.check(lib.sgd_pack_input(_ptr(x), _ptr(layout) if cl else C.c_void_p(0), _ptr(mask_u8),
-                                   _ptr(m.null_layout_emb) if cl else C.c_void_p(0), B, n, m.in_channels, cl,
-                                   self.h, self.w, _ptr(self.x_in), stream), "pack_input")
+        if lfmt:
+            L.check(lib.sgd_pack_input_compact(_ptr(x), _ptr(layout), lfmt, _ptr(mask_u8), _ptr(m.null_layout_emb), B, n,
+                                               m.in_channels, cl, self.h, self.w, _ptr(self.x_in), stream), "pack_input")
+        else:
+            L.check(lib.sgd_pack_input(_ptr(x), _ptr(layout) if cl else C.c_void_p(0), _ptr(mask_u8),
+                                       _ptr(m.null_layout_emb) if cl else C.c_void_p(0), B, n, m.in_channels, cl,
+                                       self.h, self.w, _ptr(self.x_in), stream), "pack_input")
+        self.cond_ids = None
         if m._cond_width:
-            L.check(lib.sgd_cond_select(_ptr(cond), int(is_i64), _ptr(mask_u8), _ptr(m.null_cond_emb), B, n,
-                                        m._cond_width, _ptr(self.cond_m), stream), "cond_select")
+            if is_i64 == 2 and getattr(self, "gather_cond", False) and not self._train_mode:
+                self.cond_ids = (cond, mask_u8, B)           # mlp_cond.0 runs as a column gather (see _build_cond_path)
+            else:
+                L.check(lib.sgd_cond_select(_ptr(cond), int(is_i64), _ptr(mask_u8), _ptr(m.null_cond_emb), B, n,
+                                            m._cond_width, _ptr(self.cond_m), stream), "cond_select")
         self.prog.run(stream)
         self.ran = True
 
@@ -851,10 +874,30 @@ class UNetModel(UNetModelBase):
             ksplit = max(1, min(64, self.cond_dim // 128))
             work = eng.buf(ksplit, eng.n, ted // 2)
             wt, bs = P("mlp_cond.0.weight"), P("mlp_cond.0.bias")
-            eng.prog.add("mlp_cond.0", eng.lib.sgd_linear_splitk, _ptr(eng.cond_m), self.cond_dim, _ptr(wt), _ptr(bs),
-                         eng.n, ted // 2, self.cond_dim, _ptr(work), ksplit, _ptr(c1), ted // 2,
-                         flops=2.0 * eng.n * self.cond_dim * (ted // 2),
-                         nbytes=4.0 * (eng.n * self.cond_dim + self.cond_dim * (ted // 2) + eng.n * (ted // 2)))
+            lib, n, nout, K = eng.lib, eng.n, ted // 2, self.cond_dim
+            nullproj = eng.buf(nout)
+            nwork = eng.buf(ksplit, 1, nout)
+            eng.gather_cond = True
+            box = dict(sig=None)
+
+            def mlp_cond0(stream):
+                """dense skinny GEMM for one-hot / float cond rows; for class / cluster IDS the same result as a column
+                gather of the weight (sgd_linear_gather), dropped rows taking the projection of the null embedding"""
+                if eng.cond_ids is None:
+                    return lib.sgd_linear_splitk(_ptr(eng.cond_m), K, _ptr(wt), _ptr(bs), n, nout, K, _ptr(work), ksplit,
+                                                 _ptr(c1), nout, stream)
+                ids, mask_u8, B = eng.cond_ids
+                sig = (wt._version, bs._version, self.null_cond_emb._version)
+                if sig != box["sig"]:                       # w . null_cond_emb + b, recomputed only when weights change
+                    rc = lib.sgd_linear_splitk(_ptr(self.null_cond_emb), K, _ptr(wt), _ptr(bs), 1, nout, K, _ptr(nwork),
+                                               ksplit, _ptr(nullproj), nout, stream)
+                    if rc:
+                        return rc
+                    box["sig"] = sig
+                return lib.sgd_linear_gather(_ptr(ids), _ptr(mask_u8), _ptr(wt), _ptr(bs), _ptr(nullproj), B, n, nout, K,
+                                             _ptr(c1), nout, stream)
+            mlp_cond0.__name__ = "sgd_linear_splitk"
+            eng.prog.add("mlp_cond.0", mlp_cond0, flops=2.0 * n * K * nout, nbytes=4.0 * (n * K + K * nout + n * nout))
             eng.prog.keep.append((wt, bs))
         a2 = eng.igemm("mlp_cond.2", c1, ted // 2, eng.emb_c, ted // 2, eng.pack(["mlp_cond.2.weight"], 1), m=eng.n,
                        silu=1, bias=P("mlp_cond.2.bias"))
@@ -1082,7 +1125,7 @@ class UNetModelCA(UNetModelBase):
             if self.condition_method == "layout":
                 mask = cond_drop_mask if cond_drop_mask is not None else self._draw_mask(n, cond_drop_prob, x.device)
         else:
-            assert cond is not None and len(cond.shape) == 2                      # :961
+            assert cond is not None and (len(cond.shape) == 2 or cond.dtype == torch.int64)   # :961 (+ compact ids [B])
             mask = cond_drop_mask if cond_drop_mask is not None else self._draw_mask(n, cond_drop_prob, x.device)
         eng = self._run(x, timesteps, cond, layout, mask, n)
         if isinstance(eng, tuple):
