@@ -25,6 +25,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
                                                         float* __restrict__ lse) {
     constexpr int LD = D + 4;
     constexpr int DT = (D + 31) / 32;             // 32-row tiles of the O^T accumulator
+    constexpr int KT = D > 64 ? 32 : 64;          // keys per LDS tile (head dim 128 of the *_s64 widths: 2 x 32 x 132 floats)
     __shared__ __attribute__((aligned(16))) float Ks[KT * LD];
     __shared__ __attribute__((aligned(16))) float Vs[KT * LD];
 
@@ -322,6 +323,7 @@ extern "C" int sgd_attention(const float* q, int32_t q_ld, int32_t q_hs, const f
         case 16: hipLaunchKernelGGL((attention_kernel<16>), grid, dim3(256), 0, st, q, q_ld, q_hs, k, v, kv_ld, kv_hs, tq, tk, scale, out, out_ld, lse); break;
         case 32: hipLaunchKernelGGL((attention_kernel<32>), grid, dim3(256), 0, st, q, q_ld, q_hs, k, v, kv_ld, kv_hs, tq, tk, scale, out, out_ld, lse); break;
         case 64: hipLaunchKernelGGL((attention_kernel<64>), grid, dim3(256), 0, st, q, q_ld, q_hs, k, v, kv_ld, kv_hs, tq, tk, scale, out, out_ld, lse); break;
+        case 128: hipLaunchKernelGGL((attention_kernel<128>), grid, dim3(256), 0, st, q, q_ld, q_hs, k, v, kv_ld, kv_hs, tq, tk, scale, out, out_ld, lse); break;
         default: return SGD_ERR_ARG;
     }
     return sgd_check_launch();

@@ -912,6 +912,7 @@ class UNetModel(UNetModelBase):
         t, c, hh, ww = src
         n, T, P = eng.n, hh * ww, self.P
         d = ch // heads
+        _check_head_dim(d, ch, heads)
         a, b = eng.gn(p + ".norm", [(t, c)], T, p + ".norm")
         sums = eng._last_sums
         qkv = eng.buf(n, T, 3 * ch)
@@ -1077,6 +1078,7 @@ class UNetModelCA(UNetModelBase):
         t, c, hh, ww = src
         n, T, P, lib = eng.n, hh * ww, self.P, eng.lib
         d = ch // heads
+        _check_head_dim(d, ch, heads)
         ntok = eng.ntok
         J = ntok + 1 + T                                   # [context | null | self]
         st = eng.buf(n * T, 2)
@@ -1159,6 +1161,12 @@ def _cfg_eval(model, x, t, cond_scale, cond, layout, probs):
     if not isinstance(cond_scale, (int, float)):
         raise TypeError(f"cond_scale must be a number or a tensor, got {type(cond_scale)}")
     return model._cfg_combine(eng, cond_scale, B)
+
+
+def _check_head_dim(d, ch, heads):
+    if d not in (16, 32, 64, 128):
+        raise ValueError(f"the MFMA attention core takes head dims 16 / 32 / 64 / 128, got {ch} channels / {heads} heads = {d} "
+                         "(set num_head_channels to one of them)")
 
 
 def _layout_dim(condition, method):

@@ -87,23 +87,28 @@ def test_train_step_unetca_vs_reference(prec, tol):
     assert abs(sq - float(v[tag + ".grad_sqnorm"])) < 1e-3 * float(v[tag + ".grad_sqnorm"])
 
 
-def _ddp_rank(rank, world, port, outdir):
+def _ddp_rank(rank, world, port, outdir, name, backend):
     import os
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)       # 1-GPU box: both ranks share cuda:0, gloo moves the buckets
-    grads = _grads_for_seed(100 + rank, ddp=True)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if backend == "nccl":
+        torch.cuda.set_device(rank)                                    # RCCL: one rank per GPU
+    dist.init_process_group(backend, rank=rank, world_size=world)      # gloo on a 1-GPU box: both ranks share cuda:0
+    grads = _grads_for_seed(100 + rank, ddp=True, name=name)
     torch.save({k: v.cpu() for k, v in grads.items()}, os.path.join(outdir, f"rank{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def _grads_for_seed(seed, ddp):
+def _grads_for_seed(seed, ddp, name="uf_clusterlayout_c32_s16"):
     import bench
     from sgdm_amd.diffusion import LatentDiffusion
     from sgdm_amd.synth import synth_batch
-    m, entry = build_model("uf_clusterlayout_c32_s16", "f32")
+    m, entry = build_model(name, "f32")
+    if torch.cuda.current_device() != 0:
+        m = m.cuda()
     m.train()
     m.hip_ddp = ddp
     m.hip_bucket_bytes = 1 << 20                                       # force many buckets on the tiny model
@@ -121,23 +126,31 @@ def _grads_for_seed(seed, ddp):
     return {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}
 
 
-def test_ddp_bucketed_allreduce_two_ranks():
+@pytest.mark.parametrize("name,backend", [("uf_clusterlayout_c32_s16", "gloo"), ("ca_clusterlayout_c32_s16", "gloo"),
+                                          ("uf_clusterlayout_c32_s16", "nccl"), ("ca_clusterlayout_c32_s16", "nccl")])
+def test_ddp_bucketed_allreduce_two_ranks(name, backend):
     """world_size 2: every rank must end with the MEAN of the per-rank gradients (torch DDP semantics), produced by
-    the arena + overlapped bucket all-reduce inside the backward program"""
+    the arena + overlapped bucket all-reduce inside the backward program.  `ca_clusterlayout` is the C4 shape
+    (BASELINE.json configs[3]): its to_cond_tokens_2d.* parameters are unused (README.md:90-94 needs
+    find_unused_parameters for torch DDP) -- every rank must lay out the same buckets without them.  The nccl (= RCCL)
+    variant needs two GPUs and skips on the single-GPU test box."""
     import socket
     import tempfile
     import torch.multiprocessing as mp
+    if backend == "nccl" and torch.cuda.device_count() < 2:
+        pytest.skip("RCCL variant needs 2 GPUs")
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     with tempfile.TemporaryDirectory() as td:
         ctx = mp.get_context("spawn")
-        procs = [ctx.Process(target=_ddp_rank, args=(r, 2, port, td)) for r in range(2)]
+        procs = [ctx.Process(target=_ddp_rank, args=(r, 2, port, td, name, backend)) for r in range(2)]
         for p in procs:
             p.start()
         for p in procs:
             p.join(timeout=300)
             assert p.exitcode == 0
         got = [torch.load(f"{td}/rank{r}.pt") for r in range(2)]
-    ref0, ref1 = _grads_for_seed(100, ddp=False), _grads_for_seed(101, ddp=False)
+    ref0, ref1 = _grads_for_seed(100, ddp=False, name=name), _grads_for_seed(101, ddp=False, name=name)
+    assert not any(k.startswith("to_cond_tokens_2d") for k in ref0)
     for k in ref0:
         exp = 0.5 * (ref0[k].cpu() + ref1[k].cpu())
         if float(exp.abs().max()) < 1e-6:

@@ -117,3 +117,49 @@ def test_state_dict_roundtrip_and_repack():
         e3 = m(x, t, cond=cond, cond_drop_prob=0.0)[0]
     assert rel_l2(e2.cpu(), e1.cpu()) > 1e-2
     assert torch.equal(e1, e3)
+
+
+@pytest.mark.parametrize("kind", ["unet_fast_s64", "unetca_fast_s64_hc32"])
+def test_s64_widths_vs_oracle(kind):
+    """config/dynamic/unet_fast_s64.yaml (ch=256, mult [1,2,4], 8 heads -> head dim 128) and the unetca_fast_s64.yaml
+    width (ch=224, mult [1,2,3,4], attention at ds 4 AND 8 -> T = 256 and 64) with num_head_channels=32 (21 / 28 heads of
+    32; the yaml's num_heads=32 gives head dims 21 / 28, which the MFMA attention core does not take -- it raises): CFG evaluation at B=1
+    against the CPU oracle on seeded weights"""
+    from oracle import unet_ref as U
+    from sgdm_amd.synth import synth_batch, weights_from_seed
+    from sgdm_amd.unet import UNetModel, UNetModelCA
+    if kind == "unet_fast_s64":
+        kw = dict(image_size=64, in_channels=3, out_channels=3, model_channels=256, num_res_blocks=2, channel_mult=[1, 2, 4],
+                  attention_resolutions=[4], num_heads=8, use_scale_shift_norm=True, resblock_updown=True, dropout=0.1,
+                  cond_dim=1000, condition_method="cluster")
+        m = UNetModel(condition=AttrDict(scale_type="imagen"), **kw)
+        cfg = U.make_cfg("unet_fast", 64, model_channels=256, cond_dim=1000, condition_method="cluster")
+        batch = synth_batch("cluster", 1, 64, 1000, 0, seed=3)
+        cond, layout = batch["cond"], None
+    else:
+        kw = dict(image_size=64, in_channels=3, out_channels=3, model_channels=224, num_res_blocks=2, channel_mult=[1, 2, 3, 4],
+                  attention_resolutions=[4, 8], num_heads=-1, num_head_channels=32, use_scale_shift_norm=True, use_ca_block=True,
+                  legacy=False,
+                  dropout=0.0, cond_token_num=1, cond_dim=27, context_dim=32, use_cls_token_as_pooled=True,
+                  condition_method="stegoclusterlayout")
+        m = UNetModelCA(condition=AttrDict(scale_type="imagen", stegoclusterlayout=AttrDict(layout_dim=27)), **kw)
+        cfg = U.make_cfg("unetca_fast", 64, model_channels=224, channel_mult=(1, 2, 3, 4), attention_resolutions=(4, 8),
+                         num_heads=-1, num_head_channels=32, cond_dim=27, condition_method="stegoclusterlayout", layout_dim=27, cond_token_num=1,
+                         context_dim=32)
+        batch = synth_batch("stegoclusterlayout", 1, 64, 27, 27, seed=3)
+        cond, layout = batch["cond"].float(), batch["layout"]
+    manifest = [(k, tuple(v.shape)) for k, v in m.state_dict().items()]
+    assert [k for k, _ in manifest] == [k for k, _, _ in U.param_manifest(cfg)]
+    sd = weights_from_seed(manifest, 23)
+    m.load_state_dict(sd)
+    m = m.cuda().eval()
+    g = torch.Generator().manual_seed(4)
+    x, t = torch.randn(1, 3, 64, 64, generator=g), torch.tensor([321])
+    with torch.no_grad():
+        ref = U.forward_with_cond_scale(cfg, sd, x, t, 2.0, cond, layout)
+        for prec, tol in (("f32", 2e-5), ("f16x3", 5e-5)):
+            m.hip_precision = prec
+            got = m.forward_with_cond_scale(x.cuda(), t.cuda(), cond_scale=2.0, cond=cond.cuda(),
+                                            layout=None if layout is None else layout.cuda())
+            err = max_rel(got.cpu(), ref)
+            assert err < tol, (prec, err)
