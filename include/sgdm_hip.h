@@ -225,6 +225,21 @@ int sgd_ddim_step_dev(const float* x, const float* eps_nhwc, const float* z, int
                       const float* coef_dev, float temperature, int32_t clip, int32_t b, int32_t c, int32_t hw,
                       float* x_out, float* x0_out, void* stream);
 /* ((x+1)*127.5).clamp(0,255).to(uint8)  (diffusion_utils/util.py:99-100) */
+/* Dynamic thresholding (sampling kwarg dtp < 1; clip_x0_minus_one_to_one, diffusion_utils/util.py:70-79):
+ *   s[n] = max(1, quantile(|x0[n]|, dtp)),  x0 <- clamp(x0, -s, s) / s
+ * sgd_x0_quantile forms x0 like the step kernels (kind 0: DDPM coef[5], kind 1: DDIM coef[4]) and selects the two order
+ * statistics lo / hi of |x0| per sample (exact radix select), interpolating with frac like torch.quantile;
+ * the *_dyn steps are sgd_ddpm_step / sgd_ddim_step with that per-sample scale instead of the static clip. */
+int sgd_x0_quantile(int32_t kind, const float* x, const float* eps_nhwc, int32_t cfg_mode, float w,
+                    const float* coef /* HOST */, int32_t b, int32_t c, int32_t hw, int32_t lo, int32_t hi, float frac,
+                    float* s_out /* [b] */, void* stream);
+int sgd_ddpm_step_dyn(const float* x, const float* eps_nhwc, const float* z, int32_t cfg_mode, float w,
+                      const float* coef /* HOST [5] */, const float* dyn_s, int32_t b, int32_t c, int32_t hw,
+                      float* x_out, float* x0_out, void* stream);
+int sgd_ddim_step_dyn(const float* x, const float* eps_nhwc, const float* z, int32_t cfg_mode, float w,
+                      const float* coef /* HOST [4] */, float temperature, const float* dyn_s, int32_t b, int32_t c,
+                      int32_t hw, float* x_out, float* x0_out, void* stream);
+
 /* GEGLU gate of the SpatialTransformer feed-forward (reference dynamic/attention.py:38-45, GEGLU.forward):
  * in [rows, 2*inner] = Linear(x) -> out[r, c] = in[r, c] * gelu(in[r, inner + c]), exact erf GELU; inner % 4 == 0 */
 int sgd_geglu(const float* in, int64_t rows, int32_t inner, float* out, void* stream);

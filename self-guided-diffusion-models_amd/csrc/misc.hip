@@ -143,7 +143,8 @@ struct Coef5 { float v[5]; };
 // x / x_out carry no __restrict__: the graph-replayed form updates x in place
 __global__ void ddpm_step_kernel(const float* x, const float* __restrict__ eps,
                                  const float* __restrict__ z, int cfg_mode, float w, Coef5 k, const float* kdev, int clip,
-                                 int b, int c, int hw, float* x_out, float* __restrict__ x0_out) {
+                                 int b, int c, int hw, float* x_out, float* __restrict__ x0_out,
+                                 const float* __restrict__ dyn_s) {
     const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
     if (i >= (long)b * c * hw) return;
     if (kdev) {
@@ -156,7 +157,10 @@ __global__ void ddpm_step_kernel(const float* x, const float* __restrict__ eps,
     const float e = guided(eps, cfg_mode, w, b, n, c, hw, cc, p);
     const float xv = x[i];
     float x0 = k.v[0] * xv - k.v[1] * e;                      // predict_start_from_noise (ddpm_sampler.py:132-137)
-    if (clip) x0 = fminf(fmaxf(x0, -1.f), 1.f);               // clip_x0_minus_one_to_one, dtp == 1
+    if (dyn_s) {                                              // dynamic thresholding, dtp < 1 (diffusion_utils/util.py:70-79)
+        const float s = dyn_s[n];
+        x0 = fminf(fmaxf(x0, -s), s) / s;
+    } else if (clip) x0 = fminf(fmaxf(x0, -1.f), 1.f);        // clip_x0_minus_one_to_one, dtp == 1
     const float mean = k.v[2] * x0 + k.v[3] * xv;             // q_posterior (ddpm_sampler.py:121-125)
     x_out[i] = mean + k.v[4] * z[i];                          // :190-191, k4 = nonzero*exp(.5 logvar)*temperature
     if (x0_out) x0_out[i] = x0;
@@ -165,7 +169,7 @@ __global__ void ddpm_step_kernel(const float* x, const float* __restrict__ eps,
 __global__ void ddim_step_kernel(const float* x, const float* __restrict__ eps,
                                  const float* __restrict__ z, int cfg_mode, float w, Coef5 k, const float* kdev,
                                  float temperature, int clip, int b, int c, int hw, float* x_out,
-                                 float* __restrict__ x0_out) {
+                                 float* __restrict__ x0_out, const float* __restrict__ dyn_s) {
     const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
     if (i >= (long)b * c * hw) return;
     if (kdev) {
@@ -178,7 +182,10 @@ __global__ void ddim_step_kernel(const float* x, const float* __restrict__ eps,
     const float e = guided(eps, cfg_mode, w, b, n, c, hw, cc, p);
     const float s1m = k.v[0], a_t = k.v[1], a_prev = k.v[2], sigma = k.v[3];
     float x0 = (x[i] - s1m * e) / sqrtf(a_t);                 // ddim_plms_sampler.py:369-370
-    if (clip) x0 = fminf(fmaxf(x0, -1.f), 1.f);
+    if (dyn_s) {
+        const float s = dyn_s[n];
+        x0 = fminf(fmaxf(x0, -s), s) / s;
+    } else if (clip) x0 = fminf(fmaxf(x0, -1.f), 1.f);
     const float dir = sqrtf(1.0f - a_prev - sigma * sigma) * e;   // :381-382
     const float noise = sigma * z[i] * temperature;              // :383-387
     x_out[i] = sqrtf(a_prev) * x0 + dir + noise;                 // :390
@@ -300,16 +307,16 @@ extern "C" int sgd_fill_null_kv(const float* null_kv, int32_t batch, int32_t row
     return sgd_check_launch();
 }
 
-extern "C" int sgd_ddpm_step(const float* x, const float* eps_nhwc, const float* z, int32_t cfg_mode, float w,
-                             const float* coef, int32_t clip, int32_t b, int32_t c, int32_t hw, float* x_out,
-                             float* x0_out, void* stream) {
+static int ddpm_step_impl(const float* x, const float* eps_nhwc, const float* z, int32_t cfg_mode, float w,
+                          const float* coef, int32_t clip, int32_t b, int32_t c, int32_t hw, float* x_out,
+                          float* x0_out, const float* dyn_s, void* stream) {
     SGD_CLEAR_ERR();
     if (!x || !eps_nhwc || !z || !coef || !x_out || b <= 0 || c <= 0 || hw <= 0 || cfg_mode < 0 || cfg_mode > 2)
         return SGD_ERR_ARG;
     Coef5 k;
     for (int i = 0; i < 5; ++i) k.v[i] = coef[i];
     hipLaunchKernelGGL(ddpm_step_kernel, dim3(nblk((long)b * c * hw)), dim3(256), 0, (hipStream_t)stream, x, eps_nhwc,
-                       z, cfg_mode, w, k, (const float*)nullptr, clip, b, c, hw, x_out, x0_out);
+                       z, cfg_mode, w, k, (const float*)nullptr, clip, b, c, hw, x_out, x0_out, dyn_s);
     return sgd_check_launch();
 }
 
@@ -321,13 +328,13 @@ extern "C" int sgd_ddpm_step_dev(const float* x, const float* eps_nhwc, const fl
         return SGD_ERR_ARG;
     Coef5 k = {};
     hipLaunchKernelGGL(ddpm_step_kernel, dim3(nblk((long)b * c * hw)), dim3(256), 0, (hipStream_t)stream, x, eps_nhwc,
-                       z, cfg_mode, w, k, coef_dev, clip, b, c, hw, x_out, x0_out);
+                       z, cfg_mode, w, k, coef_dev, clip, b, c, hw, x_out, x0_out, (const float*)nullptr);
     return sgd_check_launch();
 }
 
-extern "C" int sgd_ddim_step(const float* x, const float* eps_nhwc, const float* z, int32_t cfg_mode, float w,
-                             const float* coef, float temperature, int32_t clip, int32_t b, int32_t c, int32_t hw,
-                             float* x_out, float* x0_out, void* stream) {
+static int ddim_step_impl(const float* x, const float* eps_nhwc, const float* z, int32_t cfg_mode, float w,
+                          const float* coef, float temperature, int32_t clip, int32_t b, int32_t c, int32_t hw,
+                          float* x_out, float* x0_out, const float* dyn_s, void* stream) {
     SGD_CLEAR_ERR();
     if (!x || !eps_nhwc || !z || !coef || !x_out || b <= 0 || c <= 0 || hw <= 0 || cfg_mode < 0 || cfg_mode > 2)
         return SGD_ERR_ARG;
@@ -335,7 +342,7 @@ extern "C" int sgd_ddim_step(const float* x, const float* eps_nhwc, const float*
     for (int i = 0; i < 4; ++i) k.v[i] = coef[i];
     k.v[4] = 0.f;
     hipLaunchKernelGGL(ddim_step_kernel, dim3(nblk((long)b * c * hw)), dim3(256), 0, (hipStream_t)stream, x, eps_nhwc,
-                       z, cfg_mode, w, k, (const float*)nullptr, temperature, clip, b, c, hw, x_out, x0_out);
+                       z, cfg_mode, w, k, (const float*)nullptr, temperature, clip, b, c, hw, x_out, x0_out, dyn_s);
     return sgd_check_launch();
 }
 
@@ -347,7 +354,100 @@ extern "C" int sgd_ddim_step_dev(const float* x, const float* eps_nhwc, const fl
         return SGD_ERR_ARG;
     Coef5 k = {};
     hipLaunchKernelGGL(ddim_step_kernel, dim3(nblk((long)b * c * hw)), dim3(256), 0, (hipStream_t)stream, x, eps_nhwc,
-                       z, cfg_mode, w, k, coef_dev, temperature, clip, b, c, hw, x_out, x0_out);
+                       z, cfg_mode, w, k, coef_dev, temperature, clip, b, c, hw, x_out, x0_out, (const float*)nullptr);
+    return sgd_check_launch();
+}
+
+extern "C" int sgd_ddpm_step(const float* x, const float* eps_nhwc, const float* z, int32_t cfg_mode, float w,
+                             const float* coef, int32_t clip, int32_t b, int32_t c, int32_t hw, float* x_out,
+                             float* x0_out, void* stream) {
+    return ddpm_step_impl(x, eps_nhwc, z, cfg_mode, w, coef, clip, b, c, hw, x_out, x0_out, nullptr, stream);
+}
+extern "C" int sgd_ddim_step(const float* x, const float* eps_nhwc, const float* z, int32_t cfg_mode, float w,
+                             const float* coef, float temperature, int32_t clip, int32_t b, int32_t c, int32_t hw,
+                             float* x_out, float* x0_out, void* stream) {
+    return ddim_step_impl(x, eps_nhwc, z, cfg_mode, w, coef, temperature, clip, b, c, hw, x_out, x0_out, nullptr, stream);
+}
+extern "C" int sgd_ddpm_step_dyn(const float* x, const float* eps_nhwc, const float* z, int32_t cfg_mode, float w,
+                                 const float* coef, const float* dyn_s, int32_t b, int32_t c, int32_t hw, float* x_out,
+                                 float* x0_out, void* stream) {
+    if (!dyn_s) return SGD_ERR_ARG;
+    return ddpm_step_impl(x, eps_nhwc, z, cfg_mode, w, coef, 0, b, c, hw, x_out, x0_out, dyn_s, stream);
+}
+extern "C" int sgd_ddim_step_dyn(const float* x, const float* eps_nhwc, const float* z, int32_t cfg_mode, float w,
+                                 const float* coef, float temperature, const float* dyn_s, int32_t b, int32_t c, int32_t hw,
+                                 float* x_out, float* x0_out, void* stream) {
+    if (!dyn_s) return SGD_ERR_ARG;
+    return ddim_step_impl(x, eps_nhwc, z, cfg_mode, w, coef, temperature, 0, b, c, hw, x_out, x0_out, dyn_s, stream);
+}
+
+// Dynamic thresholding scale (dtp < 1; clip_x0_minus_one_to_one, diffusion_utils/util.py:70-79): per sample
+//   s = max(1, quantile(|x0|, dtp)) with torch.quantile's linear interpolation between the order statistics `lo` and `hi`
+//   (rank = dtp * (n - 1) in fp32, formed by the caller exactly as torch forms it; frac = rank - lo).
+// One block per sample; x0 is recomputed from (x, guided eps) like the step kernels do; the k-th smallest |x0| comes from
+// a 4-pass byte-wise radix select over the float bit patterns (non-negative floats order like their bits) -- exact order
+// statistics, no sort, no atomics on global memory.
+template <int KIND>
+__global__ __launch_bounds__(256) void x0_quantile_kernel(const float* __restrict__ x, const float* __restrict__ eps,
+                                                          int cfg_mode, float w, Coef5 k, int b, int c, int hw, int lo,
+                                                          int hi, float frac, float* __restrict__ s_out) {
+    __shared__ unsigned hist[256];
+    __shared__ unsigned sel_prefix, sel_k;
+    const int n = blockIdx.x, cnt = c * hw;
+    auto key_of = [&](int j) -> unsigned {
+        const int cc = j / hw, p = j - cc * hw;
+        const float e = guided(eps, cfg_mode, w, b, n, c, hw, cc, p);
+        const float xv = x[(long)n * cnt + j];
+        const float x0 = KIND == 0 ? k.v[0] * xv - k.v[1] * e : (xv - k.v[0] * e) / sqrtf(k.v[1]);
+        return __float_as_uint(fabsf(x0));
+    };
+    float vals[2];
+    for (int which = 0; which < 2; ++which) {
+        if (threadIdx.x == 0) { sel_prefix = 0; sel_k = which == 0 ? lo : hi; }
+        unsigned mask = 0;
+        for (int pass = 3; pass >= 0; --pass) {
+            for (int j = threadIdx.x; j < 256; j += blockDim.x) hist[j] = 0;
+            __syncthreads();
+            const unsigned prefix = sel_prefix;
+            for (int j = threadIdx.x; j < cnt; j += blockDim.x) {
+                const unsigned key = key_of(j);
+                if ((key & mask) == prefix) atomicAdd(&hist[(key >> (8 * pass)) & 255u], 1u);
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                unsigned kk = sel_k, cum = 0;
+                int bkt = 0;
+                for (; bkt < 256; ++bkt) {
+                    if (cum + hist[bkt] > kk) break;
+                    cum += hist[bkt];
+                }
+                sel_k = kk - cum;
+                sel_prefix = prefix | ((unsigned)bkt << (8 * pass));
+            }
+            mask |= 0xFFu << (8 * pass);
+            __syncthreads();
+        }
+        vals[which] = __uint_as_float(sel_prefix);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        // torch.lerp(v_lo, v_hi, frac)
+        const float d = vals[1] - vals[0];
+        const float q = frac < 0.5f ? vals[0] + frac * d : vals[1] - d * (1.0f - frac);
+        s_out[n] = fmaxf(q, 1.0f);                            // s.clamp_(min=1.0): only takes effect if s > 1
+    }
+}
+
+extern "C" int sgd_x0_quantile(int32_t kind, const float* x, const float* eps_nhwc, int32_t cfg_mode, float w,
+                               const float* coef, int32_t b, int32_t c, int32_t hw, int32_t lo, int32_t hi, float frac,
+                               float* s_out, void* stream) {
+    SGD_CLEAR_ERR();
+    if (!x || !eps_nhwc || !coef || !s_out || b <= 0 || c <= 0 || hw <= 0 || cfg_mode < 0 || cfg_mode > 2) return SGD_ERR_ARG;
+    if (lo < 0 || hi < lo || hi >= c * hw || (kind != 0 && kind != 1)) return SGD_ERR_ARG;
+    Coef5 k = {};
+    for (int i = 0; i < (kind == 0 ? 5 : 4); ++i) k.v[i] = coef[i];
+    if (kind == 0) hipLaunchKernelGGL((x0_quantile_kernel<0>), dim3(b), dim3(256), 0, (hipStream_t)stream, x, eps_nhwc, cfg_mode, w, k, b, c, hw, lo, hi, frac, s_out);
+    else hipLaunchKernelGGL((x0_quantile_kernel<1>), dim3(b), dim3(256), 0, (hipStream_t)stream, x, eps_nhwc, cfg_mode, w, k, b, c, hw, lo, hi, frac, s_out);
     return sgd_check_launch();
 }
 

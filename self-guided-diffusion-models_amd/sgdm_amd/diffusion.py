@@ -226,6 +226,14 @@ def _graph_ok(runner, sk, kwargs):
     return sk.get("noise_dropout", 0) == 0 and sk.get("dtp", 1) >= 1.0
 
 
+def _quantile_rank(dtp, count):
+    """(lo, hi, frac) of torch.quantile(., dtp) over `count` fp32 values: rank = q * (count - 1) in the input dtype,
+    linear interpolation between the order statistics floor(rank) and ceil(rank)"""
+    rank = torch.tensor(dtp, dtype=torch.float32) * (count - 1)
+    lo = torch.floor(rank)
+    return int(lo), int(torch.ceil(rank)), float(rank - lo)
+
+
 class Schedule_DDPM(nn.Module):
     """ddpm_sampler.py:16-238"""
 
@@ -322,8 +330,7 @@ class Schedule_DDPM(nn.Module):
         h = self.hparams
         self.register_schedule(timesteps=timesteps, given_betas=h.given_betas, beta_schedule=h.beta_schedule,
                                linear_start=h.linear_start, linear_end=h.linear_end, cosine_s=h.cosine_s)
-        if sk.get("dtp", 1) < 1.0:
-            raise NotImplementedError("dynamic thresholding (dtp < 1) is not on the fused step path yet")
+        dyn = sk.get("dtp", 1) < 1.0            # dynamic thresholding (diffusion_utils/util.py:70-79)
         if h.parameterization not in ("eps", "x0"):
             raise NotImplementedError()                                        # ddpm_sampler.py:162-163
         x0_param = h.parameterization == "x0"
@@ -374,8 +381,18 @@ class Schedule_DDPM(nn.Module):
                 coef[0], coef[1] = 0.0, -1.0        # x_recon = model_out (ddpm_sampler.py:160-161): 0*x - (-1)*out, exact
             coef[4] = (float(row[4]) * float(temperature[i])) if i != 0 else 0.0      # no noise when t == 0
             x0 = torch.empty_like(img) if want else None
-            L.check(lib.sgd_ddpm_step(_ptr(img), _ptr(eps), _ptr(z), mode, w, coef, clip, bb, cc, hw,
-                                      _ptr(nxt), _ptr(x0), _stream()), "sgd_ddpm_step")
+            if dyn:
+                lo, hi, frac = _quantile_rank(sk["dtp"], Cc * hw)
+                s_dyn = torch.empty(B, device=dev)
+                # the step kernels see a guided NCHW eps as (B*C) one-channel planes; the quantile is per SAMPLE
+                e4 = eps if mode else eps.reshape(B, Cc, hw).permute(0, 2, 1).contiguous()
+                L.check(lib.sgd_x0_quantile(0, _ptr(img), _ptr(e4), mode, w, coef, B, Cc, hw, lo, hi, frac, _ptr(s_dyn),
+                                            _stream()), "sgd_x0_quantile")
+                L.check(lib.sgd_ddpm_step_dyn(_ptr(img), _ptr(e4), _ptr(z), mode, w, coef, _ptr(s_dyn), B, Cc, hw,
+                                              _ptr(nxt), _ptr(x0), _stream()), "sgd_ddpm_step_dyn")
+            else:
+                L.check(lib.sgd_ddpm_step(_ptr(img), _ptr(eps), _ptr(z), mode, w, coef, clip, bb, cc, hw,
+                                          _ptr(nxt), _ptr(x0), _stream()), "sgd_ddpm_step")
             img, nxt = nxt, img
             if want:
                 pred.append(x0.unsqueeze(0))
@@ -423,7 +440,7 @@ class DDIMSampler(object):
         RNG order of the reference: x_T, then one randn per p_sample_plms call (num_steps + 1 draws)."""
         sk = sampling_kwargs
         if sk.get("dtp", 1) < 1.0:
-            raise NotImplementedError("dynamic thresholding (dtp < 1) is not on the fused step path yet")
+            raise NotImplementedError("dynamic thresholding (dtp < 1) is built for the native and ddim samplers, not plms")
         dev = torch.device(self.device)
         B, Cc = shape[0], shape[1]
         hw = int(np.prod(shape[2:]))
@@ -493,8 +510,7 @@ class DDIMSampler(object):
     @torch.no_grad()
     def ddim_sampling(self, shape, sampling_kwargs, denoise_sample_fn_kwargs=None, denoise_sample_fn=None, **kwargs):
         sk = sampling_kwargs
-        if sk.get("dtp", 1) < 1.0:
-            raise NotImplementedError("dynamic thresholding (dtp < 1) is not on the fused step path yet")
+        dyn = sk.get("dtp", 1) < 1.0
         dev = torch.device(self.device)
         x_T = kwargs.get("x_T")
         img = torch.randn(shape, device=dev) if x_T is None else x_T.to(dev).float().contiguous()
@@ -504,8 +520,14 @@ class DDIMSampler(object):
         def should_vis(name):                                   # eval/test_exps/common_stuff.py:35-36
             return vis is not None and hasattr(vis, name) and bool(getattr(vis, name))
 
-        if should_vis("interp") or should_vis("scoremix_vis"):
-            raise NotImplementedError("the interp / scoremix vis variants need the reference's eval helpers")
+        if should_vis("scoremix_vis"):
+            raise NotImplementedError                           # the reference raises here too (ddim_plms_sampler.py:177-178)
+        if should_vis("interp"):
+            # guidance interpolation strips (ddim_plms_sampler.py:142-155): `samples` pairs of neighbouring conds, `n` slerp
+            # points each, ONE start noise shared by the whole batch; the float cond rows go through the UNet unchanged
+            from .util import batch_to_conditioninterp
+            dkw["cond"] = batch_to_conditioninterp(dkw["cond"], interp_num=vis.interp_c.n, samples=vis.interp_c.samples)
+            img = torch.randn(list(shape[1:]), device=dev).unsqueeze(0).repeat(len(dkw["cond"]), 1, 1, 1).contiguous()
         if should_vis("condscale"):
             # guidance-weight sweep (ddim_plms_sampler.py:107-140): `samples` start noises x 8 weights 0, 3/8, .. 21/8,
             # per-sample tensor cond_scale; only the `layout` entry of the kwargs is re-batched, as in the reference
@@ -566,8 +588,17 @@ class DDIMSampler(object):
             coef[2] = float(self.ddim_alphas_prev[index])
             coef[3] = float(self.ddim_sigmas[index])
             x0 = torch.empty_like(img) if want else None
-            L.check(lib.sgd_ddim_step(_ptr(img), _ptr(eps), _ptr(z), mode, w, coef, float(sk["temperature"]), clip,
-                                      bb, cc, hw, _ptr(nxt), _ptr(x0), _stream()), "sgd_ddim_step")
+            if dyn:
+                lo, hi, frac = _quantile_rank(sk["dtp"], Cc * hw)
+                s_dyn = torch.empty(B, device=dev)
+                e4 = eps if mode else eps.reshape(B, Cc, hw).permute(0, 2, 1).contiguous()
+                L.check(lib.sgd_x0_quantile(1, _ptr(img), _ptr(e4), mode, w, coef, B, Cc, hw, lo, hi, frac, _ptr(s_dyn),
+                                            _stream()), "sgd_x0_quantile")
+                L.check(lib.sgd_ddim_step_dyn(_ptr(img), _ptr(e4), _ptr(z), mode, w, coef, float(sk["temperature"]),
+                                              _ptr(s_dyn), B, Cc, hw, _ptr(nxt), _ptr(x0), _stream()), "sgd_ddim_step_dyn")
+            else:
+                L.check(lib.sgd_ddim_step(_ptr(img), _ptr(eps), _ptr(z), mode, w, coef, float(sk["temperature"]), clip,
+                                          bb, cc, hw, _ptr(nxt), _ptr(x0), _stream()), "sgd_ddim_step")
             img, nxt = nxt, img
             if want:
                 inter.append(img.detach().cpu().unsqueeze(0))

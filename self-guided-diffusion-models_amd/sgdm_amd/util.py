@@ -2,6 +2,8 @@
 diffusion_utils/lr_scheduler.py:36-98)."""
 import importlib
 
+import torch
+
 
 def instantiate_from_config(config):
     assert "target" in config
@@ -39,3 +41,31 @@ class LambdaLinearScheduler:
 
     def __call__(self, n, **kwargs):
         return self.schedule(n, **kwargs)
+
+
+def slerp_batch_torch(val, low, high):
+    """diffusion_utils/util.py:48-60: spherical interpolation, val [K], low / high [1, C] -> [K, C]"""
+    assert len(low.shape) == 2
+    low_norm = low / torch.norm(low, dim=1, keepdim=True)
+    high_norm = high / torch.norm(high, dim=1, keepdim=True)
+    omega = torch.acos((low_norm * high_norm).sum(1))
+    so = torch.sin(omega)
+    return (torch.sin((1.0 - val) * omega) / so).unsqueeze(1) * low + (torch.sin(val * omega) / so).unsqueeze(1) * high
+
+
+def batch_to_conditioninterp(cond_tensor, interp_num=9, samples=10, is_slerp=True):
+    """eval/papervis_utils.py:362-394 (batch_to_conditioninterp_papervis): for i < samples interpolate cond[i] -> cond[i+1]
+    in `interp_num` steps; result [(samples * interp_num), C] (host-side guidance preparation, a few rows)"""
+    batch_size = len(cond_tensor)
+    if batch_size < interp_num:
+        interp_num = batch_size
+    out = []
+    for i in range(samples):
+        c1, c2 = cond_tensor[i].reshape(1, -1), cond_tensor[i + 1].reshape(1, -1)
+        lin_w = torch.linspace(0, 1, interp_num).to(cond_tensor.device)
+        if is_slerp:
+            feat = slerp_batch_torch(lin_w, c1, c2)
+        else:
+            feat = c1 * lin_w.reshape(-1, 1) + c2 * (1 - lin_w.reshape(-1, 1))
+        out.append(feat.unsqueeze(0))
+    return torch.cat(out, 0).reshape(-1, out[0].shape[-1])

@@ -232,3 +232,74 @@ def test_graph_step_does_not_touch_the_callers_x_T():
                     denoise_sample_fn_kwargs=dict(cond=_cond(), layout=None, cond_scale=2.0), condition_kwargs={},
                     x_T=x_T, step_indices=[999, 998, 997])
     assert torch.equal(x_T, keep)
+
+
+def test_dynamic_thresholding_native_step_vs_oracle():
+    """dtp < 1 (clip_x0_minus_one_to_one, diffusion_utils/util.py:70-79) through the sampler: per-sample quantile of |x0|
+    by the radix-select kernel + the *_dyn step, against the oracle's torch.quantile restatement fed the same guided eps"""
+    from oracle import diffusion_ref as D
+    from sgdm_amd.synth import synth_batch
+    m, _ = build_model("uf_label_c32_s16", "f32")
+    d = _diffusion(m)
+    g = torch.Generator().manual_seed(77)
+    B, i = 3, 700
+    x = torch.randn(B, 3, 16, 16, generator=g) * 1.7
+    z = torch.randn(B, 3, 16, 16, generator=g)
+    dkw = dict(cond=synth_batch("label", B, 16, 10, seed=5)["cond"].cuda(), layout=None, cond_scale=2.0)
+    t = torch.full((B,), i, dtype=torch.long)
+    with torch.no_grad():
+        eps = m.forward_with_cond_scale(x.cuda(), t.cuda(), **dkw).cpu()
+    got, _ = d.sampler.sample((B, 3, 16, 16), sampling_kwargs=dict(_skw("native", 1000), dtp=0.9), denoise_sample_fn=d.denoise_sample_fn,
+                              denoise_sample_fn_kwargs=dkw, x_T=x, noise_fn=lambda _i: z, step_indices=[i])
+    sched = D.make_schedule()
+    want, x0 = D.ddpm_step(sched, x, t, eps, z, True, 0.9, 1.0)
+    assert max_rel(got.cpu(), want) < 2e-5
+    unclipped = D.ddpm_step(sched, x, t, eps, z, False, 1.0, 1.0)[1]
+    assert float(torch.quantile(unclipped.reshape(B, -1).abs(), 0.9, dim=-1).min()) > 1.0      # the threshold was active
+
+
+@pytest.mark.parametrize("kind", [0, 1])
+@pytest.mark.parametrize("dtp", [0.9, 0.995, 0.5])
+def test_x0_quantile_kernel_matches_torch_quantile(kind, dtp):
+    """sgd_x0_quantile (exact order statistics by radix select + torch's interpolation) == torch.quantile on the same x0"""
+    import ctypes as C
+    from sgdm_amd import _lib as L
+    from sgdm_amd.diffusion import _quantile_rank
+    lib = L.load()
+    g = torch.Generator().manual_seed(int(dtp * 1000) + kind)
+    B, Cc, hw = 5, 3, 64 * 64
+    x = torch.randn(B, Cc, hw, generator=g) * 2
+    eps_c, eps_u = torch.randn(B, hw, Cc, generator=g), torch.randn(B, hw, Cc, generator=g)
+    eps = torch.cat([eps_c, eps_u]).cuda()                                  # UNet output at 2B, NHWC
+    w = 2.0
+    guided = ((1 - w) * eps_u + w * eps_c).permute(0, 2, 1)                  # imagen scale type
+    coef = (C.c_float * 5)(1.3, 0.8, 0.0, 0.0, 0.0) if kind == 0 else (C.c_float * 5)(0.6, 0.7, 0.0, 0.0, 0.0)
+    x0 = coef[0] * x - coef[1] * guided if kind == 0 else (x - coef[0] * guided) / torch.tensor(coef[1]).sqrt()
+    want = torch.quantile(x0.reshape(B, -1).abs(), dtp, dim=-1).clamp(min=1.0)
+    lo, hi, frac = _quantile_rank(dtp, Cc * hw)
+    s = torch.empty(B, device="cuda")
+    xd = x.cuda()
+    L.check(lib.sgd_x0_quantile(kind, C.c_void_p(xd.data_ptr()), C.c_void_p(eps.data_ptr()), 1, w, coef, B, Cc, hw, lo, hi,
+                                frac, C.c_void_p(s.data_ptr()), torch.cuda.current_stream().cuda_stream), "quantile")
+    assert max_rel(s.cpu(), want) < 2e-6
+
+
+def test_ddim_interp_variant_runs_and_batches_like_the_reference():
+    """vis.interp (ddim_plms_sampler.py:142-155): samples * n interpolated (slerp) float cond rows, one shared start noise"""
+    from sgdm_amd.synth import synth_batch
+
+    class NS:
+        def __init__(self, **kw):
+            self.__dict__.update(kw)
+    m, _ = build_model("uf_label_c32_s16", "f32")
+    d = _diffusion(m)
+    cond = torch.rand(4, 10).cuda() + 0.1
+    vis = NS(interp=True, interp_c=NS(n=3, samples=2))
+    torch.manual_seed(5)
+    samples, inter = d.p_sample_loop("ddim", (4, 3, 16, 16), dict(_skw("ddim", 10, 0.0), vis=vis),
+                                     denoise_sample_fn_kwargs=dict(cond=cond, layout=None, cond_scale=2.0), condition_kwargs={})
+    assert tuple(samples.shape) == (6, 3, 16, 16) and samples.dtype == torch.uint8
+    from sgdm_amd.util import batch_to_conditioninterp
+    rows = batch_to_conditioninterp(cond, 3, 2)
+    assert tuple(rows.shape) == (6, 10)
+    assert torch.allclose(rows[0], cond[0], atol=1e-5) and torch.allclose(rows[2], cond[1], atol=1e-5)   # slerp ends = the pair
