@@ -240,6 +240,10 @@ int sgd_ddim_step_dyn(const float* x, const float* eps_nhwc, const float* z, int
                       const float* coef /* HOST [4] */, float temperature, const float* dyn_s, int32_t b, int32_t c,
                       int32_t hw, float* x_out, float* x0_out, void* stream);
 
+/* pooled guidance token of the token-guidance path (cond_token_num > 1, openaimodel_ca.py:999-1004):
+ * cond [n, tokens, c] -> out [n, c] = cond[:, 0, :] (cls = 1, use_cls_token_as_pooled) or mean over tokens (cls = 0) */
+int sgd_token_pool(const float* cond, int32_t n, int32_t tokens, int32_t c, int32_t cls, float* out, void* stream);
+
 /* GEGLU gate of the SpatialTransformer feed-forward (reference dynamic/attention.py:38-45, GEGLU.forward):
  * in [rows, 2*inner] = Linear(x) -> out[r, c] = in[r, c] * gelu(in[r, inner + c]), exact erf GELU; inner % 4 == 0 */
 int sgd_geglu(const float* in, int64_t rows, int32_t inner, float* out, void* stream);

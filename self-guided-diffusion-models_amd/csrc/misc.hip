@@ -451,6 +451,27 @@ extern "C" int sgd_x0_quantile(int32_t kind, const float* x, const float* eps_nh
     return sgd_check_launch();
 }
 
+// pooled guidance token (openaimodel_ca.py:999-1004): cond [n, T, c] -> out [n, c]; cls = 1: token 0, else the mean over T
+__global__ void token_pool_kernel(const float* __restrict__ cond, int n, int T, int c, int cls, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * c) return;
+    const int r = i / c, j = i % c;
+    const float* p = cond + (long)r * T * c + j;
+    float v = p[0];
+    if (!cls) {
+        for (int t = 1; t < T; ++t) v += p[(long)t * c];
+        v /= (float)T;
+    }
+    out[i] = v;
+}
+
+extern "C" int sgd_token_pool(const float* cond, int32_t n, int32_t tokens, int32_t c, int32_t cls, float* out, void* stream) {
+    SGD_CLEAR_ERR();
+    if (!cond || !out || n <= 0 || tokens <= 0 || c <= 0) return SGD_ERR_ARG;
+    hipLaunchKernelGGL(token_pool_kernel, dim3(nblk((long)n * c)), dim3(256), 0, (hipStream_t)stream, cond, n, tokens, c, cls, out);
+    return sgd_check_launch();
+}
+
 extern "C" int sgd_geglu(const float* in, int64_t rows, int32_t inner, float* out, void* stream) {
     SGD_CLEAR_ERR();
     if (!in || !out || rows <= 0 || inner <= 0 || (inner & 3)) return SGD_ERR_ARG;

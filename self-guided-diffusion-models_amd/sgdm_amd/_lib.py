@@ -85,6 +85,7 @@ SIGNATURES = {
     "sgd_x0_quantile": (i32, [i32, vp, vp, i32, f32, C.POINTER(f32), i32, i32, i32, i32, i32, f32, vp, vp]),
     "sgd_ddpm_step_dyn": (i32, [vp, vp, vp, i32, f32, C.POINTER(f32), vp, i32, i32, i32, vp, vp, vp]),
     "sgd_ddim_step_dyn": (i32, [vp, vp, vp, i32, f32, C.POINTER(f32), f32, vp, i32, i32, i32, vp, vp, vp]),
+    "sgd_token_pool": (i32, [vp, i32, i32, i32, i32, vp, vp]),
     "sgd_geglu": (i32, [vp, i64, i32, vp, vp]),
     "sgd_to_uint8": (i32, [vp, i64, vp, vp]),
     "sgd_cfg_combine": (i32, [vp, i32, f32, i32, i32, i32, vp, vp]),

@@ -546,6 +546,8 @@ def forward_train(model, x, t, cond, layout, mask, n):
     if getattr(model, "use_spatial_transformer", False):
         raise NotImplementedError("training through the SpatialTransformer path is not built (inference only; no shipped "
                                   "config sets use_spatial_transformer)")
+    if getattr(model, "cond_token_num", 0) > 1:
+        raise NotImplementedError("training with cond_token_num > 1 (token guidance) is not built (inference only)")
     prec = L.PREC_BY_NAME[model.hip_precision]
     eng = model._engine(n, H, W, prec)
     params = [p for p in model.parameters() if p.requires_grad]

@@ -976,8 +976,6 @@ class UNetModelCA(UNetModelBase):
         super().__init__()
         if not use_ca_block:
             raise NotImplementedError("openaimodel_ca without use_ca_block is not a shipped configuration")
-        if cond_token_num > 1:
-            raise NotImplementedError("cond_token_num > 1 (token guidance) is not built yet")
         assert isinstance(cond_dim, int) and cond_token_num >= 0                 # openaimodel_ca.py:559-560
         if cond_token_num == 0:
             assert cond_dim == 0                                                 # :563
@@ -993,10 +991,11 @@ class UNetModelCA(UNetModelBase):
         ted = 4 * mc
         cd = self.cond_dim
         self._emb_ch = ted
-        self._cond_width = cd if cond_token_num == 1 else 0
+        # cond rows as the boundary kernels see them: [cd] (one guidance vector) or the flattened [T, cd] token matrix
+        self._cond_width = cd * cond_token_num
         sp = _Spec()
-        if cond_token_num == 1:
-            sp.items.append(("null_cond_emb", (1, cd), "frozen", _zeros))
+        if cond_token_num >= 1:
+            sp.items.append(("null_cond_emb", (cond_token_num, cd), "frozen", _zeros))      # openaimodel_ca.py:566-575
         ld = 0
         if condition_method in ("clusterlayout", "stegoclusterlayout", "layout"):
             sp.items.append(("null_layout_emb", (1, 1, image_size, image_size), "frozen", _zeros))
@@ -1040,7 +1039,8 @@ class UNetModelCA(UNetModelBase):
         n, P = eng.n, self.P
         mc, ctx = self.model_channels, self.context_dim
         ted = 4 * mc
-        ntok = NUM_TIME_TOKENS + (NUM_COND_TOKENS if self.cond_token_num == 1 else 0)
+        T = self.cond_token_num
+        ntok = NUM_TIME_TOKENS + (NUM_COND_TOKENS if T == 1 else (T if T > 1 else 0))
         raw = eng.buf(n, ntok, ctx)
         raw2 = raw.view(n, ntok * ctx)
         wt = ctx * NUM_TIME_TOKENS
@@ -1065,6 +1065,28 @@ class UNetModelCA(UNetModelBase):
                            bias=P("cond_mlp.2.bias"), res=emb)                    # emb = emb + cond_condensed, :977
             eng.tape.append(dict(kind="mlp2", name="cond_mlp", x=eng.cond_m, h=c1, y=emb, a0=b0, a2=b2,
                                  cin=self.cond_dim, mid=ted, cout=ted, add_to_y=True))
+        if T > 1:
+            # token guidance (openaimodel_ca.py:987-1013): cond [n, T, cd] -> per-token MLP to_cond_tokens_2d -> T context
+            # tokens behind the 8 time tokens; emb += cond_mlp(pooled token).  Inference only (no tape records).
+            cd = self.cond_dim
+            mid = int(math.sqrt(ctx * cd))
+            rows = n * T
+            src, width = eng.cond_m, cd
+            for li, (idx, wout) in enumerate(((0, mid), (2, mid), (4, mid), (6, ctx))):
+                name = f"to_cond_tokens_2d.{idx}"
+                last = idx == 6
+                dst = raw if last else eng.buf(rows, wout)
+                eng.igemm(name, src, width, dst, wout, eng.pack([name + ".weight"], 1), m=rows, silu=int(li > 0),
+                          bias=P(name + ".bias"), orows=(T, ntok, NUM_TIME_TOKENS) if last else (0, 0, 0))
+                src, width = dst, wout
+            pooled = eng.buf(n, cd)
+            eng.prog.add("cond_pooled", eng.lib.sgd_token_pool, _ptr(eng.cond_m), n, T, cd,
+                         1 if self.use_cls_token_as_pooled == True else 0, _ptr(pooled))     # noqa: E712  (reference: == True)
+            c1 = eng.buf(n, ted)
+            eng.igemm("cond_mlp.0", pooled, cd, c1, ted, eng.pack(["cond_mlp.0.weight"], 1), m=n, bias=P("cond_mlp.0.bias"))
+            eng.igemm("cond_mlp.2", c1, ted, emb, ted, eng.pack(["cond_mlp.2.weight"], 1), m=n, silu=1,
+                      bias=P("cond_mlp.2.bias"), res=emb)
+            eng.token_guidance = True
         context = eng.buf(n, ntok, ctx)
         eng.prog.add("norm_cond", eng.lib.sgd_ln_apply, _ptr(raw), _ptr(P("norm_cond.weight")),
                      _ptr(P("norm_cond.bias")), C.c_void_p(0), n * ntok, ctx, LN_EPS, _ptr(context))
@@ -1127,7 +1149,12 @@ class UNetModelCA(UNetModelBase):
             if self.condition_method == "layout":
                 mask = cond_drop_mask if cond_drop_mask is not None else self._draw_mask(n, cond_drop_prob, x.device)
         else:
-            assert cond is not None and (len(cond.shape) == 2 or cond.dtype == torch.int64)   # :961 (+ compact ids [B])
+            if self.cond_token_num > 1:
+                assert cond is not None and len(cond.shape) == 3                  # :988  [B, T, C]
+                if self.condition_method == "clusterlayout":
+                    raise NotImplementedError                                     # :1006-1007
+            else:
+                assert cond is not None and (len(cond.shape) == 2 or cond.dtype == torch.int64)   # :961 (+ compact ids [B])
             mask = cond_drop_mask if cond_drop_mask is not None else self._draw_mask(n, cond_drop_prob, x.device)
         eng = self._run(x, timesteps, cond, layout, mask, n)
         if isinstance(eng, tuple):

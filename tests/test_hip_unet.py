@@ -163,3 +163,22 @@ def test_s64_widths_vs_oracle(kind):
                                             layout=None if layout is None else layout.cuda())
             err = max_rel(got.cpu(), ref)
             assert err < tol, (prec, err)
+
+
+def test_token_guidance_mean_pooling_vs_reference_golden():
+    """cond_token_num > 1 with use_cls_token_as_pooled=False (mean over tokens, openaimodel_ca.py:1003-1004); the CLS
+    variant runs through the parametrised golden tests above"""
+    from sgdm_amd.synth import weights_from_seed
+    from sgdm_amd.unet import UNetModelCA
+    entry = INDEX["ca_tokens_c32_s16"]
+    kw = dict(entry["ctor"], use_cls_token_as_pooled=False)
+    m = UNetModelCA(condition=AttrDict(scale_type="imagen"), **kw)
+    m.load_state_dict(weights_from_seed(entry["manifest"], entry["seed"]))
+    m = m.cuda().eval()
+    v, x, t, cond, layout = inputs("ca_tokens_c32_s16")
+    for prec, tol in (("f32", 2e-5), ("f16x3", 5e-5)):
+        m.hip_precision = prec
+        for tag, p in (("keep", [0.0, 0.0]), ("mixed", [0.0, 1.0])):
+            with torch.no_grad():
+                got = m(x, t, cond=cond.float(), cond_drop_prob=torch.tensor(p).cuda())[0]
+            assert max_rel(got.cpu(), v[f"meanpool.eps_{tag}"]) < tol, (prec, tag)
