@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define SGD_ABI_VERSION 5
+#define SGD_ABI_VERSION 6
 int sgd_abi_version(void);
 
 /* --------------------------------------------------------------------------------------
@@ -87,6 +87,12 @@ typedef struct sgd_igemm_args {
      * sgd_igemm_stats_parts(args) (0: this geometry cannot produce them; leave stats NULL).  Folded into
      * the sums[n, c, 2] layout of sgd_chan_stats by sgd_stats_reduce.  NULL: off. */
     float* stats;
+    /* Per-tensor power-of-two scale of the packed weights (split-precision modes): the packed values are w * 2^k with k
+     * chosen by sgd_pack_weight_scaled so that max|w| * 2^k lies in [1, 2) -- the 16-bit hi AND lo halves then sit in
+     * fp16's normal range whatever the magnitude of the tensor (zero-initialised convs early in training are ~1e-4: their
+     * lo halves would be fp16 subnormals with 2-3 significant bits).  The epilogue multiplies the accumulator by
+     * *w_scale_inv = 2^-k (exact) before bias / residual.  DEVICE pointer to one float; NULL: 1. */
+    const float* w_scale_inv;
 } sgd_igemm_args;
 
 /* the keep/drop hash, shared by device code and host tests:
@@ -101,6 +107,16 @@ int sgd_igemm_stats_parts(const sgd_igemm_args* args /* HOST pointer */);
 int64_t sgd_packed_weight_bytes(int32_t cout, int32_t cin, int32_t ksize, int32_t prec);
 int sgd_pack_weight(const float* w_src, void* w_dst, int32_t cout, int32_t cin, int32_t ksize,
                     int32_t prec, int32_t* cin_p, int32_t* cout_p /* HOST out */, void* stream);
+
+/* sgd_pack_weight / sgd_pack_weight_dgrad with the per-tensor power-of-two scale described at sgd_igemm_args.w_scale_inv:
+ * amax_bits is a DEVICE uint32 the caller zeroes; sgd_weight_amax (one or more calls: concatenated sources) folds
+ * max|w| into it (bit pattern of a non-negative float, atomicMax); the packer derives 2^k from it, scales before the
+ * hi/lo split and writes 2^-k to scale_inv_out (DEVICE float).  All on the stream, no host round trip. */
+int sgd_weight_amax(const float* w, int64_t count, uint32_t* amax_bits, void* stream);
+int sgd_pack_weight_scaled(const float* w_src, void* w_dst, int32_t cout, int32_t cin, int32_t ksize, int32_t prec,
+                           int32_t transpose /* 1: dgrad operator, dims are the FORWARD weight's */,
+                           const uint32_t* amax_bits, float* scale_inv_out, int32_t* cin_p, int32_t* cout_p /* HOST out */,
+                           void* stream);
 
 /* Skinny linear with a long reduction (mlp_cond.0 of the cluster-k5000 config, openaimodel.py:597-607: [2B, 5000] x
  * [256, 5000]^T): exact fp32 FMA, the K range split over `ksplit` blocks per 64-column tile, partial sums in

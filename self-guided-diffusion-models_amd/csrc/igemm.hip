@@ -978,6 +978,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
                 rpm[mt] = RES ? a.res + (long)rrow * a.cout : nullptr;
             }
             const bool vec = ((a.cout | a.y_ld) & 3) == 0;
+            const float wsi = a.w_scale_inv ? *a.w_scale_inv : 1.f;        // 2^-k of the packed weights (exact)
             if (vec) {
                 // cout % 4 == 0: 16-byte quads.  Quad-outer / row-inner: the residual loads of both rows are in flight
                 // together, and the GroupNorm statistics of a quad (args.stats) live in 8 registers at a time.
@@ -1027,7 +1028,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
                         for (int mt = 0; mt < MT; ++mt) {
                             f32x4 v;
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) v[j] = acc[mt][nt][gq * 4 + j];
+                            for (int j = 0; j < 4; ++j) v[j] = acc[mt][nt][gq * 4 + j] * wsi;
                             v += rv[gq][mt];
                             if (okm[mt]) {
                                 if (!(DBG(8)) && !ABL(1)) *reinterpret_cast<f32x4*>(ypm[mt] + c) = v;
@@ -1062,7 +1063,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
                             for (int j = 0; j < 4; ++j) {
                                 const int c = cb + nt * 32 + gq * 8 + j;
                                 if (c >= a.cout) continue;
-                                float x = acc[mt][nt][gq * 4 + j] + (a.bias ? a.bias[c] : 0.f);
+                                float x = acc[mt][nt][gq * 4 + j] * wsi + (a.bias ? a.bias[c] : 0.f);
                                 if (RES == 1 || RES == 3) x += rp[c];
                                 if (RES == 2) {
                                     const long rw = (long)a.wo * 2 * a.cout;
@@ -1100,9 +1101,28 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
 //   (exactly the A-operand lane map of v_mfma_f32_32x32x16_f16 / four v_mfma_f32_32x32x2_f32 k-pairs).
 // One thread produces one lane's 16 bytes (f32) or its hi AND lo 16 bytes (split) of one sub-step.
 // ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float pow2_scale_of(uint32_t amax_bits) {
+    // 2^k with max|w| * 2^k in [1, 2): k = -(exponent of amax); all-zero / non-finite tensors: 1
+    const float amax = __uint_as_float(amax_bits);
+    if (!(amax > 0.f) || !(amax < 3.0e38f)) return 1.f;
+    int e;
+    frexpf(amax, &e);                                          // amax = m * 2^e, m in [0.5, 1)
+    return ldexpf(1.f, 1 - e);
+}
+
+__global__ void weight_amax_kernel(const float* __restrict__ w, long count, uint32_t* __restrict__ amax_bits) {
+    float m = 0.f;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x) m = fmaxf(m, fabsf(w[i]));
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) atomicMax(amax_bits, __float_as_uint(m));
+}
+
 template <int PREC>
 __global__ void pack_weight_kernel(const float* __restrict__ src, float* __restrict__ dst, int cout, int cin,
-                                   int ks, int cout_p, int cin_p, int transpose) {
+                                   int ks, int cout_p, int cin_p, int transpose, const uint32_t* __restrict__ amax_bits,
+                                   float* __restrict__ scale_inv_out) {
+    const float wscale = amax_bits ? pow2_scale_of(*amax_bits) : 1.f;
+    if (scale_inv_out && blockIdx.x == 0 && threadIdx.x == 0) *scale_inv_out = 1.f / wscale;     // exact: power of two
     constexpr int NKS = PREC == SGD_PREC_F32 ? 4 : 2;         // sub-steps per unit
     constexpr int CPL = PREC == SGD_PREC_F32 ? 4 : 8;         // input channels per lane per sub-step
     const int kk = ks * ks, nblk = cout_p >> 5;
@@ -1128,7 +1148,7 @@ __global__ void pack_weight_kernel(const float* __restrict__ src, float* __restr
                 if (!transpose) x = src[((long)co * cin + ci) * kk + tap];
                 else x = src[((long)ci * cout + co) * kk + (kk - 1 - tap)];
             }
-            v[j] = x;
+            v[j] = x * wscale;
         }
         if constexpr (PREC == SGD_PREC_F32) {
             *reinterpret_cast<f32x4*>(dst + unit * 1024 + sub * 256 + lane * 4) = f32x4{v[0], v[1], v[2], v[3]};
@@ -1187,7 +1207,8 @@ extern "C" int64_t sgd_packed_weight_bytes(int32_t cout, int32_t cin, int32_t ks
 }
 
 static int pack_weight_impl(const float* w_src, void* w_dst, int32_t cout, int32_t cin, int32_t ksize, int32_t prec,
-                            int32_t* cin_p_out, int32_t* cout_p_out, int transpose, void* stream) {
+                            int32_t* cin_p_out, int32_t* cout_p_out, int transpose, void* stream,
+                            const uint32_t* amax_bits = nullptr, float* scale_inv_out = nullptr) {
     SGD_CLEAR_ERR();
     if (!w_src || !w_dst || cout <= 0 || cin <= 0 || (ksize != 1 && ksize != 3)) return SGD_ERR_ARG;
     const int bn = pick_bn(cout);
@@ -1200,9 +1221,9 @@ static int pack_weight_impl(const float* w_src, void* w_dst, int32_t cout, int32
     if (grid > 4096) grid = 4096;
     hipStream_t st = (hipStream_t)stream;
     float* dst = reinterpret_cast<float*>(w_dst);
-    if (prec == SGD_PREC_F32) hipLaunchKernelGGL((pack_weight_kernel<SGD_PREC_F32>), dim3(grid), dim3(256), 0, st, w_src, dst, cout, cin, ksize, cout_p, cin_p, transpose);
-    else if (prec == SGD_PREC_F16X3) hipLaunchKernelGGL((pack_weight_kernel<SGD_PREC_F16X3>), dim3(grid), dim3(256), 0, st, w_src, dst, cout, cin, ksize, cout_p, cin_p, transpose);
-    else if (prec == SGD_PREC_BF16X3) hipLaunchKernelGGL((pack_weight_kernel<SGD_PREC_BF16X3>), dim3(grid), dim3(256), 0, st, w_src, dst, cout, cin, ksize, cout_p, cin_p, transpose);
+    if (prec == SGD_PREC_F32) hipLaunchKernelGGL((pack_weight_kernel<SGD_PREC_F32>), dim3(grid), dim3(256), 0, st, w_src, dst, cout, cin, ksize, cout_p, cin_p, transpose, amax_bits, scale_inv_out);
+    else if (prec == SGD_PREC_F16X3) hipLaunchKernelGGL((pack_weight_kernel<SGD_PREC_F16X3>), dim3(grid), dim3(256), 0, st, w_src, dst, cout, cin, ksize, cout_p, cin_p, transpose, amax_bits, scale_inv_out);
+    else if (prec == SGD_PREC_BF16X3) hipLaunchKernelGGL((pack_weight_kernel<SGD_PREC_BF16X3>), dim3(grid), dim3(256), 0, st, w_src, dst, cout, cin, ksize, cout_p, cin_p, transpose, amax_bits, scale_inv_out);
     else return SGD_ERR_ARG;
     return sgd_check_launch();
 }
@@ -1217,6 +1238,23 @@ extern "C" int sgd_pack_weight(const float* w_src, void* w_dst, int32_t cout, in
 extern "C" int sgd_pack_weight_dgrad(const float* w_src, void* w_dst, int32_t cout_fwd, int32_t cin_fwd, int32_t ksize,
                                      int32_t prec, int32_t* cin_p_out, int32_t* cout_p_out, void* stream) {
     return pack_weight_impl(w_src, w_dst, cin_fwd, cout_fwd, ksize, prec, cin_p_out, cout_p_out, 1, stream);
+}
+
+extern "C" int sgd_weight_amax(const float* w, int64_t count, uint32_t* amax_bits, void* stream) {
+    SGD_CLEAR_ERR();
+    if (!w || !amax_bits || count <= 0) return SGD_ERR_ARG;
+    int grid = (int)((count + 1023) / 1024);
+    if (grid > 512) grid = 512;
+    hipLaunchKernelGGL(weight_amax_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, (long)count, amax_bits);
+    return sgd_check_launch();
+}
+
+extern "C" int sgd_pack_weight_scaled(const float* w_src, void* w_dst, int32_t cout, int32_t cin, int32_t ksize, int32_t prec,
+                                      int32_t transpose, const uint32_t* amax_bits, float* scale_inv_out, int32_t* cin_p_out,
+                                      int32_t* cout_p_out, void* stream) {
+    if (!amax_bits || !scale_inv_out) return SGD_ERR_ARG;
+    if (transpose) return pack_weight_impl(w_src, w_dst, cin, cout, ksize, prec, cin_p_out, cout_p_out, 1, stream, amax_bits, scale_inv_out);
+    return pack_weight_impl(w_src, w_dst, cout, cin, ksize, prec, cin_p_out, cout_p_out, 0, stream, amax_bits, scale_inv_out);
 }
 
 // tile geometry of a launch (everything that does not depend on the packed-weight dims)

@@ -46,6 +46,14 @@ class _PackedAdj:
         self.buf = torch.empty(nbytes // 4, dtype=torch.float32, device=device)
         self.cin_p = self.cout_p = 0
         self.sig = None
+        self.scaled = prec != L.PREC_F32           # per-tensor power-of-two scale, as unet._Packed
+        if self.scaled:
+            self.amax = torch.zeros(1, dtype=torch.int32, device=device)
+            self.scale_inv = torch.ones(1, dtype=torch.float32, device=device)
+
+    @property
+    def scale_ptr(self):
+        return self.scale_inv.data_ptr() if self.scaled else 0
 
     def refresh(self, stream):
         sig = tuple((p.data_ptr(), p._version) for p in self.deps)
@@ -53,8 +61,16 @@ class _PackedAdj:
             return
         src = self.src_fn().detach().contiguous().float()
         cin_p, cout_p = C.c_int32(0), C.c_int32(0)
-        L.check(L.load().sgd_pack_weight_dgrad(_ptr(src), _ptr(self.buf), self.cout_fwd, self.cin_fwd, self.ksize,
-                                               self.prec, C.byref(cin_p), C.byref(cout_p), stream), "pack_dgrad")
+        lib = L.load()
+        if self.scaled:
+            self.amax.zero_()
+            L.check(lib.sgd_weight_amax(_ptr(src), src.numel(), _ptr(self.amax), stream), "sgd_weight_amax")
+            L.check(lib.sgd_pack_weight_scaled(_ptr(src), _ptr(self.buf), self.cout_fwd, self.cin_fwd, self.ksize, self.prec,
+                                               1, _ptr(self.amax), _ptr(self.scale_inv), C.byref(cin_p), C.byref(cout_p),
+                                               stream), "sgd_pack_weight_scaled")
+        else:
+            L.check(lib.sgd_pack_weight_dgrad(_ptr(src), _ptr(self.buf), self.cout_fwd, self.cin_fwd, self.ksize,
+                                              self.prec, C.byref(cin_p), C.byref(cout_p), stream), "pack_dgrad")
         self.cin_p, self.cout_p = cin_p.value, cout_p.value
         self._keep = src
         self.sig = sig
@@ -142,6 +158,7 @@ class Backward:
         else:
             a.mode, a.m, a.stride = L.MODE_FLAT, m, 1
         a.w = pk.buf.data_ptr()
+        a.w_scale_inv = pk.scale_ptr
         a.y, a.cout, a.y_ld, a.prec = y.data_ptr(), cout_of_y, (y_ld or cout_of_y), self.prec
         if acc:
             a.res, a.res_mode = y.data_ptr(), L.RS_NONE

@@ -126,6 +126,16 @@ class _Packed:
         self.buf = torch.empty(nbytes // 4, dtype=torch.float32, device=srcs[0].device)
         self.cin_p = self.cout_p = 0
         self.sig = None
+        # split precisions: per-tensor power-of-two scale so hi AND lo halves stay in fp16's normal range whatever the
+        # tensor's magnitude (include/sgdm_hip.h: sgd_igemm_args.w_scale_inv); formed on the device, no host round trip
+        self.scaled = prec != L.PREC_F32
+        if self.scaled:
+            self.amax = torch.zeros(1, dtype=torch.int32, device=srcs[0].device)
+            self.scale_inv = torch.ones(1, dtype=torch.float32, device=srcs[0].device)
+
+    @property
+    def scale_ptr(self):
+        return self.scale_inv.data_ptr() if self.scaled else 0
 
     def refresh(self, stream):
         sig = tuple((s.data_ptr(), s._version) for s in self.srcs)
@@ -135,8 +145,15 @@ class _Packed:
         src = self.srcs[0].detach() if len(self.srcs) == 1 else torch.cat([s.detach() for s in self.srcs], 0)
         src = src.contiguous().float()
         cin_p, cout_p = C.c_int32(0), C.c_int32(0)
-        L.check(lib.sgd_pack_weight(_ptr(src), _ptr(self.buf), self.cout, self.cin, self.ksize, self.prec,
-                                    C.byref(cin_p), C.byref(cout_p), stream), "sgd_pack_weight")
+        if self.scaled:
+            self.amax.zero_()
+            L.check(lib.sgd_weight_amax(_ptr(src), src.numel(), _ptr(self.amax), stream), "sgd_weight_amax")
+            L.check(lib.sgd_pack_weight_scaled(_ptr(src), _ptr(self.buf), self.cout, self.cin, self.ksize, self.prec, 0,
+                                               _ptr(self.amax), _ptr(self.scale_inv), C.byref(cin_p), C.byref(cout_p),
+                                               stream), "sgd_pack_weight_scaled")
+        else:
+            L.check(lib.sgd_pack_weight(_ptr(src), _ptr(self.buf), self.cout, self.cin, self.ksize, self.prec,
+                                        C.byref(cin_p), C.byref(cout_p), stream), "sgd_pack_weight")
         self.cin_p, self.cout_p = cin_p.value, cout_p.value
         self._keep = src
         self.sig = sig
@@ -429,6 +446,7 @@ class _Engine:
         a.pb = pb.data_ptr() if pb is not None else 0
         a.pc = pc.data_ptr() if pc is not None else 0
         a.w = pk.buf.data_ptr()
+        a.w_scale_inv = pk.scale_ptr
         a.bias = bias.data_ptr() if bias is not None else 0
         a.res = res.data_ptr() if res is not None else 0
         a.res_mode = res_mode

@@ -363,3 +363,57 @@ def test_resample_adjoints():
     gpd = _nhwc(gp).cuda()
     L.check(lib.sgd_resample_bwd(_p(gpd), n, h, h, c, L.RS_AVGPOOL2, _p(dst), 0, _stream()), "pool_adj")
     assert max_rel(dst.cpu().permute(0, 3, 1, 2), x.grad) < 2e-6
+
+
+@pytest.mark.parametrize("prec,tol", [("f16x3", 2e-5), ("bf16x3", 3e-4)])
+@pytest.mark.parametrize("xs,ws", [(1e3, 1e-4), (1.0, 1e-6), (3e-3, 30.0), (1.0, 1.0)])
+def test_split_precision_out_of_range_magnitudes(xs, ws, prec, tol):
+    """f16x3 outside the comfortable range: activations x1e3 / weights x1e-4 (and friends).  fp16 halves go subnormal
+    below 6e-5 (2-3 significant bits left in `lo`) and overflow above 65504; the packed weights therefore carry a
+    per-tensor power-of-two scale (sgd_pack_weight_scaled, undone exactly in the epilogue) and the training program
+    scales gradients the same way.  Forward conv, its dgrad (adjoint-packed weights) and the split-precision wgrad vs
+    float64; the (1, 1) row is the in-range control."""
+    L, lib = _lib()
+    n, cin, h, cout = 4, 128, 16, 128
+    g = torch.Generator().manual_seed(31)
+    x = (torch.randn(n, cin, h, h, generator=g) * xs).double().requires_grad_(True)
+    w = (torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(cin * 9) * ws).double().requires_grad_(True)
+    gy = torch.randn(n, cout, h, h, generator=g).double()
+    y = F.conv2d(x, w, padding=1)
+    y.backward(gy)
+    p = L.PREC_BY_NAME[prec]
+
+    def pack(transpose):
+        co, ci = (cin, cout) if transpose else (cout, cin)
+        buf = torch.empty(lib.sgd_packed_weight_bytes(co, ci, 3, p) // 4, device="cuda")
+        amax = torch.zeros(1, dtype=torch.int32, device="cuda")
+        sinv = torch.ones(1, device="cuda")
+        cp, op = C.c_int32(), C.c_int32()
+        wd = w.detach().float().cuda()
+        L.check(lib.sgd_weight_amax(_p(wd), wd.numel(), _p(amax), _stream()), "amax")
+        L.check(lib.sgd_pack_weight_scaled(_p(wd), _p(buf), cout, cin, 3, p, int(transpose), _p(amax), _p(sinv), C.byref(cp),
+                                           C.byref(op), _stream()), "pack")
+        return buf, sinv, cp.value, op.value
+    # forward
+    buf, sinv, cp, op = pack(False)
+    xd = _nhwc(x.detach().float()).cuda()
+    out = torch.full((n, h, h, cout), float("nan"), device="cuda")
+    a = _igemm_args(L, xd, conv=(n, h, h, h, h))
+    a.w, a.cin_p, a.cout_p, a.y, a.cout, a.y_ld, a.prec, a.w_scale_inv = buf.data_ptr(), cp, op, out.data_ptr(), cout, cout, p, sinv.data_ptr()
+    L.check(lib.sgd_igemm(C.byref(a), _stream()), "fwd")
+    assert max_rel(out.cpu().permute(0, 3, 1, 2), y.detach().float()) < tol
+    s = float(sinv.item())
+    assert s == 2.0 ** round(math.log2(s)) and 1.0 <= float(w.detach().abs().max()) / s < 2.0      # amax * 2^k in [1, 2)
+    # dgrad (gradients of O(1): the training program keeps them there with its own power-of-two loss scale)
+    bufT, sinvT, cpT, opT = pack(True)
+    gyd = _nhwc(gy.float()).cuda()
+    gx = torch.full((n, h, h, cin), float("nan"), device="cuda")
+    b = _igemm_args(L, gyd, conv=(n, h, h, h, h))
+    b.w, b.cin_p, b.cout_p, b.y, b.cout, b.y_ld, b.prec, b.w_scale_inv = bufT.data_ptr(), cpT, opT, gx.data_ptr(), cin, cin, p, sinvT.data_ptr()
+    L.check(lib.sgd_igemm(C.byref(b), _stream()), "dgrad")
+    assert max_rel(gx.cpu().permute(0, 3, 1, 2), x.grad.float()) < tol
+    # wgrad reads the raw activations: their magnitude is the tensor's own (activations x1e3 stay below fp16's 65504)
+    fwd = _igemm_args(L, xd, conv=(n, h, h, h, h))
+    fwd.prec = p
+    dw = _wgrad(L, lib, fwd, gyd, cout, cin, 9, 3)
+    assert max_rel(dw.reshape(cout, cin, 3, 3), w.grad.float()) < max(tol, 3e-5)
