@@ -377,12 +377,14 @@ def main():
                 shape1 = (C1["batch"], 3, C1["image"], C1["image"])
                 run1 = lambda: diff1.p_sample_loop("ddim", shape1, kw_, denoise_sample_fn_kwargs=dict(k1), condition_kwargs={})
                 run1()
-                barrier()
-                t0_ = time.perf_counter()
-                for _ in range(5):
+                ts_ = []
+                for _ in range(9):                      # median of 9 whole trajectories (host hiccups are outliers here)
+                    barrier()
+                    t0_ = time.perf_counter()
                     run1()
-                barrier()
-                c1[name + "_ms_per_trajectory"] = round(1000.0 * (time.perf_counter() - t0_) / 5, 3)
+                    barrier()
+                    ts_.append(1000.0 * (time.perf_counter() - t0_))
+                c1[name + "_ms_per_trajectory"] = round(sorted(ts_)[len(ts_) // 2], 3)
         c1.update(workload=C1["desc"], images_per_s=round(C1["batch"] / (c1["graph_ms_per_trajectory"] * 1e-3), 1),
                   graph_speedup=round(c1["eager_ms_per_trajectory"] / c1["graph_ms_per_trajectory"], 2),
                   note="whole p_sample_loop (10 steps, all of them snapshot steps, uint8 conversion); the captured step is cached on the model, capture cost excluded by the warm-up call")
