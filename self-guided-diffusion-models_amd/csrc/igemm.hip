@@ -344,17 +344,22 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
             // per-tile work (source rows, padding flags) is hoisted, chunk pointers are wave-uniform scalars.  Everything is
             // branch-free so the in-order vmcnt waits stay exact.
             // =================================================================================
-            const bool uni = VEC && g.nb == 1 && a.pro == SGD_PRO_AFFINE_NC;
-            const bool lean2 = g.fast_a && VEC && (uni || a.pro == SGD_PRO_NONE) && a.drop_p == 0.f && cin % KC == 0
-                               && (a.c1 == 0 || a.c0 % KC == 0) && !DBG(3);
+            // two straight-line instantiations: GroupNorm affine + SiLU (every ResBlock conv of the sampler) and no prologue at
+            // all (input gradients, plain convs).  With the mode as RUN-time flags each of the six items of a chunk was a
+            // chain of small basic blocks (selects between the transformed and untransformed value, moves at the joins),
+            // which the scheduler could neither interleave nor strip -- and loader issue slots are what paces the block.
+            const bool uni_rt = VEC && g.nb == 1 && a.pro == SGD_PRO_AFFINE_NC;
+            const bool lean2 = g.fast_a && VEC && ((uni_rt && a.pro_silu) || (a.pro == SGD_PRO_NONE && !a.pro_silu))
+                               && a.drop_p == 0.f && cin % KC == 0 && (a.c1 == 0 || a.c0 % KC == 0) && !DBG(3);
             if (lean2) {
                 constexpr int LT = NTHREADS - 256;                       // 256 loader threads
                 constexpr int AJ = (FAST_PIX * 8 + LT - 1) / LT;         // input items per thread per chunk (6)
                 const int lt = tid - 256;
                 const int c4 = lt & 7;                                   // channel quad (inputs and weights alike)
                 const int items = g.pix * 8;
-                auto go = [&](auto latec, auto poolc) {
-                    constexpr bool LATE = decltype(latec)::value;
+                auto go = [&](auto unic, auto poolc) {
+                    constexpr bool uni = decltype(unic)::value;          // true: GN affine + SiLU, false: raw input
+                    constexpr bool LATE = false;
                     constexpr int NS = decltype(poolc)::value ? 4 : 1;   // source pixels per item (fused 2x2 average pool)
                     constexpr int T0 = LATE ? 5 : 1;
                     typedef std::integral_constant<int, 0> R0;
@@ -404,8 +409,8 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
                     Coef kq;
                     auto transform = [&](f32x4 v, bool ok) {
                         if (ABL(256)) return v;
-                        if (uni) v = v * kq.p + kq.q;
-                        if (a.pro_silu) {
+                        if constexpr (uni) {
+                            v = v * kq.p + kq.q;
 #pragma unroll
                             for (int e = 0; e < 4; ++e) v[e] = sgd_silu(v[e]);
                         }
@@ -422,7 +427,9 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
                             araw[j][3] = ld4(p0 + (long)(a.wi + 1) * c.stride);
                         }
                     };
-                    auto issue_coef = [&](const S& c) { kq.p = ld4(c.ka + c4 * 4); kq.q = ld4(c.kb + c4 * 4); };
+                    auto issue_coef = [&](const S& c) {
+                        if constexpr (uni) { kq.p = ld4(c.ka + c4 * 4); kq.q = ld4(c.kb + c4 * 4); }
+                    };
                     // Branch-free: an item slot past the end of the tile is a DUPLICATE of the tile's last pixel (same source
                     // row, same channel quad as the thread that owns it, hence the same bytes to the same LDS address).  A
                     // branch per item made six separate basic blocks: the six dependency chains (affine -> exp -> rcp -> split)
@@ -473,8 +480,13 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
                         SYNC();                                         // barrier q+1
                     }
                 };
-                if (a.resample == SGD_RS_AVGPOOL2) go(std::false_type(), std::true_type());
-                else go(std::false_type(), std::false_type());
+                if (uni_rt) {
+                    if (a.resample == SGD_RS_AVGPOOL2) go(std::true_type(), std::true_type());
+                    else go(std::true_type(), std::false_type());
+                } else {
+                    if (a.resample == SGD_RS_AVGPOOL2) go(std::false_type(), std::true_type());
+                    else go(std::false_type(), std::false_type());
+                }
                 PROBE_END(1);
                 return;
             }
@@ -486,11 +498,16 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
             // Lean cases only: no prologue, or a per-image GroupNorm affine whose image boundaries fall on tile
             // boundaries (rows_per_n % 128 == 0), so the coefficients of a tile are one (n, channel quad) vector.
             // =================================================================================
-            const bool tile_uni = a.pro == SGD_PRO_AFFINE_NC && a.rows_per_n % BM == 0;
-            const bool ln = a.pro == SGD_PRO_LN_ROW;              // per-row (mean, rstd) + per-channel gamma / beta
-            const bool leanf = VEC && (a.pro == SGD_PRO_NONE || tile_uni || ln) && a.drop_p == 0.f && cin % KC == 0
+            const bool tile_uni_rt = a.pro == SGD_PRO_AFFINE_NC && a.rows_per_n % BM == 0;
+            const bool ln_rt = a.pro == SGD_PRO_LN_ROW;           // per-row (mean, rstd) + per-channel gamma / beta
+            const bool leanf = VEC && (a.pro == SGD_PRO_NONE || tile_uni_rt || ln_rt) && a.drop_p == 0.f && cin % KC == 0
                                && (a.c1 == 0 || a.c0 % KC == 0) && !DBG(3);
-            if (leanf) {
+            // straight-line instantiations per (prologue, SiLU) -- same reason as the conv loader above: with run-time mode
+            // flags every item was a chain of small blocks, and on the 1x1 launches the loader IS the critical path
+            auto flat_loader = [&](auto modec, auto siluc) {
+                constexpr int MODE = decltype(modec)::value;              // 0 none, 1 per-image GroupNorm affine, 2 LayerNorm rows
+                constexpr bool SILU = decltype(siluc)::value;
+                constexpr bool tile_uni = MODE == 1, ln = MODE == 2;
                 constexpr int AI = BM * 8 / (NTHREADS - 256);             // input quads per thread per step (4)
                 constexpr int AROWS = (NTHREADS - 256) / 8;               // rows covered by one pass of the loader threads (32)
                 const int lt = tid - 256;
@@ -528,14 +545,16 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
                     int stride;
                     if (ch < a.c0) { src = a.x0 + ch; stride = a.c0; }
                     else { src = a.x1 + (ch - a.c0); stride = a.c1; }
-                    kq[R].p = ld4(ci.ka + ((tile_uni || ln) ? ch : 0));
-                    kq[R].q = ld4(ci.kb + ((tile_uni || (ln && a.pc)) ? ch : 0));
+                    if constexpr (MODE != 0) {
+                        kq[R].p = ld4(ci.ka + ch);
+                        kq[R].q = ld4(ci.kb + ((tile_uni || a.pc) ? ch : 0));
+                    }
 #pragma unroll
                     for (int j = 0; j < AI; ++j) {
                         int row = ci.m0 + arow + j * AROWS;
                         row = row < M ? row : M - 1;
                         araw[R][j] = ld4(src + (long)row * stride + c4 * 4);
-                        rst[R][j] = *reinterpret_cast<const float2*>(ln ? a.pa + (long)row * 2 : a.x0);
+                        if constexpr (ln) rst[R][j] = *reinterpret_cast<const float2*>(a.pa + (long)row * 2);
                     }
                     advance(ci);
                 };
@@ -544,12 +563,12 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
 #pragma unroll
                     for (int j = 0; j < AI; ++j) {
                         f32x4 v = araw[R][j];
-                        if (tile_uni) v = v * kq[R].p + kq[R].q;
-                        if (ln) {
+                        if constexpr (tile_uni) v = v * kq[R].p + kq[R].q;
+                        if constexpr (ln) {
                             v = (v - rst[R][j].x) * rst[R][j].y * kq[R].p;
                             if (a.pc) v += kq[R].q;
                         }
-                        if (a.pro_silu) {
+                        if constexpr (SILU) {
 #pragma unroll
                             for (int e = 0; e < 4; ++e) v[e] = sgd_silu(v[e]);
                         }
@@ -581,6 +600,14 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
                     body(2, R2());
                     if (step + 1 < S) body(0, R0());
                 }
+            };
+            if (leanf) {
+                typedef std::integral_constant<int, 0> M0;
+                typedef std::integral_constant<int, 1> M1;
+                typedef std::integral_constant<int, 2> M2;
+                if (tile_uni_rt) { if (a.pro_silu) flat_loader(M1(), std::true_type()); else flat_loader(M1(), std::false_type()); }
+                else if (ln_rt) { if (a.pro_silu) flat_loader(M2(), std::true_type()); else flat_loader(M2(), std::false_type()); }
+                else { if (a.pro_silu) flat_loader(M0(), std::true_type()); else flat_loader(M0(), std::false_type()); }
                 PROBE_END(1);
                 return;
             }
