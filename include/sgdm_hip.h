@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define SGD_ABI_VERSION 6
+#define SGD_ABI_VERSION 7
 int sgd_abi_version(void);
 
 /* --------------------------------------------------------------------------------------
@@ -159,7 +159,9 @@ int sgd_ln_apply(const float* x, const float* gamma, const float* beta, const fl
  *  multi-query attention over [context | null | self] keys (crossattetion_lr.py:90-139)
  * q rows: [b, tq, *] with row stride q_ld, head h at +h*q_hs; k/v rows: [b, tk, *] with row
  * stride kv_ld, head h at +h*kv_hs (0 for multi-query).  out[b, tq, heads*d] head-major.
- * softmax(scale * q.k) ; d in {16, 32, 64}.
+ * softmax(scale * q.k) ; d in {16, 32, 64, 128}.
+ * sgd_attention: exact fp32 MFMA.  sgd_attention_split: the same contract in split precision (every fp32 operand as
+ * hi + lo f16, three products, fp32 accumulate -- the arithmetic of SGD_PREC_F16X3); out must be 16-byte aligned.
  * -------------------------------------------------------------------------------------- */
 int sgd_attention(const float* q, int32_t q_ld, int32_t q_hs,
                   const float* k, const float* v, int32_t kv_ld, int32_t kv_hs,
@@ -167,6 +169,10 @@ int sgd_attention(const float* q, int32_t q_ld, int32_t q_hs,
                   float* out, int32_t out_ld,
                   float* lse /* [batch, heads, tq] log-sum-exp of the scaled logits for the backward, or NULL */,
                   void* stream);
+int sgd_attention_split(const float* q, int32_t q_ld, int32_t q_hs,
+                        const float* k, const float* v, int32_t kv_ld, int32_t kv_hs,
+                        int32_t batch, int32_t heads, int32_t tq, int32_t tk, int32_t d, float scale,
+                        float* out, int32_t out_ld, float* lse, void* stream);
 
 /* --------------------------------------------------------------------------------------
  * Small glue kernels on the UNet boundary.

@@ -136,6 +136,208 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
 
 
 // =============================================================================================
+// split-precision forward (prec f16x3): the same S^T = K Q^T / O^T = V^T P^T orientation on
+// v_mfma_f32_32x32x16_f16 with every fp32 operand carried as hi + lo 16-bit halves and three products
+// (hi.hi + hi.lo + lo.hi, fp32 accumulate) -- 24 MFMAs of 32 cycles per 32-key tile at D = 64 instead of 64 MFMAs
+// of 64 cycles.  K is staged row-major as two f16 planes (16-byte fragment reads); V is staged TRANSPOSED,
+// [d][key], in the k order the accumulator-as-operand idiom imposes: the P^T fragment of k-step s is registers
+// 8s..8s+7 of the score accumulator, whose element j on lane half h is key 16s + 8(j>>2) + 4h + (j&3); V^T's
+// fragment must present the same key at the same (h, j), so key kk = 8a + 4h + c of a 16-key group is stored at
+// position 8h + 4a + c.  P is scaled by 2^14 before the split (its lo half would otherwise sit in fp16's
+// subnormal range); the scale cancels in O / l.
+// =============================================================================================
+__device__ __forceinline__ void split_f16(float v, _Float16& hi, _Float16& lo) {
+    SGD_ROUNDED(v);
+    hi = (_Float16)v;
+    lo = (_Float16)(v - (float)hi);
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void attention_split_kernel(const float* __restrict__ q, int q_ld, int q_hs,
+                                                              const float* __restrict__ k, const float* __restrict__ v,
+                                                              int kv_ld, int kv_hs, int tq, int tk, float scale,
+                                                              float* __restrict__ out, int out_ld,
+                                                              float* __restrict__ lse) {
+    constexpr int DT = (D + 31) / 32;             // 32-row tiles of the O^T accumulator
+    constexpr int DP = DT * 32;                   // rows of the V^T image (zero beyond D)
+    constexpr int KS = (D + 15) / 16;             // 16-channel k steps of the score product
+    constexpr int DK = KS * 16;
+    constexpr int KT = D > 64 ? 32 : 64;          // keys per LDS tile
+    constexpr int LDK = DK + 8;                   // f16 elements per K row (16-byte aligned, 4-bank skew)
+    constexpr int LDV = KT + 8;                   // f16 elements per V^T row
+    __shared__ __attribute__((aligned(16))) _Float16 Kh[KT * LDK];
+    __shared__ __attribute__((aligned(16))) _Float16 Kl[KT * LDK];
+    __shared__ __attribute__((aligned(16))) _Float16 Vh[DP * LDV];
+    __shared__ __attribute__((aligned(16))) _Float16 Vl[DP * LDV];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int head = blockIdx.y, b = blockIdx.z;
+    const int qi = blockIdx.x * 128 + wave * 32 + li;      // this lane's query
+    const int qc = qi < tq ? qi : tq - 1;
+
+    // Q^T fragments (B operand): k step s, lane half lh: channels 16s + 8lh .. +7 of query li
+    f16x8 qh[KS], ql[KS];
+    {
+        const float* qp = q + ((long)b * tq + qc) * q_ld + head * q_hs;
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+            for (int j4 = 0; j4 < 2; ++j4) {
+                const int c = s * 16 + lh * 8 + j4 * 4;
+                f32x4 t = {0.f, 0.f, 0.f, 0.f};
+                if (c < D) t = *reinterpret_cast<const f32x4*>(qp + c);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    _Float16 h, l;
+                    split_f16(t[j] * scale, h, l);
+                    qh[s][j4 * 4 + j] = h;
+                    ql[s][j4 * 4 + j] = l;
+                }
+            }
+    }
+
+    f32x16 oacc[DT];
+#pragma unroll
+    for (int i = 0; i < DT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    constexpr float LOG2E = 1.4426950408889634f;
+    constexpr float PSHIFT = 14.0f;               // P is carried times 2^14
+
+    const float* kb = k + (long)b * tk * kv_ld + head * kv_hs;
+    const float* vb = v + (long)b * tk * kv_ld + head * kv_hs;
+
+    if (DP > D) {                                 // rows of the V^T image no channel writes (D = 16)
+        for (int idx = tid; idx < (DP - D) * LDV; idx += 256) {
+            Vh[D * LDV + idx] = (_Float16)0.f;
+            Vl[D * LDV + idx] = (_Float16)0.f;
+        }
+    }
+
+    for (int kt0 = 0; kt0 < tk; kt0 += KT) {
+        __syncthreads();
+        // K rows: one float4 -> 4 hi + 4 lo (8-byte stores)
+        constexpr int VPR = D / 4;
+        for (int idx = tid; idx < KT * VPR; idx += 256) {
+            const int row = idx / VPR, c4 = idx % VPR;
+            f32x4 t = {0.f, 0.f, 0.f, 0.f};
+            if (kt0 + row < tk) t = *reinterpret_cast<const f32x4*>(kb + (long)(kt0 + row) * kv_ld + c4 * 4);
+            f16x4 h4, l4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                _Float16 h, l;
+                split_f16(t[j], h, l);
+                h4[j] = h;
+                l4[j] = l;
+            }
+            *reinterpret_cast<f16x4*>(Kh + row * LDK + c4 * 4) = h4;
+            *reinterpret_cast<f16x4*>(Kl + row * LDK + c4 * 4) = l4;
+        }
+        // V^T: a thread takes two neighbouring keys (neighbours in the permuted order too) x 4 channels
+        for (int idx = tid; idx < (KT / 2) * VPR; idx += 256) {
+            const int kp = idx / VPR, c4 = idx % VPR;
+            const int key = kp * 2;
+            f32x4 t0 = {0.f, 0.f, 0.f, 0.f}, t1 = {0.f, 0.f, 0.f, 0.f};
+            if (kt0 + key < tk) t0 = *reinterpret_cast<const f32x4*>(vb + (long)(kt0 + key) * kv_ld + c4 * 4);
+            if (kt0 + key + 1 < tk) t1 = *reinterpret_cast<const f32x4*>(vb + (long)(kt0 + key + 1) * kv_ld + c4 * 4);
+            const int kk = key & 15;
+            const int pos = (key & ~15) + (((kk >> 2) & 1) << 3) + ((kk >> 3) << 2) + (kk & 3);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                _Float16 h0, l0, h1, l1;
+                split_f16(t0[j], h0, l0);
+                split_f16(t1[j], h1, l1);
+                typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+                f16x2 hh = {h0, h1}, ll = {l0, l1};
+                *reinterpret_cast<f16x2*>(Vh + (c4 * 4 + j) * LDV + pos) = hh;
+                *reinterpret_cast<f16x2*>(Vl + (c4 * 4 + j) * LDV + pos) = ll;
+            }
+        }
+        __syncthreads();
+
+#pragma unroll
+        for (int st = 0; st < KT / 32; ++st) {
+            if (kt0 + st * 32 >= tk) break;
+            // S^T tile [32 keys x 32 queries]
+            f32x16 sacc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const f16x8 kh = *reinterpret_cast<const f16x8*>(Kh + (st * 32 + li) * LDK + s * 16 + lh * 8);
+                const f16x8 kl = *reinterpret_cast<const f16x8*>(Kl + (st * 32 + li) * LDK + s * 16 + lh * 8);
+                sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[s], sacc, 0, 0, 0);
+                sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[s], sacc, 0, 0, 0);
+                sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[s], sacc, 0, 0, 0);
+            }
+            float mx = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kt0 + st * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (key >= tk) sacc[r] = -INFINITY;
+                mx = fmaxf(mx, sacc[r]);
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * LOG2E);
+            float psum = 0.f;
+            const float mb = PSHIFT - m_new * LOG2E;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                sacc[r] = __builtin_amdgcn_exp2f(fmaf(sacc[r], LOG2E, mb));
+                psum += sacc[r];
+            }
+            l_run = l_run * alpha + psum;
+            m_run = m_new;
+            // P^T fragments of the two 16-key steps: registers 8s .. 8s+7
+            f16x8 ph[2], pl[2];
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    _Float16 h, l;
+                    split_f16(sacc[s2 * 8 + j], h, l);
+                    ph[s2][j] = h;
+                    pl[s2][j] = l;
+                }
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const f16x8 vh = *reinterpret_cast<const f16x8*>(Vh + (dt * 32 + li) * LDV + st * 32 + s2 * 16 + lh * 8);
+                    const f16x8 vl = *reinterpret_cast<const f16x8*>(Vl + (dt * 32 + li) * LDV + st * 32 + s2 * 16 + lh * 8);
+                    oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph[s2], oacc[dt], 0, 0, 0);
+                    oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl[s2], oacc[dt], 0, 0, 0);
+                    oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph[s2], oacc[dt], 0, 0, 0);
+                }
+            }
+        }
+    }
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    if (lse && qi < tq && lh == 0) lse[((long)b * gridDim.y + head) * tq + qi] = m_run + __logf(l_tot) - PSHIFT * 0.6931471805599453f;
+    if (qi < tq) {
+        float* op = out + ((long)b * tq + qi) * out_ld + head * D;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int dd = dt * 32 + 8 * g + 4 * lh;
+                if (dd >= D) continue;
+                f32x4 o4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o4[j] = oacc[dt][g * 4 + j] * inv;
+                *reinterpret_cast<f32x4*>(op + dd) = o4;
+            }
+    }
+}
+
+
+// =============================================================================================
 // backward.  With LSE (from the forward) and D[q] = dO[q].O[q] both softmax statistics are known, so
 // every (key tile, query tile) pair is independent:
 //     S = scale q k^T, P = exp(S - LSE), dP = dO v^T, dS = P (dP - D)
@@ -324,6 +526,25 @@ extern "C" int sgd_attention(const float* q, int32_t q_ld, int32_t q_hs, const f
         case 32: hipLaunchKernelGGL((attention_kernel<32>), grid, dim3(256), 0, st, q, q_ld, q_hs, k, v, kv_ld, kv_hs, tq, tk, scale, out, out_ld, lse); break;
         case 64: hipLaunchKernelGGL((attention_kernel<64>), grid, dim3(256), 0, st, q, q_ld, q_hs, k, v, kv_ld, kv_hs, tq, tk, scale, out, out_ld, lse); break;
         case 128: hipLaunchKernelGGL((attention_kernel<128>), grid, dim3(256), 0, st, q, q_ld, q_hs, k, v, kv_ld, kv_hs, tq, tk, scale, out, out_ld, lse); break;
+        default: return SGD_ERR_ARG;
+    }
+    return sgd_check_launch();
+}
+
+extern "C" int sgd_attention_split(const float* q, int32_t q_ld, int32_t q_hs, const float* k, const float* v,
+                                   int32_t kv_ld, int32_t kv_hs, int32_t batch, int32_t heads, int32_t tq, int32_t tk,
+                                   int32_t d, float scale, float* out, int32_t out_ld, float* lse, void* stream) {
+    SGD_CLEAR_ERR();
+    if (!q || !k || !v || !out || batch <= 0 || heads <= 0 || tq <= 0 || tk <= 0) return SGD_ERR_ARG;
+    if ((q_ld & 3) || (q_hs & 3) || (kv_ld & 3) || (kv_hs & 3) || (out_ld & 3)) return SGD_ERR_ARG;
+    if ((((uintptr_t)q) | ((uintptr_t)k) | ((uintptr_t)v) | ((uintptr_t)out)) & 15) return SGD_ERR_ARG;
+    dim3 grid((tq + 127) / 128, heads, batch);
+    hipStream_t st = (hipStream_t)stream;
+    switch (d) {
+        case 16: hipLaunchKernelGGL((attention_split_kernel<16>), grid, dim3(256), 0, st, q, q_ld, q_hs, k, v, kv_ld, kv_hs, tq, tk, scale, out, out_ld, lse); break;
+        case 32: hipLaunchKernelGGL((attention_split_kernel<32>), grid, dim3(256), 0, st, q, q_ld, q_hs, k, v, kv_ld, kv_hs, tq, tk, scale, out, out_ld, lse); break;
+        case 64: hipLaunchKernelGGL((attention_split_kernel<64>), grid, dim3(256), 0, st, q, q_ld, q_hs, k, v, kv_ld, kv_hs, tq, tk, scale, out, out_ld, lse); break;
+        case 128: hipLaunchKernelGGL((attention_split_kernel<128>), grid, dim3(256), 0, st, q, q_ld, q_hs, k, v, kv_ld, kv_hs, tq, tk, scale, out, out_ld, lse); break;
         default: return SGD_ERR_ARG;
     }
     return sgd_check_launch();

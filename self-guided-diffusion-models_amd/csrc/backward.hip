@@ -196,7 +196,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_conv_kernel(const WArgs w) {
     auto split_store = [&](T* hp, T* lp, f32x4 v) {
         T4 h, l;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { h[j] = Split<PREC>::hi(v[j]); l[j] = Split<PREC>::hi(v[j] - Split<PREC>::back(h[j])); }
+        for (int j = 0; j < 4; ++j) {
+            T hj, lj;
+            Split<PREC>::split(v[j], hj, lj);
+            h[j] = hj;
+            l[j] = lj;
+        }
         *reinterpret_cast<T4*>(hp) = h;
         *reinterpret_cast<T4*>(lp) = l;
     };

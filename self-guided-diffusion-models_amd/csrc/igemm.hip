@@ -122,8 +122,7 @@ __device__ __forceinline__ void lds_store_act(float* rowp, int c4, f32x4 v) {
         T h[4], l[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            h[j] = Split<PREC>::hi(v[j]);
-            l[j] = Split<PREC>::hi(v[j] - Split<PREC>::back(h[j]));
+            Split<PREC>::split(v[j], h[j], l[j]);
         }
         typedef T T4 __attribute__((ext_vector_type(4)));
         *reinterpret_cast<T4*>(base) = T4{h[0], h[1], h[2], h[3]};
@@ -1185,8 +1184,10 @@ __global__ void pack_weight_kernel(const float* __restrict__ src, float* __restr
             T8 h, l;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                h[j] = Split<PREC>::hi(v[j]);
-                l[j] = Split<PREC>::hi(v[j] - Split<PREC>::back(h[j]));
+                T hj, lj;
+                Split<PREC>::split(v[j], hj, lj);
+                h[j] = hj;
+                l[j] = lj;
             }
             T* up = reinterpret_cast<T*>(dst + unit * 1024) + sub * 1024 + lane * 8;
             *reinterpret_cast<T8*>(up) = h;

@@ -12,11 +12,22 @@ template <> struct Split<SGD_PREC_F16X3> {
     typedef _Float16 T;
     static __device__ __forceinline__ T hi(float v) { return (T)v; }
     static __device__ __forceinline__ float back(T h) { return (float)h; }
+    // v = h + l (+ 2^-22 |v|); SGD_ROUNDED (sgdm_common.h): h must be the same number at both of its uses
+    static __device__ __forceinline__ void split(float v, T& h, T& l) {
+        SGD_ROUNDED(v);
+        h = (T)v;
+        l = (T)(v - (float)h);
+    }
 };
 template <> struct Split<SGD_PREC_BF16X3> {
     typedef __bf16 T;
     static __device__ __forceinline__ T hi(float v) { return (T)v; }
     static __device__ __forceinline__ float back(T h) { return (float)h; }
+    static __device__ __forceinline__ void split(float v, T& h, T& l) {
+        SGD_ROUNDED(v);
+        h = (T)v;
+        l = (T)(v - (float)h);
+    }
 };
 
 

@@ -11,6 +11,18 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 #define SGD_WAVE 64
 
+// The fp32 value about to be split into 16-bit hi + lo halves must be ONE rounded fp32 number.  If it is visibly a
+// product, the backend may form hi with v_fma_mixlo_f16 (one rounding of the exact product) at one use and with
+// v_cvt(_pk)_f16_f32 of the rounded product at another; the two differ by an fp16 ulp whenever the fp32 rounding
+// crosses an fp16 tie (probability 2^-13 per element), and lo = v - hi is then paired with the wrong hi: a 2^-11
+// relative error where the split promises 2^-22 (found in round 2: 1 attention row in 2,000 off by 3e-5).
+// SGD_ROUNDED pins the value in a register without emitting an instruction.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define SGD_ROUNDED(x) asm("" : "+v"(x))
+#else
+#define SGD_ROUNDED(x) ((void)0)
+#endif
+
 __device__ __forceinline__ float sgd_silu(float v) {
     // x * sigmoid(x); v_exp_f32 and v_rcp_f32 are 1 ulp each; the reference uses aten silu (fp32)
     return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));

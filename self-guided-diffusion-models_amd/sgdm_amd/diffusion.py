@@ -439,8 +439,7 @@ class DDIMSampler(object):
         update kernel as DDIM (p_sample_plms == p_sample_ddim with a given eps, ddim_plms_sampler.py:484-525).
         RNG order of the reference: x_T, then one randn per p_sample_plms call (num_steps + 1 draws)."""
         sk = sampling_kwargs
-        if sk.get("dtp", 1) < 1.0:
-            raise NotImplementedError("dynamic thresholding (dtp < 1) is built for the native and ddim samplers, not plms")
+        dyn = sk.get("dtp", 1) < 1.0                             # ddim_plms_sampler.py:505-512 (same helper as ddim)
         dev = torch.device(self.device)
         B, Cc = shape[0], shape[1]
         hw = int(np.prod(shape[2:]))
@@ -476,6 +475,15 @@ class DDIMSampler(object):
             coef[3] = float(self.ddim_sigmas[index])
             nxt = torch.empty_like(x)
             x0 = torch.empty_like(x) if want_x0 else None
+            if dyn:
+                lo, hi, frac = _quantile_rank(sk["dtp"], Cc * hw)
+                s_dyn = torch.empty(B, device=dev)
+                e4 = e.reshape(B, Cc, hw).permute(0, 2, 1).contiguous()
+                L.check(lib.sgd_x0_quantile(1, _ptr(x), _ptr(e4), 0, 0.0, coef, B, Cc, hw, lo, hi, frac, _ptr(s_dyn),
+                                            _stream()), "sgd_x0_quantile")
+                L.check(lib.sgd_ddim_step_dyn(_ptr(x), _ptr(e4), _ptr(z), 0, 0.0, coef, float(sk["temperature"]),
+                                              _ptr(s_dyn), B, Cc, hw, _ptr(nxt), _ptr(x0), _stream()), "sgd_ddim_step_dyn")
+                return nxt, x0
             e = e.contiguous()
             # a guided NCHW eps is "NHWC with one channel" over B*C planes
             L.check(lib.sgd_ddim_step(_ptr(x), _ptr(e), _ptr(z), 0, 0.0, coef, float(sk["temperature"]), clip,

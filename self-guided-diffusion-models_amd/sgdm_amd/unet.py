@@ -423,6 +423,11 @@ class _Engine:
         self.bufs.append(t)
         return t
 
+    def attention_fn(self):
+        """the attention core in the engine's arithmetic: split-precision MFMA for f16x3, exact fp32 otherwise
+        (bf16x3 keeps the exact kernel: 8 mantissa bits per half do not hold the softmax weights)"""
+        return self.lib.sgd_attention_split if self.prec == L.PREC_F16X3 else self.lib.sgd_attention
+
     def pack(self, names, ksize):
         pk = _Packed([self.m.P(nm) for nm in names], ksize, self.prec)
         self.packed.append(pk)
@@ -851,7 +856,7 @@ class UNetModel(UNetModelBase):
                           m=rows, pro=L.PRO_LN_ROW, pa=st, pb=P(blk + nrm + ".weight"), pc=P(blk + nrm + ".bias"))
                 o = eng.buf(n, T, inner)
                 lse = eng.buf(n, heads, T)
-                eng.prog.add(blk + att + ".attn", lib.sgd_attention, _ptr(qkv), 3 * inner, d,
+                eng.prog.add(blk + att + ".attn", eng.attention_fn(), _ptr(qkv), 3 * inner, d,
                              C.c_void_p(qkv.data_ptr() + 4 * inner), C.c_void_p(qkv.data_ptr() + 8 * inner), 3 * inner, d,
                              n, heads, T, T, d, d ** -0.5, _ptr(o), inner, _ptr(lse))
                 xn = eng.buf(n, T, inner)
@@ -939,7 +944,7 @@ class UNetModel(UNetModelBase):
         att = eng.buf(n, T, ch)
         lse = eng.buf(n, heads, T)                         # softmax statistics kept for the backward
         # legacy layout: channel = head*3d + {q: 0, k: d, v: 2d}; scale = (d^-1/4)^2 applied to q.k
-        eng.prog.add(p + ".attn", eng.lib.sgd_attention, _ptr(qkv), 3 * ch, 3 * d,
+        eng.prog.add(p + ".attn", eng.attention_fn(), _ptr(qkv), 3 * ch, 3 * d,
                      C.c_void_p(qkv.data_ptr() + 4 * d), C.c_void_p(qkv.data_ptr() + 8 * d), 3 * ch, 3 * d,
                      n, heads, T, T, d, 1.0 / math.sqrt(d), _ptr(att), ch, _ptr(lse))
         y = eng.buf(n, hh, ww, ch)
@@ -1140,7 +1145,7 @@ class UNetModelCA(UNetModelBase):
         eng.prog.add(p + ".null_kv", lib.sgd_fill_null_kv, _ptr(P(p + ".null_kv")), n, J, ntok, d, _ptr(kv))
         att = eng.buf(n, T, heads * d)
         lse = eng.buf(n, heads, T)
-        eng.prog.add(p + ".attn", lib.sgd_attention, _ptr(q), heads * d, d, _ptr(kv),
+        eng.prog.add(p + ".attn", eng.attention_fn(), _ptr(q), heads * d, d, _ptr(kv),
                      C.c_void_p(kv.data_ptr() + 4 * d), 2 * d, 0, n, heads, T, J, d, d ** -0.5, _ptr(att),
                      heads * d, _ptr(lse))
         o = eng.buf(n, T, ch)

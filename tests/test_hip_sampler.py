@@ -258,6 +258,30 @@ def test_dynamic_thresholding_native_step_vs_oracle():
     assert float(torch.quantile(unclipped.reshape(B, -1).abs(), 0.9, dim=-1).min()) > 1.0      # the threshold was active
 
 
+def test_plms_with_dynamic_thresholding_vs_oracle():
+    """sampling_method='plms' with dtp < 1 (p_sample_plms hands dtp to the same clip helper as ddim,
+    ddim_plms_sampler.py:505-512): an analytic denoiser evaluated identically on both sides isolates the update"""
+    from oracle import diffusion_ref as D
+    m, _ = build_model("uf_label_c32_s16", "f32")
+    d = _diffusion(m)
+
+    def eps_fn(x, t, **_):
+        return torch.tanh(1.3 * x) * (0.5 + t.view(-1, 1, 1, 1).float() / 1000.0)
+
+    d.set_denoise_fn(m.forward, eps_fn)
+    g = torch.Generator().manual_seed(41)
+    x_T = torch.randn(2, 3, 16, 16, generator=g) * 1.5
+    z = torch.randn(12, 2, 3, 16, 16, generator=g)        # make_ddim_timesteps(6) has 7 entries -> 8 draws
+    skw = dict(_skw("plms", 6, 0.0), dtp=0.9)
+    samples, inter = d.p_sample_loop("plms", (2, 3, 16, 16), skw, denoise_sample_fn_kwargs={}, condition_kwargs={},
+                                     x_T=x_T, noise_fn=lambda j: z[j])
+    want, pred, xi, _ = D.plms_sample(D.make_schedule(), eps_fn, x_T, lambda j: z[j], 6, dtp=0.9)
+    assert rel_l2(inter["x_inter"].cpu(), xi) < 2e-5
+    assert (samples.cpu().int() - D.to_uint8(want).int()).abs().max() <= 1
+    loose, _, _, _ = D.plms_sample(D.make_schedule(), eps_fn, x_T, lambda j: z[j], 6, dtp=1.0)
+    assert (loose - want).abs().max() > 1e-3                      # the threshold changed the trajectory
+
+
 @pytest.mark.parametrize("kind", [0, 1])
 @pytest.mark.parametrize("dtp", [0.9, 0.995, 0.5])
 def test_x0_quantile_kernel_matches_torch_quantile(kind, dtp):
