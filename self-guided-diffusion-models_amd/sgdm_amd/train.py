@@ -270,6 +270,8 @@ class Backward:
                 self._up(rec)
             elif kind == "norm_cond":
                 self._norm_cond(rec)
+            elif kind == "mlp_chain":
+                self._mlp_chain(rec)
             elif kind == "linear":
                 gy = self.gread(rec["y"])
                 self.wgrad(rec["name"], rec["a"], gy, rec["cout"], rec["cout"], rec["cin"], 1, n,
@@ -493,6 +495,25 @@ class Backward:
         self.prog.add(name + ".silu_bwd", self.lib.sgd_silu_bwd, _ptr(rec["h"]), _ptr(gh_act), n * mid, _ptr(gh))
         self.wgrad(name + ".0", rec["a0"], gh, mid, mid, cin, 1, n, name + ".0.weight", name + ".0.bias")
 
+    def _mlp_chain(self, rec):
+        """to_cond_tokens_2d (openaimodel_ca.py:606-614): Linear -> SiLU -> Linear -> SiLU -> Linear -> SiLU -> Linear over
+        the n*T token rows; every SiLU was the next GEMM's prologue, so each layer's input tensor is pre-activation"""
+        rows, P = rec["rows"], self.m.P
+        g = self.gread(rec["y"])                          # [n, T*ctx] == [n*T, ctx] rows of the last layer's output
+        layers = rec["layers"]
+        for li in range(len(layers) - 1, -1, -1):
+            ly = layers[li]
+            name, cin, cout = ly["name"], ly["cin"], ly["cout"]
+            self.wgrad(name, ly["a"], g, cout, cout, cin, 1, rows, name + ".weight", name + ".bias")
+            if li == 0:
+                break                                      # the layer input is the guidance itself: no gradient wanted
+            w = P(name + ".weight")
+            gact = self.buf(rows, cin)
+            self.dgrad(name + ".dgrad", g, cout, gact, cin, [w], lambda w=w: w, cout, cin, 1, m=rows)
+            gpre = self.buf(rows, cin)
+            self.prog.add(name + ".silu_bwd", self.lib.sgd_silu_bwd, _ptr(ly["x"]), _ptr(gact), rows * cin, _ptr(gpre))
+            g = gpre
+
     # ---------------------------------------------------------------- execution
     def run(self, geps_nchw):
         lib = self.lib
@@ -561,10 +582,11 @@ def forward_train(model, x, t, cond, layout, mask, n):
     """autograd-capable UNet evaluation (called from UNetModelBase._run when grads are required)"""
     B, cx, H, W = x.shape
     if getattr(model, "use_spatial_transformer", False):
-        raise NotImplementedError("training through the SpatialTransformer path is not built (inference only; no shipped "
-                                  "config sets use_spatial_transformer)")
-    if getattr(model, "cond_token_num", 0) > 1:
-        raise NotImplementedError("training with cond_token_num > 1 (token guidance) is not built (inference only)")
+        # the reference cannot train this variant either: BasicTransformerBlock checkpoints _forward(x, context) with
+        # context=None (openaimodel.py:915, attention.py:213-214) and CheckpointFunction.backward calls None.detach()
+        # (diffusionmodules/util.py:132 -> AttributeError); tests/golden/make_golden_train_tokens.py documents the run
+        raise NotImplementedError("training through the SpatialTransformer path is not built: the reference raises "
+                                  "AttributeError in its backward for this variant (checkpoint with context=None)")
     prec = L.PREC_BY_NAME[model.hip_precision]
     eng = model._engine(n, H, W, prec)
     params = [p for p in model.parameters() if p.requires_grad]

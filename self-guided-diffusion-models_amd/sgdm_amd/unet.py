@@ -1090,30 +1090,36 @@ class UNetModelCA(UNetModelBase):
                                  cin=self.cond_dim, mid=ted, cout=ted, add_to_y=True))
         if T > 1:
             # token guidance (openaimodel_ca.py:987-1013): cond [n, T, cd] -> per-token MLP to_cond_tokens_2d -> T context
-            # tokens behind the 8 time tokens; emb += cond_mlp(pooled token).  Inference only (no tape records).
+            # tokens behind the 8 time tokens; emb += cond_mlp(pooled token)
             cd = self.cond_dim
             mid = int(math.sqrt(ctx * cd))
             rows = n * T
             src, width = eng.cond_m, cd
+            layers = []
             for li, (idx, wout) in enumerate(((0, mid), (2, mid), (4, mid), (6, ctx))):
                 name = f"to_cond_tokens_2d.{idx}"
                 last = idx == 6
                 dst = raw if last else eng.buf(rows, wout)
-                eng.igemm(name, src, width, dst, wout, eng.pack([name + ".weight"], 1), m=rows, silu=int(li > 0),
-                          bias=P(name + ".bias"), orows=(T, ntok, NUM_TIME_TOKENS) if last else (0, 0, 0))
+                al = eng.igemm(name, src, width, dst, wout, eng.pack([name + ".weight"], 1), m=rows, silu=int(li > 0),
+                               bias=P(name + ".bias"), orows=(T, ntok, NUM_TIME_TOKENS) if last else (0, 0, 0))
+                layers.append(dict(name=name, x=src, cin=width, cout=wout, a=al))
                 src, width = dst, wout
+            eng.tape.append(dict(kind="mlp_chain", layers=layers, y=raw_c, rows=rows))
             pooled = eng.buf(n, cd)
             eng.prog.add("cond_pooled", eng.lib.sgd_token_pool, _ptr(eng.cond_m), n, T, cd,
                          1 if self.use_cls_token_as_pooled == True else 0, _ptr(pooled))     # noqa: E712  (reference: == True)
             c1 = eng.buf(n, ted)
-            eng.igemm("cond_mlp.0", pooled, cd, c1, ted, eng.pack(["cond_mlp.0.weight"], 1), m=n, bias=P("cond_mlp.0.bias"))
-            eng.igemm("cond_mlp.2", c1, ted, emb, ted, eng.pack(["cond_mlp.2.weight"], 1), m=n, silu=1,
-                      bias=P("cond_mlp.2.bias"), res=emb)
+            b0 = eng.igemm("cond_mlp.0", pooled, cd, c1, ted, eng.pack(["cond_mlp.0.weight"], 1), m=n,
+                           bias=P("cond_mlp.0.bias"))
+            b2 = eng.igemm("cond_mlp.2", c1, ted, emb, ted, eng.pack(["cond_mlp.2.weight"], 1), m=n, silu=1,
+                           bias=P("cond_mlp.2.bias"), res=emb)
+            eng.tape.append(dict(kind="mlp2", name="cond_mlp", x=pooled, h=c1, y=emb, a0=b0, a2=b2, cin=cd, mid=ted,
+                                 cout=ted, add_to_y=True))
             eng.token_guidance = True
         context = eng.buf(n, ntok, ctx)
         eng.prog.add("norm_cond", eng.lib.sgd_ln_apply, _ptr(raw), _ptr(P("norm_cond.weight")),
                      _ptr(P("norm_cond.bias")), C.c_void_p(0), n * ntok, ctx, LN_EPS, _ptr(context))
-        eng.tape.append(dict(kind="norm_cond", raw=raw, raw_t=raw_t, raw_c=raw_c if self.cond_token_num == 1 else None,
+        eng.tape.append(dict(kind="norm_cond", raw=raw, raw_t=raw_t, raw_c=raw_c if self.cond_token_num >= 1 else None,
                              context=context, ntok=ntok, ctx=ctx, wt=wt))
         eng.context, eng.ntok = context, ntok
 

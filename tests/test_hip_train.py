@@ -477,3 +477,51 @@ def test_full_width_train_step_vs_reference(name, prec, tol):
     assert checked >= 20
     sq = sum(float((g.double() ** 2).sum()) for g in grads.values() if g is not None)
     assert abs(sq - float(v[tag + ".grad_sqnorm"])) < 1e-3 * float(v[tag + ".grad_sqnorm"])
+
+
+@pytest.mark.parametrize("prec,tol", [("f32", 5e-5), ("f16x3", 1e-4)])
+def test_train_step_token_guidance_vs_reference(prec, tol):
+    """unetca_fast with cond_token_num > 1 (openaimodel_ca.py:606-614, 987-1013): the per-token to_cond_tokens_2d chain, the
+    pooled-token cond_mlp and the T extra context tokens, forward + backward, vs the reference's own training step
+    (tests/golden/train_tokens.npz); `to_cond_tokens.0.*` stay without a gradient exactly as in the reference"""
+    import bench
+    from sgdm_amd.diffusion import LatentDiffusion
+    name = "ca_tokens_c32_s16"
+    v = load_npz("train_tokens.npz")
+    tag = f"train.{name}"
+    m, entry = build_model(name, prec)
+    m.dropout = 0.0
+    m.train()
+    d = LatentDiffusion(device="cuda", **bench.MODEL_PARAMS).train()
+    d.set_denoise_fn(m.forward, m.forward_with_cond_scale)
+    loss, ld = d.p_losses(torch.from_numpy(v[tag + ".image"]).cuda(), torch.from_numpy(v[tag + ".t"]).cuda(),
+                          torch.from_numpy(v[tag + ".noise"]).cuda(), cond=torch.from_numpy(v[tag + ".cond"]).cuda(), layout=None,
+                          cond_drop_prob=0.5, cond_drop_mask=torch.from_numpy(v[tag + ".drop_mask"]).cuda())
+    loss.backward()
+    ref = float(v[tag + ".loss"])
+    assert abs(loss.item() - ref) < 2e-5 * abs(ref)
+    assert max_rel(ld["train/epoch_stats_y"].cpu(), v[tag + ".per_sample"]) < 2e-5
+    grads = {k: p.grad for k, p in m.named_parameters()}
+    assert sorted(k for k, p in m.named_parameters() if p.requires_grad and p.grad is None) == list(v[tag + ".unused_params"])
+    checked = 0
+    for key in v:
+        if key.startswith(tag + ".grad."):
+            pname = key[len(tag + ".grad."):]
+            got, want = grads[pname].cpu(), torch.from_numpy(v[key])
+        elif key.startswith(tag + ".gsample."):
+            pname = key[len(tag + ".gsample."):]
+            got = grads[pname].cpu().reshape(-1)[::int(v[f"{tag}.gstride.{pname}"])]
+            want = torch.from_numpy(v[key])
+        else:
+            continue
+        scale = float(v[f"{tag}.gmax.{pname}"])
+        if scale < 1e-6:
+            assert float(grads[pname].abs().max()) < 1e-5, pname      # a bias cancelled by the following norm: rounding noise
+            continue
+        err = float((got.double() - want.double()).abs().max()) / scale
+        assert err < tol, (pname, err)
+        checked += 1
+    assert checked > 150
+    assert any(k.startswith(tag + ".grad.to_cond_tokens_2d.") for k in v)
+    sq = sum(float((g.double() ** 2).sum()) for g in grads.values() if g is not None)
+    assert abs(sq - float(v[tag + ".grad_sqnorm"])) < 1e-3 * float(v[tag + ".grad_sqnorm"])
