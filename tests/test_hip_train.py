@@ -435,12 +435,12 @@ def test_stale_forward_raises_in_backward():
 # gradients recorded from the reference (tests/golden/train_full.npz, make_golden_train_full.py)
 # ------------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("name,prec,tol", [("uf_cluster5000_c128_s64", "f32", 5e-5), ("uf_cluster5000_c128_s64", "f16x3", 1e-4),
-                                           ("ca_stego_c128_s64", "f16x3", 1e-4)])
+                                           ("ca_stego_c128_s64", "f16x3", 1e-4), ("ca_clusterlayout_c128_s64", "f16x3", 1e-4)])
 def test_full_width_train_step_vs_reference(name, prec, tol):
     import bench
     from sgdm_amd.diffusion import LatentDiffusion
     from sgdm_amd.synth import synth_batch
-    v = load_npz("train_full.npz")
+    v = load_npz("train_c4_full.npz" if name == "ca_clusterlayout_c128_s64" else "train_full.npz")     # C4: configs[3]
     tag = f"train.{name}"
     m, entry = build_model(name, prec)
     m.dropout = 0.0

@@ -73,7 +73,7 @@ def test_cfg_paths_match_reference(name):
 
 
 def test_cfg_full_width_instances():
-    for name in ("uf_cluster5000_c128_s64", "ca_stego_c128_s64"):
+    for name in ("uf_cluster5000_c128_s64", "ca_stego_c128_s64", "ca_clusterlayout_c128_s64"):
         entry = INDEX[name]
         cfg = cfg_from_index(entry)
         v = load_npz(f"unet_{name}.npz")
