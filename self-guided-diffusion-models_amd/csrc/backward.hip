@@ -194,16 +194,23 @@ __global__ __launch_bounds__(256, 2) void wgrad_conv_kernel(const WArgs w) {
         return __builtin_bit_cast(T4, v);
     };
     auto split_store = [&](T* hp, T* lp, f32x4 v) {
-        T4 h, l;
+        if constexpr (PREC == SGD_PREC_F16X3) {
+            u32x2 h, l;
+            split4_f16(v, h, l);                             // 8 vector instructions (prologue.h)
+            *reinterpret_cast<u32x2*>(hp) = h;
+            *reinterpret_cast<u32x2*>(lp) = l;
+        } else {
+            T4 h, l;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            T hj, lj;
-            Split<PREC>::split(v[j], hj, lj);
-            h[j] = hj;
-            l[j] = lj;
+            for (int j = 0; j < 4; ++j) {
+                T hj, lj;
+                Split<PREC>::split(v[j], hj, lj);
+                h[j] = hj;
+                l[j] = lj;
+            }
+            *reinterpret_cast<T4*>(hp) = h;
+            *reinterpret_cast<T4*>(lp) = l;
         }
-        *reinterpret_cast<T4*>(hp) = h;
-        *reinterpret_cast<T4*>(lp) = l;
     };
 
     f32x4 bsum = {0.f, 0.f, 0.f, 0.f};                   // bias gradient: column sums of the staged gy rows

@@ -38,6 +38,7 @@ constexpr int KC = 32;        // input channels per K chunk
 constexpr int LDA = KC + 4;   // LDS row stride in floats (144 B): conflict-free b128 fragment reads
 constexpr int BM = 128;
 constexpr int NB_RING = 3;    // register ring depth of the 1x1 loaders (input rows requested 3 steps ahead)
+constexpr int BIAS_LDS_MAX = 4096;   // layers up to this many (padded) output channels keep their bias in LDS (16 KB)
 constexpr int NTHREADS = 512;  // 4 compute waves + 4 input-tile loader waves
 constexpr int A_THREADS = NTHREADS - 256;
 constexpr int WUNIT = 4096;   // bytes of one packed weight unit: 32 output x 32 input channels of one tap, fragment order
@@ -115,9 +116,15 @@ template <int PREC>
 __device__ __forceinline__ void lds_store_act(float* rowp, int c4, f32x4 v) {
     if constexpr (PREC == SGD_PREC_F32) {
         *reinterpret_cast<f32x4*>(rowp + c4 * 4) = v;
+    } else if constexpr (PREC == SGD_PREC_F16X3) {
+        // channels c4*4 .. +3 -> group g = c4 >> 1, position (c4 & 1) * 4 inside the 8-group (2-byte elements)
+        _Float16* base = reinterpret_cast<_Float16*>(rowp) + (c4 >> 1) * 16 + (c4 & 1) * 4;
+        u32x2 h, l;
+        split4_f16(v, h, l);
+        *reinterpret_cast<u32x2*>(base) = h;
+        *reinterpret_cast<u32x2*>(base + 8) = l;
     } else {
         typedef typename Split<PREC>::T T;
-        // channels c4*4 .. +3 -> group g = c4 >> 1, position (c4 & 1) * 4 inside the 8-group
         T* base = reinterpret_cast<T*>(rowp) + (c4 >> 1) * 16 + (c4 & 1) * 4;
         T h[4], l[4];
 #pragma unroll
@@ -265,6 +272,11 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
     const int a_floats = g.pix * LDA;
     float* As = smem;                                       // [NA][pix][LDA]
     int2* pixtab = reinterpret_cast<int2*>(smem + (size_t)NA * a_floats);   // [4][pix] (source row or -1, image n)
+    // bias of the whole layer (zeros without one): the epilogue reads it from LDS -- a global load there is a ~2k-cycle
+    // dependent wait per batch of quads on a wave that has nothing else to issue (measured: 7.8k cycles per tile for the
+    // bias-only epilogue of a conv without residual)
+    float* bias_s = smem + (size_t)NA * a_floats + (size_t)g.pix * 8;       // [cout_p]
+    const bool bias_lds = a.cout_p <= BIAS_LDS_MAX;        // very wide layers (all FiLM projections as one GEMM) read it from global
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
@@ -323,6 +335,8 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
     build_pixtab(1, tid, NTHREADS);
     build_pixtab(2, tid, NTHREADS);
     build_pixtab(3, tid, NTHREADS);
+    if (bias_lds)
+        for (int i = tid; i < a.cout_p; i += NTHREADS) bias_s[i] = (a.bias && i < a.cout && !ABL(2)) ? a.bias[i] : 0.f;
     __syncthreads();
     PROBE_BEGIN();
 
@@ -409,11 +423,15 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
                     auto transform = [&](f32x4 v, bool ok) {
                         if (ABL(256)) return v;
                         if constexpr (uni) {
+                            // SiLU with the padding mask folded into the denominator: t / (den + e^-t), den = 1 or +inf
+                            // (rcp(inf) = 0 and t is finite: a clamped, real input row) -- one select per item instead of four
+                            const float den = ok ? 1.0f : __builtin_inff();
                             v = v * kq.p + kq.q;
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] = sgd_silu(v[e]);
+                            for (int e = 0; e < 4; ++e) v[e] = v[e] * __builtin_amdgcn_rcpf(den + __expf(-v[e]));
+                        } else {
+                            if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
                         }
-                        if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
                         return v;
                     };
                     auto issue_item = [&](const S& c, int j) {
@@ -846,6 +864,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
     auto wtile_of = [&](int k) { return wlane + (size_t)(tile_at(g, lin_of(k), BN, TW, TH).n0c >> 5) * WUNIT; };
 
     f32x16 acc[MT][NT];
+    const float wsi = a.w_scale_inv ? *a.w_scale_inv : 1.f;        // 2^-k of the packed weights (exact); once per block
 
     // One K step, per sub-step: [wait input frags(cur)] [issue LDS reads(next)] [MFMA block(cur)] [request the weight
     // frags of the SAME sub-step of the next K step].  Strict alternation keeps at most ONE batch of LDS reads
@@ -1004,7 +1023,6 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
                 rpm[mt] = RES ? a.res + (long)rrow * a.cout : nullptr;
             }
             const bool vec = ((a.cout | a.y_ld) & 3) == 0;
-            const float wsi = a.w_scale_inv ? *a.w_scale_inv : 1.f;        // 2^-k of the packed weights (exact)
             if (vec) {
                 // cout % 4 == 0: 16-byte quads.  Quad-outer / row-inner: the residual loads of both rows are in flight
                 // together, and the GroupNorm statistics of a quad (args.stats) live in 8 registers at a time.
@@ -1033,7 +1051,8 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
                         const int c = cb + nt * 32 + gq * 8;
                         const int cl = c < a.cout ? c : 0;    // clamped: the quad is skipped below
                         f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-                        if (a.bias && !ABL(2)) bv = ld4(a.bias + cl);
+                        if (bias_lds) bv = *reinterpret_cast<const f32x4*>(bias_s + cl);
+                        else if (a.bias && !ABL(2)) bv = ld4(a.bias + cl);
 #pragma unroll
                         for (int mt = 0; mt < MT; ++mt) {
                             rv[gq][mt] = bv;
@@ -1089,7 +1108,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
                             for (int j = 0; j < 4; ++j) {
                                 const int c = cb + nt * 32 + gq * 8 + j;
                                 if (c >= a.cout) continue;
-                                float x = acc[mt][nt][gq * 4 + j] * wsi + (a.bias ? a.bias[c] : 0.f);
+                                float x = acc[mt][nt][gq * 4 + j] * wsi + (bias_lds ? bias_s[c] : (a.bias ? a.bias[c] : 0.f));
                                 if (RES == 1 || RES == 3) x += rp[c];
                                 if (RES == 2) {
                                     const long rw = (long)a.wo * 2 * a.cout;
@@ -1388,7 +1407,8 @@ extern "C" int sgd_igemm(const sgd_igemm_args* args, void* stream) {
         g.trace = tp ? reinterpret_cast<unsigned long long*>(strtoull(tp, nullptr, 0)) : nullptr;
     }
 #endif
-    const size_t smem = (size_t)na * g.pix * LDA * sizeof(float) + (size_t)g.pix * 32;
+    const size_t smem = (size_t)na * g.pix * LDA * sizeof(float) + (size_t)g.pix * 32
+                        + (a.cout_p <= BIAS_LDS_MAX ? (size_t)a.cout_p * sizeof(float) : 0);
     if (smem > 160 * 1024) return SGD_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     const bool conv = a.mode == SGD_MODE_CONV3;

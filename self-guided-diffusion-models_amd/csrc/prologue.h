@@ -30,6 +30,28 @@ template <> struct Split<SGD_PREC_BF16X3> {
     }
 };
 
+// Four fp32 values -> packed f16 hi pairs and lo pairs in 8 vector instructions: v_cvt_pk_f16_f32 (RNE, two values per
+// instruction) for hi, v_fma_mix_f32 for lo_f32 = v - float(hi) reading the f16 half directly (no v_cvt_f32_f16), and
+// v_cvt_pk_f16_f32 again for lo.  The compiler's own sequence for the same arithmetic is 16 instructions (it converts hi
+// twice: scalar for the subtraction, packed for the store); loader issue slots are what paces the conv kernel.
+// h = {hi(v0) | hi(v1) << 16, hi(v2) | hi(v3) << 16}, l likewise.  Bit-identical to Split<F16X3>::split per element.
+struct alignas(8) u32x2 { uint32_t x, y; };
+__device__ __forceinline__ void split4_f16(f32x4 v, u32x2& h, u32x2& l) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    float v0 = v[0], v1 = v[1], v2 = v[2], v3 = v[3], l0, l1, l2, l3;
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h.x) : "v"(v0), "v"(v1));
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h.y) : "v"(v2), "v"(v3));
+    asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(h.x), "v"(v0));
+    asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(h.x), "v"(v1));
+    asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(l2) : "v"(h.y), "v"(v2));
+    asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l3) : "v"(h.y), "v"(v3));
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(l.x) : "v"(l0), "v"(l1));
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(l.y) : "v"(l2), "v"(l3));
+#else
+    h.x = h.y = l.x = l.y = 0;
+    (void)v;
+#endif
+}
 
 // raw input vector: 4 consecutive channels starting at c of source row `row` (virtual concat x0|x1)
 template <bool VEC>
