@@ -398,12 +398,16 @@ def main():
         if not args.no_profile:
             eng = model._engines[(2 * B, S, S, __import__("sgdm_amd._lib", fromlist=["x"]).PREC_BY_NAME[args.prec])]
             stream = torch.cuda.current_stream().cuda_stream
-            agg = {}
+            agg, inst = {}, {}
             reps = 3
+            conv3 = (".in_layers.2", ".out_layers.3", ".op", ".conv", "input_blocks.0.0", "out.2")
             for _ in range(reps):
                 for tag, sym, ms, fl, nb in eng.prog.run_profiled(stream):
                     a = agg.setdefault(sym, [0.0, 0.0, 0.0, 0])
                     a[0] += ms; a[1] += fl; a[2] += nb; a[3] += 1
+                    if sym == "sgd_igemm":        # the two template instantiations rocprofv3 lists separately
+                        b = inst.setdefault("taps9_conv3x3" if tag.endswith(conv3) else "taps1_conv1x1_linear", [0.0, 0.0, 0])
+                        b[0] += ms; b[1] += fl; b[2] += 1
             tot_ms = sum(a[0] for a in agg.values()) / reps
             ig = agg["sgd_igemm"]
             ig_ms, ig_fl, ig_nb, ig_n = ig[0] / reps, ig[1] / reps, ig[2] / reps, ig[3] // reps
@@ -419,7 +423,11 @@ def main():
                         hbm_algorithmic_frac=round((ig_nb / (ig_ms * 1e-3)) / 8.0e12, 4),
                         peak_note=("exact fp32 MFMA peak" if args.prec == "f32" else
                                    "2.5 PF dense 16-bit MFMA / 3 products per fp32-equivalent product"),
-                        per_kernel_ms={k: round(v[0] / reps, 3) for k, v in sorted(agg.items())})
+                        per_kernel_ms={k: round(v[0] / reps, 3) for k, v in sorted(agg.items())},
+                        igemm_by_instance={k: dict(launches=v[2] // reps, ms_per_step=round(v[0] / reps, 3),
+                                                   tflops_per_s=round(v[1] / (v[0] * 1e-3) / 1e12, 1),
+                                                   frac=round(v[1] / (v[0] * 1e-3) / 1e12 / peak, 4))
+                                           for k, v in sorted(inst.items())})
         cpu = None
         if not args.no_cpu_baseline:
             cpu = cpu_baseline(wl, sd)
