@@ -175,10 +175,22 @@ def test_optimizer_chunk_table():
     assert chunk_table([]) == [0]
 
 
-def test_committed_bench_line_has_the_contract_fields():
-    """the bench line committed under profiles/ (produced by bench.py on the MI355X) carries every field of the contract"""
+@pytest.mark.parametrize("fname", ["r1_bench_c2_f16x3.json", "r2_bench_c2_f16x3_final.json", "r2_bench_c2_f16x3_final_b.json"])
+def test_committed_bench_line_has_the_contract_fields(fname):
+    """the bench lines committed under profiles/ (produced by bench.py on the MI355X) carry every field of the contract"""
     import json
-    line = json.loads(open(os.path.join(ROOT, "profiles", "r1_bench_c2_f16x3.json")).read().strip().splitlines()[-1])
+    line = json.loads(open(os.path.join(ROOT, "profiles", fname)).read().strip().splitlines()[-1])
+    if fname.startswith("r2_"):
+        # round 2: the line is self-sufficient (exact-fp32 figure, C5 and C1 legs, instantiation split, traffic label)
+        for k in ("f32_exact", "c5", "c1"):
+            assert k in line, k
+        assert line["f32_exact"]["frac_of_fp32_mfma_peak"] > 0.5 and "train_step" in line["c5"]
+        if "igemm_by_instance" in line["roofline"]:        # added with the last line of the round
+            assert set(line["roofline"]["igemm_by_instance"]) == {"taps9_conv3x3", "taps1_conv1x1_linear"}
+        else:
+            assert fname.endswith("_b.json")
+        assert "traffic_source" in line["roofline"] and "c1_full" in line["cpu_baseline"]
+        assert line["config"]["launch"].startswith("hipGraph")
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "train_step"):
         assert k in line, k
