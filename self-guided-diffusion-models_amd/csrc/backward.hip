@@ -214,11 +214,37 @@ __global__ __launch_bounds__(256, 2) void wgrad_conv_kernel(const WArgs w) {
     };
 
     f32x4 bsum = {0.f, 0.f, 0.f, 0.f};                   // bias gradient: column sums of the staged gy rows
+    const bool gy_fast = w.gvec && co0 + WT <= w.cout && w.rows > 0;
+    const bool u_fast = CONV && VEC && a.resample == SGD_RS_NONE && (a.pro == SGD_PRO_NONE || a.pro == SGD_PRO_AFFINE_NC);
     for (int kt = ks; kt < w.ktiles; kt += w.ksplit) {
         const int n = CONV ? kt / ppi : 0, pr = kt - n * ppi;
         const int y0 = CONV ? (pr / pw) * 8 : 0, x0 = CONV ? (pr - (pr / pw) * pw) * 8 : 0;
         __syncthreads();
         // ---- stage GY[64 rows][128 co]
+        // Fast path (whole 128-channel block inside cout, 16-byte rows): all eight row quads of a thread are requested
+        // before the first is used, from clamped addresses, and masked afterwards.  With the bounds checks around the
+        // loads the compiler emitted load -> s_waitcnt vmcnt(0) -> store per item: eight memory latencies in a row per
+        // stage (SQ_WAIT_ANY 56 % of the wave cycles, matrix pipe 27 % busy).
+        if (gy_fast) {
+            f32x4 gv[8];
+            const int qd = tid & 31, r0 = tid >> 5;
+            const float* gcol = w.gy + co0 + qd * 4;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int r = r0 + i * 8;
+                long row = CONV ? ((long)n * a.ho + y0 + (r >> 3)) * a.wo + x0 + (r & 7) : (long)kt * 64 + r;
+                row = row < w.rows ? row : w.rows - 1;
+                gv[i] = ld4(gcol + row * w.gy_ld);
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int r = r0 + i * 8;
+                const long row = CONV ? ((long)n * a.ho + y0 + (r >> 3)) * a.wo + x0 + (r & 7) : (long)kt * 64 + r;
+                if (row >= w.rows) gv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                split_store(Gh + r * FGP + qd * 4, Gl + r * FGP + qd * 4, gv[i]);
+                bsum += gv[i];
+            }
+        } else {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int idx = tid + i * 256;
@@ -236,8 +262,39 @@ __global__ __launch_bounds__(256, 2) void wgrad_conv_kernel(const WArgs w) {
             split_store(Gh + r * FGP + qd * 4, Gl + r * FGP + qd * 4, gv);
             bsum += gv;                                   // this thread's co quad (idx & 31) is the same for all its items
         }
+        }
         // ---- stage the activated input
         if constexpr (CONV) {
+            if (u_fast) {
+                // halo U[10 x 10 px][32 ci], same idea: the (up to) four items of a thread share their channel quad (idx & 7 is
+                // tid & 7 for all of them) and their image, so the GroupNorm coefficients are loaded once per stage; raw rows
+                // come from clamped addresses and the padding / tail items are masked after the transform
+                const int qd = tid & 7, c = ci0 + qd * 4;
+                const int cc = c < cin ? c : 0;
+                const Coef kq = load_coef<VEC>(a, n, 0, cc);
+                f32x4 ur[4];
+                long rrs[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int hp = (tid >> 3) + i * 32;
+                    const int hy = hp / 10, hx = hp - hy * 10;
+                    int y = y0 + hy - 1, x = x0 + hx - 1;
+                    y = y < 0 ? 0 : (y >= w.hc ? w.hc - 1 : y);
+                    x = x < 0 ? 0 : (x >= w.wc ? w.wc - 1 : x);
+                    rrs[i] = ((long)n * a.hi + y) * a.wi + x;
+                    ur[i] = load_raw<VEC>(a, rrs[i], cc);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int hp = (tid >> 3) + i * 32;
+                    if (hp >= 100) break;                         // i == 3: only the first 4 pixel rows of threads exist
+                    const int hy = hp / 10, hx = hp - hy * 10;
+                    const int y = y0 + hy - 1, x = x0 + hx - 1;
+                    f32x4 uv = apply_pro(a, ur[i], kq, cc, rrs[i]);
+                    if (!(c < cin && y >= 0 && y < w.hc && x >= 0 && x < w.wc)) uv = f32x4{0.f, 0.f, 0.f, 0.f};
+                    split_store(Uh + hp * UPITCH + qd * 4, Ul + hp * UPITCH + qd * 4, uv);
+                }
+            } else
             // halo U[10 x 10 px][32 ci] (conv-input space, zero outside the image)
             for (int idx = tid; idx < 100 * (CIT / 4); idx += 256) {
                 const int hp = idx >> 3, qd = idx & 7;
