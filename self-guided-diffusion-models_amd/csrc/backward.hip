@@ -213,13 +213,52 @@ __global__ __launch_bounds__(256, 2) void wgrad_conv_kernel(const WArgs w) {
         }
     };
 
+    // halo U[10 x 10 px][32 ci] fast path: the (up to) four items of a thread share their channel quad (idx & 7 is tid & 7 for
+    // all of them) and their image, so the GroupNorm coefficients are loaded once per stage; raw rows come from clamped
+    // addresses and the padding / tail items are masked after the transform.  Requests and transform are separate so that
+    // the requests can go out BEFORE the GY rows are transformed: one memory latency per stage instead of two.
+    f32x4 ur[4];
+    long rrs[4];
+    Coef ukq;
+    int un = 0, uy0 = 0, ux0 = 0;
+    auto u_request = [&]() {
+        const int c = ci0 + (tid & 7) * 4;
+        const int cc = c < cin ? c : 0;
+        ukq = load_coef<VEC>(a, un, 0, cc);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int hp = (tid >> 3) + i * 32;
+            const int hy = hp / 10, hx = hp - hy * 10;
+            int y = uy0 + hy - 1, x = ux0 + hx - 1;
+            y = y < 0 ? 0 : (y >= w.hc ? w.hc - 1 : y);
+            x = x < 0 ? 0 : (x >= w.wc ? w.wc - 1 : x);
+            rrs[i] = a.resample == SGD_RS_UP2 ? ((long)un * a.hi + (y >> 1)) * a.wi + (x >> 1) : ((long)un * a.hi + y) * a.wi + x;
+            ur[i] = load_raw<VEC>(a, rrs[i], cc);
+        }
+    };
+    auto u_finish = [&]() {
+        const int qd = tid & 7, c = ci0 + qd * 4;
+        const int cc = c < cin ? c : 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int hp = (tid >> 3) + i * 32;
+            if (hp >= 100) break;                                 // i == 3: only the threads of the first 4 pixel rows
+            const int hy = hp / 10, hx = hp - hy * 10;
+            const int y = uy0 + hy - 1, x = ux0 + hx - 1;
+            f32x4 uv = apply_pro(a, ur[i], ukq, cc, rrs[i]);
+            if (!(c < cin && y >= 0 && y < w.hc && x >= 0 && x < w.wc)) uv = f32x4{0.f, 0.f, 0.f, 0.f};
+            split_store(Uh + hp * UPITCH + qd * 4, Ul + hp * UPITCH + qd * 4, uv);
+        }
+    };
     f32x4 bsum = {0.f, 0.f, 0.f, 0.f};                   // bias gradient: column sums of the staged gy rows
     const bool gy_fast = w.gvec && co0 + WT <= w.cout && w.rows > 0;
-    const bool u_fast = CONV && VEC && a.resample == SGD_RS_NONE && (a.pro == SGD_PRO_NONE || a.pro == SGD_PRO_AFFINE_NC);
+    const bool u_fast = CONV && VEC && (a.resample == SGD_RS_NONE || a.resample == SGD_RS_UP2)
+                        && (a.pro == SGD_PRO_NONE || a.pro == SGD_PRO_AFFINE_NC);
     for (int kt = ks; kt < w.ktiles; kt += w.ksplit) {
         const int n = CONV ? kt / ppi : 0, pr = kt - n * ppi;
         const int y0 = CONV ? (pr / pw) * 8 : 0, x0 = CONV ? (pr - (pr / pw) * pw) * 8 : 0;
         __syncthreads();
+        un = n; uy0 = y0; ux0 = x0;
         // ---- stage GY[64 rows][128 co]
         // Fast path (whole 128-channel block inside cout, 16-byte rows): all eight row quads of a thread are requested
         // before the first is used, from clamped addresses, and masked afterwards.  With the bounds checks around the
@@ -266,34 +305,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_conv_kernel(const WArgs w) {
         // ---- stage the activated input
         if constexpr (CONV) {
             if (u_fast) {
-                // halo U[10 x 10 px][32 ci], same idea: the (up to) four items of a thread share their channel quad (idx & 7 is
-                // tid & 7 for all of them) and their image, so the GroupNorm coefficients are loaded once per stage; raw rows
-                // come from clamped addresses and the padding / tail items are masked after the transform
-                const int qd = tid & 7, c = ci0 + qd * 4;
-                const int cc = c < cin ? c : 0;
-                const Coef kq = load_coef<VEC>(a, n, 0, cc);
-                f32x4 ur[4];
-                long rrs[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int hp = (tid >> 3) + i * 32;
-                    const int hy = hp / 10, hx = hp - hy * 10;
-                    int y = y0 + hy - 1, x = x0 + hx - 1;
-                    y = y < 0 ? 0 : (y >= w.hc ? w.hc - 1 : y);
-                    x = x < 0 ? 0 : (x >= w.wc ? w.wc - 1 : x);
-                    rrs[i] = ((long)n * a.hi + y) * a.wi + x;
-                    ur[i] = load_raw<VEC>(a, rrs[i], cc);
-                }
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int hp = (tid >> 3) + i * 32;
-                    if (hp >= 100) break;                         // i == 3: only the first 4 pixel rows of threads exist
-                    const int hy = hp / 10, hx = hp - hy * 10;
-                    const int y = y0 + hy - 1, x = x0 + hx - 1;
-                    f32x4 uv = apply_pro(a, ur[i], kq, cc, rrs[i]);
-                    if (!(c < cin && y >= 0 && y < w.hc && x >= 0 && x < w.wc)) uv = f32x4{0.f, 0.f, 0.f, 0.f};
-                    split_store(Uh + hp * UPITCH + qd * 4, Ul + hp * UPITCH + qd * 4, uv);
-                }
+                u_request();
+                u_finish();
             } else
             // halo U[10 x 10 px][32 ci] (conv-input space, zero outside the image)
             for (int idx = tid; idx < 100 * (CIT / 4); idx += 256) {
@@ -319,6 +332,33 @@ __global__ __launch_bounds__(256, 2) void wgrad_conv_kernel(const WArgs w) {
                     }
                 }
                 split_store(Uh + hp * UPITCH + qd * 4, Ul + hp * UPITCH + qd * 4, uv);
+            }
+        } else if (VEC && (a.pro == SGD_PRO_NONE || a.pro == SGD_PRO_AFFINE_NC) && w.rows > 0) {
+            // 1x1 / linear: eight row quads per thread, requested four at a time from clamped addresses (raw row + the
+            // GroupNorm coefficients of its image), masked after the transform
+            const int qd = tid & 31, r0 = tid >> 5;
+            const int c = ci0 + qd * 4;
+            const int cc = c < cin ? c : 0;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                f32x4 uraw[4];
+                Coef kq[4];
+                long rows4[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const long row = (long)kt * 64 + r0 + (half * 4 + i) * 8;
+                    rows4[i] = row < w.rows ? row : w.rows - 1;
+                    const int ni = a.pro == SGD_PRO_AFFINE_NC ? (int)(rows4[i] / a.rows_per_n) : 0;
+                    kq[i] = load_coef<VEC>(a, ni, rows4[i], cc);
+                    uraw[i] = load_raw<VEC>(a, rows4[i], cc);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int r = r0 + (half * 4 + i) * 8;
+                    f32x4 uv = apply_pro(a, uraw[i], kq[i], cc, rows4[i]);
+                    if (!((long)kt * 64 + r < w.rows && c < cin)) uv = f32x4{0.f, 0.f, 0.f, 0.f};
+                    split_store(Uh + r * UPITCH + qd * 4, Ul + r * UPITCH + qd * 4, uv);
+                }
             }
         } else {
 #pragma unroll
