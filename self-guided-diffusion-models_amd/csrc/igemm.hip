@@ -1155,9 +1155,31 @@ __device__ __forceinline__ float pow2_scale_of(uint32_t amax_bits) {
     return ldexpf(1.f, 1 - e);
 }
 
-__global__ void weight_amax_kernel(const float* __restrict__ w, long count, uint32_t* __restrict__ amax_bits) {
+// max |w| of a tensor: every thread takes 16 elements as four independent 16-byte loads (the one-element grid-stride loop
+// this replaces was a chain of dependent-latency iterations: 20 us per conv weight, 142 tensors per training step)
+__global__ void weight_amax_kernel(const float* __restrict__ w, long count, uint32_t* __restrict__ amax_bits, int vec) {
     float m = 0.f;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x) m = fmaxf(m, fabsf(w[i]));
+    if (vec) {
+        const long nq = count >> 2;                                        // float4 quads
+        const long q0 = (blockIdx.x * (long)blockDim.x + threadIdx.x) * 4;
+        const long step = (long)gridDim.x * blockDim.x * 4;
+        for (long q = q0; q < nq; q += step) {
+            f32x4 v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const long qq = q + j < nq ? q + j : nq - 1;               // clamped: a duplicate does not change a maximum
+                v[j] = *reinterpret_cast<const f32x4*>(w + qq * 4);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) m = fmaxf(m, fabsf(v[j][e]));
+        }
+        for (long i = (nq << 2) + blockIdx.x * (long)blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x)
+            m = fmaxf(m, fabsf(w[i]));
+    } else {
+        for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x) m = fmaxf(m, fabsf(w[i]));
+    }
     m = wave_max(m);
     if ((threadIdx.x & 63) == 0) atomicMax(amax_bits, __float_as_uint(m));
 }
@@ -1290,9 +1312,10 @@ extern "C" int sgd_pack_weight_dgrad(const float* w_src, void* w_dst, int32_t co
 extern "C" int sgd_weight_amax(const float* w, int64_t count, uint32_t* amax_bits, void* stream) {
     SGD_CLEAR_ERR();
     if (!w || !amax_bits || count <= 0) return SGD_ERR_ARG;
-    int grid = (int)((count + 1023) / 1024);
-    if (grid > 512) grid = 512;
-    hipLaunchKernelGGL(weight_amax_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, (long)count, amax_bits);
+    const int vec = (((uintptr_t)w) & 15) == 0 && count >= 4;
+    long grid = vec ? (count + 4095) / 4096 : (count + 1023) / 1024;       // 16 elements per thread on the vector path
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(weight_amax_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, w, (long)count, amax_bits, vec);
     return sgd_check_launch();
 }
 
