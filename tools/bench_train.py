@@ -12,11 +12,12 @@ from sgdm_amd.ema import LitEma
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=40); ap.add_argument("--prec", default="f16x3")
 ap.add_argument("--steps", type=int, default=5); ap.add_argument("--warmup", type=int, default=2)
-ap.add_argument("--profile", action="store_true")
+ap.add_argument("--profile", action="store_true"); ap.add_argument("--dropout", type=float, default=-1.0, help="override the model dropout")
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
 wl = bench.WORKLOADS["c2"]
 m, sd, data = bench.build_model(wl, dev, a.prec, a.batch)
+if a.dropout >= 0: m.dropout = a.dropout
 m.train()
 d = LatentDiffusion(device="cuda", **bench.MODEL_PARAMS).train()
 d.set_denoise_fn(m.forward, m.forward_with_cond_scale)
