@@ -457,8 +457,18 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slabs, int ksplit,
         const int ci = i % cin;
         const long t = i / cin;
         const int co = t % cout, tap = t / cout;
+        // the slabs are summed in index order (deterministic); eight independent loads in flight per thread -- the plain
+        // loop compiled to load -> s_waitcnt vmcnt(0) -> add per slab, one memory latency each
         float s = 0.f;
-        for (int k = 0; k < ksplit; ++k) s += slabs[k * per + i];
+        int k = 0;
+        for (; k + 8 <= ksplit; k += 8) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = slabs[(k + j) * per + i];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += v[j];
+        }
+        for (; k < ksplit; ++k) s += slabs[k * per + i];
         const long o = ((long)co * cin + ci) * taps + tap;
         s *= scale;
         dw[o] = accumulate ? dw[o] + s : s;
@@ -474,8 +484,17 @@ __global__ __launch_bounds__(256) void colsum_stage1_kernel(const float* __restr
     const long per = ((long)rows + chunks - 1) / chunks;
     const long r0 = chunk * per, r1 = (r0 + per < rows) ? r0 + per : rows;
     float s = 0.f;
-    if (col < c)
-        for (long r = r0 + rl; r < r1; r += 8) s += g[r * ld + col];
+    if (col < c) {
+        long r = r0 + rl;
+        for (; r + 56 < r1; r += 64) {                   // eight rows of this lane in flight (same order of additions)
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = g[(r + 8 * j) * ld + col];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += v[j];
+        }
+        for (; r < r1; r += 8) s += g[r * ld + col];
+    }
     __shared__ float red[8][32];
     red[rl][threadIdx.x & 31] = s;
     __syncthreads();
