@@ -218,12 +218,38 @@ __global__ __launch_bounds__(256) void attention_split_kernel(const float* __res
 
     for (int kt0 = 0; kt0 < tk; kt0 += KT) {
         __syncthreads();
-        // K rows: one float4 -> 4 hi + 4 lo (8-byte stores)
+        // Every K / V quad of the tile is requested (clamped addresses, no branch around a load) before the first one is
+        // split and stored: with the bounds check around the load each item was load -> s_waitcnt vmcnt(0) -> store, six
+        // memory latencies in a row per 64-key tile.
         constexpr int VPR = D / 4;
-        for (int idx = tid; idx < KT * VPR; idx += 256) {
+        constexpr int NKI = (KT * VPR + 255) / 256;                // K quads per thread
+        constexpr int NVI = ((KT / 2) * VPR + 255) / 256;          // V key-pair quads per thread
+        f32x4 kq[NKI], vq0[NVI], vq1[NVI];
+        const int klast = tk - 1;
+#pragma unroll
+        for (int i = 0; i < NKI; ++i) {
+            int idx = tid + i * 256;
+            idx = idx < KT * VPR ? idx : KT * VPR - 1;
             const int row = idx / VPR, c4 = idx % VPR;
-            f32x4 t = {0.f, 0.f, 0.f, 0.f};
-            if (kt0 + row < tk) t = *reinterpret_cast<const f32x4*>(kb + (long)(kt0 + row) * kv_ld + c4 * 4);
+            const int key = kt0 + row < tk ? kt0 + row : klast;
+            kq[i] = *reinterpret_cast<const f32x4*>(kb + (long)key * kv_ld + c4 * 4);
+        }
+#pragma unroll
+        for (int i = 0; i < NVI; ++i) {
+            int idx = tid + i * 256;
+            idx = idx < (KT / 2) * VPR ? idx : (KT / 2) * VPR - 1;
+            const int key = kt0 + (idx / VPR) * 2, c4 = idx % VPR;
+            vq0[i] = *reinterpret_cast<const f32x4*>(vb + (long)(key < tk ? key : klast) * kv_ld + c4 * 4);
+            vq1[i] = *reinterpret_cast<const f32x4*>(vb + (long)(key + 1 < tk ? key + 1 : klast) * kv_ld + c4 * 4);
+        }
+        // K rows: one float4 -> 4 hi + 4 lo (8-byte stores)
+#pragma unroll
+        for (int i = 0; i < NKI; ++i) {
+            const int idx = tid + i * 256;
+            if (idx >= KT * VPR) break;
+            const int row = idx / VPR, c4 = idx % VPR;
+            f32x4 t = kq[i];
+            if (kt0 + row >= tk) t = f32x4{0.f, 0.f, 0.f, 0.f};
             f16x4 h4, l4;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -236,12 +262,15 @@ __global__ __launch_bounds__(256) void attention_split_kernel(const float* __res
             *reinterpret_cast<f16x4*>(Kl + row * LDK + c4 * 4) = l4;
         }
         // V^T: a thread takes two neighbouring keys (neighbours in the permuted order too) x 4 channels
-        for (int idx = tid; idx < (KT / 2) * VPR; idx += 256) {
+#pragma unroll
+        for (int i = 0; i < NVI; ++i) {
+            const int idx = tid + i * 256;
+            if (idx >= (KT / 2) * VPR) break;
             const int kp = idx / VPR, c4 = idx % VPR;
             const int key = kp * 2;
-            f32x4 t0 = {0.f, 0.f, 0.f, 0.f}, t1 = {0.f, 0.f, 0.f, 0.f};
-            if (kt0 + key < tk) t0 = *reinterpret_cast<const f32x4*>(vb + (long)(kt0 + key) * kv_ld + c4 * 4);
-            if (kt0 + key + 1 < tk) t1 = *reinterpret_cast<const f32x4*>(vb + (long)(kt0 + key + 1) * kv_ld + c4 * 4);
+            f32x4 t0 = vq0[i], t1 = vq1[i];
+            if (kt0 + key >= tk) t0 = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (kt0 + key + 1 >= tk) t1 = f32x4{0.f, 0.f, 0.f, 0.f};
             const int kk = key & 15;
             const int pos = (key & ~15) + (((kk >> 2) & 1) << 3) + ((kk >> 3) << 2) + (kk & 3);
 #pragma unroll
@@ -423,19 +452,31 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(
 
     for (int t0 = 0; t0 < str_n; t0 += TT) {
         __syncthreads();
+        // all row quads of the tile requested (clamped rows, no branch around a load) before the first is stored
         constexpr int VPR = D / 4;
-        for (int idx = tid; idx < TT * VPR; idx += 256) {
+        constexpr int NI = (TT * VPR + 255) / 256;
+        f32x4 ureg[NI], wreg[NI];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            int idx = tid + i * 256;
+            idx = idx < TT * VPR ? idx : TT * VPR - 1;
             const int row = idx / VPR, c4 = idx % VPR;
-            f32x4 u = {0.f, 0.f, 0.f, 0.f}, w = {0.f, 0.f, 0.f, 0.f};
-            if (t0 + row < str_n) {
-                if (SWEEP == 0) {
-                    u = *reinterpret_cast<const f32x4*>(qb + (long)(t0 + row) * q_ld + c4 * 4);
-                    w = *reinterpret_cast<const f32x4*>(gb + (long)(t0 + row) * dout_ld + c4 * 4);
-                } else {
-                    u = *reinterpret_cast<const f32x4*>(kb + (long)(t0 + row) * kv_ld + c4 * 4);
-                    w = *reinterpret_cast<const f32x4*>(vb + (long)(t0 + row) * kv_ld + c4 * 4);
-                }
+            const long rr = t0 + row < str_n ? t0 + row : str_n - 1;
+            if (SWEEP == 0) {
+                ureg[i] = *reinterpret_cast<const f32x4*>(qb + rr * q_ld + c4 * 4);
+                wreg[i] = *reinterpret_cast<const f32x4*>(gb + rr * dout_ld + c4 * 4);
+            } else {
+                ureg[i] = *reinterpret_cast<const f32x4*>(kb + rr * kv_ld + c4 * 4);
+                wreg[i] = *reinterpret_cast<const f32x4*>(vb + rr * kv_ld + c4 * 4);
             }
+        }
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int idx = tid + i * 256;
+            if (idx >= TT * VPR) break;
+            const int row = idx / VPR, c4 = idx % VPR;
+            f32x4 u = ureg[i], w = wreg[i];
+            if (t0 + row >= str_n) { u = f32x4{0.f, 0.f, 0.f, 0.f}; w = u; }
             *reinterpret_cast<f32x4*>(Us + row * LD + c4 * 4) = u;
             *reinterpret_cast<f32x4*>(Ws + row * LD + c4 * 4) = w;
         }
