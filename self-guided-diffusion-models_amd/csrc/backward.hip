@@ -567,9 +567,7 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const float* __restr
     float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
     if (ch < c) {
         const f32x4 av = ld4(a + (long)n * c_total + c_off + ch), bv = ld4(b + (long)n * c_total + c_off + ch);
-        for (int p = rl; p < hw; p += 32) {
-            const f32x4 xv = ld4(x + ((long)n * hw + p) * c + ch);
-            f32x4 gv = fetch_g(gu, gu_ld, gu_mode, n, p / w, p % w, h, w, c_off + ch);
+        auto fold = [&](const f32x4& xv, f32x4 gv, int p) {
             if (drop_p > 0.f) gv = drop_mask(gv, drop_p, drop_seed, ((long)n * hw + p) * c_total + c_off + ch);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -578,6 +576,26 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const float* __restr
                 s1[j] += gp;
                 s2[j] += gp * xv[j];
             }
+        };
+        int p = rl;
+        if (gu_mode == SGD_RS_NONE) {
+            // same-resolution gradient (every launch but the resampling blocks): four pixels of this lane in flight -- the
+            // plain loop was one load pair -> s_waitcnt vmcnt(0) per pixel; the additions keep their order
+            for (; p + 96 < hw; p += 128) {
+                f32x4 xv[4], gv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    xv[u] = ld4(x + ((long)n * hw + p + 32 * u) * c + ch);
+                    gv[u] = ld4(gu + ((long)n * hw + p + 32 * u) * gu_ld + c_off + ch);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) fold(xv[u], gv[u], p + 32 * u);
+            }
+        }
+        for (; p < hw; p += 32) {
+            const f32x4 xv = ld4(x + ((long)n * hw + p) * c + ch);
+            const f32x4 gv = fetch_g(gu, gu_ld, gu_mode, n, p / w, p % w, h, w, c_off + ch);
+            fold(xv, gv, p);
         }
     }
     __shared__ double red[32][8][8];
