@@ -1180,8 +1180,12 @@ __global__ void weight_amax_kernel(const float* __restrict__ w, long count, uint
     } else {
         for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x) m = fmaxf(m, fabsf(w[i]));
     }
+    // one atomic per BLOCK: 2,300 same-address atomics (one per wave) took longer than reading the tensor
     m = wave_max(m);
-    if ((threadIdx.x & 63) == 0) atomicMax(amax_bits, __float_as_uint(m));
+    __shared__ float wm[4];
+    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMax(amax_bits, __float_as_uint(fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]))));
 }
 
 template <int PREC>
@@ -1314,7 +1318,7 @@ extern "C" int sgd_weight_amax(const float* w, int64_t count, uint32_t* amax_bit
     if (!w || !amax_bits || count <= 0) return SGD_ERR_ARG;
     const int vec = (((uintptr_t)w) & 15) == 0 && count >= 4;
     long grid = vec ? (count + 4095) / 4096 : (count + 1023) / 1024;       // 16 elements per thread on the vector path
-    if (grid > 2048) grid = 2048;
+    if (grid > 256) grid = 256;
     hipLaunchKernelGGL(weight_amax_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, w, (long)count, amax_bits, vec);
     return sgd_check_launch();
 }

@@ -63,10 +63,19 @@ class _PackedAdj:
         cin_p, cout_p = C.c_int32(0), C.c_int32(0)
         lib = L.load()
         if self.scaled:
-            self.amax.zero_()
-            L.check(lib.sgd_weight_amax(_ptr(src), src.numel(), _ptr(self.amax), stream), "sgd_weight_amax")
+            amax = None
+            if len(self.deps) == 1 and src.data_ptr() == self.deps[0].data_ptr():
+                # the whole parameter, already reduced by the forward pack at this version (same stream, earlier)
+                from .unet import AMAX_OF
+                hit = AMAX_OF.get(self.deps[0].data_ptr())
+                if hit is not None and hit[0] == self.deps[0]._version:
+                    amax = hit[1]
+            if amax is None:
+                amax = self.amax
+                amax.zero_()
+                L.check(lib.sgd_weight_amax(_ptr(src), src.numel(), _ptr(amax), stream), "sgd_weight_amax")
             L.check(lib.sgd_pack_weight_scaled(_ptr(src), _ptr(self.buf), self.cout_fwd, self.cin_fwd, self.ksize, self.prec,
-                                               1, _ptr(self.amax), _ptr(self.scale_inv), C.byref(cin_p), C.byref(cout_p),
+                                               1, _ptr(amax), _ptr(self.scale_inv), C.byref(cin_p), C.byref(cout_p),
                                                stream), "sgd_pack_weight_scaled")
         else:
             L.check(lib.sgd_pack_weight_dgrad(_ptr(src), _ptr(self.buf), self.cout_fwd, self.cin_fwd, self.ksize,

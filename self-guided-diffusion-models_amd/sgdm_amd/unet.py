@@ -111,6 +111,9 @@ class _Spec:
 # ------------------------------------------------------------------------------------------------
 # packed weights
 # ------------------------------------------------------------------------------------------------
+AMAX_OF = {}       # parameter data_ptr -> (version, device int32 holding the bits of max |w|), written by _Packed.refresh
+
+
 class _Packed:
     """device buffer holding one conv/linear weight in the igemm layout, refreshed when the source
     parameter(s) change (optimizer step / load_state_dict bump ``_version``)."""
@@ -148,6 +151,9 @@ class _Packed:
         if self.scaled:
             self.amax.zero_()
             L.check(lib.sgd_weight_amax(_ptr(src), src.numel(), _ptr(self.amax), stream), "sgd_weight_amax")
+            if len(self.srcs) == 1:
+                # max |w| of this parameter at this version: the adjoint pack of the same tensor (train._PackedAdj) reuses it
+                AMAX_OF[self.srcs[0].data_ptr()] = (self.srcs[0]._version, self.amax)
             L.check(lib.sgd_pack_weight_scaled(_ptr(src), _ptr(self.buf), self.cout, self.cin, self.ksize, self.prec, 0,
                                                _ptr(self.amax), _ptr(self.scale_inv), C.byref(cin_p), C.byref(cout_p),
                                                stream), "sgd_pack_weight_scaled")
