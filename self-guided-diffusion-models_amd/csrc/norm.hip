@@ -121,9 +121,25 @@ __global__ __launch_bounds__(256) void gn_coef_parts_kernel(const float* __restr
         float s, ss;
         if (parts > 0) {
             const float* q = p + (long)nn * parts * 2 * cs + cl;
+            // eight partial pairs in flight per thread, folded in index order (the unroll-by-4 loop still waited once per four)
             double t0 = 0, t1 = 0;
-#pragma unroll 4
-            for (int k = 0; k < parts; ++k) { t0 += q[(long)k * 2 * cs]; t1 += q[(long)k * 2 * cs + cs]; }
+            int k = 0;
+            for (; k + 8 <= parts; k += 8) {
+                float v0[8], v1[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { v0[j] = q[(long)(k + j) * 2 * cs]; v1[j] = q[(long)(k + j) * 2 * cs + cs]; }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { t0 += v0[j]; t1 += v1[j]; }
+            }
+            if (k + 4 <= parts) {
+                float v0[4], v1[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { v0[j] = q[(long)(k + j) * 2 * cs]; v1[j] = q[(long)(k + j) * 2 * cs + cs]; }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { t0 += v0[j]; t1 += v1[j]; }
+                k += 4;
+            }
+            for (; k < parts; ++k) { t0 += q[(long)k * 2 * cs]; t1 += q[(long)k * 2 * cs + cs]; }
             s = (float)t0;
             ss = (float)t1;
             sums[((long)nn * c + ch) * 2] = s;
