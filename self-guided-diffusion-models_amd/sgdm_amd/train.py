@@ -553,6 +553,7 @@ class _UNetTrainFn(torch.autograd.Function):
         eng.generation = getattr(eng, "generation", 0) + 1
         ctx.model, ctx.eng, ctx.generation = model, eng, eng.generation
         ctx.names = [n for n, p in model.named_parameters() if p.requires_grad]
+        ctx.params = params
         return model._to_nchw(eng)
 
     @staticmethod
@@ -564,10 +565,25 @@ class _UNetTrainFn(torch.autograd.Function):
                                "activations; call backward() before the next forward")
         if getattr(eng, "backward", None) is None:
             eng.backward = make_backward(eng)
+        # The program writes every parameter gradient into a persistent buffer (a view of the DDP arena when there is one).
+        # Handing those to autograd made AccumulateGrad clone each of them -- ~390 device copies per step (it cannot steal a
+        # tensor somebody else still references).  A parameter whose .grad is None gets the buffer itself as .grad (what
+        # DDP's gradient_as_bucket_view does); one whose .grad already IS the buffer from an earlier backward (zero_grad(
+        # set_to_none=False), gradient accumulation) is un-aliased first, so accumulation keeps torch's semantics.
+        held = eng.backward.pgrad
+        for name, p in zip(ctx.names, ctx.params):
+            g = held.get(name)
+            if g is not None and p.grad is not None and p.grad.data_ptr() == g.data_ptr():
+                p.grad = p.grad.clone()
         grads = eng.backward.run(geps)
         out = []
-        for name in ctx.names:
-            out.append(grads.get(name))      # None: parameter not on the path (e.g. to_cond_tokens_2d, README.md:90-94)
+        with torch.no_grad():
+            for name, p in zip(ctx.names, ctx.params):
+                g = grads.get(name)          # None: parameter not on the path (e.g. to_cond_tokens_2d, README.md:90-94)
+                if g is not None and p.grad is None and g.shape == p.shape:
+                    p.grad = g
+                    g = None
+                out.append(g)
         return (None, None, None) + tuple(out)
 
 
