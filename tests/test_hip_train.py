@@ -525,3 +525,53 @@ def test_train_step_token_guidance_vs_reference(prec, tol):
     assert any(k.startswith(tag + ".grad.to_cond_tokens_2d.") for k in v)
     sq = sum(float((g.double() ** 2).sum()) for g in grads.values() if g is not None)
     assert abs(sq - float(v[tag + ".grad_sqnorm"])) < 1e-3 * float(v[tag + ".grad_sqnorm"])
+
+
+def test_gradient_buffers_alias_without_breaking_accumulation():
+    """the backward program's persistent gradient buffers become the parameters' .grad directly (no clone per parameter);
+    a second backward without zero_grad -- or after zero_grad(set_to_none=False) -- must still ACCUMULATE as torch does"""
+    import bench
+    from sgdm_amd.diffusion import LatentDiffusion
+    from sgdm_amd.synth import synth_batch
+    m, entry = build_model("uf_clusterlayout_c32_s16", "f32")
+    m.dropout = 0.0
+    m.train()
+    d = LatentDiffusion(device="cuda", **bench.MODEL_PARAMS).train()
+    d.set_denoise_fn(m.forward, m.forward_with_cond_scale)
+    kw = entry["ctor"]
+
+    def backward(seed):
+        batch = synth_batch(kw["condition_method"], 4, 16, kw["cond_dim"], entry["layout_dim"], seed=seed)
+        g = torch.Generator().manual_seed(seed)
+        t = torch.randint(0, 1000, (4,), generator=g).cuda()
+        noise = torch.randn(4, 3, 16, 16, generator=g).cuda()
+        loss, _ = d.p_losses(batch["image"].cuda(), t, noise, cond=batch["cond"].float().cuda(), layout=batch["layout"].cuda(),
+                             cond_drop_prob=0.5, cond_drop_mask=torch.tensor([False, True, False, False]).cuda())
+        loss.backward()
+
+    def grads():
+        return {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}
+
+    m.zero_grad(set_to_none=True)
+    backward(1)
+    ga = grads()
+    held = {k: p.grad for k, p in m.named_parameters() if p.grad is not None}     # the aliases a caller might keep
+    m.zero_grad(set_to_none=True)
+    backward(2)
+    gb = grads()
+    # same buffers again (no clone happened), new contents
+    assert all(held[k].data_ptr() == p.grad.data_ptr() for k, p in m.named_parameters() if p.grad is not None)
+    # accumulation: backward(1) then backward(2) with no zeroing in between
+    m.zero_grad(set_to_none=True)
+    backward(1)
+    backward(2)
+    for k, p in m.named_parameters():
+        if p.grad is not None:
+            want = ga[k] + gb[k]
+            assert float((p.grad - want).abs().max()) <= 1e-6 * max(1.0, float(want.abs().max())), k
+    # zero_grad(set_to_none=False): .grad stays a tensor (possibly our buffer, zeroed) -> the next backward must add to zero
+    m.zero_grad(set_to_none=False)
+    backward(2)
+    for k, p in m.named_parameters():
+        if p.grad is not None:
+            assert float((p.grad - gb[k]).abs().max()) <= 1e-6 * max(1.0, float(gb[k].abs().max())), k
