@@ -467,8 +467,13 @@ class Backward:
         views = []
         off = 0
         for p, co in zip(names, couts):
-            views.append((self.pg(p + ".emb_layers.1.weight"), dwcat[off:off + 2 * co]))
-            views.append((self.pg(p + ".emb_layers.1.bias"), dbcat[off:off + 2 * co]))
+            if self.arena is None:
+                # single process: the per-block gradients ARE row slices of the concatenated result (contiguous), no copies
+                self.pgrad[p + ".emb_layers.1.weight"] = dwcat[off:off + 2 * co]
+                self.pgrad[p + ".emb_layers.1.bias"] = dbcat[off:off + 2 * co]
+            else:
+                views.append((self.pg(p + ".emb_layers.1.weight"), dwcat[off:off + 2 * co]))
+                views.append((self.pg(p + ".emb_layers.1.bias"), dbcat[off:off + 2 * co]))
             off += 2 * co
 
         def film_split(stream):
