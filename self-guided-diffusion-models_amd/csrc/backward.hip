@@ -477,8 +477,12 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slabs, int ksplit,
 
 // column sums, deterministic two-stage: stage 1 = grid (32-column slab, row chunk), 8 row lanes x 32 columns
 // per block, partial sums to work[chunk][c]; stage 2 folds the chunks (fixed order, double accumulation).
+// With ONE row chunk (rows <= 256: the per-sample GroupNorm dgamma / dbeta tables, bias gradients of the embedding linears)
+// the fold of stage 2 is the identity on one float, so stage 1 writes the scaled result itself: one launch instead of two,
+// bit-identical (float row sums, then double * scale exactly as stage 2 does).
 __global__ __launch_bounds__(256) void colsum_stage1_kernel(const float* __restrict__ g, int rows, int c, int ld,
-                                                            int chunks, float* __restrict__ work) {
+                                                            int chunks, float* __restrict__ work,
+                                                            float* __restrict__ out, int accumulate, float scale) {
     const int col = blockIdx.x * 32 + (threadIdx.x & 31), rl = threadIdx.x >> 5;     // 8 row lanes
     const int chunk = blockIdx.y;
     const long per = ((long)rows + chunks - 1) / chunks;
@@ -502,7 +506,13 @@ __global__ __launch_bounds__(256) void colsum_stage1_kernel(const float* __restr
         float t = 0;
 #pragma unroll
         for (int k = 0; k < 8; ++k) t += red[k][threadIdx.x];
-        work[(long)chunk * c + col] = t;
+        if (out) {
+            double u = t;
+            u *= scale;
+            out[col] = accumulate ? out[col] + (float)u : (float)u;
+        } else {
+            work[(long)chunk * c + col] = t;
+        }
     }
 }
 
@@ -803,7 +813,7 @@ extern "C" int sgd_wgrad(const sgd_igemm_args* fwd, const float* gy, int32_t gy_
     }
     if (bias_slabs)          // exact-f32 / strided fallback: the same [ksplit][cout] partial column sums, by the colsum kernel
         hipLaunchKernelGGL(colsum_stage1_kernel, dim3((cout + 31) / 32, w.ksplit), dim3(256), 0, st, gy, w.rows, cout, gy_ld,
-                           w.ksplit, bias_slabs);
+                           w.ksplit, bias_slabs, (float*)nullptr, 0, 1.f);
     const long grid = (long)w.taps * w.co_tiles * w.ci_tiles * w.ksplit;
     if (grid > 0x7fffffffL) return SGD_ERR_ARG;
     if (vec) hipLaunchKernelGGL((wgrad_kernel<true>), dim3((unsigned)grid), dim3(256), 0, st, w);
@@ -827,7 +837,13 @@ extern "C" int sgd_colsum(const float* g, int32_t rows, int32_t c, int32_t ld, f
     int chunks = (rows + 255) / 256;
     if (chunks > work_chunks) chunks = work_chunks;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(colsum_stage1_kernel, dim3((c + 31) / 32, chunks), dim3(256), 0, st, g, rows, c, ld, chunks, work);
+    if (chunks == 1) {
+        hipLaunchKernelGGL(colsum_stage1_kernel, dim3((c + 31) / 32, 1), dim3(256), 0, st, g, rows, c, ld, 1, work, out,
+                           accumulate, scale);
+        return sgd_check_launch();
+    }
+    hipLaunchKernelGGL(colsum_stage1_kernel, dim3((c + 31) / 32, chunks), dim3(256), 0, st, g, rows, c, ld, chunks, work,
+                       (float*)nullptr, 0, 1.f);
     hipLaunchKernelGGL(colsum_stage2_kernel, dim3((c + 31) / 32), dim3(256), 0, st, work, chunks, c, out, accumulate,
                        scale);
     return sgd_check_launch();
