@@ -68,7 +68,7 @@ class _PackedAdj:
                 # the whole parameter, already reduced by the forward pack at this version (same stream, earlier)
                 from .unet import AMAX_OF
                 hit = AMAX_OF.get(self.deps[0].data_ptr())
-                if hit is not None and hit[0] == self.deps[0]._version:
+                if hit is not None and hit[0] == self.deps[0]._version and hit[2]() is self.deps[0]:
                     amax = hit[1]
             if amax is None:
                 amax = self.amax

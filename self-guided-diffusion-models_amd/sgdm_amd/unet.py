@@ -13,6 +13,7 @@ for parameter storage, device memory and streams only.  There is no CPU / eager 
 HIP library or a GPU the forward raises.
 """
 import ctypes as C
+import weakref
 import math
 import os
 
@@ -111,7 +112,8 @@ class _Spec:
 # ------------------------------------------------------------------------------------------------
 # packed weights
 # ------------------------------------------------------------------------------------------------
-AMAX_OF = {}       # parameter data_ptr -> (version, device int32 holding the bits of max |w|), written by _Packed.refresh
+AMAX_OF = {}       # parameter data_ptr -> (version, device int32 holding the bits of max |w|, weakref to the parameter:
+                   # an address can be recycled by another tensor), written by _Packed.refresh
 
 
 class _Packed:
@@ -153,7 +155,7 @@ class _Packed:
             L.check(lib.sgd_weight_amax(_ptr(src), src.numel(), _ptr(self.amax), stream), "sgd_weight_amax")
             if len(self.srcs) == 1:
                 # max |w| of this parameter at this version: the adjoint pack of the same tensor (train._PackedAdj) reuses it
-                AMAX_OF[self.srcs[0].data_ptr()] = (self.srcs[0]._version, self.amax)
+                AMAX_OF[self.srcs[0].data_ptr()] = (self.srcs[0]._version, self.amax, weakref.ref(self.srcs[0]))
             L.check(lib.sgd_pack_weight_scaled(_ptr(src), _ptr(self.buf), self.cout, self.cin, self.ksize, self.prec, 0,
                                                _ptr(self.amax), _ptr(self.scale_inv), C.byref(cin_p), C.byref(cout_p),
                                                stream), "sgd_pack_weight_scaled")
