@@ -75,11 +75,25 @@ def self_launch(n):
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out)
+    # poll ALL children: if any rank dies, the others would sit in RCCL until its timeout -- end them instead
+    import threading
+    out_box = []
+    reader = threading.Thread(target=lambda: out_box.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    failed = False
+    while any(p.poll() is None for p in procs):
+        if any(p.poll() not in (None, 0) for p in procs):
+            failed = True
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            break
+        time.sleep(0.2)
+    rcs = [p.wait() for p in procs]
+    reader.join(timeout=10)
+    sys.stdout.write(out_box[0] if out_box else "")
     sys.stdout.flush()
-    return max(abs(rc) for rc in rcs)
+    return max([abs(rc) for rc in rcs] + [1 if failed else 0])
 
 
 def build_model(wl, device, prec, batch=None):

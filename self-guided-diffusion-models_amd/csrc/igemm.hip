@@ -1149,10 +1149,11 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
 __device__ __forceinline__ float pow2_scale_of(uint32_t amax_bits) {
     // 2^k with max|w| * 2^k in [1, 2): k = -(exponent of amax); all-zero / non-finite tensors: 1
     const float amax = __uint_as_float(amax_bits);
-    if (!(amax > 0.f) || !(amax < 3.0e38f)) return 1.f;
+    // subnormal maxima count as zero: 2^(1-e) would overflow to +inf for e <= -127 (1/inf = 0 -> NaN weights)
+    if (!(amax >= 1.17549435e-38f) || !(amax < 3.0e38f)) return 1.f;
     int e;
     frexpf(amax, &e);                                          // amax = m * 2^e, m in [0.5, 1)
-    return ldexpf(1.f, 1 - e);
+    return ldexpf(1.f, 1 - e);                                 // e >= -125: at most 2^126
 }
 
 // max |w| of a tensor: every thread takes 16 elements as four independent 16-byte loads (the one-element grid-stride loop

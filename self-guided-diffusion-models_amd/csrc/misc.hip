@@ -30,7 +30,11 @@ __global__ void cond_select_kernel(const void* __restrict__ cond, int is_i64, co
     const int r = i / k, j = i % k;
     float v;
     if (mask && mask[r]) v = null_row[j];
-    else if (is_i64 == 2) v = reinterpret_cast<const int64_t*>(cond)[r % n_src] == j ? 1.f : 0.f;   // class / cluster id -> one-hot
+    else if (is_i64 == 2) {                                   // class / cluster id -> one-hot
+        // an id outside [0, k) has no one-hot row (F.one_hot raises on it): the row becomes NaN, so the failure is loud
+        const int64_t id = reinterpret_cast<const int64_t*>(cond)[r % n_src];
+        v = (uint64_t)id < (uint64_t)k ? (id == j ? 1.f : 0.f) : __builtin_nanf("");
+    }
     else if (is_i64) v = (float)reinterpret_cast<const int64_t*>(cond)[(long)(r % n_src) * k + j];
     else v = reinterpret_cast<const float*>(cond)[(long)(r % n_src) * k + j];
     out[i] = v;
@@ -108,7 +112,11 @@ __global__ void linear_gather_kernel(const int64_t* __restrict__ ids, const uint
     const int r = i / nout, c = i % nout;
     float v;
     if (mask && mask[r]) v = nullproj[c];
-    else v = w[(long)c * k + ids[r % n_src]] + (bias ? bias[c] : 0.f);
+    else {
+        const int64_t id = ids[r % n_src];
+        // no out-of-bounds read for an id outside [0, k): NaN out (the reference's F.one_hot raises on such ids)
+        v = (uint64_t)id < (uint64_t)k ? w[(long)c * k + id] + (bias ? bias[c] : 0.f) : __builtin_nanf("");
+    }
     out[(long)r * ldo + c] = v;
 }
 

@@ -126,6 +126,8 @@ class _GraphedStep:
     device-bound at C1 size (ch=64, 32x32, bs=8).  Reference loops: ddpm_sampler.py:194-238, ddim_plms_sampler.py:302-344.
     """
 
+    MAX_PER_ENGINE = 8          # captured steps kept per (model, batch, resolution, precision) engine
+
     @classmethod
     def get(cls, runner, img, kind, clip, temperature=1.0):
         """the captured step for this (model, batch, resolution, precision, guidance, sampler) -- built on first use and
@@ -140,8 +142,13 @@ class _GraphedStep:
         cache = m.__dict__.setdefault("_hip_graph_steps", {})
         g = cache.get(key)
         if g is None:
-            for k in [k for k in cache if k[0] != id(eng)]:
+            live = {id(e) for e in m._engines.values()}
+            for k in [k for k in cache if k[0] not in live]:
                 del cache[k]                                # graphs of a replaced engine (parameters re-allocated)
+            mine = [k for k in cache if k[0] == id(eng)]
+            for k in mine[:max(0, len(mine) - (cls.MAX_PER_ENGINE - 1))]:
+                del cache[k]                                # oldest first (dicts keep insertion order): a sweep over
+                                                            # guidance weights / temperatures must not grow without bound
             g = cache[key] = cls(runner, eng, img, kind, clip, temperature)
         g.begin(img, cond, layout)
         return g

@@ -1,7 +1,8 @@
 """``dynamic.ema.LitEma`` drop-in (reference dynamic/ema.py:5-76): same buffers (dot-stripped names,
 ``decay``, ``num_updates``), same decay warm-up; the update itself is one multi-tensor pass per call
-(``torch._foreach``) instead of one kernel per parameter -- the fused AdamW+EMA HIP kernel is the
-'next' row of SURVEY 8(f)."""
+(``torch._foreach``) instead of one kernel per parameter.  Inside a training loop the shadow update normally does not
+go through ``forward`` at all: ``optim.FusedAdamWEma`` folds it into the optimizer's single launch
+(``sgd_adamw_ema_step``) and only advances ``num_updates`` here."""
 import torch
 from torch import nn
 

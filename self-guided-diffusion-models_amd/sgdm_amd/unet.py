@@ -423,6 +423,7 @@ class _Engine:
         self.lse = {}             # attention log-sum-exp buffers (written only when present)
         self.stats_of = {}        # tensor data_ptr -> (partial statistics buffer, parts, channels) written by its producer
         self._p_drop = 0.0
+        self.refresh_hooks = []   # derived device state that follows the parameters (run by refresh(), never captured)
         self._build()
 
     # ---- helpers
@@ -664,6 +665,8 @@ class _Engine:
             pk.refresh(stream)
         for a, pk in self._late:
             a.cin_p, a.cout_p = pk.cin_p, pk.cout_p
+        for hook in self.refresh_hooks:
+            hook(stream)
         sig = tuple((b.data_ptr(), b._version) for b in self._film_bias_src)
         if sig != getattr(self, "_film_sig", None):
             self._film_bias.copy_(torch.cat([b.detach().reshape(-1) for b in self._film_bias_src]))
@@ -918,16 +921,22 @@ class UNetModel(UNetModelBase):
                     return lib.sgd_linear_splitk(_ptr(eng.cond_m), K, _ptr(wt), _ptr(bs), n, nout, K, _ptr(work), ksplit,
                                                  _ptr(c1), nout, stream)
                 ids, mask_u8, B = eng.cond_ids
-                sig = (wt._version, bs._version, self.null_cond_emb._version)
-                if sig != box["sig"]:                       # w . null_cond_emb + b, recomputed only when weights change
-                    rc = lib.sgd_linear_splitk(_ptr(self.null_cond_emb), K, _ptr(wt), _ptr(bs), 1, nout, K, _ptr(nwork),
-                                               ksplit, _ptr(nullproj), nout, stream)
-                    if rc:
-                        return rc
-                    box["sig"] = sig
                 return lib.sgd_linear_gather(_ptr(ids), _ptr(mask_u8), _ptr(wt), _ptr(bs), _ptr(nullproj), B, n, nout, K,
                                              _ptr(c1), nout, stream)
             mlp_cond0.__name__ = "sgd_linear_splitk"
+
+            def refresh_nullproj(stream):
+                """w . null_cond_emb + b (the projection the dropped rows of the id path take), recomputed when a weight
+                changes.  It runs from Engine.refresh -- OUTSIDE the launch program -- so a hipGraph-captured step, which
+                holds only the gather, reads the current projection after an optimizer step / EMA swap / load_state_dict
+                (begin() of a captured trajectory calls refresh)."""
+                srcs = (wt, bs, self.null_cond_emb)
+                sig = tuple((s_.data_ptr(), s_._version) for s_ in srcs)
+                if sig != box["sig"]:
+                    L.check(lib.sgd_linear_splitk(_ptr(self.null_cond_emb), K, _ptr(wt), _ptr(bs), 1, nout, K, _ptr(nwork),
+                                                  ksplit, _ptr(nullproj), nout, stream), "sgd_linear_splitk(null)")
+                    box["sig"] = sig
+            eng.refresh_hooks.append(refresh_nullproj)
             eng.prog.add("mlp_cond.0", mlp_cond0, flops=2.0 * n * K * nout, nbytes=4.0 * (n * K + K * nout + n * nout))
             eng.prog.keep.append((wt, bs))
         a2 = eng.igemm("mlp_cond.2", c1, ted // 2, eng.emb_c, ted // 2, eng.pack(["mlp_cond.2.weight"], 1), m=eng.n,

@@ -1,0 +1,403 @@
+"""Parity AT THE SIZE THE BENCHMARK TIMES.  GPU only.
+
+`sgd_igemm` launches at most 256 persistent blocks; a block streams several tiles (tile-table ring, loaders staging
+tile t+1 under tile t's epilogue) only when a launch has more than 256 tiles.  The golden fixtures are B = 1 / 2
+(<= 64 tiles per launch), so this file drives the same entry points in the regime `bench.py` runs them in:
+
+  (a) kernel level, N = 80 (UNet batch of BASELINE.json configs[1]): the production conv / 1x1 shapes, forward and
+      input gradient (the forward kernel on adjoint-packed weights), exact f32 and f16x3, against float64 torch-CPU;
+  (b) whole model: one CFG evaluation of C2 at UNet batch 80 and of C5 at UNet batch 160 against the CPU oracle
+      (pinned to the reference by tests/golden), direct call, eager sampler step and the hipGraph-captured step;
+  (c) one training step at B = 16 (512 tiles per 64x64 launch) against the oracle's autograd.
+
+Tolerances: kernel f32 5e-6 / f16x3 2e-5 of max|ref| (float64 reference); whole model f32 2e-5 / f16x3 5e-5
+(north_star budget 1e-4); gradients 5e-5 / 1e-4 of the tensor's max.
+"""
+import ctypes as C
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import max_rel
+from test_hip_kernels import _lib, _nhwc, _p, _stream
+
+pytestmark = pytest.mark.gpu
+
+KPRECS = [("f32", 5e-6), ("f16x3", 2e-5)]
+NB = 80           # UNet batch of the headline workload (bs 40, cond + uncond)
+
+
+class AD(dict):
+    __getattr__ = dict.__getitem__
+
+
+def _pack(w, ks, prec, adjoint=False):
+    L, lib = _lib()
+    cout, cin = w.shape[0], w.shape[1]
+    oc, ic = (cin, cout) if adjoint else (cout, cin)
+    buf = torch.empty(lib.sgd_packed_weight_bytes(oc, ic, ks, prec) // 4, device="cuda")
+    cp, op = C.c_int32(), C.c_int32()
+    fn = lib.sgd_pack_weight_dgrad if adjoint else lib.sgd_pack_weight
+    L.check(fn(_p(w), _p(buf), cout, cin, ks, prec, C.byref(cp), C.byref(op), _stream()), "pack")
+    return buf, cp.value, op.value
+
+
+# float64 torch-CPU convs run at a few tens of GFLOP/s: the tight check (KPRECS) is on these images of the batch -- the
+# first, middle and last tiles of the persistent blocks' streams -- and EVERY image is held to 3e-5 against fp32 torch-CPU
+SUB = [0, 1, 2, 3, 38, 39, 40, 41, 76, 77, 78, 79]
+LOOSE = 3e-5
+
+
+def _check(got, ref64_fn, ref32, tol):
+    """got: all images (cpu); ref64_fn(idx) -> float64 reference of those images; ref32: fp32 reference of all"""
+    loose = max_rel(got, ref32)
+    assert loose < LOOSE, ("all images vs fp32 torch-CPU", loose)
+    idx = [i for i in SUB if i < got.shape[0]]
+    err = max_rel(got[idx], ref64_fn(idx))
+    assert err < tol, ("float64 subset", err)
+
+
+def _tiles(rows, cout):
+    return ((rows + 127) // 128) * ((cout + 127) // 128 if cout % 128 == 0 else (cout + 31) // 32)
+
+
+def _conv(L, lib, prec, x0, x1, wbuf, cin_p, cout_p, cout, dims, bias=None, pa=None, pb=None, silu=0, resample=0, stride=1,
+          res=None, res_mode=0, stats=False):
+    """x0/x1/res: NHWC device tensors; returns the NHWC output (and the folded statistics)"""
+    n, hi, wi, ho, wo = dims
+    a = L.IgemmArgs()
+    a.x0, a.c0 = x0.data_ptr(), x0.shape[-1]
+    if x1 is not None:
+        a.x1, a.c1 = x1.data_ptr(), x1.shape[-1]
+    a.mode, a.n, a.hi, a.wi, a.ho, a.wo, a.stride, a.resample = L.MODE_CONV3, n, hi, wi, ho, wo, stride, resample
+    if pa is not None:
+        a.pro, a.pa, a.pb = L.PRO_AFFINE_NC, pa.data_ptr(), pb.data_ptr()
+    a.pro_silu = silu
+    a.w, a.cin_p, a.cout_p = wbuf.data_ptr(), cin_p, cout_p
+    a.bias = bias.data_ptr() if bias is not None else 0
+    a.res, a.res_mode = (res.data_ptr() if res is not None else 0), res_mode
+    y = torch.full((n, ho, wo, cout), float("nan"), device="cuda")
+    a.y, a.cout, a.y_ld, a.prec = y.data_ptr(), cout, cout, prec
+    sums = None
+    if stats:
+        parts = lib.sgd_igemm_stats_parts(C.byref(a))
+        assert parts > 0
+        partial = torch.full((n, parts, 2, cout), float("nan"), device="cuda")
+        a.stats = partial.data_ptr()
+    L.check(lib.sgd_igemm(C.byref(a), _stream()), "igemm")
+    if stats:
+        sums = torch.zeros(n, cout, 2, device="cuda")
+        L.check(lib.sgd_stats_reduce(_p(partial), n, parts, cout, _p(sums), cout, 0, _stream()), "reduce")
+    torch.cuda.synchronize()
+    return y, sums
+
+
+# (name, c0, c1, cout, h, mode) -- the production layers of Appendix A at UNet batch 80
+CONV_CASES = [
+    ("rb128_64", 128, 0, 128, 64, "res"),          # in1/in2, out7/out8 second conv: GN+SiLU prologue, residual, 2560 tiles
+    ("rb256_32", 256, 0, 256, 32, "res"),          # in5: 1280 tiles, 2 N tiles per M tile
+    ("cat1024_512_16", 512, 512, 512, 16, "plain"),    # out0/out1 first conv: two-source concat, 640 tiles
+    ("cat384_128_64", 256, 128, 128, 64, "plain"),     # out6 first conv
+    ("down128_64", 128, 0, 128, 64, "down"),       # in3: avg-pool prologue 64 -> 32, avg-pooled residual
+    ("up512_16", 512, 0, 512, 16, "up"),           # out2 RB(up): nearest x2 prologue + upsampled residual, 16 -> 32
+    ("stem3_64", 3, 0, 128, 64, "stem"),           # input_blocks.0.0 (scalar loader: cin % 4 != 0)
+    ("head128_3_64", 128, 0, 3, 64, "head"),       # out.2: BN = 32 instance, 3 output channels
+]
+
+
+def _case_tensors(name, c0, c1, cout, h, mode, n):
+    g = torch.Generator().manual_seed(sum(map(ord, name)) + 7)
+    cin = c0 + c1
+    x0 = torch.randn(n, c0, h, h, generator=g)
+    x1 = torch.randn(n, c1, h, h, generator=g) if c1 else None
+    w = torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(cin * 9)
+    b = torch.randn(cout, generator=g)
+    pa = 1 + 0.3 * torch.randn(n, cin, generator=g)
+    pb = 0.3 * torch.randn(n, cin, generator=g)
+    return g, x0, x1, w, b, pa, pb
+
+
+@pytest.mark.parametrize("prec,tol", KPRECS)
+@pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv3x3_forward_at_unet_batch_80(case, prec, tol):
+    name, c0, c1, cout, h, mode = case
+    L, lib = _lib()
+    p = L.PREC_BY_NAME[prec]
+    n = NB
+    g, x0, x1, w, b, pa, pb = _case_tensors(name, c0, c1, cout, h, mode, n)
+    fused = mode != "stem"
+    res = torch.randn(n, cout, h, h, generator=g) if mode == "res" else (x0 if mode in ("down", "up") else None)
+    ho = {"down": h // 2, "up": h * 2}.get(mode, h)
+    rs = {"down": 1, "up": 2}.get(mode, 0)
+
+    def ref(dt, idx=None):
+        sel = (lambda t: t.to(dt)) if idx is None else (lambda t: t[idx].to(dt))
+        xin = sel(torch.cat([x0, x1], 1) if c1 else x0)
+        act = F.silu(xin * sel(pa)[:, :, None, None] + sel(pb)[:, :, None, None]) if fused else xin
+        rsf = {1: lambda t: F.avg_pool2d(t, 2), 2: lambda t: F.interpolate(t, scale_factor=2, mode="nearest")}.get(rs, lambda t: t)
+        out = F.conv2d(rsf(act), w.to(dt), b.to(dt), padding=1)
+        return out if res is None else out + rsf(sel(res))
+
+    assert _tiles(n * ho * ho, cout) > 256, "the case must put the kernel in its multi-tile persistent regime"
+    wbuf, cin_p, cout_p = _pack(w.cuda(), 3, p)
+    x0d, x1d = _nhwc(x0).cuda(), (_nhwc(x1).cuda() if c1 else None)
+    resd = x0d if res is x0 else (_nhwc(res).cuda() if res is not None else None)
+    pad, pbd, bd = pa.cuda(), pb.cuda(), b.cuda()
+    want_stats = cout % 4 == 0 and (ho * ho) % 128 == 0
+    y, sums = _conv(L, lib, p, x0d, x1d, wbuf, cin_p, cout_p, cout, (n, h, h, ho, ho), bias=bd,
+                    pa=pad if fused else None, pb=pbd if fused else None, silu=1 if fused else 0, resample=rs,
+                    res=resd, res_mode=rs, stats=want_stats)
+    got = y.cpu().permute(0, 3, 1, 2)
+    ref32 = ref(torch.float32)
+    _check(got, lambda idx: ref(torch.float64, idx), ref32, tol)
+    if want_stats:       # the GroupNorm statistics the epilogue produced for the consumer: every image, from the stored y
+        yy = got.double()
+        exact = torch.stack([yy.sum((2, 3)), (yy * yy).sum((2, 3))], -1)
+        serr = float((sums.cpu().double() - exact).abs().max() / exact.abs().max())
+        assert serr < 2e-6, serr
+
+
+@pytest.mark.parametrize("prec,tol", KPRECS)
+@pytest.mark.parametrize("shape", [(128, 128, 64, 1), (256, 256, 32, 1), (1024, 512, 16, 1), (128, 128, 64, 2)],
+                         ids=["128_64", "256_32", "1024to512_16", "stride2_adjoint_128_64"])
+def test_conv3x3_dgrad_at_unet_batch_80(shape, prec, tol):
+    """input gradient = the forward kernel on adjoint-packed weights (stride 2: zero insertion in the loader)"""
+    L, lib = _lib()
+    cin, cout, h, stride = shape
+    n = NB
+    p = L.PREC_BY_NAME[prec]
+    g = torch.Generator().manual_seed(31)
+    w = torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(cin * 9)
+    ho = h // stride
+    gy = torch.randn(n, cout, ho, ho, generator=g)
+
+    def ref(dt, idx=None):
+        gg = gy if idx is None else gy[idx]
+        return F.conv_transpose2d(gg.to(dt), w.to(dt), stride=stride, padding=1, output_padding=stride - 1)
+
+    assert _tiles(n * h * h, cin) > 256
+    wbuf, cp, op = _pack(w.cuda(), 3, p, adjoint=True)
+    gyd = _nhwc(gy).cuda()
+    if stride == 1:
+        y, _ = _conv(L, lib, p, gyd, None, wbuf, cp, op, cin, (n, h, h, h, h))
+    else:
+        y, _ = _conv(L, lib, p, gyd, None, wbuf, cp, op, cin, (n, ho, ho, h, h), resample=L.RS_ZEROUP2)
+    got = y.cpu().permute(0, 3, 1, 2)
+    assert got.shape == (n, cin, h, h)
+    _check(got, lambda idx: ref(torch.float64, idx), ref(torch.float32), tol)
+
+
+def _flat(L, lib, prec, x0, x1, w, bias, m, rows_per_n=0, pa=None, pb=None, silu=0, res=None, adjoint=False):
+    wbuf, cp, op = _pack(w.cuda(), 1, prec, adjoint=adjoint)
+    nout = w.shape[1] if adjoint else w.shape[0]
+    a = L.IgemmArgs()
+    a.x0, a.c0 = x0.data_ptr(), x0.shape[-1]
+    if x1 is not None:
+        a.x1, a.c1 = x1.data_ptr(), x1.shape[-1]
+    a.mode, a.m, a.rows_per_n, a.stride = L.MODE_FLAT, m, rows_per_n, 1
+    if pa is not None:
+        a.pro, a.pa, a.pb = L.PRO_AFFINE_NC, pa.data_ptr(), pb.data_ptr()
+    a.pro_silu = silu
+    a.w, a.cin_p, a.cout_p = wbuf.data_ptr(), cp, op
+    a.bias = bias.data_ptr() if bias is not None else 0
+    a.res = res.data_ptr() if res is not None else 0
+    y = torch.full((m, nout), float("nan"), device="cuda")
+    a.y, a.cout, a.y_ld, a.prec = y.data_ptr(), nout, nout, prec
+    L.check(lib.sgd_igemm(C.byref(a), _stream()), "igemm")
+    torch.cuda.synchronize()
+    return y
+
+
+FLAT_CASES = {  # c0, c1, cout, hw, GroupNorm prologue, residual
+    "skip384_128_64": (256, 128, 128, 4096, False, False),      # output_blocks.6.0.skip_connection on the raw concat
+    "skip1024_512_16": (512, 512, 512, 256, False, False),
+    "qkv512_16": (512, 0, 1536, 256, True, False),              # AttentionBlock.qkv behind its GroupNorm
+    "proj512_16": (512, 0, 512, 256, False, True),              # proj_out + the block's residual
+}
+
+
+@pytest.mark.parametrize("prec,tol", KPRECS)
+@pytest.mark.parametrize("case", sorted(FLAT_CASES))
+def test_conv1x1_at_unet_batch_80(case, prec, tol):
+    """the 1x1 instance of the kernel at production shapes -- forward and the input gradient (float64 reference: these are
+    plain matrix products, cheap on the CPU)"""
+    L, lib = _lib()
+    p = L.PREC_BY_NAME[prec]
+    n = NB
+    g = torch.Generator().manual_seed(41)
+    c0, c1, cout, hw, gn, resid = FLAT_CASES[case]
+    cin, m = c0 + c1, n * hw
+    x0 = torch.randn(m, c0, generator=g)
+    x1 = torch.randn(m, c1, generator=g) if c1 else None
+    w = torch.randn(cout, cin, generator=g) / math.sqrt(cin)
+    b = torch.randn(cout, generator=g)
+    pa, pb = 1 + 0.3 * torch.randn(n, cin, generator=g), 0.3 * torch.randn(n, cin, generator=g)
+    res = torch.randn(m, cout, generator=g) if resid else None
+    xin = (torch.cat([x0, x1], 1) if c1 else x0).double()
+    if gn:
+        xin = (xin.reshape(n, hw, cin) * pa.double()[:, None] + pb.double()[:, None]).reshape(m, cin)
+    ref = xin @ w.double().t() + b.double()
+    if resid:
+        ref = ref + res.double()
+    assert _tiles(m, cout) > 256
+    x0d, x1d, bd = x0.cuda(), (x1.cuda() if c1 else None), b.cuda()
+    pad, pbd = pa.cuda(), pb.cuda()
+    resd = res.cuda() if resid else None
+    y = _flat(L, lib, p, x0d, x1d, w, bd, m, rows_per_n=hw, pa=pad if gn else None, pb=pbd if gn else None, res=resd)
+    err = max_rel(y.cpu(), ref)
+    assert err < tol, err
+    gy = torch.randn(m, cout, generator=g)              # input gradient: gy [m, cout] x W -> [m, cin]
+    gx = _flat(L, lib, p, gy.cuda(), None, w, None, m, adjoint=True)
+    gerr = max_rel(gx.cpu(), gy.double() @ w.double())
+    assert gerr < tol, gerr
+
+
+@pytest.mark.parametrize("prec,tol", KPRECS)
+def test_image_packed_tiles_ragged_batch(prec, tol):
+    """8x8 maps (the 4-level `*_s64` plans): two images per 128-row tile and an odd batch, so the last M tile of the stream
+    is half empty; 161 images x 512 channels = 81 M tiles x 4 N tiles"""
+    L, lib = _lib()
+    p = L.PREC_BY_NAME[prec]
+    n, c, h = 161, 512, 8
+    g = torch.Generator().manual_seed(43)
+    x = torch.randn(n, c, h, h, generator=g)
+    w = torch.randn(c, c, 3, 3, generator=g) / math.sqrt(c * 9)
+    b = torch.randn(c, generator=g)
+    pa, pb = 1 + 0.3 * torch.randn(n, c, generator=g), 0.3 * torch.randn(n, c, generator=g)
+    res = torch.randn(n, c, h, h, generator=g)
+
+    def ref(dt, idx=None):
+        sel = (lambda t: t.to(dt)) if idx is None else (lambda t: t[idx].to(dt))
+        act = F.silu(sel(x) * sel(pa)[:, :, None, None] + sel(pb)[:, :, None, None])
+        return F.conv2d(act, w.to(dt), b.to(dt), padding=1) + sel(res)
+
+    assert _tiles(n * h * h, c) > 256
+    wbuf, cp, op = _pack(w.cuda(), 3, p)
+    pad, pbd, bd = pa.cuda(), pb.cuda(), b.cuda()
+    y, _ = _conv(L, lib, p, _nhwc(x).cuda(), None, wbuf, cp, op, c, (n, h, h, h, h), bias=bd, pa=pad, pb=pbd, silu=1,
+                 res=_nhwc(res).cuda())
+    got = y.cpu().permute(0, 3, 1, 2)
+    loose = max_rel(got, ref(torch.float32))
+    assert loose < LOOSE, loose
+    idx = [0, 1, 2, 79, 80, 81, 158, 159, 160]
+    err = max_rel(got[idx], ref(torch.float64, idx))
+    assert err < tol, err
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# (b) whole model at the benchmarked batch
+# --------------------------------------------------------------------------------------------------------------------
+def _bench_model(workload, prec):
+    import bench
+    wl = bench.WORKLOADS[workload]
+    m, sd, data = bench.build_model(wl, torch.device("cuda"), prec, wl["batch"])
+    return wl, m, sd, data
+
+
+def _oracle_cfg(wl):
+    from oracle import unet_ref as U
+    ca = wl["kind"] == "unetca_fast"
+    return U.make_cfg(wl["kind"], wl["image"], model_channels=128, cond_dim=wl["cond_dim"], condition_method=wl["method"],
+                      layout_dim=wl["layout_dim"], cond_token_num=1 if ca else 0, context_dim=32 if ca else None,
+                      resblock_updown=not ca, dropout=0.0)
+
+
+@pytest.mark.parametrize("workload", ["c2", "c5"])
+def test_cfg_evaluation_at_benchmark_batch_vs_oracle(workload):
+    """BASELINE.json configs[1] at UNet batch 80 and configs[4] at UNet batch 160: one CFG evaluation against the CPU
+    oracle, as a direct forward_with_cond_scale call and as one native sampler step -- eager launches and the
+    hipGraph-captured step `bench.py` replays -- in exact f32 and in f16x3"""
+    import bench
+    from oracle import diffusion_ref as D
+    from oracle import unet_ref as U
+    from sgdm_amd.diffusion import LatentDiffusion
+    wl, m, sd, data = _bench_model(workload, "f32")
+    B, S = wl["batch"], wl["image"]
+    cfg = _oracle_cfg(wl)
+    cond = data["cond"] if wl["kind"] == "unet_fast" else data["cond"].float()
+    layout = data.get("layout")
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(B, 3, S, S, generator=g)
+    z = torch.randn(B, 3, S, S, generator=g)
+    t0 = 437
+    t = torch.full((B,), t0, dtype=torch.long)
+    with torch.no_grad():
+        ref_eps = U.forward_with_cond_scale(cfg, sd, x, t, 2.0, cond, layout)
+    sched = D.make_schedule()
+    ref_next, ref_x0 = D.ddpm_step(sched, x, t, ref_eps, z, clip_denoised=True)[:2]
+    diff = LatentDiffusion(device="cuda", **bench.MODEL_PARAMS)
+    diff.set_denoise_fn(m.forward, m.forward_with_cond_scale)
+    dkw = dict(cond=cond.cuda(), layout=None if layout is None else layout.cuda(), cond_scale=2.0)
+    skw = dict(sampling_method="native", num_timesteps=1000, ddim_eta=0.0, log_num_per_prog=10, clip_denoised=True, dtp=1,
+               temperature=1.0, noise_dropout=0, random_sample_condition=False, return_inter_dict=True)
+    eager = {}
+    for prec, tol in (("f32", 2e-5), ("f16x3", 5e-5)):
+        m.hip_precision = prec
+        with torch.no_grad():
+            got = m.forward_with_cond_scale(x.cuda(), t.cuda(), **dkw)
+        err = max_rel(got.cpu(), ref_eps)
+        assert err < tol, (prec, "eps", err)
+        for graph in (False, True):
+            with torch.no_grad():
+                img, _ = diff.sampler.sample((B, 3, S, S), sampling_kwargs=dict(skw, hip_graph=graph),
+                                             denoise_sample_fn=diff.denoise_sample_fn, denoise_sample_fn_kwargs=dkw,
+                                             x_T=x.cuda(), step_indices=[t0], noise_fn=lambda i: z)
+            serr = max_rel(img.cpu(), ref_next)
+            assert serr < tol, (prec, "graph" if graph else "eager", serr)
+            if graph:
+                assert torch.equal(img, eager[prec]), "captured step differs from the eager launches"
+            else:
+                eager[prec] = img.clone()
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# (c) one training step with > 256 tiles per launch
+# --------------------------------------------------------------------------------------------------------------------
+GRAD_TENSORS = ["input_blocks.0.0.weight", "input_blocks.1.0.in_layers.2.weight", "input_blocks.1.0.out_layers.3.weight",
+                "input_blocks.3.0.in_layers.2.weight", "input_blocks.4.0.skip_connection.weight",
+                "input_blocks.7.1.qkv.weight", "middle_block.0.emb_layers.1.weight", "middle_block.2.out_layers.0.weight",
+                "output_blocks.0.0.in_layers.2.weight", "output_blocks.2.2.in_layers.2.weight",
+                "output_blocks.8.0.out_layers.3.weight", "output_blocks.8.0.out_layers.3.bias", "out.2.weight",
+                "time_embed.0.weight", "mlp_cond.0.weight"]
+
+
+@pytest.mark.parametrize("prec,tol", [("f32", 5e-5), ("f16x3", 1e-4)])
+def test_train_step_at_batch_16_vs_oracle(prec, tol):
+    """unet_fast ch128 64x64 (C2's model), B = 16 -> 512 tiles per 64x64 launch: loss, per-sample loss and 15 gradient
+    tensors (first / last conv, ResBlock convs at every resolution, down / up blocks, skip 1x1, qkv, FiLM projection,
+    GroupNorm affine, embedding MLPs) against the oracle's autograd on the CPU"""
+    import bench
+    from oracle import diffusion_ref as D
+    from oracle import unet_ref as U
+    from sgdm_amd.diffusion import LatentDiffusion
+    from sgdm_amd.synth import synth_batch
+    wl = bench.WORKLOADS["c2"]
+    B, S = 16, 64
+    m, sd, _ = bench.build_model(wl, torch.device("cuda"), prec, B)
+    m.dropout = 0.0
+    m.train()
+    d = LatentDiffusion(device="cuda", **bench.MODEL_PARAMS).train()
+    d.set_denoise_fn(m.forward, m.forward_with_cond_scale)
+    batch = synth_batch(wl["method"], B, S, wl["cond_dim"], 0, seed=91)
+    g = torch.Generator().manual_seed(92)
+    t = torch.randint(0, 1000, (B,), generator=g)
+    noise = torch.randn(B, 3, S, S, generator=g)
+    mask = torch.rand(B, generator=g) < 0.25
+    loss, ld = d.p_losses(batch["image"].cuda(), t.cuda(), noise.cuda(), cond=batch["cond"].cuda(), cond_drop_prob=0.25,
+                          cond_drop_mask=mask.cuda())
+    loss.backward()
+    cfg = _oracle_cfg(wl)
+    w = {k: v.clone().requires_grad_(k in GRAD_TENSORS) for k, v in sd.items()}
+    ref_loss, ref_per, _, _ = D.p_losses(D.make_schedule(),
+                                          lambda xx, tt: U.unet_forward(cfg, w, xx, tt, batch["cond"], None, drop_mask=mask),
+                                          batch["image"], t, noise)
+    ref_loss.backward()
+    assert abs(loss.item() - float(ref_loss)) < 2e-5 * abs(float(ref_loss))
+    assert max_rel(ld["train/epoch_stats_y"].cpu(), ref_per.detach()) < 2e-5
+    params = dict(m.named_parameters())
+    for name in GRAD_TENSORS:
+        got, want = params[name].grad.cpu(), w[name].grad
+        err = max_rel(got, want)
+        assert err < tol, (name, err)

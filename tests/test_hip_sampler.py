@@ -327,3 +327,33 @@ def test_ddim_interp_variant_runs_and_batches_like_the_reference():
     rows = batch_to_conditioninterp(cond, 3, 2)
     assert tuple(rows.shape) == (6, 10)
     assert torch.allclose(rows[0], cond[0], atol=1e-5) and torch.allclose(rows[2], cond[1], atol=1e-5)   # slerp ends = the pair
+
+
+def test_graph_step_with_cluster_ids_follows_weight_updates():
+    """with class / cluster IDS as `cond`, the dropped (unconditional) CFG rows take w . null_cond_emb + b,
+    a projection cached on the device.  It used to be refreshed inside the launch program, which a captured hipGraph does
+    not re-run: after an optimizer step / EMA swap / load_state_dict a cached graph kept the OLD projection.  Graph
+    sample -> change the weights -> graph sample must equal the eager path on the new weights, bit for bit."""
+    from sgdm_amd.synth import weights_from_seed
+    m, entry = build_model("uf_cluster5000_c32_s16", "f16x3")
+    d = _diffusion(m)
+    ids = torch.tensor([17, 4999]).cuda()
+    dkw = dict(cond=ids, layout=None, cond_scale=2.0)
+    skw = _skw("native", 1000)
+
+    def run(graph):
+        torch.manual_seed(99)
+        return d.p_sample_loop("native", (2, 3, 16, 16), dict(skw, hip_graph=graph), denoise_sample_fn_kwargs=dict(dkw),
+                               condition_kwargs={}, step_indices=[999, 998, 997, 0])[0].cpu()
+
+    assert torch.equal(run(True), run(False))
+    first = run(True)
+    with torch.no_grad():                                         # what an optimizer step / LitEma.copy_to does: in place
+        for name in ("mlp_cond.0.weight", "mlp_cond.0.bias", "null_cond_emb"):
+            p = m.P(name)
+            p.add_(torch.randn(p.shape, generator=torch.Generator().manual_seed(5)).cuda() * 0.05)
+    after_graph, after_eager = run(True), run(False)
+    assert not torch.equal(after_eager, first)
+    assert torch.equal(after_graph, after_eager)
+    m.load_state_dict(weights_from_seed(entry["manifest"], entry["seed"]))
+    assert torch.equal(run(True), first)
