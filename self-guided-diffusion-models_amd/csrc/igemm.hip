@@ -27,6 +27,7 @@
 // Replaces (reference): nn.Conv2d/Conv1d/Linear call sites listed in include/sgdm_hip.h.
 #include <stdlib.h>
 #include <type_traits>
+#include <utility>
 
 #include "sgdm_common.h"
 #include "../../include/sgdm_hip.h"
@@ -39,8 +40,9 @@ constexpr int LDA = KC + 4;   // LDS row stride in floats (144 B): conflict-free
 constexpr int BM = 128;
 constexpr int NB_RING = 3;    // register ring depth of the 1x1 loaders (input rows requested 3 steps ahead)
 constexpr int BIAS_LDS_MAX = 4096;   // layers up to this many (padded) output channels keep their bias in LDS (16 KB)
-constexpr int NTHREADS = 512;  // 4 compute waves + 4 input-tile loader waves
-constexpr int A_THREADS = NTHREADS - 256;
+constexpr int A_THREADS = 256;  // 4 input-tile loader waves
+constexpr int NCOMP = 256;      // 4 compute (MFMA) waves, one per SIMD
+constexpr int NTHREADS = NCOMP + A_THREADS;
 constexpr int WUNIT = 4096;   // bytes of one packed weight unit: 32 output x 32 input channels of one tap, fragment order
 constexpr int FAST_PIX = 192;  // halo tiles up to this many pixels (16x8 outputs + halo = 180) use the split-phase A loader
 
@@ -137,24 +139,22 @@ __device__ __forceinline__ void lds_store_act(float* rowp, int c4, f32x4 v) {
     }
 }
 
-// MFMA operand fragments of one K sub-step of one wave tile.  A: the input side (pixels), read from the LDS tile;
-// B: the weight side, loaded from the fragment-ordered packed weights in global memory (`p` already carries lane * 16).
-template <int PREC, int MT, int NT> struct Frag {
+// MFMA operand fragments.  AU: the input side (pixels) of ONE stage = one 32-row block x one K sub-step, read from the LDS
+// tile; B: the weight side of one K sub-step for the wave's NT 32-column blocks, loaded from the fragment-ordered packed
+// weights in global memory (`p` already carries lane * 16).  A stage multiplies one AU into NT accumulator tiles.
+template <int PREC, int NT> struct Frag {
     typedef typename Split<PREC>::T T;
     typedef T T8 __attribute__((ext_vector_type(8)));
     static constexpr int NKS = KC / 16;           // 16 channels per sub-step
-    static constexpr int NREADS = 2 * MT;         // ds_read_b128 per sub-step
+    static constexpr int NREADS = 2;              // ds_read_b128 per stage
     static constexpr int NWLOADS = 2 * NT;        // 16-byte global loads per sub-step
-    static constexpr int NMMA = 3 * MT * NT;      // MFMAs per sub-step
-    struct A {
-        T8 h[MT], l[MT];
-        __device__ __forceinline__ void load(const float* const* ap, int ks, int lh) {
+    static constexpr int NMMA = 3 * NT;           // MFMAs per stage
+    struct AU {
+        T8 h, l;
+        __device__ __forceinline__ void load(const float* rowp, int ks, int lh) {
             const int goff = (ks * 2 + lh) * 8;   // float offset of this lane-half's 8-channel group
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                h[mt] = *reinterpret_cast<const T8*>(ap[mt] + goff);
-                l[mt] = *reinterpret_cast<const T8*>(ap[mt] + goff + 4);
-            }
+            h = *reinterpret_cast<const T8*>(rowp + goff);
+            l = *reinterpret_cast<const T8*>(rowp + goff + 4);
         }
     };
     struct B {
@@ -167,33 +167,30 @@ template <int PREC, int MT, int NT> struct Frag {
             }
         }
     };
-    static __device__ __forceinline__ void mma(f32x16 (&acc)[MT][NT], const A& a, const B& b) {
+    static __device__ __forceinline__ void mma(f32x16 (&acc)[NT], const AU& a, const B& b) {
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                if constexpr (PREC == SGD_PREC_F16X3) {
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b.h[nt], a.l[mt], acc[mt][nt], 0, 0, 0);
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b.l[nt], a.h[mt], acc[mt][nt], 0, 0, 0);
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b.h[nt], a.h[mt], acc[mt][nt], 0, 0, 0);
-                } else {
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b.h[nt], a.l[mt], acc[mt][nt], 0, 0, 0);
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b.l[nt], a.h[mt], acc[mt][nt], 0, 0, 0);
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b.h[nt], a.h[mt], acc[mt][nt], 0, 0, 0);
-                }
+        for (int nt = 0; nt < NT; ++nt) {
+            if constexpr (PREC == SGD_PREC_F16X3) {
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b.h[nt], a.l, acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b.l[nt], a.h, acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b.h[nt], a.h, acc[nt], 0, 0, 0);
+            } else {
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b.h[nt], a.l, acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b.l[nt], a.h, acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b.h[nt], a.h, acc[nt], 0, 0, 0);
             }
+        }
     }
 };
-template <int MT, int NT> struct Frag<SGD_PREC_F32, MT, NT> {
+template <int NT> struct Frag<SGD_PREC_F32, NT> {
     static constexpr int NKS = KC / 8;            // 8 channels per sub-step (4 MFMA k-pairs)
-    static constexpr int NREADS = MT;
+    static constexpr int NREADS = 1;
     static constexpr int NWLOADS = NT;
-    static constexpr int NMMA = 4 * MT * NT;
-    struct A {
-        f32x4 v[MT];
-        __device__ __forceinline__ void load(const float* const* ap, int ks, int lh) {
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) v[mt] = *reinterpret_cast<const f32x4*>(ap[mt] + ks * 8 + lh * 4);
+    static constexpr int NMMA = 4 * NT;
+    struct AU {
+        f32x4 v;
+        __device__ __forceinline__ void load(const float* rowp, int ks, int lh) {
+            v = *reinterpret_cast<const f32x4*>(rowp + ks * 8 + lh * 4);
         }
     };
     struct B {
@@ -203,14 +200,12 @@ template <int MT, int NT> struct Frag<SGD_PREC_F32, MT, NT> {
             for (int nt = 0; nt < NT; ++nt) v[nt] = *reinterpret_cast<const f32x4*>(p + nt * WUNIT + ks * 1024);
         }
     };
-    static __device__ __forceinline__ void mma(f32x16 (&acc)[MT][NT], const A& a, const B& b) {
+    static __device__ __forceinline__ void mma(f32x16 (&acc)[NT], const AU& a, const B& b) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(b.v[nt][j], a.v[mt][j], acc[mt][nt], 0, 0, 0);
+            for (int nt = 0; nt < NT; ++nt)
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(b.v[nt][j], a.v[j], acc[nt], 0, 0, 0);
     }
 };
 
@@ -229,6 +224,14 @@ __device__ __forceinline__ float half_wave_sum_hi(float v) {
     v = dpp_add<0x141, 0xF>(v);      // row_half_mirror
     v = dpp_add<0x140, 0xF>(v);      // row_mirror: every lane holds its row-of-16 total
     return dpp_add<0x142, 0xA>(v);   // row_bcast15 into rows 1 and 3: + the total of the row below
+}
+
+// compile-time loop: f(std::integral_constant<int, 0>()) ... f(std::integral_constant<int, N - 1>())
+template <class F, int... I> __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>()), ...);
+}
+template <int N, class F> __device__ __forceinline__ void static_for(F&& f) {
+    static_for_impl(f, std::make_integer_sequence<int, N>());
 }
 
 struct Tile {
@@ -257,15 +260,16 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
     const Geo& g = ka.g;
     constexpr bool CONV = TAPS == 9;
     constexpr int NA = 3;                         // A tile ring depth (CONV: chunks, loaders two ahead; FLAT: K steps)
-    // wave tile: BN = 128 -> every MFMA wave owns ALL 128 rows x its own 32 columns, so the four waves of a block load
+    // wave tile: BN >= 128 -> every MFMA wave owns ALL 128 rows x its own BN / 4 columns, so the four waves of a block load
     // disjoint weight fragments (a 64 x 64 split made two waves fetch the same 8 KB per step: the per-CU vector memory
     // pipe was > 50 % busy and its full queue stalled the in-order MFMA waves at their loads); the input fragments they
-    // share come from LDS, which has the bandwidth to spare now.  BN = 32: four 32 x 32 waves stacked along M.
-    constexpr int WM = (BN == 128) ? 128 : 32;    // wave tile rows
-    constexpr int WN = 32;                        // wave tile cols
+    // share come from LDS.  BN = 256 (64 columns per wave, 128 accumulator registers) multiplies every staged input
+    // chunk into twice the MFMAs: the loaders' transform work per flop halves.  BN = 32: four 32 x 32 waves stacked along M.
+    constexpr int WM = (BN >= 128) ? 128 : 32;    // wave tile rows
+    constexpr int WN = (BN >= 128) ? BN / 4 : 32; // wave tile cols
     constexpr int MT = WM / 32, NT = WN / 32;
     constexpr int WAVES_N = BN / WN;
-    typedef Frag<PREC, MT, NT> FragT;
+    typedef Frag<PREC, NT> FragT;
     constexpr int NKS = FragT::NKS;
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -340,7 +344,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
     __syncthreads();
     PROBE_BEGIN();
 
-    if (tid >= 256) {
+    if (tid >= NCOMP) {
         // The loader shares its SIMD's vector issue with an MFMA wave that always has an instruction waiting; at equal
         // priority the older (MFMA) wave wins every arbitration and the loader got ~1 issue slot per MFMA (measured: ~460
         // vector instructions per chunk took 10k cycles and the compute waves waited 27 % of the time at the chunk
@@ -365,9 +369,9 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
             const bool lean2 = g.fast_a && VEC && ((uni_rt && a.pro_silu) || (a.pro == SGD_PRO_NONE && !a.pro_silu))
                                && a.drop_p == 0.f && cin % KC == 0 && (a.c1 == 0 || a.c0 % KC == 0) && !DBG(3);
             if (lean2) {
-                constexpr int LT = NTHREADS - 256;                       // 256 loader threads
+                constexpr int LT = A_THREADS;                            // 256 loader threads
                 constexpr int AJ = (FAST_PIX * 8 + LT - 1) / LT;         // input items per thread per chunk (6)
-                const int lt = tid - 256;
+                const int lt = tid - NCOMP;
                 const int c4 = lt & 7;                                   // channel quad (inputs and weights alike)
                 const int items = g.pix * 8;
                 auto go = [&](auto unic, auto poolc) {
@@ -462,8 +466,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
                     };
                     // ---- ONE barrier per chunk; the loaders run two chunks ahead of the compute waves in LDS (ring of 3)
                     // and three ahead in global memory: in period q they transform chunk q+2 (requested in period q-1) into
-                    // slot (q+2) % 3 and request chunk q+3.  Prologue: chunk 0 staged synchronously; period 0 additionally
-                    // stages chunk 1 (the compute waves read it only after barrier 1).
+                    // slot (q+2) % 3 and request chunk q+3.  Prologue: chunks 0 and 1 staged before barrier 0.
                     S s2;                                               // chunk whose raw rows are in flight / in registers
                     auto stage = [&](int slot) {                        // transform the chunk under s2, request the next one
                         valid1 = valid2;
@@ -488,8 +491,9 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
 #pragma unroll
                     for (int j = 0; j < AJ; ++j) issue_item(s2, j);
                     stage(0);                                           // chunk 0 -> slot 0, request chunk 1
-                    SYNC();                                             // barrier 0
-                    stage(1);                                           // period 0: chunk 1 -> slot 1, request chunk 2
+                    stage(1);                                           // chunk 1 -> slot 1, request chunk 2
+                    SYNC();                                             // barrier 0: the compute waves' fragment
+                                                                        // prefetch runs DEPTH stages into the next chunk
                     for (int q = 0; q < Q; ++q) {
                         stage((q + 2) % NA);                            // chunk q+2 -> slot (q+2) % 3, request chunk q+3
                         // table of the tile that chunk q+4 opens (read by load_rows one period later)
@@ -525,9 +529,9 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
                 constexpr int MODE = decltype(modec)::value;              // 0 none, 1 per-image GroupNorm affine, 2 LayerNorm rows
                 constexpr bool SILU = decltype(siluc)::value;
                 constexpr bool tile_uni = MODE == 1, ln = MODE == 2;
-                constexpr int AI = BM * 8 / (NTHREADS - 256);             // input quads per thread per step (4)
-                constexpr int AROWS = (NTHREADS - 256) / 8;               // rows covered by one pass of the loader threads (32)
-                const int lt = tid - 256;
+                constexpr int AI = BM * 8 / A_THREADS;                    // input quads per thread per step (4)
+                constexpr int AROWS = A_THREADS / 8;                      // rows covered by one pass of the loader threads (32)
+                const int lt = tid - NCOMP;
                 const int c4 = lt & 7;
                 const int arow = lt >> 3;                                 // + AROWS * j
                 typedef std::integral_constant<int, 0> R0;
@@ -637,7 +641,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
         // (harmless duplicates written to ring slots nobody reads any more) instead of being branched around.
         // =====================================================================================
         // -------------------------------------------------------------------- A loader
-        const int lt = tid - 256;
+        const int lt = tid - NCOMP;
         const int c4 = lt & 7;                        // this thread's channel quad inside every chunk
         const int items = g.pix * 8;                  // float4 items of one A tile
         // row entry of tile-row `pix`: CONV reads the tile table; FLAT rows are m0 + pix (tab carries m0)
@@ -752,16 +756,16 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
                     request();
                 };
                 request();
-                SYNC();                                                  // barrier 0
                 stage(1, 2);
+                SYNC();                                                  // barrier 0 (chunks 0 and 1 staged)
                 for (int q = 0; q < Q; ++q) {
                     stage(q + 2, q + 3);
                     if (q + 4 < Q && (q + 4) % nchunks == 0) build_pixtab((q + 4) / nchunks, lt, A_THREADS);
                     SYNC();
                 }
             } else {
-                SYNC();                                                  // barrier 0
                 stage_A_sync(1, 1);
+                SYNC();                                                  // barrier 0 (chunks 0 and 1 staged)
                 for (int q = 0; q < Q; ++q) {
                     stage_A_sync(q + 2, q + 2);
                     if (q + 4 < Q && (q + 4) % nchunks == 0) build_pixtab((q + 4) / nchunks, lt, A_THREADS);
@@ -866,31 +870,45 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
     f32x16 acc[MT][NT];
     const float wsi = a.w_scale_inv ? *a.w_scale_inv : 1.f;        // 2^-k of the packed weights (exact); once per block
 
-    // One K step, per sub-step: [wait input frags(cur)] [issue LDS reads(next)] [MFMA block(cur)] [request the weight
-    // frags of the SAME sub-step of the next K step].  Strict alternation keeps at most ONE batch of LDS reads
-    // outstanding (they were issued one whole MFMA block earlier, so the explicit lgkmcnt(0) never stalls); the last
-    // sub-step's reads belong to the NEXT step and are issued before this step's barrier.  The weight loads have a whole
-    // K step (>= 768 matrix-pipe cycles) to return from L2; their vmcnt waits are the compiler's (plain loads).
-    typename FragT::A fa[2];
+    // The K loop is a software pipeline over STAGES: a stage = (K sub-step ks, 32-row block mt) multiplies ONE input
+    // fragment unit (2 ds_read_b128) into the wave's NT accumulator tiles (3 NT MFMAs).  The units live in a register
+    // ring of RING slots and are requested DEPTH stages before they are used -- across K steps, chunk seams and tile
+    // seams alike -- so the wave holds 8 registers per stage in flight instead of a double-buffered set of all MT row
+    // blocks (64 registers): that is what leaves room for the 128 accumulator registers of the 64-column wave tile.
+    // The weight fragments of sub-step ks are reloaded (for the next K step) right after their last use in this one:
+    // they have (NKS - 1) * MT stages (>= 768 matrix-pipe cycles) to return from L2.  All waits are the compiler's
+    // (plain loads: exact counted s_waitcnt); the sched_group_barriers only pin the issue order.
+    constexpr int STAGES = NKS * MT;               // per K step
+    constexpr int RING = STAGES >= 4 ? 4 : 2;      // STAGES % RING == 0: a K step always starts at ring slot 0
+    constexpr int DEPTH = RING - 1;
+    static_assert(STAGES % RING == 0, "ring position must be a compile-time constant inside a K step");
+    typename FragT::AU ring[RING];
     typename FragT::B fb[NKS];
-    auto do_step = [&](const float* const* ap, const float* const* nap, const char* wnext, auto barrier_after) {
-#pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) {
-            __builtin_amdgcn_s_waitcnt(0xC07F);                        // lgkmcnt(0) only
-            __builtin_amdgcn_sched_barrier(0);
-            if (!(DBG(128)) && !ABL(64)) {
-            if (ks + 1 < NKS) fa[(ks + 1) & 1].load(ap, ks + 1, lh);
-            else fa[(ks + 1) & 1].load(nap, 0, lh);
-            }   // unconditional (a branch here would block the interleave); past the
-                                                            // last step it reads a valid ring slot nobody needs
-            if (!(DBG(4)) && !ABL(16)) FragT::mma(acc, fa[ks & 1], fb[ks]);
-            if (!(DBG(2)) && !ABL(32)) fb[ks].load(wnext, ks);
-            // Interleave: one MFMA, ONE LDS read, ... then one MFMA, ONE weight load, ...; the rest of the MFMAs cover
-            // the latency of the last reads (a burst of reads in front of the MFMAs fills the LDS queue and the in-order
-            // wave cannot issue its MFMAs until they are accepted).
-            if (!(DBG(32))) {
-                constexpr int P1 = FragT::NREADS < FragT::NMMA ? FragT::NREADS : FragT::NMMA;
-                constexpr int P2 = FragT::NWLOADS < FragT::NMMA - P1 ? FragT::NWLOADS : FragT::NMMA - P1;
+    const int rowstep = g.hw * LDA;                // LDS floats between halo rows
+    auto tap_off = [&](int tap) { return CONV ? (tap / 3) * rowstep + (tap % 3) * LDA : 0; };
+    // one K step: `acur` holds this step's chunk, `anext` the chunk the prefetches run into when `seam` (last tap)
+    auto do_step = [&](const float* acur, const float* anext, auto tapc, const char* wnext) {
+        constexpr int tap = decltype(tapc)::value;
+        constexpr bool seam = tap + 1 == TAPS;
+        static_for<STAGES>([&](auto stc) {
+            constexpr int st = decltype(stc)::value;
+            constexpr int ks = st / MT, mt = st % MT;
+            // the unit of stage st + DEPTH: this step, or the first stages of the next one (next tap / next chunk)
+            constexpr int pst = (st + DEPTH) % STAGES;
+            constexpr bool wrap = st + DEPTH >= STAGES;
+            const float* pbase = (wrap && seam) ? anext : acur;
+            constexpr int ptap = wrap ? (seam ? 0 : tap + 1) : tap;
+            if (!ABL(64)) ring[(st + DEPTH) % RING].load(pbase + tap_off(ptap) + aoff[pst % MT], pst / MT, lh);
+            if (!ABL(16)) FragT::mma(acc[mt], ring[st % RING], fb[ks]);
+            if (mt == MT - 1 && !ABL(32)) fb[ks].load(wnext, ks);
+            // issue order: one MFMA, ONE LDS read, ... then one MFMA, ONE weight load, ...; the remaining MFMAs last
+            // (a burst of reads in front of the MFMAs fills the LDS queue and the in-order wave cannot issue its MFMAs
+            // until they are accepted)
+            {
+                constexpr int NM = FragT::NMMA;
+                constexpr int P1 = FragT::NREADS < NM ? FragT::NREADS : NM;
+                constexpr int nw = (mt == MT - 1) ? FragT::NWLOADS : 0;
+                constexpr int P2 = nw < NM - P1 ? nw : NM - P1;
 #pragma unroll
                 for (int i = 0; i < P1; ++i) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -901,31 +919,25 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                     __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
                 }
-                if constexpr (FragT::NMMA - P1 - P2 > 0) __builtin_amdgcn_sched_group_barrier(0x008, FragT::NMMA - P1 - P2, 0);
+                if constexpr (NM - P1 - P2 > 0) __builtin_amdgcn_sched_group_barrier(0x008, NM - P1 - P2, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
-        }
-        if constexpr (decltype(barrier_after)::value) SYNC();
+        });
+        if constexpr (seam) SYNC();
     };
-    const int rowstep = g.hw * LDA;                // LDS floats between halo rows
 
     const char* wp = wtile_of(0);                  // weight fragments of the CURRENT step
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) fb[ks].load(wp, ks);
-    SYNC();                               // pairs with the loaders' prologue barrier
-    {
-        const float* ap0[MT];
+    SYNC();                               // pairs with the loaders' prologue barrier: chunks 0 AND 1 are staged
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) ap0[mt] = As + aoff[mt];
-        fa[0].load(ap0, 0, lh);
-    }
+    for (int st = 0; st < DEPTH; ++st) ring[st].load(As + aoff[st % MT], st / MT, lh);
     int aslot = 0;                                 // ring position of the current chunk
     // CONV: ONE barrier per 32-channel chunk (9 K steps).  The weights never pass through LDS and the input tile of a
     // chunk is immutable while its 9 taps run, so nothing inside a chunk needs the loaders: period q (between barriers
-    // q and q+1) computes chunk q from ring slot q % 3 and, at its end, prefetches the first fragments of chunk q+1
-    // (slot complete since barrier q), while the loaders fill slot (q+2) % 3 (last read in period q-1).  Only the very
-    // first period is different: chunk 1 is still being written during it, so its fragments are read after barrier 1.
-    bool first_period = CONV;
+    // q and q+1) computes chunk q from ring slot q % 3 and, in its last DEPTH stages, prefetches the first fragments of
+    // chunk q+1 (slot complete since barrier q: the loaders run two chunks ahead, from the prologue on), while the
+    // loaders fill slot (q+2) % 3 (last read in period q-1).
     for (int k = 0; k < ntiles; ++k) {
 #pragma unroll
         for (int i = 0; i < MT; ++i)
@@ -939,49 +951,16 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
             const float* acur = As + (size_t)aslot * a_floats;
             const float* anext = As + (size_t)naslot * a_floats;
             // step after this chunk's last one: next chunk, next tile, or (end of the stream) the same slice again
-            const bool last_chunk = chunk + 1 == nchunks;
-            if (CONV) {
-                // 9 taps fully unrolled: tap offsets are compile-time, so no scalar index math sits between the MFMA blocks.
-#pragma unroll
-                for (int tap = 0; tap < TAPS; ++tap) {
-                    const float* ap[MT];
-                    const float* nap[MT];
-                    const int toff = (tap / 3) * rowstep + (tap % 3) * LDA;
-                    const int ntap = tap + 1 == TAPS ? 0 : tap + 1;
-                    const int ntoff = (ntap / 3) * rowstep + (ntap % 3) * LDA;
-                    const float* nab = tap + 1 == TAPS ? anext : acur;
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) { ap[mt] = acur + toff + aoff[mt]; nap[mt] = nab + ntoff + aoff[mt]; }
-                    const char* wnext = wp + wstep;
-                    if (tap + 1 == TAPS) {
-                        if (last_chunk) wnext = wseam ? wseam : wp;
-                        if (first_period) {
-#pragma unroll
-                            for (int mt = 0; mt < MT; ++mt) nap[mt] = acur + aoff[mt];      // harmless: re-read below
-                        }
-                        do_step(ap, nap, wnext, std::true_type());
-                        if (first_period) {
-                            const float* rp[MT];
-#pragma unroll
-                            for (int mt = 0; mt < MT; ++mt) rp[mt] = anext + aoff[mt];
-                            fa[0].load(rp, 0, lh);                 // NKS is even: the next sub-step uses fa[0]
-                            first_period = false;
-                        }
-                    } else {
-                        do_step(ap, nap, wnext, std::false_type());
-                    }
-                    wp = wnext;
-                }
-            } else {
-                const float* ap[MT];
-                const float* nap[MT];
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) { ap[mt] = acur + aoff[mt]; nap[mt] = anext + aoff[mt]; }
+            const char* const wlast = chunk + 1 == nchunks ? (wseam ? wseam : wp + (TAPS - 1) * wstep) : nullptr;
+            // taps fully unrolled: tap offsets are compile-time, so no scalar index math sits between the MFMA blocks
+            auto step = [&](auto tapc) {
+                constexpr int tap = decltype(tapc)::value;
                 const char* wnext = wp + wstep;
-                if (last_chunk) wnext = wseam ? wseam : wp;
-                do_step(ap, nap, wnext, std::true_type());
+                if (tap + 1 == TAPS && wlast) wnext = wlast;
+                do_step(acur, anext, tapc, wnext);
                 wp = wnext;
-            }
+            };
+            static_for<TAPS>(step);
             aslot = naslot;
         }
 
@@ -1042,7 +1021,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
                 for (int nt = 0; nt < NT; ++nt) {
                     // load phase: bias + residual of the four quads of this 32-channel block for both rows -- 12 independent
                     // loads in flight (the compiler may not hoist them itself: y and res could alias), then the stores
-                    constexpr int QB = RES == 2 ? 1 : 2;      // quads per batch, bounded by the register budget (168 with 12 waves per CU)
+                    constexpr int QB = (RES == 2 || NT > 1) ? 1 : 2;   // quads per batch, bounded by the register budget
 #pragma unroll
                     for (int q0 = 0; q0 < 4; q0 += QB) {
                     f32x4 rv[4][MT];
@@ -1129,8 +1108,21 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
         if (DBG(16) || ABL(8)) keep_acc();
         else if (!a.res) epilogue(std::integral_constant<int, 0>());
         else if (a.res_mode == SGD_RS_NONE) epilogue(std::integral_constant<int, 1>());
+        else if (NT > 1) __builtin_trap();          // resampled residuals: 128-column tiles only (sgd_igemm picks the tile)
         else if (a.res_mode == SGD_RS_AVGPOOL2) epilogue(std::integral_constant<int, 2>());
         else epilogue(std::integral_constant<int, 3>()));
+        if constexpr (NT > 1) {
+            // 64-column wave tile: 128 accumulator registers.  The operands prefetched for the next tile (weights of its
+            // first step, DEPTH input units) are NOT carried across the epilogue -- 56 registers the epilogue needs --
+            // but requested again here: one L2 round trip per tile (~1 % of a tile's K loop).
+            if (k + 1 < ntiles) {
+#pragma unroll
+                for (int ks = 0; ks < NKS; ++ks) fb[ks].load(wp, ks);
+                const float* a0 = As + (size_t)aslot * a_floats;
+#pragma unroll
+                for (int st = 0; st < DEPTH; ++st) ring[st].load(a0 + aoff[st % MT], st / MT, lh);
+            }
+        }
     }
     PROBE_END(0);
 }
@@ -1378,7 +1370,7 @@ static int make_geo(const sgd_igemm_args& a, Geo& g, int bn, int& na) {
     }
     // epilogue statistics (args.stats): whole 128-row tiles of ONE image, 16-byte stores
     g.sparts = 0;
-    const int ppt = bn == 128 ? 1 : 4;                        // M slices per tile = compute-wave rows
+    const int ppt = bn >= 128 ? 1 : 4;                        // M slices per tile = compute-wave rows
     if (((a.cout | a.y_ld) & 3) == 0 && a.orows_in == 0) {
         if (a.mode == SGD_MODE_CONV3) {
             if (g.nb == 1 && (1 << (g.tw_l2 + g.th_l2)) == BM) g.sparts = g.tiles_x * g.tiles_y * ppt;
@@ -1387,6 +1379,20 @@ static int make_geo(const sgd_igemm_args& a, Geo& g, int bn, int& na) {
         }
     }
     return SGD_OK;
+}
+
+// SGDM_BN256: 0 never, 1 whenever the shape allows, unset: when the launch has enough tiles to keep every CU busy
+static bool want_bn256(const sgd_igemm_args& a) {
+    const char* e = getenv("SGDM_BN256");          // read per call: tools flip it between launches of one process
+    const int mode = e ? atoi(e) : -1;
+    if (mode == 0) return false;
+    if (mode == 1) return true;
+    // whole rounds of 256 persistent blocks: a 128 x 256 tile costs 2 / 1.07 of a 128 x 128 one (measured, tools/ab_conv.py:
+    // +5..9 % where both shapes fill the chip evenly), so it wins unless the coarser tiles quantise worse
+    const long rows = (long)a.n * a.ho * a.wo;
+    const long mt = (rows + BM - 1) / BM;
+    const long r256 = (mt * (a.cout_p / 256) + 255) / 256, r128 = (mt * (a.cout_p / 128) + 255) / 256;
+    return r256 * 2.0 < r128 * 1.07;
 }
 
 extern "C" int sgd_igemm_stats_parts(const sgd_igemm_args* args) {
@@ -1409,9 +1415,13 @@ extern "C" int sgd_igemm(const sgd_igemm_args* args, void* stream) {
     if (a.y_ld < a.cout) return SGD_ERR_ARG;
     if (a.pro != SGD_PRO_NONE && (!a.pa || !a.pb)) return SGD_ERR_ARG;
     const int cin = a.c0 + a.c1;
-    const int bn = pick_bn(a.cout);
+    int bn = pick_bn(a.cout);
     if (a.cout_p % bn != 0 || a.cout_p < a.cout || a.cin_p % KC != 0 || a.cin_p < cin) return SGD_ERR_ARG;
     const bool vec = (a.c0 % 4 == 0) && (a.c1 % 4 == 0);
+    // 128 x 256 tile (8 compute waves): 3x3 convs whose output channels allow it.  The packed-weight layout does not
+    // depend on the tile (units of 32 output channels), so this is a launch-time choice.
+    if (bn == 128 && a.cout_p % 256 == 0 && vec && a.mode == SGD_MODE_CONV3 && (!a.res || a.res_mode == SGD_RS_NONE)
+        && want_bn256(a)) bn = 256;
     int na;
     {
         const int rc = make_geo(a, g, bn, na);
@@ -1441,11 +1451,14 @@ extern "C" int sgd_igemm(const sgd_igemm_args* args, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     const bool conv = a.mode == SGD_MODE_CONV3;
 #define SGD_DISPATCH(P)                                                            \
-    (bn == 128 ? launch<128, P>(ka, vec, conv, smem, st) : launch<32, P>(ka, vec, conv, smem, st))
+    (bn == 256 ? launch1<256, P, true, 9>(ka, smem, st)                                \
+               : (bn == 128 ? launch<128, P>(ka, vec, conv, smem, st) : launch<32, P>(ka, vec, conv, smem, st)))
     switch (a.prec) {
+#ifndef SGDM_DEV_F16_ONLY      /* development builds: one precision = a third of the compile time */
         case SGD_PREC_F32: return SGD_DISPATCH(SGD_PREC_F32);
-        case SGD_PREC_F16X3: return SGD_DISPATCH(SGD_PREC_F16X3);
         case SGD_PREC_BF16X3: return SGD_DISPATCH(SGD_PREC_BF16X3);
+#endif
+        case SGD_PREC_F16X3: return SGD_DISPATCH(SGD_PREC_F16X3);
         default: return SGD_ERR_ARG;
     }
 #undef SGD_DISPATCH
