@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define SGD_ABI_VERSION 7
+#define SGD_ABI_VERSION 8
 int sgd_abi_version(void);
 
 /* --------------------------------------------------------------------------------------
@@ -93,7 +93,17 @@ typedef struct sgd_igemm_args {
      * lo halves would be fp16 subnormals with 2-3 significant bits).  The epilogue multiplies the accumulator by
      * *w_scale_inv = 2^-k (exact) before bias / residual.  DEVICE pointer to one float; NULL: 1. */
     const float* w_scale_inv;
+    /* Optional scratch for the balanced tail of the persistent schedule.  A launch whose tile count is not a multiple of
+     * the 256 resident blocks ends in a partial round; with a workspace the tiles of that round are split along K over the
+     * otherwise idle blocks: the blocks of the first K parts store their fp32 partial accumulators here, the block of the
+     * last part adds them (fixed order: deterministic) and runs the epilogue.  DEVICE buffer of sgd_igemm_work_bytes()
+     * bytes, ZEROED ONCE by the caller (the arrival counters at its head reset themselves), reusable by any number of
+     * launches that are ordered on one stream.  NULL (or too small): plain schedule, same results bit for bit except
+     * for the summation order of the split tiles. */
+    void* work;
+    int64_t work_bytes;
 } sgd_igemm_args;
+int64_t sgd_igemm_work_bytes(void);
 
 /* the keep/drop hash, shared by device code and host tests:
  *   h = seed ^ (lo * 0x9E3779B1) ^ (hi * 0x632BE5AB); h ^= h>>16; h *= 0x85EBCA6B; h ^= h>>13; h *= 0xC2B2AE35; h ^= h>>16;

@@ -34,13 +34,29 @@ def _deps_mtime():
     return max(os.path.getmtime(h) for h in hdrs)
 
 
-def _compile(src, force):
-    obj = os.path.join(OBJ, src[:-4] + ".o")
+# translation units compiled from ONE source with different defines (igemm.hip: the host unit + one unit per arithmetic
+# mode, see the end of that file) -- they build in parallel
+VARIANTS = {"igemm.hip": [("", []), ("_f32", ["-DSGDM_IGEMM_PREC=0"]), ("_f16x3", ["-DSGDM_IGEMM_PREC=1"]),
+                          ("_bf16x3", ["-DSGDM_IGEMM_PREC=2"])]}
+
+
+def _units():
+    """(source, object suffix, extra flags) of every translation unit, longest compile first"""
+    units = []
+    for src in _sources():
+        for suffix, extra in VARIANTS.get(src, [("", [])]):
+            units.append((src, suffix, extra))
+    return sorted(units, key=lambda u: (u[0] != "igemm.hip" or not u[1], u[0], u[1]))
+
+
+def _compile(unit, force):
+    src, suffix, extra = unit
+    obj = os.path.join(OBJ, src[:-4] + suffix + ".o")
     sp = os.path.join(CSRC, src)
     if (not force and os.path.exists(obj)
             and os.path.getmtime(obj) >= max(os.path.getmtime(sp), _deps_mtime())):
         return obj
-    cmd = [HIPCC, *FLAGS, *FILE_FLAGS.get(src, []), "-c", sp, "-o", obj]
+    cmd = [HIPCC, *FLAGS, *FILE_FLAGS.get(src, []), *extra, "-c", sp, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
@@ -54,9 +70,9 @@ def build_probe():
     os.makedirs(OBJ, exist_ok=True)
     out = os.path.join(LIBDIR, "libsgdm_hip_probe.so")
     objs = []
-    for src in _sources():
-        obj = os.path.join(OBJ, src[:-4] + ".probe.o")
-        r = subprocess.run([HIPCC, *FLAGS, *FILE_FLAGS.get(src, []), "-DSGDM_PROBE", *os.environ.get("SGDM_PROBE_FLAGS", "").split(), "-c",
+    for src, suffix, extra in _units():
+        obj = os.path.join(OBJ, src[:-4] + suffix + ".probe.o")
+        r = subprocess.run([HIPCC, *FLAGS, *FILE_FLAGS.get(src, []), *extra, "-DSGDM_PROBE", *os.environ.get("SGDM_PROBE_FLAGS", "").split(), "-c",
                             os.path.join(CSRC, src), "-o", obj],
                            capture_output=True, text=True)
         if r.returncode != 0:
@@ -71,16 +87,17 @@ def build_ablation(mask):
     os.makedirs(OBJ, exist_ok=True)
     out = os.path.join(LIBDIR, f"libsgdm_hip_abl{mask}.so")
     objs = []
-    for src in _sources():
+    for unit in _units():
+        src, suffix, extra = unit
         if src == "igemm.hip":
-            obj = os.path.join(OBJ, f"igemm.abl{mask}.o")
-            r = subprocess.run([HIPCC, *FLAGS, *FILE_FLAGS.get(src, []), f"-DSGDM_ABL={mask}", *os.environ.get("SGDM_EXTRA_FLAGS", "").split(), "-c",
+            obj = os.path.join(OBJ, f"igemm{suffix}.abl{mask}.o")
+            r = subprocess.run([HIPCC, *FLAGS, *FILE_FLAGS.get(src, []), *extra, f"-DSGDM_ABL={mask}", *os.environ.get("SGDM_EXTRA_FLAGS", "").split(), "-c",
                                 os.path.join(CSRC, src), "-o", obj],
                                capture_output=True, text=True)
             if r.returncode != 0:
                 raise RuntimeError(r.stderr)
         else:
-            obj = _compile(src, False)
+            obj = _compile(unit, False)
         objs.append(obj)
     subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out, *objs], check=True)
     return out
@@ -89,9 +106,8 @@ def build_ablation(mask):
 def build_lib(force=False):
     os.makedirs(OBJ, exist_ok=True)
     os.makedirs(LIBDIR, exist_ok=True)
-    srcs = _sources()
-    with ThreadPoolExecutor(max_workers=4) as ex:
-        objs = list(ex.map(lambda s: _compile(s, force), srcs))
+    with ThreadPoolExecutor(max_workers=int(os.environ.get("SGDM_BUILD_JOBS", "6"))) as ex:
+        objs = list(ex.map(lambda u: _compile(u, force), _units()))
     if (force or not os.path.exists(LIB)
             or os.path.getmtime(LIB) < max(os.path.getmtime(o) for o in objs)):
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]

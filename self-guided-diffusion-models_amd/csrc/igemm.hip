@@ -44,6 +44,9 @@ constexpr int A_THREADS = 256;  // 4 input-tile loader waves
 constexpr int NCOMP = 256;      // 4 compute (MFMA) waves, one per SIMD
 constexpr int NTHREADS = NCOMP + A_THREADS;
 constexpr int WUNIT = 4096;   // bytes of one packed weight unit: 32 output x 32 input channels of one tap, fragment order
+constexpr int SPLIT_MAX = 4;   // K parts of a tile of the balanced tail (sgd_igemm_args.work)
+constexpr int WORK_TILES = 256;                        // split tiles of one launch: < blocks
+constexpr int WORK_HEAD = WORK_TILES * 8;              // bytes: per split tile {arrived, consumed} wave counters
 constexpr int FAST_PIX = 192;  // halo tiles up to this many pixels (16x8 outputs + halo = 180) use the split-phase A loader
 
 struct Geo {
@@ -292,15 +295,44 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
     const int nloc = gridDim.x >> 3;              // blocks per XCD
     const int xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
     const int xbeg = xcd * xchunk, xend = (xbeg + xchunk < total) ? xbeg + xchunk : total;
-    const int ntiles = (xbeg + loc < xend) ? (xend - xbeg - loc + nloc - 1) / nloc : 0;
-    if (ntiles == 0) return;
-    auto lin_of = [&](int k) { return xbeg + loc + k * nloc; };
-
     const int cin = a.c0 + a.c1;
     const int nchunks = (cin + KC - 1) / KC;
-    const int G = nchunks * TAPS;                 // K steps per tile
-    const int S = ntiles * G;                     // K steps of this block
-    const int Q = ntiles * nchunks;               // channel chunks of this block
+    // Balanced tail (args.work): the XCD's tiles are nfull whole rounds of its nloc blocks plus R < nloc tiles.  Instead of
+    // a last round that keeps R blocks busy and nloc - R idle, each of those R tiles is split along K into `split` chunk
+    // ranges computed by `split` different blocks at the same time: parts 0 .. split-2 store their partial accumulators to
+    // the workspace and signal, the block of the LAST range adds them in part order and runs the epilogue.  Producers
+    // never wait, so the protocol cannot deadlock whatever the residency of the blocks; every block meets its split tile
+    // LAST, after its whole tiles.
+    const int xtiles = xend > xbeg ? xend - xbeg : 0;
+    const int nfull = xtiles / nloc, xrem = xtiles - nfull * nloc;
+    int split = 0;
+    if (xrem > 0 && a.work && nchunks >= 2 && !ABL(2048)) {
+        split = nloc / xrem;
+        if (split > nchunks) split = nchunks;
+        if (split > SPLIT_MAX) split = SPLIT_MAX;
+        if (split < 2) split = 0;
+    }
+    int ntiles, rem_lin = -1, rem_part = 0, last_c0 = 0, last_c1 = nchunks;
+    if (!split) {
+        ntiles = loc < xtiles ? (xtiles - loc + nloc - 1) / nloc : 0;
+    } else {
+        ntiles = nfull;
+        if (loc < xrem * split) {
+            rem_lin = xbeg + nfull * nloc + loc / split;
+            rem_part = loc % split;
+            last_c0 = rem_part * nchunks / split;
+            last_c1 = (rem_part + 1) * nchunks / split;
+            ++ntiles;
+        }
+    }
+    if (ntiles == 0) return;
+    auto lin_of = [&](int k) { return (rem_lin >= 0 && k == ntiles - 1) ? rem_lin : xbeg + loc + k * nloc; };
+    // chunk range of the block's k-th tile: only the last one can be partial
+    auto cbeg = [&](int k) { return k == ntiles - 1 ? last_c0 : 0; };
+    auto cend = [&](int k) { return k == ntiles - 1 ? last_c1 : nchunks; };
+
+    const int Q = (ntiles - 1) * nchunks + (last_c1 - last_c0);   // channel chunks of this block
+    const int S = Q * TAPS;                       // K steps of this block
     const int s = CONV ? a.stride : 1;
     const int TW = 1 << g.tw_l2, TH = 1 << g.th_l2;
     const int M = CONV ? a.n * a.ho * a.wo : a.m;
@@ -412,12 +444,12 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
                         c.kb = uni ? a.pb + ko : a.x0;
                     };
                     auto advance = [&](S c) {
-                        if (++c.chunk == nchunks) {
+                        if (++c.chunk == cend(c.k)) {
                             if (c.k + 1 < ntiles) {      // tile index math (integer divisions) once per tile, not per chunk
-                                c.chunk = 0; ++c.k;
+                                ++c.k; c.chunk = cbeg(c.k);
                                 c.img0 = tile_at(g, lin_of(c.k), BN, TW, TH).img0;
                             }
-                            else c.chunk = nchunks - 1;
+                            else c.chunk = cend(c.k) - 1;
                         }
                         fill(c);
                         return c;
@@ -485,7 +517,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
 #pragma unroll
                         for (int j = 0; j < AJ; ++j) issue_item(s2, j);
                     };
-                    s2.k = 0; s2.chunk = 0; s2.img0 = tile_at(g, lin_of(0), BN, TW, TH).img0; fill(s2);
+                    s2.k = 0; s2.chunk = cbeg(0); s2.img0 = tile_at(g, lin_of(0), BN, TW, TH).img0; fill(s2);
                     load_rows(0);
                     issue_coef(s2);
 #pragma unroll
@@ -551,13 +583,13 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
                     c.kb = tile_uni ? a.pb + ko + c4 * 4 : ((ln && a.pc) ? a.pc + c4 * 4 : a.x0);
                 };
                 auto advance = [&](Cur& c) {
-                    if (++c.chunk == nchunks) {
-                        if (c.k + 1 < ntiles) { c.chunk = 0; ++c.k; open_tile(c); }
-                        else c.chunk = nchunks - 1;
+                    if (++c.chunk == cend(c.k)) {
+                        if (c.k + 1 < ntiles) { ++c.k; c.chunk = cbeg(c.k); open_tile(c); }
+                        else c.chunk = cend(c.k) - 1;
                     }
                 };
                 Cur ci, cf;
-                ci.k = 0; ci.chunk = 0; open_tile(ci);
+                ci.k = 0; ci.chunk = cbeg(0); open_tile(ci);
                 cf = ci;
                 auto issue = [&](auto rc) {                              // request the chunk under the issue cursor
                     constexpr int R = decltype(rc)::value;
@@ -684,7 +716,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
         // everything at once: first chunk of the stream, avg-pool, big halo tiles
         auto stage_A_sync = [&](int slot, int q) {
             q = q < Q ? q : Q - 1;
-            const int k = q / nchunks, chunk = q - k * nchunks;
+            const int k = q / nchunks, chunk = q - k * nchunks + cbeg(k);
             float* abuf = As + (size_t)(slot % NA) * a_floats;
             const TabRef tab = tabref(k);
             for (int idx = lt; idx < items; idx += A_THREADS) item_sync(abuf, tab, idx, chunk * KC);
@@ -727,7 +759,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
                     q = q < Q ? q : Q - 1;
                     Ctx cx;
                     const int k = q / nchunks;
-                    cx.chunk = q - k * nchunks;
+                    cx.chunk = q - k * nchunks + cbeg(k);
                     cx.tab = pixtab + (size_t)(k & 3) * g.pix;
                     cx.c = cx.chunk * KC + c4 * 4;
                     // per-image GroupNorm coefficients of this thread's channel quad (tile = one image)
@@ -782,7 +814,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
             auto issue = [&](int q, auto rc) {
                 constexpr int R = decltype(rc)::value;
                 q = q < Q ? q : Q - 1;
-                const int k = q / nchunks, chunk = q - k * nchunks;
+                const int k = q / nchunks, chunk = q - k * nchunks + cbeg(k);
                 const TabRef tab = tabref(k);
                 const int c = chunk * KC + c4 * 4;
 #pragma unroll
@@ -791,7 +823,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
             auto finish = [&](int slot, auto rc) {
                 constexpr int R = decltype(rc)::value;
                 const int q = slot < Q ? slot : Q - 1;
-                const int k = q / nchunks, chunk = q - k * nchunks;
+                const int k = q / nchunks, chunk = q - k * nchunks + cbeg(k);
                 const TabRef tab = tabref(k);
                 Coef knone;
                 knone.p = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -926,7 +958,9 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
         if constexpr (seam) SYNC();
     };
 
-    const char* wp = wtile_of(0);                  // weight fragments of the CURRENT step
+    // first K step of the block's k-th tile (the last tile may start in the middle of its K range: balanced tail)
+    auto wstart_of = [&](int k) { return wtile_of(k) + (size_t)cbeg(k) * TAPS * wstep; };
+    const char* wp = wstart_of(0);                 // weight fragments of the CURRENT step
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) fb[ks].load(wp, ks);
     SYNC();                               // pairs with the loaders' prologue barrier: chunks 0 AND 1 are staged
@@ -945,13 +979,14 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
             for (int j = 0; j < NT; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-        const char* const wseam = k + 1 < ntiles ? wtile_of(k + 1) : nullptr;    // first step of the next tile
-        for (int chunk = 0; chunk < nchunks; ++chunk) {
+        const char* const wseam = k + 1 < ntiles ? wstart_of(k + 1) : nullptr;   // first step of the next tile
+        const int c_end = cend(k);
+        for (int chunk = cbeg(k); chunk < c_end; ++chunk) {
             const int naslot = aslot + 1 == NA ? 0 : aslot + 1;
             const float* acur = As + (size_t)aslot * a_floats;
             const float* anext = As + (size_t)naslot * a_floats;
             // step after this chunk's last one: next chunk, next tile, or (end of the stream) the same slice again
-            const char* const wlast = chunk + 1 == nchunks ? (wseam ? wseam : wp + (TAPS - 1) * wstep) : nullptr;
+            const char* const wlast = chunk + 1 == c_end ? (wseam ? wseam : wp + (TAPS - 1) * wstep) : nullptr;
             // taps fully unrolled: tap offsets are compile-time, so no scalar index math sits between the MFMA blocks
             auto step = [&](auto tapc) {
                 constexpr int tap = decltype(tapc)::value;
@@ -964,6 +999,55 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
             aslot = naslot;
         }
 
+        // ---- balanced tail: this tile's K range is shared with other blocks (see the schedule at the top) ----
+        constexpr size_t SLAB = (size_t)MT * NT * 4 * NCOMP * 16;      // bytes of one block's partial accumulators
+        const char* part_base = nullptr;                               // finisher: this thread's quads in the producers' slabs
+        int nparts = 0;
+        int* part_cnt = nullptr;
+        if (rem_lin >= 0 && k == ntiles - 1) {
+            // workspace: [WORK_TILES] {arrived, consumed} counters, then one slab per (split tile, producing part);
+            // slab element (mt, nt, quad q) of compute thread tid at (((mt * NT + nt) * 4 + q) * NCOMP + tid) * 16 bytes:
+            // every store / load instruction of a wave moves 1 KiB of consecutive bytes
+            // split tile of this launch, numbered densely: an XCD has at most nloc / split of them, so the slabs of a
+            // launch number at most 8 * (nloc / split) * (split - 1) <= 192 (sgd_igemm_work_bytes)
+            const int gi = xcd * (nloc / split) + loc / split;
+            int* const cnt = reinterpret_cast<int*>(a.work) + gi * 2;
+            char* const slab0 = reinterpret_cast<char*>(a.work) + WORK_HEAD + (size_t)gi * (split - 1) * SLAB;
+            if (rem_part + 1 < split) {
+                // PRODUCER (R1 of the guide's publish recipe): write-through (sc1) 16-byte stores -- no release fence, no
+                // write-back of the L2's other dirty lines --, every storing wave drains its stores, then signals for itself
+                __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(slab0 + (size_t)rem_part * SLAB, 0, (int)SLAB, 0x00020000);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            f32x4 v;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) v[j] = acc[mt][nt][q * 4 + j];
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rs,
+                                                                   (((mt * NT + nt) * 4 + q) * NCOMP + tid) * 16, 0, 16 /* sc1 */);
+                        }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane == 0) __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;                                                     // no epilogue; the split tile is the block's last
+            }
+            // FINISHER (last K range): every wave polls for itself (one lane, relaxed, sleeping), ONE agent-scope acquire
+            // after the match, then plain loads of the producers' slabs (in the epilogue), added in part order
+            if (lane == 0) {
+                const int need = (split - 1) * (NCOMP / 64);
+                while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) __builtin_amdgcn_s_sleep(16);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // the producers' slabs are read by the epilogue, next to the residual (the accumulator registers themselves are
+            // not touched here: modifying 64..128 live registers under a branch costs a copy / spill storm at the join)
+            part_base = slab0 + (size_t)tid * 16;
+            nparts = split - 1;
+            part_cnt = cnt;
+        }
+
         // ---- epilogue of tile k (the loaders are already staging tile k+1) ---------------------
         // The MFMAs are issued with the WEIGHT fragment as the A operand, so an accumulator tile is
         // [32 channels x 32 pixels]: a lane owns ONE pixel (lane & 31) and its 16 registers are four runs
@@ -971,8 +1055,9 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
         // row index math runs twice per lane instead of 32 times.
         const Tile T = tile_at(g, lin_of(k), BN, TW, TH);
         const int cb = T.n0c + wn * WN + 4 * lh;          // first channel of this lane's g = 0 run (nt = 0)
-        auto epilogue = [&](auto resmode) {
+        auto epilogue = [&](auto resmode, auto partc) {
             constexpr int RES = decltype(resmode)::value;     // 0 none, 1 same rows, 2 avg-pool of 2x map, 3 nearest of 1/2 map
+            constexpr bool PART = decltype(partc)::value;     // balanced tail: add the other blocks' partial accumulators
             // per M block: output row / residual row of this lane's pixel
             bool okm[MT];
             float* ypm[MT];
@@ -1025,6 +1110,18 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
 #pragma unroll
                     for (int q0 = 0; q0 < 4; q0 += QB) {
                     f32x4 rv[4][MT];
+                    f32x4 pv[4][MT];
+                    if constexpr (PART) {
+#pragma unroll
+                        for (int gq = q0; gq < q0 + QB; ++gq)
+#pragma unroll
+                            for (int mt = 0; mt < MT; ++mt) {
+                                const char* pp = part_base + (size_t)(((mt * NT + nt) * 4 + gq) * NCOMP) * 16;
+                                f32x4 sum = *reinterpret_cast<const f32x4*>(pp);
+                                for (int pi = 1; pi < nparts; ++pi) sum += *reinterpret_cast<const f32x4*>(pp + pi * SLAB);
+                                pv[gq][mt] = sum;
+                            }
+                    }
 #pragma unroll
                     for (int gq = q0; gq < q0 + QB; ++gq) {
                         const int c = cb + nt * 32 + gq * 8;
@@ -1052,8 +1149,9 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
                         for (int mt = 0; mt < MT; ++mt) {
                             f32x4 v;
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) v[j] = acc[mt][nt][gq * 4 + j] * wsi;
-                            v += rv[gq][mt];
+                            for (int j = 0; j < 4; ++j) v[j] = acc[mt][nt][gq * 4 + j];
+                            if constexpr (PART) v += pv[gq][mt];
+                            v = v * wsi + rv[gq][mt];
                             if (okm[mt]) {
                                 if (!(DBG(8)) && !ABL(1)) *reinterpret_cast<f32x4*>(ypm[mt] + c) = v;
                                 else KEEP_LIVE(v);
@@ -1087,7 +1185,12 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
                             for (int j = 0; j < 4; ++j) {
                                 const int c = cb + nt * 32 + gq * 8 + j;
                                 if (c >= a.cout) continue;
-                                float x = acc[mt][nt][gq * 4 + j] * wsi + (bias_lds ? bias_s[c] : (a.bias ? a.bias[c] : 0.f));
+                                float x = acc[mt][nt][gq * 4 + j];
+                                if constexpr (PART) {
+                                    const float* pp = reinterpret_cast<const float*>(part_base + (size_t)(((mt * NT + nt) * 4 + gq) * NCOMP) * 16) + j;
+                                    for (int pi = 0; pi < nparts; ++pi) x += pp[pi * (SLAB / 4)];
+                                }
+                                x = x * wsi + (bias_lds ? bias_s[c] : (a.bias ? a.bias[c] : 0.f));
                                 if (RES == 1 || RES == 3) x += rp[c];
                                 if (RES == 2) {
                                     const long rw = (long)a.wo * 2 * a.cout;
@@ -1104,13 +1207,27 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
 #pragma unroll
                 for (int j = 0; j < NT; ++j) KEEP_LIVE(acc[i][j]);
         };
-        PROBE_EPI(
-        if (DBG(16) || ABL(8)) keep_acc();
-        else if (!a.res) epilogue(std::integral_constant<int, 0>());
-        else if (a.res_mode == SGD_RS_NONE) epilogue(std::integral_constant<int, 1>());
-        else if (NT > 1) __builtin_trap();          // resampled residuals: 128-column tiles only (sgd_igemm picks the tile)
-        else if (a.res_mode == SGD_RS_AVGPOOL2) epilogue(std::integral_constant<int, 2>());
-        else epilogue(std::integral_constant<int, 3>()));
+        auto run_epilogue = [&](auto partc) {
+            if (DBG(16) || ABL(8)) keep_acc();
+            else if (!a.res) epilogue(std::integral_constant<int, 0>(), partc);
+            else if (a.res_mode == SGD_RS_NONE) epilogue(std::integral_constant<int, 1>(), partc);
+            else if (NT > 1) __builtin_trap();      // resampled residuals: 128-column tiles only (sgd_igemm picks the tile)
+            else if (a.res_mode == SGD_RS_AVGPOOL2) epilogue(std::integral_constant<int, 2>(), partc);
+            else epilogue(std::integral_constant<int, 3>(), partc);
+        };
+        if (nparts) {
+            run_epilogue(std::true_type());
+            // the counters reset themselves: the last of the finisher's waves to have read the slabs zeroes both (the next
+            // launch that uses this workspace is ordered behind this one on the stream)
+            if (lane == 0) {
+                if (__hip_atomic_fetch_add(part_cnt + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == NCOMP / 64 - 1) {
+                    __hip_atomic_store(part_cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(part_cnt + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        } else {
+            PROBE_EPI(run_epilogue(std::false_type()));
+        }
         if constexpr (NT > 1) {
             // 64-column wave tile: 128 accumulator registers.  The operands prefetched for the next tile (weights of its
             // first step, DEPTH input units) are NOT carried across the epilogue -- 56 registers the epilogue needs --
@@ -1248,6 +1365,7 @@ int launch1(const KArgs& ka, size_t smem, hipStream_t st) {
     const int total = ka.g.mt * ka.g.nt;
     int grid = ((total + 7) / 8) * 8;
     if (grid > 256) grid = 256;                   // persistent: one block per CU walks its tiles
+    if (ka.a.work && total >= 8) grid = 256;      // balanced tail: blocks without a whole tile take K parts of the last ones
     hipLaunchKernelGGL((igemm_kernel<BN, PREC, VEC, TAPS>), dim3(grid), dim3(NTHREADS), smem, st, ka);
     return sgd_check_launch();
 }
@@ -1259,6 +1377,27 @@ int launch(const KArgs& ka, bool vec, bool conv, size_t smem, hipStream_t st) {
 }
 
 }  // namespace
+
+// One translation unit per arithmetic mode (build.py compiles this file with -DSGDM_IGEMM_PREC=0 / 1 / 2, in parallel: the
+// kernel template has 12 instances per mode and eight epilogue variants each): the mode's launch dispatcher has external
+// linkage, everything else lives in the host unit (no -DSGDM_IGEMM_PREC).  The argument block crosses as bytes.
+int sgd_igemm_dispatch_f32(const void* ka, int bn, bool vec, bool conv, size_t smem, hipStream_t st);
+int sgd_igemm_dispatch_f16x3(const void* ka, int bn, bool vec, bool conv, size_t smem, hipStream_t st);
+int sgd_igemm_dispatch_bf16x3(const void* ka, int bn, bool vec, bool conv, size_t smem, hipStream_t st);
+
+#ifdef SGDM_IGEMM_PREC
+#define SGD_DISPATCH_BODY(P)                                                                                        \
+    const KArgs& ka = *reinterpret_cast<const KArgs*>(kap);                                                         \
+    return bn == 256 ? launch1<256, P, true, 9>(ka, smem, st)                                                       \
+                     : (bn == 128 ? launch<128, P>(ka, vec, conv, smem, st) : launch<32, P>(ka, vec, conv, smem, st));
+#if SGDM_IGEMM_PREC == 0
+int sgd_igemm_dispatch_f32(const void* kap, int bn, bool vec, bool conv, size_t smem, hipStream_t st) { SGD_DISPATCH_BODY(SGD_PREC_F32) }
+#elif SGDM_IGEMM_PREC == 1
+int sgd_igemm_dispatch_f16x3(const void* kap, int bn, bool vec, bool conv, size_t smem, hipStream_t st) { SGD_DISPATCH_BODY(SGD_PREC_F16X3) }
+#else
+int sgd_igemm_dispatch_bf16x3(const void* kap, int bn, bool vec, bool conv, size_t smem, hipStream_t st) { SGD_DISPATCH_BODY(SGD_PREC_BF16X3) }
+#endif
+#else   // ---------------------------------------------------------------------------------- host unit
 
 extern "C" int sgd_abi_version(void) { return SGD_ABI_VERSION; }
 
@@ -1395,6 +1534,12 @@ static bool want_bn256(const sgd_igemm_args& a) {
     return r256 * 2.0 < r128 * 1.07;
 }
 
+extern "C" int64_t sgd_igemm_work_bytes(void) {
+    // counters + the most slabs one launch can need: 8 XCDs x floor(32 / split) split tiles x (split - 1) producers, at the
+    // 128 x 256 tile (128 KiB of partial accumulators per slab): split = 4 -> 192 slabs
+    return (int64_t)WORK_HEAD + 192 * (int64_t)(BM * 256 * 4);
+}
+
 extern "C" int sgd_igemm_stats_parts(const sgd_igemm_args* args) {
     if (!args) return 0;
     Geo g;
@@ -1430,6 +1575,10 @@ extern "C" int sgd_igemm(const sgd_igemm_args* args, void* stream) {
     if (a.stats && g.sparts == 0) return SGD_ERR_ARG;
     g.nt = a.cout_p / bn;
     {
+        const char* e = getenv("SGDM_BALANCE");   // 0: plain schedule even with a workspace (A/B runs)
+        if ((a.work && a.work_bytes < sgd_igemm_work_bytes()) || (e && atoi(e) == 0)) a.work = nullptr;
+    }
+    {
         // epilogue uses 32-bit row indices
         const long rows_out = a.mode == SGD_MODE_CONV3 ? (long)a.n * a.ho * a.wo : (long)a.m;
         const long rows_res = a.res_mode == SGD_RS_AVGPOOL2 ? rows_out * 4 : rows_out;
@@ -1450,16 +1599,11 @@ extern "C" int sgd_igemm(const sgd_igemm_args* args, void* stream) {
     if (smem > 160 * 1024) return SGD_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     const bool conv = a.mode == SGD_MODE_CONV3;
-#define SGD_DISPATCH(P)                                                            \
-    (bn == 256 ? launch1<256, P, true, 9>(ka, smem, st)                                \
-               : (bn == 128 ? launch<128, P>(ka, vec, conv, smem, st) : launch<32, P>(ka, vec, conv, smem, st)))
     switch (a.prec) {
-#ifndef SGDM_DEV_F16_ONLY      /* development builds: one precision = a third of the compile time */
-        case SGD_PREC_F32: return SGD_DISPATCH(SGD_PREC_F32);
-        case SGD_PREC_BF16X3: return SGD_DISPATCH(SGD_PREC_BF16X3);
-#endif
-        case SGD_PREC_F16X3: return SGD_DISPATCH(SGD_PREC_F16X3);
+        case SGD_PREC_F32: return sgd_igemm_dispatch_f32(&ka, bn, vec, conv, smem, st);
+        case SGD_PREC_F16X3: return sgd_igemm_dispatch_f16x3(&ka, bn, vec, conv, smem, st);
+        case SGD_PREC_BF16X3: return sgd_igemm_dispatch_bf16x3(&ka, bn, vec, conv, smem, st);
         default: return SGD_ERR_ARG;
     }
-#undef SGD_DISPATCH
 }
+#endif   // host unit

@@ -171,6 +171,8 @@ class Backward:
         a.y, a.cout, a.y_ld, a.prec = y.data_ptr(), cout_of_y, (y_ld or cout_of_y), self.prec
         if acc:
             a.res, a.res_mode = y.data_ptr(), L.RS_NONE
+        if self.e.work_bytes:                # the forward engine's balanced-tail scratch (same stream: launches are ordered)
+            a.work, a.work_bytes = self.e.work.data_ptr(), self.e.work_bytes
         self.late.append((a, pk))
         self.keep.append(a)
         self.prog.add(tag, self.lib.sgd_igemm, C.byref(a))

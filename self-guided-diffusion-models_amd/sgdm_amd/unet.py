@@ -424,6 +424,10 @@ class _Engine:
         self.stats_of = {}        # tensor data_ptr -> (partial statistics buffer, parts, channels) written by its producer
         self._p_drop = 0.0
         self.refresh_hooks = []   # derived device state that follows the parameters (run by refresh(), never captured)
+        # scratch of sgd_igemm's balanced tail (partial accumulators of K-split tiles + self-resetting arrival counters):
+        # zeroed once, shared by every launch of this engine's programs -- they are ordered on one stream
+        self.work_bytes = int(self.lib.sgd_igemm_work_bytes()) if os.environ.get("SGDM_BALANCE", "1") != "0" else 0
+        self.work = torch.zeros(max(1, self.work_bytes // 4), dtype=torch.float32, device=dev)
         self._build()
 
     # ---- helpers
@@ -469,6 +473,8 @@ class _Engine:
         a.y_ld = y_ld if y_ld is not None else cout
         a.orows_in, a.orows_out, a.orow_off = orows
         a.prec = self.prec
+        if self.work_bytes:
+            a.work, a.work_bytes = self.work.data_ptr(), self.work_bytes
         if stats and os.environ.get("SGDM_FUSED_STATS", "1") != "0":
             parts = self.lib.sgd_igemm_stats_parts(C.byref(a))
             if parts > 0:

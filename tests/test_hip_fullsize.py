@@ -287,6 +287,84 @@ def test_image_packed_tiles_ragged_batch(prec, tol):
 
 
 # --------------------------------------------------------------------------------------------------------------------
+# balanced tail of the persistent schedule (sgd_igemm_args.work): tiles of the last, partial round are split along K
+# over the idle blocks; partial accumulators cross blocks through the workspace
+# --------------------------------------------------------------------------------------------------------------------
+def _work():
+    L, lib = _lib()
+    nbytes = int(lib.sgd_igemm_work_bytes())
+    return torch.zeros(nbytes // 4, device="cuda"), nbytes
+
+
+# n, cin, cout, hw, taps: tiles (128-wide) / expected split
+BALANCE_CASES = [(80, 512, 512, 16, 9),     # 640 tiles: 2 whole rounds + 16 per XCD split in 2
+                 (80, 256, 256, 16, 9),     # 320 tiles as 128-wide (1 round + 8 per XCD split in 4); 160 as 256-wide
+                 (20, 128, 128, 32, 9),     # 160 tiles: no whole round, 20 per XCD: no split possible (1 block each)
+                 (12, 256, 128, 16, 9),     # 24 tiles: 3 per XCD split in 4 (8 chunks)
+                 (5, 96, 128, 16, 9),       # 10 tiles, 3 chunks: split capped by the chunk count
+                 (9, 64, 32, 8, 9),         # BN = 32 instance, 8x8 maps (two images per tile, ragged), 2 chunks
+                 (80, 512, 1536, 16, 1),    # qkv: FLAT, 160 x 12 = 1920 tiles: 7 rounds + 16 per XCD
+                 (3, 384, 128, 32, 1)]      # FLAT, 24 tiles, 12 chunks
+
+
+@pytest.mark.parametrize("prec,tol", KPRECS)
+@pytest.mark.parametrize("case", BALANCE_CASES, ids=["x".join(map(str, c)) for c in BALANCE_CASES])
+def test_balanced_tail_equals_plain_schedule(case, prec, tol):
+    """same launch with and without the workspace: equal up to the summation order of the split tiles (and both against
+    float64); the workspace is reused by consecutive launches (its counters reset themselves), statistics included"""
+    n, cin, cout, h, taps = case
+    L, lib = _lib()
+    p = L.PREC_BY_NAME[prec]
+    g = torch.Generator().manual_seed(53)
+    x = torch.randn(n, cin, h, h, generator=g)
+    ks = 3 if taps == 9 else 1
+    w = torch.randn(cout, cin, ks, ks, generator=g) / math.sqrt(cin * taps)
+    b = torch.randn(cout, generator=g)
+    pa, pb = 1 + 0.3 * torch.randn(n, cin, generator=g), 0.3 * torch.randn(n, cin, generator=g)
+    res = torch.randn(n, cout, h, h, generator=g)
+    act = F.silu(x.double() * pa.double()[:, :, None, None] + pb.double()[:, :, None, None])
+    ref = F.conv2d(act, w.double(), b.double(), padding=ks // 2) + res.double()
+    wbuf, cp, op = _pack(w.cuda(), ks, p)
+    xd, rd, pad, pbd, bd = _nhwc(x).cuda(), _nhwc(res).cuda(), pa.cuda(), pb.cuda(), b.cuda()
+    work, nbytes = _work()
+
+    def run(with_work):
+        a = L.IgemmArgs()
+        a.x0, a.c0 = xd.data_ptr(), cin
+        if taps == 9:
+            a.mode, a.n, a.hi, a.wi, a.ho, a.wo, a.stride = L.MODE_CONV3, n, h, h, h, h, 1
+        else:
+            a.mode, a.m, a.rows_per_n, a.stride = L.MODE_FLAT, n * h * h, h * h, 1
+        a.pro, a.pa, a.pb, a.pro_silu = L.PRO_AFFINE_NC, pad.data_ptr(), pbd.data_ptr(), 1
+        a.w, a.cin_p, a.cout_p, a.bias, a.res = wbuf.data_ptr(), cp, op, bd.data_ptr(), rd.data_ptr()
+        y = torch.full((n, h, h, cout), float("nan"), device="cuda")
+        a.y, a.cout, a.y_ld, a.prec = y.data_ptr(), cout, cout, p
+        if with_work:
+            a.work, a.work_bytes = work.data_ptr(), nbytes
+        parts = lib.sgd_igemm_stats_parts(C.byref(a))
+        sums = None
+        if parts > 0:
+            partial = torch.full((n, parts, 2, cout), float("nan"), device="cuda")
+            a.stats = partial.data_ptr()
+        L.check(lib.sgd_igemm(C.byref(a), _stream()), "igemm")
+        if parts > 0:
+            sums = torch.zeros(n, cout, 2, device="cuda")
+            L.check(lib.sgd_stats_reduce(_p(partial), n, parts, cout, _p(sums), cout, 0, _stream()), "reduce")
+        torch.cuda.synchronize()
+        return y.cpu().permute(0, 3, 1, 2), (None if sums is None else sums.cpu())
+
+    plain, s_plain = run(False)
+    for rep in range(3):                                   # the same workspace, back to back
+        got, s_got = run(True)
+        assert max_rel(got, ref) < tol, (rep, max_rel(got, ref))
+        assert max_rel(got, plain) < 2e-6
+        if s_got is not None:
+            assert max_rel(s_got, s_plain) < 2e-6
+    assert max_rel(plain, ref) < tol
+    assert int(work.view(torch.int32)[:512].abs().sum()) == 0, "arrival counters must be back at zero"
+
+
+# --------------------------------------------------------------------------------------------------------------------
 # (b) whole model at the benchmarked batch
 # --------------------------------------------------------------------------------------------------------------------
 def _bench_model(workload, prec):

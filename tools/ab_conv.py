@@ -36,6 +36,7 @@ for v in a.variants:
     variants.append((name, load(path), dict(e.split("=") for e in envs)))
 prec = L.PREC_BY_NAME[a.prec]
 st = torch.cuda.current_stream().cuda_stream
+WORK = {}
 for shp in a.shapes:
     f = [int(x) for x in shp.split(",")]
     n, cin, cout, hw = f[:4]; ks = f[4] if len(f) > 4 else 3
@@ -61,6 +62,11 @@ for shp in a.shapes:
             q.res = res.data_ptr()
         q.w, q.cin_p, q.cout_p, q.bias = buf.data_ptr(), cp.value, op.value, bias.data_ptr()
         q.y, q.cout, q.y_ld, q.prec = y.data_ptr(), cout, cout, prec
+        if hasattr(lib, "sgd_igemm_work_bytes"):            # balanced tail (SGDM_BALANCE=0 in a variant's env turns it off)
+            wb = int(lib.sgd_igemm_work_bytes())
+            if name not in WORK:
+                WORK[name] = torch.zeros(wb // 4, device="cuda")
+            q.work, q.work_bytes = WORK[name].data_ptr(), wb
         runs.append((name, lib, env, q, y, buf, []))
 
     def launch(lib, env, q, reps):
