@@ -44,6 +44,7 @@ constexpr int A_THREADS = 256;  // 4 input-tile loader waves
 constexpr int NCOMP = 256;      // 4 compute (MFMA) waves, one per SIMD
 constexpr int NTHREADS = NCOMP + A_THREADS;
 constexpr int WUNIT = 4096;   // bytes of one packed weight unit: 32 output x 32 input channels of one tap, fragment order
+constexpr int MIN_PART_STEPS = 27;   // K steps (tap x 32 channels) of the smallest K part worth splitting off
 constexpr int SPLIT_MAX = 4;   // K parts of a tile of the balanced tail (sgd_igemm_args.work)
 constexpr int WORK_TILES = 256;                        // split tiles of one launch: < blocks
 constexpr int WORK_HEAD = WORK_TILES * 8;              // bytes: per split tile {arrived, consumed} wave counters
@@ -308,8 +309,11 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
     int split = 0;
     if (xrem > 0 && a.work && nchunks >= 2 && !ABL(2048)) {
         split = nloc / xrem;
-        if (split > nchunks) split = nchunks;
         if (split > SPLIT_MAX) split = SPLIT_MAX;
+        // a part must be worth its hand-off (publish + poll + acquire + the slab reads of the finisher, ~10 us): at least
+        // MIN_PART_STEPS K steps.  Measured (tools/ab_conv.py, UNet batch 80): 3x3 convs of >= 256 input channels gain
+        // 4..7 %, 128-channel ones (2 chunks per part) and every 1x1 launch lose 5..15 %.
+        while (split >= 2 && (nchunks / split) * TAPS < MIN_PART_STEPS) --split;
         if (split < 2) split = 0;
     }
     int ntiles, rem_lin = -1, rem_part = 0, last_c0 = 0, last_c1 = nchunks;
@@ -1530,7 +1534,9 @@ static bool want_bn256(const sgd_igemm_args& a) {
     // +5..9 % where both shapes fill the chip evenly), so it wins unless the coarser tiles quantise worse
     const long rows = (long)a.n * a.ho * a.wo;
     const long mt = (rows + BM - 1) / BM;
-    const long r256 = (mt * (a.cout_p / 256) + 255) / 256, r128 = (mt * (a.cout_p / 128) + 255) / 256;
+    const long t256 = mt * (a.cout_p / 256), t128 = mt * (a.cout_p / 128);
+    if (t256 <= 256 && t128 > 256) return true;    // one round of bigger tiles instead of a second, partly empty one
+    const long r256 = (t256 + 255) / 256, r128 = (t128 + 255) / 256;
     return r256 * 2.0 < r128 * 1.07;
 }
 
