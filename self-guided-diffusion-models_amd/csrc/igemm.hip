@@ -1392,7 +1392,7 @@ int sgd_igemm_dispatch_bf16x3(const void* ka, int bn, bool vec, bool conv, size_
 #ifdef SGDM_IGEMM_PREC
 #define SGD_DISPATCH_BODY(P)                                                                                        \
     const KArgs& ka = *reinterpret_cast<const KArgs*>(kap);                                                         \
-    return bn == 256 ? launch1<256, P, true, 9>(ka, smem, st)                                                       \
+    return bn == 256 ? (conv ? launch1<256, P, true, 9>(ka, smem, st) : launch1<256, P, true, 1>(ka, smem, st))     \
                      : (bn == 128 ? launch<128, P>(ka, vec, conv, smem, st) : launch<32, P>(ka, vec, conv, smem, st));
 #if SGDM_IGEMM_PREC == 0
 int sgd_igemm_dispatch_f32(const void* kap, int bn, bool vec, bool conv, size_t smem, hipStream_t st) { SGD_DISPATCH_BODY(SGD_PREC_F32) }
@@ -1532,7 +1532,7 @@ static bool want_bn256(const sgd_igemm_args& a) {
     if (mode == 1) return true;
     // whole rounds of 256 persistent blocks: a 128 x 256 tile costs 2 / 1.07 of a 128 x 128 one (measured, tools/ab_conv.py:
     // +5..9 % where both shapes fill the chip evenly), so it wins unless the coarser tiles quantise worse
-    const long rows = (long)a.n * a.ho * a.wo;
+    const long rows = a.mode == SGD_MODE_CONV3 ? (long)a.n * a.ho * a.wo : (long)a.m;
     const long mt = (rows + BM - 1) / BM;
     const long t256 = mt * (a.cout_p / 256), t128 = mt * (a.cout_p / 128);
     if (t256 <= 256 && t128 > 256) return true;    // one round of bigger tiles instead of a second, partly empty one
@@ -1569,10 +1569,9 @@ extern "C" int sgd_igemm(const sgd_igemm_args* args, void* stream) {
     int bn = pick_bn(a.cout);
     if (a.cout_p % bn != 0 || a.cout_p < a.cout || a.cin_p % KC != 0 || a.cin_p < cin) return SGD_ERR_ARG;
     const bool vec = (a.c0 % 4 == 0) && (a.c1 % 4 == 0);
-    // 128 x 256 tile (8 compute waves): 3x3 convs whose output channels allow it.  The packed-weight layout does not
-    // depend on the tile (units of 32 output channels), so this is a launch-time choice.
-    if (bn == 128 && a.cout_p % 256 == 0 && vec && a.mode == SGD_MODE_CONV3 && (!a.res || a.res_mode == SGD_RS_NONE)
-        && want_bn256(a)) bn = 256;
+    // 128 x 256 tile (64 columns per compute wave): launches whose output channels allow it.  The packed-weight layout does
+    // not depend on the tile (units of 32 output channels), so this is a launch-time choice.
+    if (bn == 128 && a.cout_p % 256 == 0 && vec && (!a.res || a.res_mode == SGD_RS_NONE) && want_bn256(a)) bn = 256;
     int na;
     {
         const int rc = make_geo(a, g, bn, na);
