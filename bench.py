@@ -226,7 +226,21 @@ def train_step_bench(model, diff, data, cond, layout, B, world, barrier, wl, ste
         opt.step()
         return loss
 
-    for _ in range(warmup):
+    # self-verification of the exchange (the first multi-GPU run is the first time this path meets RCCL): after the first
+    # step every rank must hold the SAME averaged gradients -- a checksum per rank, gathered
+    loss, _ = diff.forward_tao(x, cond=cond, layout=layout, cond_drop_prob=0.1)
+    opt.zero_grad(set_to_none=True)
+    loss.backward()
+    csum = torch.zeros(2, device=dev, dtype=torch.float64)
+    for p_ in model.parameters():
+        if p_.grad is not None:
+            csum[0] += p_.grad.double().sum()
+            csum[1] += p_.grad.double().abs().sum()
+    opt.step()
+    sums = [csum.clone() for _ in range(world)]
+    if world > 1:
+        dist.all_gather(sums, csum)
+    for _ in range(max(0, warmup - 1)):
         step()
     barrier()
     t0 = time.perf_counter()
@@ -235,14 +249,22 @@ def train_step_bench(model, diff, data, cond, layout, B, world, barrier, wl, ste
     barrier()
     dt = time.perf_counter() - t0
     tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+    per_rank = [tt.clone() for _ in range(world)]
     if world > 1:
+        dist.all_gather(per_rank, tt)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     model.eval()
     diff.eval()
+    ref = sums[0]
     return dict(ms=round(1000.0 * float(tt.item()) / steps, 2), batch_per_gpu=B, global_batch=B * world, steps=steps,
                 dropout=float(model.dropout), loss=round(float(loss.item()), 4),
                 includes="q_sample + UNet fwd/bwd + bucketed RCCL grad all-reduce (overlapped) + fused AdamW/EMA step",
-                algorithmic_tflop=round(3 * B * wl["gflop_per_eval_img"] / 1e3, 3))
+                algorithmic_tflop=round(3 * B * wl["gflop_per_eval_img"] / 1e3, 3),
+                world_size=(dist.get_world_size() if world > 1 else 1),
+                backend=(dist.get_backend() if world > 1 else None),
+                per_rank_ms=[round(1000.0 * float(t_.item()) / steps, 2) for t_ in per_rank],
+                grad_checksum_first_step=[[float(v[0]), float(v[1])] for v in sums],
+                grad_checksums_equal=bool(all(torch.equal(v, ref) for v in sums)))
 
 
 def main():

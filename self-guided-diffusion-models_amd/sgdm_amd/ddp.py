@@ -107,3 +107,37 @@ class BucketReducer:
         if self.average:
             self.arena.flat.mul_(1.0 / self.world)
         self.pending = []
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# coexistence with torch's DistributedDataParallel (the reference's unchanged launch line: pl.trainer.strategy=ddp,
+# README.md:84-94, config/pl/default.yaml:2)
+# ------------------------------------------------------------------------------------------------------------------
+def find_torch_ddp_wrapper(module):
+    """the DistributedDataParallel instance whose wrapped module tree contains `module`, or None.  The drop-in UNet sits
+    inside the LightningModule that PL's DDP strategy wraps, so it cannot see the wrapper from its own attributes: one
+    scan of the live DDP objects (at the first training backward, never again)."""
+    import gc
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    for obj in gc.get_objects():
+        try:
+            if isinstance(obj, DDP) and any(m is module for m in obj.module.modules()):
+                return obj
+        except ReferenceError:
+            continue
+    return None
+
+
+def exclude_from_torch_ddp(root, *modules):
+    """call BEFORE wrapping `root` in DistributedDataParallel: torch DDP then neither reduces the gradients nor broadcasts
+    the buffers of `modules` (the HIP UNet, its LitEma) -- their exchange is this file's bucketed all-reduce inside the
+    backward program, and EMA shadows / schedule tables are rank-deterministic.  Uses DDP's own
+    `_ddp_params_and_buffers_to_ignore` contract (fully qualified names under `root`)."""
+    ids = set()
+    for m in modules:
+        ids.update(id(t) for t in m.parameters())
+        ids.update(id(t) for t in m.buffers())
+    names = [n for n, t in list(root.named_parameters()) + list(root.named_buffers()) if id(t) in ids]
+    prev = list(getattr(root, "_ddp_params_and_buffers_to_ignore", []))
+    root._ddp_params_and_buffers_to_ignore = prev + [n for n in names if n not in prev]
+    return names

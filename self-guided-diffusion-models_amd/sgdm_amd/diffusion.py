@@ -531,6 +531,13 @@ class DDIMSampler(object):
         img = torch.randn(shape, device=dev) if x_T is None else x_T.to(dev).float().contiguous()
         dkw = dict(denoise_sample_fn_kwargs or {})
         vis = sk.get("vis")
+        vis_noise = kwargs.get("vis_noise")                     # tests: the start noise a `vis` branch would draw
+
+        def vis_randn(sh):
+            if vis_noise is None:
+                return torch.randn(sh, device=dev)
+            assert tuple(vis_noise.shape) == tuple(sh), (tuple(vis_noise.shape), tuple(sh))
+            return vis_noise.to(dev).float()
 
         def should_vis(name):                                   # eval/test_exps/common_stuff.py:35-36
             return vis is not None and hasattr(vis, name) and bool(getattr(vis, name))
@@ -542,14 +549,14 @@ class DDIMSampler(object):
             # points each, ONE start noise shared by the whole batch; the float cond rows go through the UNet unchanged
             from .util import batch_to_conditioninterp
             dkw["cond"] = batch_to_conditioninterp(dkw["cond"], interp_num=vis.interp_c.n, samples=vis.interp_c.samples)
-            img = torch.randn(list(shape[1:]), device=dev).unsqueeze(0).repeat(len(dkw["cond"]), 1, 1, 1).contiguous()
+            img = vis_randn(list(shape[1:])).unsqueeze(0).repeat(len(dkw["cond"]), 1, 1, 1).contiguous()
         if should_vis("condscale"):
             # guidance-weight sweep (ddim_plms_sampler.py:107-140): `samples` start noises x 8 weights 0, 3/8, .. 21/8,
             # per-sample tensor cond_scale; only the `layout` entry of the kwargs is re-batched, as in the reference
             ns, nw = vis.condscale_c.samples, 8
             scales = [i * 3.0 / nw for i in range(nw)]
             cs = torch.tensor(scales * ns, device=dev).reshape(-1, 1, 1, 1)
-            img = torch.randn([ns] + list(shape[1:]), device=dev).repeat_interleave(nw, 0)
+            img = vis_randn([ns] + list(shape[1:])).repeat_interleave(nw, 0)
             assert len(dkw["layout"]) >= ns
             dkw["layout"] = dkw["layout"][:ns].repeat_interleave(nw, 0)
             assert len(cs) == len(img) == len(dkw["layout"])
@@ -557,7 +564,7 @@ class DDIMSampler(object):
         if should_vis("chainvis"):
             # conditional / unconditional chain pairs from the same start noise (ddim_plms_sampler.py:157-175)
             ns = vis.chainvis_c.samples
-            img = torch.randn([ns] + list(shape[1:]), device=dev).repeat_interleave(2, 0)
+            img = vis_randn([ns] + list(shape[1:])).repeat_interleave(2, 0)
             dkw["cond"] = dkw["cond"][:ns].repeat_interleave(2, 0)
             assert len(dkw["cond"]) == len(img)
             dkw["p0"] = torch.tensor([1, 0], device=dev, dtype=torch.float32).repeat(ns)

@@ -73,3 +73,32 @@ def box_layout(boxes, H, W):
     L.check(L.load().sgd_pack_input_compact(_p(x), _p(bx), 2, None, None, B, B, 1, 1, H, W, _p(nhwc), _stream()),
             "sgd_pack_input_compact")
     return nhwc[..., 1:].permute(0, 3, 1, 2).contiguous()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# box corners through the reference's data pipeline (host integer bookkeeping, bit-exact)
+# ------------------------------------------------------------------------------------------------------------------
+def _nearest_range(a, b, src, dst):
+    """[a, b) on a length-`src` axis -> the index range [lo, hi) of a PIL NEAREST resize to `dst` that samples inside it:
+    output j reads input int((j + 0.5) * src / dst) (Pillow's nearest filter: centre of the output pixel, truncated)"""
+    scale = src / dst
+    hit = [j for j in range(dst) if a <= int((j + 0.5) * scale) < b]
+    return (hit[0], hit[-1] + 1) if hit else (0, 0)
+
+
+def lost_box_in_frame(box, orig_size, scaled_size, crop_xy, crop_size, out_size):
+    """The reference rasterises a LOST box at the ORIGINAL image size (get_lostbboxmask, complex_ds_common_util.py:
+    151-162) and pushes the MASK through the image's own transform (RandomScaleCrop, :16-99): PIL NEAREST resize to
+    `scaled_size` = (ow, oh), crop of `crop_size` at `crop_xy` = (x1, y1), PIL NEAREST resize to `out_size`.  A nearest
+    resampling of an axis-aligned box is an axis-aligned box: this returns ITS corners (x0, y0, x1, y1) in the
+    out_size x out_size frame -- the contract of ``box_layout`` / of int box corners passed as `layout`: corners are given
+    in the frame the UNet sees, produced by this index mapping, not by scaling the original corners arithmetically.
+    Pinned against masks produced by the reference's own classes (tests/golden/vis.npz, tests/test_hip_guidance.py)."""
+    (W0, H0), (ow, oh), (cx, cy) = orig_size, scaled_size, crop_xy
+    out = []
+    for (a, b, src, mid, c0) in ((box[0], box[2], W0, ow, cx), (box[1], box[3], H0, oh, cy)):
+        lo, hi = _nearest_range(a, b, src, mid)                     # after the random-scale resize
+        lo, hi = max(lo - c0, 0), min(hi - c0, crop_size)           # after the crop
+        lo, hi = _nearest_range(lo, hi, crop_size, out_size) if hi > lo else (0, 0)
+        out.append((lo, hi))
+    return [out[0][0], out[1][0], out[0][1], out[1][1]]

@@ -210,6 +210,16 @@ class Backward:
         if beta_name is not None:
             self.colsum(tag + ".dbeta", _ptr(g), rows, c, c, beta_name)
 
+    def gather_op(self, tag, pname, padded, pad):
+        """parameter gradient <- the entries of a zero-padded gradient that belong to the parameter (unet._Pad.gather)"""
+        dst = self.pg(pname)
+
+        def op(stream):
+            dst.copy_(pad.gather(padded.reshape(-1, padded.shape[-1])).reshape(dst.shape))
+            return 0
+        self.prog.add(tag, op)
+        self.wrote(pname)
+
     def copy_op(self, tag, dst, src_view):
         def op(stream):
             dst.copy_(src_view)
@@ -389,47 +399,74 @@ class Backward:
         self.wgrad(p + ".conv", rec["a"], gy, c, c, c, 9, n * 4 * hh * ww, p + ".conv.weight", p + ".conv.bias")
 
     def _attn_lr(self, rec):
-        """Attention_LR backward (autograd of crossattetion_lr.py:81-142)"""
+        """Attention_LR backward (autograd of crossattetion_lr.py:81-142).  With zero-padded heads (rec["pads"], head widths
+        the attention core has no instance for) every tensor between the projections is dp wide per head, the adjoint
+        operators are built from the padded weights and each padded weight gradient is gathered back into the parameter's
+        own shape (the padding rows / columns receive gradients that belong to no parameter)."""
         n, p, ch, heads, d, T, J, ntok = (self.n, rec["p"], rec["ch"], rec["heads"], rec["d"], rec["T"], rec["J"],
                                           rec["ntok"])
+        dp, pads = rec.get("dp", d), rec.get("pads")
         P, lib = self.m.P, self.lib
         x, gy = rec["x"], self.gread(rec["y"])
         rows = n * T
+        inner = heads * dp
+
+        def adj(w, key):                       # forward weight as the adjoint operator sees it
+            return (lambda: w) if pads is None else (lambda: pads[key].apply(w.detach().float()))
+
+        def wgrad(tag, fwd, g, cout, cin, nrows, wname, key, bias_name=None):
+            if pads is None:
+                return self.wgrad(tag, fwd, g, cout, cout, cin, 1, nrows, wname, bias_name)
+            tmp = self.buf(cout, cin)
+            self.wgrad(tag, fwd, g, cout, cout, cin, 1, nrows, wname, None, dw_view=tmp)
+            self.gather_op(tag + ".unpad", wname, tmp, pads[key])
+            if bias_name is not None:          # bias gradient = column sums of g, gathered like the weight's rows
+                tb = self.buf(1, cout)
+                self.prog.add(tag + ".bias", lib.sgd_colsum, _ptr(g), nrows, cout, cout, _ptr(tb), 0, self.unscale,
+                              _ptr(self.cwork), self.CW)
+                self.gather_op(tag + ".bias.unpad", bias_name, tb, pads["vec"])
+
         # y = x + LN_out(o):  LN_out backward (gamma trainable, beta is a buffer)
         go = self.buf(n, T, ch)
         self.ln_bwd(p + ".to_out.1", rec["o"], gy, rows, ch, p + ".to_out.1.gamma", go, 0)
         wo = P(p + ".to_out.0.weight")
-        gatt = self.buf(n, T, heads * d)
-        self.dgrad(p + ".to_out.0.dgrad", go, ch, gatt, heads * d, [wo], lambda: wo, ch, heads * d, 1, m=rows)
-        self.wgrad(p + ".to_out.0", rec["aout"], go, ch, ch, heads * d, 1, rows, p + ".to_out.0.weight")
+        gatt = self.buf(n, T, inner)
+        self.dgrad(p + ".to_out.0.dgrad", go, ch, gatt, inner, [wo], adj(wo, "out"), ch, inner, 1, m=rows)
+        wgrad(p + ".to_out.0", rec["aout"], go, ch, inner, rows, p + ".to_out.0.weight", "out")
         # multi-query attention core
         q, kv = rec["q"], rec["kv"]
-        gq, gkv = self.buf(n, T, heads * d), self.buf(n, J, 2 * d)
+        gq, gkv = self.buf(n, T, inner), self.buf(n, J, 2 * dp)
         dvec = self.buf(n, heads, T)
-        self.prog.add(p + ".attn_bwd", lib.sgd_attention_bwd, _ptr(q), heads * d, d, _ptr(kv),
-                      C.c_void_p(kv.data_ptr() + 4 * d), 2 * d, 0, _ptr(rec["att"]), heads * d, _ptr(gatt), heads * d,
-                      _ptr(rec["lse"]), _ptr(dvec), n, heads, T, J, d, d ** -0.5, _ptr(gq), _ptr(gkv),
-                      C.c_void_p(gkv.data_ptr() + 4 * d))
+        self.prog.add(p + ".attn_bwd", lib.sgd_attention_bwd, _ptr(q), inner, dp, _ptr(kv),
+                      C.c_void_p(kv.data_ptr() + 4 * dp), 2 * dp, 0, _ptr(rec["att"]), inner, _ptr(gatt), inner,
+                      _ptr(rec["lse"]), _ptr(dvec), n, heads, T, J, dp, d ** -0.5, _ptr(gq), _ptr(gkv),
+                      C.c_void_p(gkv.data_ptr() + 4 * dp))
         # to_q / to_kv share LN(x): gradient of the normalised input is the sum of both adjoints
         wq, wkv = P(p + ".to_q.weight"), P(p + ".to_kv.weight")
         gxn = self.buf(n, T, ch)
-        self.dgrad(p + ".to_q.dgrad", gq, heads * d, gxn, ch, [wq], lambda: wq, heads * d, ch, 1, m=rows)
-        self.wgrad(p + ".to_q", rec["aq"], gq, heads * d, heads * d, ch, 1, rows, p + ".to_q.weight")
-        gkv_self = self.buf(n, T, 2 * d)
+        self.dgrad(p + ".to_q.dgrad", gq, inner, gxn, ch, [wq], adj(wq, "q"), inner, ch, 1, m=rows)
+        wgrad(p + ".to_q", rec["aq"], gq, inner, ch, rows, p + ".to_q.weight", "q")
+        gkv_self = self.buf(n, T, 2 * dp)
         self.copy_op(p + ".gkv_self", gkv_self, gkv[:, ntok + 1:, :])
-        self.dgrad(p + ".to_kv.dgrad", gkv_self, 2 * d, gxn, ch, [wkv], lambda: wkv, 2 * d, ch, 1, m=rows, acc=True)
-        self.wgrad(p + ".to_kv", rec["akv"], gkv_self, 2 * d, 2 * d, ch, 1, rows, p + ".to_kv.weight")
+        self.dgrad(p + ".to_kv.dgrad", gkv_self, 2 * dp, gxn, ch, [wkv], adj(wkv, "kv"), 2 * dp, ch, 1, m=rows, acc=True)
+        wgrad(p + ".to_kv", rec["akv"], gkv_self, 2 * dp, ch, rows, p + ".to_kv.weight", "kv")
         # null key/value: summed over the batch
-        self.colsum(p + ".null_kv", C.c_void_p(gkv.data_ptr() + 4 * ntok * 2 * d), n, 2 * d, J * 2 * d, p + ".null_kv")
+        if pads is None:
+            self.colsum(p + ".null_kv", C.c_void_p(gkv.data_ptr() + 4 * ntok * 2 * d), n, 2 * d, J * 2 * d, p + ".null_kv")
+        else:
+            tn = self.buf(2, dp)
+            self.prog.add(p + ".null_kv", lib.sgd_colsum, C.c_void_p(gkv.data_ptr() + 4 * ntok * 2 * dp), n, 2 * dp,
+                          J * 2 * dp, _ptr(tn), 0, self.unscale, _ptr(self.cwork), self.CW)
+            self.gather_op(p + ".null_kv.unpad", p + ".null_kv", tn, pads["null"])
         # context keys/values -> to_context.1 (Linear) -> to_context.0 (LayerNorm) -> shared context tokens
         ctx = rec["ctx"]
-        gckv = self.buf(n, ntok, 2 * d)
+        gckv = self.buf(n, ntok, 2 * dp)
         self.copy_op(p + ".gkv_ctx", gckv, gkv[:, :ntok, :])
         wc = P(p + ".to_context.1.weight")
-        self.wgrad(p + ".to_context.1", rec["actx"], gckv, 2 * d, 2 * d, ctx, 1, n * ntok, p + ".to_context.1.weight",
-                   p + ".to_context.1.bias")
+        wgrad(p + ".to_context.1", rec["actx"], gckv, 2 * dp, ctx, n * ntok, p + ".to_context.1.weight", "kv",
+              p + ".to_context.1.bias")
         gcn = self.buf(n, ntok, ctx)
-        self.dgrad(p + ".to_context.1.dgrad", gckv, 2 * d, gcn, ctx, [wc], lambda: wc, 2 * d, ctx, 1, m=n * ntok)
+        self.dgrad(p + ".to_context.1.dgrad", gckv, 2 * dp, gcn, ctx, [wc], adj(wc, "kv"), 2 * dp, ctx, 1, m=n * ntok)
         cdst, cacc = self.gact(rec["context"])
         self.ln_bwd(p + ".to_context.0", rec["context"], gcn, n * ntok, ctx, p + ".to_context.0.weight", cdst, cacc,
                     beta_name=p + ".to_context.0.bias")
@@ -570,6 +607,25 @@ class _UNetTrainFn(torch.autograd.Function):
             raise RuntimeError("sgdm_amd: backward through a stale forward -- another training forward ran on this "
                                "model (same batch/resolution) after the one being differentiated and overwrote its "
                                "activations; call backward() before the next forward")
+        model = ctx.model
+        if not getattr(model, "_torch_ddp_checked", False):
+            # the reference's own multi-GPU command wraps the LightningModule in torch DDP (pl.trainer.strategy=ddp): then
+            # torch's reducer owns the exchange -- this path must hand it the gradients through autograd (its hooks sit
+            # on the AccumulateGrad nodes) and must NOT all-reduce them a second time
+            from .ddp import find_torch_ddp_wrapper
+            model._torch_ddp_checked = True
+            wrapper = find_torch_ddp_wrapper(model)
+            ignored = set(getattr(getattr(wrapper, "module", None), "_ddp_params_and_buffers_to_ignore", []) or [])
+            if wrapper is not None and not (ignored and all(
+                    any(n.endswith(k) for n in ignored) for k, _ in model.named_parameters())):
+                import warnings
+                model.hip_ddp = False
+                model.hip_grad_alias = False
+                warnings.warn("sgdm_amd: the model is wrapped in torch DistributedDataParallel -- gradients are handed to "
+                              "torch's reducer (one all-reduce, torch's buckets) and the HIP path's own overlapped RCCL "
+                              "exchange is off.  For the native exchange run one process per GPU WITHOUT the wrapper "
+                              "(sgdm_amd.pl_strategy.HipDDPStrategy) or call sgdm_amd.ddp.exclude_from_torch_ddp(root, "
+                              "unet, ema) before wrapping (INTEGRATION.md).")
         if getattr(eng, "backward", None) is None:
             eng.backward = make_backward(eng)
         # The program writes every parameter gradient into a persistent buffer (a view of the DDP arena when there is one).
@@ -587,7 +643,11 @@ class _UNetTrainFn(torch.autograd.Function):
         with torch.no_grad():
             for name, p in zip(ctx.names, ctx.params):
                 g = grads.get(name)          # None: parameter not on the path (e.g. to_cond_tokens_2d, README.md:90-94)
-                if g is not None and p.grad is None and g.shape == p.shape:
+                # alias fast path only when nobody observes the gradient through autograd: tensor hooks / post-accumulate
+                # hooks (gradient clipping callbacks, optimizer-in-backward, torch DDP's reducer) need AccumulateGrad to run
+                alias = getattr(model, "hip_grad_alias", True) and not p._backward_hooks \
+                    and not getattr(p, "_post_accumulate_grad_hooks", None)
+                if g is not None and alias and p.grad is None and g.shape == p.shape:
                     p.grad = g
                     g = None
                 out.append(g)

@@ -116,16 +116,72 @@ AMAX_OF = {}       # parameter data_ptr -> (version, device int32 holding the bi
                    # an address can be recycled by another tensor), written by _Packed.refresh
 
 
+HEAD_DIMS = (16, 32, 64, 128)          # head widths the MFMA attention cores are instantiated for
+
+
+def padded_head_dim(d):
+    """smallest attention-core head width >= d: other widths (config/dynamic/unetca_fast_s64.yaml: 672 / 32 = 21 and
+    896 / 32 = 28 channels per head, openaimodel_ca.py:671-693) run zero-padded -- zeros add nothing to q.k and carry
+    no value -- with the softmax scale of the TRUE width"""
+    for dp in HEAD_DIMS:
+        if dp >= d:
+            return dp
+    raise ValueError(f"attention head width {d} > {HEAD_DIMS[-1]} is not supported")
+
+
+class _Pad:
+    """zero-padded re-layout of a 2-D weight (or a vector / [2, d] table along its last dim): source row r lands at row
+    rows[r], source column c at column cols[c] of an [n_rows, n_cols] zero matrix.  ``gather`` is the adjoint (the
+    gradient of the padded tensor read back at the positions of the real entries)."""
+
+    def __init__(self, rows=None, n_rows=None, cols=None, n_cols=None):
+        self.rows = None if rows is None else torch.as_tensor(rows, dtype=torch.int64)
+        self.cols = None if cols is None else torch.as_tensor(cols, dtype=torch.int64)
+        self.n_rows, self.n_cols = n_rows, n_cols
+
+    def _idx(self, dev):
+        if self.rows is not None and self.rows.device != dev:
+            self.rows = self.rows.to(dev)
+        if self.cols is not None and self.cols.device != dev:
+            self.cols = self.cols.to(dev)
+
+    def apply(self, w):
+        self._idx(w.device)
+        w2 = w.reshape(w.shape[0], -1)
+        out = w2.new_zeros(self.n_rows if self.rows is not None else w2.shape[0],
+                           self.n_cols if self.cols is not None else w2.shape[1])
+        if self.rows is not None and self.cols is not None:
+            out[self.rows[:, None], self.cols[None, :]] = w2
+        elif self.rows is not None:
+            out[self.rows] = w2
+        else:
+            out[:, self.cols] = w2
+        return out
+
+    def gather(self, wp):
+        self._idx(wp.device)
+        if self.rows is not None:
+            wp = wp[self.rows]
+        if self.cols is not None:
+            wp = wp[:, self.cols]
+        return wp
+
+
 class _Packed:
     """device buffer holding one conv/linear weight in the igemm layout, refreshed when the source
     parameter(s) change (optimizer step / load_state_dict bump ``_version``)."""
 
-    def __init__(self, srcs, ksize, prec):
+    def __init__(self, srcs, ksize, prec, pad=None):
         self.srcs = srcs                     # list of parameters concatenated along dim 0
         self.ksize = ksize
         self.prec = prec
+        self.pad = pad                       # _Pad: the packed operator is the zero-padded re-layout of the parameter
         self.cout = sum(s.shape[0] for s in srcs)
         self.cin = srcs[0].shape[1]
+        if pad is not None:
+            assert ksize == 1
+            self.cout = pad.n_rows if pad.rows is not None else self.cout
+            self.cin = pad.n_cols if pad.cols is not None else self.cin
         lib = L.load()
         nbytes = lib.sgd_packed_weight_bytes(self.cout, self.cin, ksize, prec)
         self.buf = torch.empty(nbytes // 4, dtype=torch.float32, device=srcs[0].device)
@@ -149,11 +205,13 @@ class _Packed:
         lib = L.load()
         src = self.srcs[0].detach() if len(self.srcs) == 1 else torch.cat([s.detach() for s in self.srcs], 0)
         src = src.contiguous().float()
+        if self.pad is not None:
+            src = self.pad.apply(src).contiguous()
         cin_p, cout_p = C.c_int32(0), C.c_int32(0)
         if self.scaled:
             self.amax.zero_()
             L.check(lib.sgd_weight_amax(_ptr(src), src.numel(), _ptr(self.amax), stream), "sgd_weight_amax")
-            if len(self.srcs) == 1:
+            if len(self.srcs) == 1 and self.pad is None:
                 # max |w| of this parameter at this version: the adjoint pack of the same tensor (train._PackedAdj) reuses it
                 AMAX_OF[self.srcs[0].data_ptr()] = (self.srcs[0]._version, self.amax, weakref.ref(self.srcs[0]))
             L.check(lib.sgd_pack_weight_scaled(_ptr(src), _ptr(self.buf), self.cout, self.cin, self.ksize, self.prec, 0,
@@ -441,10 +499,26 @@ class _Engine:
         (bf16x3 keeps the exact kernel: 8 mantissa bits per half do not hold the softmax weights)"""
         return self.lib.sgd_attention_split if self.prec == L.PREC_F16X3 else self.lib.sgd_attention
 
-    def pack(self, names, ksize):
-        pk = _Packed([self.m.P(nm) for nm in names], ksize, self.prec)
+    def pack(self, names, ksize, pad=None):
+        pk = _Packed([self.m.P(nm) for nm in names], ksize, self.prec, pad)
         self.packed.append(pk)
         return pk
+
+    def padded(self, name, pad):
+        """device copy of parameter `name` in a zero-padded layout (_Pad over its last dim for vectors / tables), kept in
+        step with the parameter by refresh() like the packed weights"""
+        src = self.m.P(name)
+        buf = self.buf(*pad.apply(src.detach().reshape(-1, src.shape[-1]) if src.dim() > 1 else src.detach().reshape(1, -1)).shape)
+        box = dict(sig=None)
+
+        def hook(stream):
+            sig = (src.data_ptr(), src._version)
+            if sig != box["sig"]:
+                v = src.detach().float()
+                buf.copy_(pad.apply(v.reshape(-1, v.shape[-1]) if v.dim() > 1 else v.reshape(1, -1)))
+                box["sig"] = sig
+        self.refresh_hooks.append(hook)
+        return buf
 
     def igemm(self, tag, x0, c0, y, cout, pk, *, x1=None, c1=0, conv=None, m=0, rows_per_n=0,
               pro=L.PRO_NONE, silu=0, pa=None, pb=None, pc=None, bias=None, res=None, res_mode=L.RS_NONE,
@@ -1147,43 +1221,57 @@ class UNetModelCA(UNetModelBase):
         eng.context, eng.ntok = context, ntok
 
     def _build_attn(self, eng, p, layer, src):
-        """Attention_LR.forward (crossattetion_lr.py:81-142)"""
+        """Attention_LR.forward (crossattetion_lr.py:81-142).  Head widths the attention core has no instance for run
+        zero-padded to dp (padded_head_dim): the projections' packed weights / bias / null_kv are padded re-layouts of the
+        parameters (_Pad), every buffer between to_q / to_kv / to_context and to_out is dp wide per head, the softmax
+        scale stays dim_head ** -0.5."""
         _, ch, heads = layer
         t, c, hh, ww = src
         n, T, P, lib = eng.n, hh * ww, self.P, eng.lib
         d = ch // heads
-        _check_head_dim(d, ch, heads)
+        dp = padded_head_dim(d)
+        pads = None
+        if dp != d:
+            qmap = [h * dp + i for h in range(heads) for i in range(d)]          # (head, i) of the inner dimension
+            kvmap = list(range(d)) + [dp + i for i in range(d)]                  # [k | v] of the shared key/value head
+            pads = dict(q=_Pad(rows=qmap, n_rows=heads * dp), kv=_Pad(rows=kvmap, n_rows=2 * dp),
+                        out=_Pad(cols=qmap, n_cols=heads * dp), vec=_Pad(cols=kvmap, n_cols=2 * dp),
+                        null=_Pad(cols=list(range(d)), n_cols=dp))
+        pad = (lambda k: pads[k]) if pads else (lambda k: None)
         ntok = eng.ntok
         J = ntok + 1 + T                                   # [context | null | self]
         st = eng.buf(n * T, 2)
         eng.prog.add(p + ".norm", lib.sgd_ln_stats, _ptr(t), n * T, c, LN_EPS, _ptr(st))
-        q = eng.buf(n, T, heads * d)
+        q = eng.buf(n, T, heads * dp)
         gamma, beta = P(p + ".norm.gamma"), P(p + ".norm.beta")
-        aq = eng.igemm(p + ".to_q", t, c, q, heads * d, eng.pack([p + ".to_q.weight"], 1), m=n * T,
+        aq = eng.igemm(p + ".to_q", t, c, q, heads * dp, eng.pack([p + ".to_q.weight"], 1, pad("q")), m=n * T,
                        pro=L.PRO_LN_ROW, pa=st, pb=gamma, pc=beta)
-        kv = eng.buf(n, J, 2 * d)
-        akv = eng.igemm(p + ".to_kv", t, c, kv, 2 * d, eng.pack([p + ".to_kv.weight"], 1), m=n * T,
+        kv = eng.buf(n, J, 2 * dp)
+        akv = eng.igemm(p + ".to_kv", t, c, kv, 2 * dp, eng.pack([p + ".to_kv.weight"], 1, pad("kv")), m=n * T,
                         pro=L.PRO_LN_ROW, pa=st, pb=gamma, pc=beta, orows=(T, J, ntok + 1))
         cst = eng.buf(n * ntok, 2)
         eng.prog.add(p + ".to_context.0", lib.sgd_ln_stats, _ptr(eng.context), n * ntok, self.context_dim, LN_EPS,
                      _ptr(cst))
-        actx = eng.igemm(p + ".to_context.1", eng.context, self.context_dim, kv, 2 * d,
-                         eng.pack([p + ".to_context.1.weight"], 1), m=n * ntok, pro=L.PRO_LN_ROW, pa=cst,
+        cbias = eng.padded(p + ".to_context.1.bias", pads["vec"]) if pads else P(p + ".to_context.1.bias")
+        actx = eng.igemm(p + ".to_context.1", eng.context, self.context_dim, kv, 2 * dp,
+                         eng.pack([p + ".to_context.1.weight"], 1, pad("kv")), m=n * ntok, pro=L.PRO_LN_ROW, pa=cst,
                          pb=P(p + ".to_context.0.weight"), pc=P(p + ".to_context.0.bias"),
-                         bias=P(p + ".to_context.1.bias"), orows=(ntok, J, 0))
-        eng.prog.add(p + ".null_kv", lib.sgd_fill_null_kv, _ptr(P(p + ".null_kv")), n, J, ntok, d, _ptr(kv))
-        att = eng.buf(n, T, heads * d)
+                         bias=cbias, orows=(ntok, J, 0))
+        null_kv = eng.padded(p + ".null_kv", pads["null"]) if pads else P(p + ".null_kv")
+        eng.prog.add(p + ".null_kv", lib.sgd_fill_null_kv, _ptr(null_kv), n, J, ntok, dp, _ptr(kv))
+        att = eng.buf(n, T, heads * dp)
         lse = eng.buf(n, heads, T)
-        eng.prog.add(p + ".attn", eng.attention_fn(), _ptr(q), heads * d, d, _ptr(kv),
-                     C.c_void_p(kv.data_ptr() + 4 * d), 2 * d, 0, n, heads, T, J, d, d ** -0.5, _ptr(att),
-                     heads * d, _ptr(lse))
+        eng.prog.add(p + ".attn", eng.attention_fn(), _ptr(q), heads * dp, dp, _ptr(kv),
+                     C.c_void_p(kv.data_ptr() + 4 * dp), 2 * dp, 0, n, heads, T, J, dp, d ** -0.5, _ptr(att),
+                     heads * dp, _ptr(lse))
         o = eng.buf(n, T, ch)
-        aout = eng.igemm(p + ".to_out.0", att, heads * d, o, ch, eng.pack([p + ".to_out.0.weight"], 1), m=n * T)
+        aout = eng.igemm(p + ".to_out.0", att, heads * dp, o, ch, eng.pack([p + ".to_out.0.weight"], 1, pad("out")),
+                         m=n * T)
         y = eng.buf(n, hh, ww, ch)
         eng.prog.add(p + ".to_out.1", lib.sgd_ln_apply, _ptr(o), _ptr(P(p + ".to_out.1.gamma")),
                      _ptr(P(p + ".to_out.1.beta")), _ptr(t), n * T, ch, LN_EPS, _ptr(y))
-        eng.tape.append(dict(kind="attn_lr", p=p, x=t, ch=ch, heads=heads, d=d, T=T, J=J, ntok=ntok, hw=(hh, ww), q=q,
-                             kv=kv, att=att, lse=lse, o=o, aq=aq, akv=akv, actx=actx, aout=aout, y=y,
+        eng.tape.append(dict(kind="attn_lr", p=p, x=t, ch=ch, heads=heads, d=d, dp=dp, pads=pads, T=T, J=J, ntok=ntok,
+                             hw=(hh, ww), q=q, kv=kv, att=att, lse=lse, o=o, aq=aq, akv=akv, actx=actx, aout=aout, y=y,
                              context=eng.context, ctx=self.context_dim))
         return (y, ch, hh, ww)
 

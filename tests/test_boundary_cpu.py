@@ -213,3 +213,20 @@ def test_library_exports_nothing_undeclared():
     out = subprocess.run(["nm", "-D", "--defined-only", L.LIB_PATH], capture_output=True, text=True, check=True).stdout
     exported = {ln.split()[-1] for ln in out.splitlines() if " T sgd_" in ln}
     assert exported == set(L.SIGNATURES), exported ^ set(L.SIGNATURES)
+
+
+def test_lost_box_corner_contract_matches_reference_pipeline_masks():
+    """guidance.lost_box_in_frame (host integer bookkeeping): corners of a LOST box after the reference's RandomScaleCrop
+    (two PIL NEAREST resizes + a crop applied to the box MASK) == the bounding box of the mask the reference's own class
+    produced (tests/golden/vis.npz, make_golden_vis.py)"""
+    import numpy as np
+    from conftest import load_npz
+    from sgdm_amd.guidance import lost_box_in_frame
+    v = load_npz("vis.npz")
+    W0, H0 = (int(t) for t in v["guid.box_orig_size"])
+    base, S = (int(t) for t in v["guid.box_crop_resize"])
+    for b, p, m in zip(v["guid.box_orig"], v["guid.box_scaled_size_crop_xy"], v["guid.box_mask64"]):
+        c = lost_box_in_frame([int(t) for t in b], (W0, H0), (int(p[0]), int(p[1])), (int(p[2]), int(p[3])), base, S)
+        ref = np.zeros((S, S), dtype=np.float32)
+        ref[c[1]:c[3], c[0]:c[2]] = 1
+        assert (ref == m[0]).all(), (b, c)

@@ -85,3 +85,36 @@ def test_arena_views_are_aligned_and_ordered():
     assert [ar.bucket_of[n] for n, _ in shapes] == sorted(ar.bucket_of[n] for n, _ in shapes)
     ar.grad("b").fill_(2.0)
     assert float(ar.flat.sum()) == 50.0
+
+
+def test_torch_ddp_wrapper_detection_and_exclusion():
+    """sgdm_amd.ddp.find_torch_ddp_wrapper / exclude_from_torch_ddp on CPU modules over a single-rank gloo group: the
+    wrapper around a PARENT of the module is found; a module marked with exclude_from_torch_ddp is skipped by torch's
+    reducer (DDP's own _ddp_params_and_buffers_to_ignore contract)"""
+    import os
+    import tempfile
+    import torch.distributed as dist
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    from sgdm_amd.ddp import exclude_from_torch_ddp, find_torch_ddp_wrapper
+    with tempfile.TemporaryDirectory() as td:
+        dist.init_process_group("gloo", init_method=f"file://{os.path.join(td, 'store')}", rank=0, world_size=1)
+        try:
+            class Holder(torch.nn.Module):
+                def __init__(self):
+                    super().__init__()
+                    self.dynamic = torch.nn.Linear(4, 4)
+                    self.other = torch.nn.Linear(4, 2)
+                    self.dynamic.register_buffer("shadow", torch.zeros(3))
+
+                def forward(self, x):
+                    return self.other(self.dynamic(x))
+            free = Holder()
+            assert find_torch_ddp_wrapper(free.dynamic) is None
+            root = Holder()
+            names = exclude_from_torch_ddp(root, root.dynamic)
+            assert sorted(names) == ["dynamic.bias", "dynamic.shadow", "dynamic.weight"]
+            w = DDP(root)
+            assert find_torch_ddp_wrapper(root.dynamic) is w and find_torch_ddp_wrapper(free.dynamic) is None
+            assert w.parameters_to_ignore == set(names)
+        finally:
+            dist.destroy_process_group()

@@ -97,3 +97,26 @@ def test_unet_fast_box_corners_equal_box_mask():
         a = m.forward_with_cond_scale(x, t, cond_scale=1.5, cond=F.one_hot(ids, k).float().cuda(), layout=mask.cuda())
         b = m.forward_with_cond_scale(x, t, cond_scale=1.5, cond=ids.cuda(), layout=boxes.cuda())
     assert torch.equal(a, b)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# against expansions produced by the reference's OWN functions / transform classes (tests/golden/vis.npz,
+# make_golden_vis.py imports dataset/transforms/complex_ds_common_util.py)
+# ------------------------------------------------------------------------------------------------------------------
+def test_expansions_equal_reference_generated_fixtures():
+    from conftest import load_npz
+    from sgdm_amd import guidance as G
+    v = load_npz("vis.npz")
+    lm = torch.from_numpy(v["guid.labelmap"])
+    assert torch.equal(G.onehot_layout(lm.cuda(), 27).cpu(), torch.from_numpy(v["guid.onehot"]))
+    lm0 = lm.clone()
+    lm0[lm0 == 255] = 0
+    assert torch.equal(G.stego_attr(lm0.cuda(), 27).cpu(), torch.from_numpy(v["guid.nhot"]))
+    # LOST boxes: corners mapped through the reference pipeline's index arithmetic, rasterised on the device, against the
+    # mask the reference's RandomScaleCrop produced from the box drawn at the original size
+    W0, H0 = (int(t) for t in v["guid.box_orig_size"])
+    base, S = (int(t) for t in v["guid.box_crop_resize"])
+    corners = [G.lost_box_in_frame([int(t) for t in b], (W0, H0), (int(p[0]), int(p[1])), (int(p[2]), int(p[3])), base, S)
+               for b, p in zip(v["guid.box_orig"], v["guid.box_scaled_size_crop_xy"])]
+    got = G.box_layout(torch.tensor(corners).cuda(), S, S).cpu()
+    assert torch.equal(got, torch.from_numpy(v["guid.box_mask64"]))

@@ -357,3 +357,90 @@ def test_graph_step_with_cluster_ids_follows_weight_updates():
     assert torch.equal(after_graph, after_eager)
     m.load_state_dict(weights_from_seed(entry["manifest"], entry["seed"]))
     assert torch.equal(run(True), first)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# sampling variants against trajectories recorded from the reference WITH its noise (tests/golden/vis.npz,
+# make_golden_vis.py): the `vis` branches of the DDIM sampler and dynamic thresholding (dtp < 1)
+# ------------------------------------------------------------------------------------------------------------------
+class _NS:
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+def _vis_check(tag, samples, inter, v, tol=2e-3):
+    r = rel_l2(inter["x_inter"].cpu(), v[tag + ".x_inter"])
+    d = (samples.cpu().int() - torch.from_numpy(v[tag + ".samples_u8"]).int()).abs()
+    assert tuple(samples.shape) == tuple(v[tag + ".samples_u8"].shape)
+    assert r < tol, (tag, r)                       # free-running 7-step DDIM: plumbing tolerance
+    assert d.max() <= 2 and (d > 1).float().mean() < 1e-3, (tag, int(d.max()))
+
+
+def test_ddim_vis_interp_vs_reference():
+    v = load_npz("vis.npz")
+    m, _ = build_model("uf_label_c32_s16", "f32")
+    d = _diffusion(m)
+    z = torch.from_numpy(v["interp.z"])
+    vis = _NS(interp=True, interp_c=_NS(n=3, samples=2))
+    samples, inter = d.p_sample_loop("ddim", (4, 3, 16, 16), dict(_skw("ddim", 6, 0.5), vis=vis),
+                                     denoise_sample_fn_kwargs=dict(cond=torch.from_numpy(v["interp.cond"]).cuda(), layout=None,
+                                                                   cond_scale=2.0),
+                                     condition_kwargs={}, vis_noise=torch.from_numpy(v["interp.vis_noise"]),
+                                     noise_fn=lambda i: z[i])
+    _vis_check("interp", samples, inter, v)
+
+
+def test_ddim_vis_chainvis_vs_reference():
+    v = load_npz("vis.npz")
+    m, _ = build_model("uf_label_c32_s16", "f32")
+    d = _diffusion(m)
+    z = torch.from_numpy(v["chainvis.z"])
+    vis = _NS(chainvis=True, chainvis_c=_NS(samples=2))
+    samples, inter = d.p_sample_loop("ddim", (3, 3, 16, 16), dict(_skw("ddim", 6, 0.5), vis=vis),
+                                     denoise_sample_fn_kwargs=dict(cond=torch.from_numpy(v["chainvis.cond"]).cuda(), layout=None,
+                                                                   cond_scale=2.0),
+                                     condition_kwargs={}, vis_noise=torch.from_numpy(v["chainvis.vis_noise"]),
+                                     noise_fn=lambda i: z[i])
+    _vis_check("chainvis", samples, inter, v)
+
+
+def test_ddim_vis_condscale_vs_reference():
+    from sgdm_amd.synth import synth_batch
+    v = load_npz("vis.npz")
+    m, _ = build_model("ca_stego_c32_s16", "f32")
+    d = _diffusion(m)
+    batch = synth_batch("stegoclusterlayout", 2, 16, 27, 27, seed=23 + 44)
+    cond8 = batch["cond"][:1].float().repeat(8, 1)
+    z = torch.from_numpy(v["condscale.z"])
+    vis = _NS(condscale=True, condscale_c=_NS(samples=1))
+    samples, inter = d.p_sample_loop("ddim", (2, 3, 16, 16), dict(_skw("ddim", 6, 0.5), vis=vis),
+                                     denoise_sample_fn_kwargs=dict(cond=cond8.cuda(), layout=batch["layout"].cuda(), cond_scale=2.0),
+                                     condition_kwargs={}, vis_noise=torch.from_numpy(v["condscale.vis_noise"]),
+                                     noise_fn=lambda i: z[i])
+    _vis_check("condscale", samples, inter, v)
+
+
+def test_dynamic_thresholding_trajectories_vs_reference():
+    """dtp = 0.9 (diffusion_utils/util.py:70-82): DDIM-10 (eta = 1) with the recorded noise, and the native sampler over all
+    1000 steps with the reference's RNG stream replayed on the CPU (x_T, then uniform_(2B) + randn per step)"""
+    v = load_npz("vis.npz")
+    m, _ = build_model("uf_label_c32_s16", "f32")
+    d = _diffusion(m)
+    z = torch.from_numpy(v["dtp_ddim.z"])
+    samples, inter = d.p_sample_loop("ddim", (2, 3, 16, 16), dict(_skw("ddim", 10, 1.0), dtp=0.9),
+                                     denoise_sample_fn_kwargs=dict(cond=_cond(), layout=None, cond_scale=2.0), condition_kwargs={},
+                                     x_T=torch.from_numpy(v["dtp_ddim.x_T"]), noise_fn=lambda i: z[i])
+    _vis_check("dtp_ddim", samples, inter, v)
+    B, S = 2, 16
+    torch.manual_seed(int(v["dtp_native.rng_seed"]))
+    x_T = torch.randn(B, 3, S, S)
+
+    def noise_fn(i):
+        torch.zeros(2 * B).float().uniform_(0, 1)
+        return torch.randn(B, 3, S, S)
+    samples, inter = d.p_sample_loop("native", (B, 3, S, S), dict(_skw("native", 1000), dtp=0.9),
+                                     denoise_sample_fn_kwargs=dict(cond=_cond(), layout=None, cond_scale=2.0), condition_kwargs={},
+                                     x_T=x_T, noise_fn=noise_fn)
+    diff = (samples.cpu().int() - torch.from_numpy(v["dtp_native.samples_u8"]).int()).abs()
+    assert diff.max() <= 1 and (diff != 0).float().mean() < 1e-2
+    assert rel_l2(inter["x_inter"].cpu(), v["dtp_native.x_inter"]) < 1e-3

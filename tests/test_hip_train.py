@@ -95,14 +95,14 @@ def _ddp_rank(rank, world, port, outdir, name, backend):
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if backend == "nccl":
         torch.cuda.set_device(rank)                                    # RCCL: one rank per GPU
-    dist.init_process_group(backend, rank=rank, world_size=world)      # gloo on a 1-GPU box: both ranks share cuda:0
-    grads = _grads_for_seed(100 + rank, ddp=True, name=name)
+    dist.init_process_group(backend.split("-")[0], rank=rank, world_size=world)   # gloo on a 1-GPU box: both ranks share cuda:0
+    grads = _grads_for_seed(100 + rank, ddp=True, name=name, torch_ddp=(backend == "gloo-torchddp"))
     torch.save({k: v.cpu() for k, v in grads.items()}, os.path.join(outdir, f"rank{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def _grads_for_seed(seed, ddp, name="uf_clusterlayout_c32_s16"):
+def _grads_for_seed(seed, ddp, name="uf_clusterlayout_c32_s16", torch_ddp=False):
     import bench
     from sgdm_amd.diffusion import LatentDiffusion
     from sgdm_amd.synth import synth_batch
@@ -113,7 +113,24 @@ def _grads_for_seed(seed, ddp, name="uf_clusterlayout_c32_s16"):
     m.hip_ddp = ddp
     m.hip_bucket_bytes = 1 << 20                                       # force many buckets on the tiny model
     d = LatentDiffusion(device="cuda", **bench.MODEL_PARAMS).train()
-    d.set_denoise_fn(m.forward, m.forward_with_cond_scale)
+    fwd = m.forward
+    if torch_ddp:
+        # what `pl.trainer.strategy=ddp` does to the module that holds the UNet (README.md:84-94): torch's reducer must
+        # get the gradients (its hooks sit on AccumulateGrad) and the HIP path must not reduce them a second time
+        import warnings
+        from torch.nn.parallel import DistributedDataParallel as DDP
+
+        class Holder(torch.nn.Module):
+            def __init__(self, unet):
+                super().__init__()
+                self.dynamic = unet
+
+            def forward(self, *a, **k):
+                return self.dynamic(*a, **k)
+        wrapped = DDP(Holder(m), find_unused_parameters=True)
+        fwd = wrapped.__call__
+        warnings.simplefilter("ignore")
+    d.set_denoise_fn(fwd, m.forward_with_cond_scale)
     kw = entry["ctor"]
     batch = synth_batch(kw["condition_method"], 4, 16, kw["cond_dim"], entry["layout_dim"], seed=seed)
     g = torch.Generator().manual_seed(seed)
@@ -127,13 +144,17 @@ def _grads_for_seed(seed, ddp, name="uf_clusterlayout_c32_s16"):
 
 
 @pytest.mark.parametrize("name,backend", [("uf_clusterlayout_c32_s16", "gloo"), ("ca_clusterlayout_c32_s16", "gloo"),
-                                          ("uf_clusterlayout_c32_s16", "nccl"), ("ca_clusterlayout_c32_s16", "nccl")])
+                                          ("uf_clusterlayout_c32_s16", "nccl"), ("ca_clusterlayout_c32_s16", "nccl"),
+                                          ("uf_clusterlayout_c32_s16", "gloo-torchddp"),
+                                          ("ca_clusterlayout_c32_s16", "gloo-torchddp")])
 def test_ddp_bucketed_allreduce_two_ranks(name, backend):
     """world_size 2: every rank must end with the MEAN of the per-rank gradients (torch DDP semantics), produced by
     the arena + overlapped bucket all-reduce inside the backward program.  `ca_clusterlayout` is the C4 shape
     (BASELINE.json configs[3]): its to_cond_tokens_2d.* parameters are unused (README.md:90-94 needs
     find_unused_parameters for torch DDP) -- every rank must lay out the same buckets without them.  The nccl (= RCCL)
-    variant needs two GPUs and skips on the single-GPU test box."""
+    variant needs two GPUs and skips on the single-GPU test box.  `gloo-torchddp`: the module holding the UNet is wrapped
+    in torch's DistributedDataParallel, as under the reference's unchanged `pl.trainer.strategy=ddp`: the HIP path must
+    detect the wrapper, hand its gradients to torch's reducer and NOT reduce a second time -- same mean on every rank."""
     import socket
     import tempfile
     import torch.multiprocessing as mp
@@ -575,3 +596,57 @@ def test_gradient_buffers_alias_without_breaking_accumulation():
     for k, p in m.named_parameters():
         if p.grad is not None:
             assert float((p.grad - gb[k]).abs().max()) <= 1e-6 * max(1.0, float(gb[k].abs().max())), k
+
+
+@pytest.mark.parametrize("prec,tol", [("f32", 5e-5), ("f16x3", 1e-4)])
+def test_train_step_with_zero_padded_attention_heads_vs_oracle(prec, tol):
+    """Attention_LR with a head width the attention core has no instance for (96 channels / 4 heads = 24, padded to 32 --
+    the mechanism that runs config/dynamic/unetca_fast_s64.yaml's 21 / 28): loss and EVERY parameter gradient of one
+    training step against the oracle's autograd"""
+    import bench
+    from oracle import diffusion_ref as D
+    from oracle import unet_ref as U
+    from sgdm_amd.diffusion import LatentDiffusion
+    from sgdm_amd.synth import synth_batch, weights_from_seed
+    from sgdm_amd.unet import UNetModelCA
+    from test_hip_unet import AttrDict
+    kw = dict(image_size=16, in_channels=3, out_channels=3, model_channels=32, num_res_blocks=1, channel_mult=[1, 2, 3],
+              attention_resolutions=[4], num_heads=4, use_scale_shift_norm=True, use_ca_block=True, legacy=False, dropout=0.0,
+              cond_token_num=1, cond_dim=27, context_dim=32, use_cls_token_as_pooled=True, condition_method="stegoclusterlayout")
+    m = UNetModelCA(condition=AttrDict(scale_type="imagen", stegoclusterlayout=AttrDict(layout_dim=27)), **kw)
+    cfg = U.make_cfg("unetca_fast", 16, model_channels=32, num_res_blocks=1, channel_mult=(1, 2, 3), attention_resolutions=(4,),
+                     num_heads=4, cond_dim=27, condition_method="stegoclusterlayout", layout_dim=27, cond_token_num=1,
+                     context_dim=32)
+    manifest = [(k, tuple(v.shape)) for k, v in m.state_dict().items()]
+    assert [k for k, _ in manifest] == [k for k, _, _ in U.param_manifest(cfg)]
+    sd = weights_from_seed(manifest, 31)
+    m.load_state_dict(sd)
+    m = m.cuda().train()
+    m.hip_precision = prec
+    d = LatentDiffusion(device="cuda", **bench.MODEL_PARAMS).train()
+    d.set_denoise_fn(m.forward, m.forward_with_cond_scale)
+    B = 3
+    batch = synth_batch("stegoclusterlayout", B, 16, 27, 27, seed=7)
+    g = torch.Generator().manual_seed(8)
+    t = torch.randint(0, 1000, (B,), generator=g)
+    noise = torch.randn(B, 3, 16, 16, generator=g)
+    mask = torch.tensor([False, True, False])
+    loss, _ = d.p_losses(batch["image"].cuda(), t.cuda(), noise.cuda(), cond=batch["cond"].float().cuda(),
+                         layout=batch["layout"].cuda(), cond_drop_prob=0.5, cond_drop_mask=mask.cuda())
+    loss.backward()
+    trainable = [k for k, p in m.named_parameters() if p.requires_grad]
+    w = {k: v.clone().requires_grad_(k in trainable) for k, v in sd.items()}
+    ref_loss, _, _, _ = D.p_losses(D.make_schedule(), lambda xx, tt: U.unet_forward(cfg, w, xx, tt, batch["cond"].float(),
+                                                                                      batch["layout"], drop_mask=mask),
+                                   batch["image"], t, noise)
+    ref_loss.backward()
+    assert abs(loss.item() - float(ref_loss.detach())) < 2e-5 * abs(float(ref_loss.detach()))
+    checked = 0
+    for name, p in m.named_parameters():
+        if w[name].grad is None:
+            continue
+        assert p.grad is not None, name
+        err = max_rel(p.grad.cpu(), w[name].grad)
+        assert err < tol, (name, err)
+        checked += 1
+    assert checked > 60 and any(".to_q." in k for k in trainable)

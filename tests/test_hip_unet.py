@@ -119,12 +119,11 @@ def test_state_dict_roundtrip_and_repack():
     assert torch.equal(e1, e3)
 
 
-@pytest.mark.parametrize("kind", ["unet_fast_s64", "unetca_fast_s64_hc32"])
+@pytest.mark.parametrize("kind", ["unet_fast_s64", "unetca_fast_s64_hc32", "unetca_fast_s64"])
 def test_s64_widths_vs_oracle(kind):
-    """config/dynamic/unet_fast_s64.yaml (ch=256, mult [1,2,4], 8 heads -> head dim 128) and the unetca_fast_s64.yaml
-    width (ch=224, mult [1,2,3,4], attention at ds 4 AND 8 -> T = 256 and 64) with num_head_channels=32 (21 / 28 heads of
-    32; the yaml's num_heads=32 gives head dims 21 / 28, which the MFMA attention core does not take -- it raises): CFG evaluation at B=1
-    against the CPU oracle on seeded weights"""
+    """config/dynamic/unet_fast_s64.yaml (ch=256, mult [1,2,4], 8 heads -> head dim 128) and unetca_fast_s64.yaml
+    (ch=224, mult [1,2,3,4], attention at ds 4 AND 8 -> T = 256 and 64), as shipped (num_heads=32: head dims 21 / 28) and
+    with num_head_channels=32: CFG evaluation at B=1 against the CPU oracle on seeded weights"""
     from oracle import unet_ref as U
     from sgdm_amd.synth import synth_batch, weights_from_seed
     from sgdm_amd.unet import UNetModel, UNetModelCA
@@ -137,14 +136,18 @@ def test_s64_widths_vs_oracle(kind):
         batch = synth_batch("cluster", 1, 64, 1000, 0, seed=3)
         cond, layout = batch["cond"], None
     else:
+        # "unetca_fast_s64": the yaml AS SHIPPED (num_heads: 32 -> 672 / 32 = 21 and 896 / 32 = 28 channels per head,
+        # openaimodel_ca.py:671-693) with the README's cond_token_num / context_dim overrides; the attention core runs these
+        # head widths zero-padded to 32.  "_hc32": num_head_channels=32 instead (21 / 28 heads of 32).
+        heads = dict(num_heads=32, num_head_channels=-1) if kind == "unetca_fast_s64" else dict(num_heads=-1, num_head_channels=32)
         kw = dict(image_size=64, in_channels=3, out_channels=3, model_channels=224, num_res_blocks=2, channel_mult=[1, 2, 3, 4],
-                  attention_resolutions=[4, 8], num_heads=-1, num_head_channels=32, use_scale_shift_norm=True, use_ca_block=True,
+                  attention_resolutions=[4, 8], **heads, use_scale_shift_norm=True, use_ca_block=True,
                   legacy=False,
                   dropout=0.0, cond_token_num=1, cond_dim=27, context_dim=32, use_cls_token_as_pooled=True,
                   condition_method="stegoclusterlayout")
         m = UNetModelCA(condition=AttrDict(scale_type="imagen", stegoclusterlayout=AttrDict(layout_dim=27)), **kw)
         cfg = U.make_cfg("unetca_fast", 64, model_channels=224, channel_mult=(1, 2, 3, 4), attention_resolutions=(4, 8),
-                         num_heads=-1, num_head_channels=32, cond_dim=27, condition_method="stegoclusterlayout", layout_dim=27, cond_token_num=1,
+                         **heads, cond_dim=27, condition_method="stegoclusterlayout", layout_dim=27, cond_token_num=1,
                          context_dim=32)
         batch = synth_batch("stegoclusterlayout", 1, 64, 27, 27, seed=3)
         cond, layout = batch["cond"].float(), batch["layout"]
