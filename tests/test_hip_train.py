@@ -646,7 +646,10 @@ def test_train_step_with_zero_padded_attention_heads_vs_oracle(prec, tol):
         if w[name].grad is None:
             continue
         assert p.grad is not None, name
+        if float(w[name].grad.abs().max()) < 1e-6:     # conv bias in front of a GroupNorm: the true gradient is zero
+            assert float(p.grad.abs().max()) < 1e-5, name
+            continue
         err = max_rel(p.grad.cpu(), w[name].grad)
         assert err < tol, (name, err)
         checked += 1
-    assert checked > 60 and any(".to_q." in k for k in trainable)
+    assert checked > 50 and any(".to_q." in k for k in trainable)
