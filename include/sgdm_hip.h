@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define SGD_ABI_VERSION 8
+#define SGD_ABI_VERSION 9
 int sgd_abi_version(void);
 
 /* --------------------------------------------------------------------------------------
@@ -355,6 +355,18 @@ int sgd_ln_bwd(const float* x, const float* g, const float* gamma, int32_t rows,
 int sgd_resample_bwd(const float* g, int32_t n, int32_t h, int32_t w, int32_t c, int32_t mode, float* dst,
                      int32_t accumulate, void* stream);
 
+/* attention_ldm.CrossAttention / LinearCrossAttention (dynamic/attention_ldm.py:198-298), SURVEY row A23.
+ * sgd_attention_masked: sgd_attention's exact-fp32 core with a per-key validity mask kmask[batch, tk] (bytes, 1 = attend):
+ * a masked key gets weight 0, the result of sim.masked_fill(~mask, -FLT_MAX) before the softmax (:246-249); key 0 (the
+ * null key the module prepends, always valid) must be unmasked.
+ * sgd_linear_attention: out = (softmax over channels of q) * scale . (softmax over KEYS of k)^T v per (batch, head)
+ * (:283-296), masked keys taking k = -FLT_MAX, v = 0; out has q's head layout (head stride q_hs, row stride out_ld). */
+int sgd_attention_masked(const float* q, int32_t q_ld, int32_t q_hs, const float* k, const float* v, int32_t kv_ld,
+                         int32_t kv_hs, const uint8_t* kmask, int32_t batch, int32_t heads, int32_t tq, int32_t tk, int32_t d,
+                         float scale, float* out, int32_t out_ld, float* lse, void* stream);
+int sgd_linear_attention(const float* q, int32_t q_ld, int32_t q_hs, const float* k, const float* v, int32_t kv_ld,
+                         int32_t kv_hs, const uint8_t* kmask, int32_t batch, int32_t heads, int32_t tq, int32_t tk, int32_t d,
+                         float scale, float* out, int32_t out_ld, void* stream);
 /* legacy QKV attention backward (autograd of openaimodel.py:403-420), same addressing as sgd_attention:
  * dq/dk/dv are written with the same row strides / head strides as q/k/v (i.e. into a gqkv tensor).
  * Multi-query (kv_hs == 0, crossattetion_lr.py:115-137): dk/dv are summed over the heads inside the kernel. */

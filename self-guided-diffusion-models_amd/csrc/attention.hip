@@ -22,7 +22,11 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
                                                         const float* __restrict__ k, const float* __restrict__ v,
                                                         int kv_ld, int kv_hs, int tq, int tk, float scale,
                                                         float* __restrict__ out, int out_ld,
-                                                        float* __restrict__ lse) {
+                                                        float* __restrict__ lse,
+                                                        const uint8_t* __restrict__ kmask = nullptr) {
+    // kmask [batch, tk], 1 = attend (sgd_attention_masked): a masked key gets -inf like the keys past tk, i.e. weight 0
+    // -- the result of masked_fill(~mask, -FLT_MAX) before the softmax (attention_ldm.py:246-249) whenever at least one
+    // key of the row is valid.  Key 0 must be valid (the callers' null key is: the mask is padded with True in front).
     constexpr int LD = D + 4;
     constexpr int DT = (D + 31) / 32;             // 32-row tiles of the O^T accumulator
     constexpr int KT = D > 64 ? 32 : 64;          // keys per LDS tile (head dim 128 of the *_s64 widths: 2 x 32 x 132 floats)
@@ -90,7 +94,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int key = kt0 + st * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (key >= tk) sacc[r] = -INFINITY;
+                if (key >= tk || (kmask && !kmask[(long)b * tk + key])) sacc[r] = -INFINITY;
                 mx = fmaxf(mx, sacc[r]);
             }
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
@@ -551,6 +555,67 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Linear attention core of attention_ldm.LinearCrossAttention (dynamic/attention_ldm.py:261-298): per (batch, head)
+//   q~ = softmax_d(q) * scale        k~ = softmax over the KEYS of k (column-wise)        out = q~ (k~^T v)
+// with masked keys taking k = -FLT_MAX (weight exactly 0 after the softmax) and v = 0.  A handful of context tokens x a
+// 16..128-wide head: one block per (batch, head) keeps k~^T v (d x d) in LDS; pure fp32 FMA (the reference runs these
+// einsums in fp32), nothing here is MFMA-shaped.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void linear_attention_kernel(const float* __restrict__ q, int q_ld, int q_hs,
+                                                               const float* __restrict__ k, const float* __restrict__ v,
+                                                               int kv_ld, int kv_hs, int tq, int tk, int d, float scale,
+                                                               const uint8_t* __restrict__ kmask,
+                                                               float* __restrict__ out, int out_ld) {
+    extern __shared__ float sh[];                    // ctx[d][d + 1] | cmax[d] | csum[d]
+    float* ctx = sh;
+    float* cmax = sh + d * (d + 1);
+    float* csum = cmax + d;
+    const int head = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const float* kb = k + (long)b * tk * kv_ld + head * kv_hs;
+    const float* vb = v + (long)b * tk * kv_ld + head * kv_hs;
+    const uint8_t* mb = kmask ? kmask + (long)b * tk : nullptr;
+    // column softmax statistics of k over the keys
+    for (int c = tid; c < d; c += 256) {
+        float m = -INFINITY;
+        for (int j = 0; j < tk; ++j) m = fmaxf(m, (mb && !mb[j]) ? -3.402823466e38f : kb[(long)j * kv_ld + c]);
+        float sum = 0.f;
+        for (int j = 0; j < tk; ++j) sum += __expf(((mb && !mb[j]) ? -3.402823466e38f : kb[(long)j * kv_ld + c]) - m);
+        cmax[c] = m;
+        csum[c] = sum;
+    }
+    __syncthreads();
+    // ctx[c][e] = sum_j k~[j][c] v[j][e]
+    for (int i = tid; i < d * d; i += 256) {
+        const int c = i / d, e = i % d;
+        float acc = 0.f;
+        for (int j = 0; j < tk; ++j) {
+            const bool ok = !mb || mb[j];
+            const float kk = ok ? kb[(long)j * kv_ld + c] : -3.402823466e38f;
+            const float vv = ok ? vb[(long)j * kv_ld + e] : 0.f;
+            acc += __expf(kk - cmax[c]) / csum[c] * vv;
+        }
+        ctx[c * (d + 1) + e] = acc;
+    }
+    __syncthreads();
+    // one query row per thread: feature softmax, then the d x d product
+    for (int i = tid; i < tq; i += 256) {
+        const float* qp = q + ((long)b * tq + i) * q_ld + head * q_hs;
+        float m = -INFINITY;
+        for (int c = 0; c < d; ++c) m = fmaxf(m, qp[c]);
+        float sum = 0.f;
+        for (int c = 0; c < d; ++c) sum += __expf(qp[c] - m);
+        const float inv = scale / sum;
+        float* op = out + ((long)b * tq + i) * out_ld + head * q_hs;
+        for (int e = 0; e < d; ++e) {
+            float acc = 0.f;
+            for (int c = 0; c < d; ++c) acc += __expf(qp[c] - m) * inv * ctx[c * (d + 1) + e];
+            op[e] = acc;
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int sgd_attention(const float* q, int32_t q_ld, int32_t q_hs, const float* k, const float* v,
@@ -617,5 +682,38 @@ extern "C" int sgd_attention_bwd(const float* q, int32_t q_ld, int32_t q_hs, con
         default: return SGD_ERR_ARG;
     }
 #undef SGD_ATTN_BWD
+    return sgd_check_launch();
+}
+
+// attention with a per-key validity mask (exact fp32 core): kmask [batch, tk] bytes, 1 = attend; key 0 must be valid
+extern "C" int sgd_attention_masked(const float* q, int32_t q_ld, int32_t q_hs, const float* k, const float* v,
+                                    int32_t kv_ld, int32_t kv_hs, const uint8_t* kmask, int32_t batch, int32_t heads,
+                                    int32_t tq, int32_t tk, int32_t d, float scale, float* out, int32_t out_ld, float* lse,
+                                    void* stream) {
+    SGD_CLEAR_ERR();
+    if (!q || !k || !v || !out || batch <= 0 || heads <= 0 || tq <= 0 || tk <= 0) return SGD_ERR_ARG;
+    if ((q_ld & 3) || (q_hs & 3) || (kv_ld & 3) || (kv_hs & 3)) return SGD_ERR_ARG;
+    if ((((uintptr_t)q) | ((uintptr_t)k) | ((uintptr_t)v)) & 15) return SGD_ERR_ARG;
+    dim3 grid((tq + 127) / 128, heads, batch);
+    hipStream_t st = (hipStream_t)stream;
+    switch (d) {
+        case 16: hipLaunchKernelGGL((attention_kernel<16>), grid, dim3(256), 0, st, q, q_ld, q_hs, k, v, kv_ld, kv_hs, tq, tk, scale, out, out_ld, lse, kmask); break;
+        case 32: hipLaunchKernelGGL((attention_kernel<32>), grid, dim3(256), 0, st, q, q_ld, q_hs, k, v, kv_ld, kv_hs, tq, tk, scale, out, out_ld, lse, kmask); break;
+        case 64: hipLaunchKernelGGL((attention_kernel<64>), grid, dim3(256), 0, st, q, q_ld, q_hs, k, v, kv_ld, kv_hs, tq, tk, scale, out, out_ld, lse, kmask); break;
+        case 128: hipLaunchKernelGGL((attention_kernel<128>), grid, dim3(256), 0, st, q, q_ld, q_hs, k, v, kv_ld, kv_hs, tq, tk, scale, out, out_ld, lse, kmask); break;
+        default: return SGD_ERR_ARG;
+    }
+    return sgd_check_launch();
+}
+
+extern "C" int sgd_linear_attention(const float* q, int32_t q_ld, int32_t q_hs, const float* k, const float* v,
+                                    int32_t kv_ld, int32_t kv_hs, const uint8_t* kmask, int32_t batch, int32_t heads,
+                                    int32_t tq, int32_t tk, int32_t d, float scale, float* out, int32_t out_ld,
+                                    void* stream) {
+    SGD_CLEAR_ERR();
+    if (!q || !k || !v || !out || batch <= 0 || heads <= 0 || tq <= 0 || tk <= 0 || d <= 0 || d > 128) return SGD_ERR_ARG;
+    const size_t smem = ((size_t)d * (d + 1) + 2 * d) * sizeof(float);
+    hipLaunchKernelGGL(linear_attention_kernel, dim3(heads, batch), dim3(256), smem, (hipStream_t)stream, q, q_ld, q_hs, k,
+                       v, kv_ld, kv_hs, tq, tk, d, scale, kmask, out, out_ld);
     return sgd_check_launch();
 }

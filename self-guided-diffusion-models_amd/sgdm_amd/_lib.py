@@ -20,7 +20,7 @@ RS_NONE, RS_AVGPOOL2, RS_UP2, RS_ZEROUP2 = 0, 1, 2, 3
 PRO_NONE, PRO_AFFINE_NC, PRO_LN_ROW = 0, 1, 2
 PREC_F32, PREC_F16X3, PREC_BF16X3 = 0, 1, 2
 PREC_BY_NAME = {"f32": PREC_F32, "f16x3": PREC_F16X3, "bf16x3": PREC_BF16X3}
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
@@ -58,6 +58,8 @@ SIGNATURES = {
     "sgd_ln_apply": (i32, [vp, vp, vp, vp, i32, i32, f32, vp, vp]),
     "sgd_attention": (i32, [vp, i32, i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, vp, i32, vp, vp]),
     "sgd_attention_split": (i32, [vp, i32, i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, vp, i32, vp, vp]),
+    "sgd_attention_masked": (i32, [vp, i32, i32, vp, vp, i32, i32, vp, i32, i32, i32, i32, i32, f32, vp, i32, vp, vp]),
+    "sgd_linear_attention": (i32, [vp, i32, i32, vp, vp, i32, i32, vp, i32, i32, i32, i32, i32, f32, vp, i32, vp]),
     "sgd_attention_bwd": (i32, [vp, i32, i32, vp, vp, i32, i32, vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, i32, f32,
                               vp, vp, vp, vp]),
     "sgd_pack_weight_dgrad": (i32, [vp, vp, i32, i32, i32, i32, C.POINTER(i32), C.POINTER(i32), vp]),
