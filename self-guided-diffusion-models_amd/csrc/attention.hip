@@ -89,12 +89,24 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
 #pragma unroll
                 for (int j = 0; j < 4; ++j) sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[j], qreg[s][j], sacc, 0, 0, 0);
             }
-            // mask keys beyond tk, tile max
+            // mask keys beyond tk (and the caller's masked keys), tile max.  The mask bytes are gathered into a bit set
+            // first, from clamped addresses: written as one short-circuit condition around the element assignment
+            // (key >= tk || (kmask && !kmask[..])) hipcc 7.2 dropped the assignment for the masked lanes altogether.
+            unsigned dead = 0;
+            if (kmask) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kt0 + st * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    const uint8_t keep = kmask[(long)b * tk + (key < tk ? key : tk - 1)];
+                    dead |= (keep ? 0u : 1u) << r;
+                }
+            }
             float mx = -INFINITY;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int key = kt0 + st * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (key >= tk || (kmask && !kmask[(long)b * tk + key])) sacc[r] = -INFINITY;
+                const bool drop = key >= tk || ((dead >> r) & 1u);
+                sacc[r] = drop ? -INFINITY : sacc[r];
                 mx = fmaxf(mx, sacc[r]);
             }
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
