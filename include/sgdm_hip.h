@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define SGD_ABI_VERSION 9
+#define SGD_ABI_VERSION 10
 int sgd_abi_version(void);
 
 /* --------------------------------------------------------------------------------------
@@ -305,6 +305,14 @@ int sgd_pack_weight_dgrad(const float* w_src, void* w_dst, int32_t cout_fwd, int
  * the gy rows the kernel stages anyway; fold with sgd_colsum_fold. */
 int sgd_wgrad(const sgd_igemm_args* fwd /* HOST */, const float* gy, int32_t gy_ld, int32_t cout,
               float* slabs, int32_t ksplit, float* bias_slabs, void* stream);
+/* sgd_wgrad with a scratch buffer (DEVICE, sgd_wgrad_scratch_bytes(fwd, cout) bytes; any launch may reuse it): 3x3 stride-1
+ * convolutions in the split-precision modes first write the gradient rows and the activated input once as 16-bit hi / lo
+ * planes (two element-wise passes) and the weight-gradient kernel's loader waves only copy them -- without it every block
+ * repeats the GroupNorm-affine + SiLU + split of its operands (cin / 32 resp. cout / 128 times per element).  Same
+ * results bit for bit; cases the planes form does not cover run exactly as sgd_wgrad. */
+int64_t sgd_wgrad_scratch_bytes(const sgd_igemm_args* fwd /* HOST pointer */, int32_t cout);
+int sgd_wgrad_scratch(const sgd_igemm_args* fwd /* HOST pointer */, const float* gy, int32_t gy_ld, int32_t cout,
+                      float* slabs, int32_t ksplit, float* bias_slabs, void* scratch, int64_t scratch_bytes, void* stream);
 /* out[c] (+)= scale * sum_k partial[k, c]   (fixed order, double accumulation) */
 int sgd_colsum_fold(const float* partial, int32_t chunks, int32_t c, float* out, int32_t accumulate, float scale,
                     void* stream);

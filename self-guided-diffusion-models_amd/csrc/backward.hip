@@ -28,6 +28,9 @@ struct WArgs {
     int gy_ld, cout, ksplit, taps, rows, co_tiles, ci_tiles, ktiles, hc, wc, wo_l2, ho_l2, gvec;
     float* slabs;
     float* bslab;               // [ksplit][cout] partial column sums of gy (bias gradient), or NULL
+    // wave-specialised kernel with pre-split operands (split_rows_kernel / act_split_kernel): 16-bit hi / lo planes of the
+    // gradient [rows][cout] and of the activated input [source rows][cin]
+    const void* gh; const void* gl; const void* uh; const void* ul;
 };
 
 template <bool VEC>
@@ -437,6 +440,436 @@ __global__ __launch_bounds__(256, 2) void wgrad_conv_kernel(const WArgs w) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Pre-passes of the wave-specialised weight-gradient kernel below.  Its loader waves can issue about one vector
+// instruction per 16 cycles next to the MFMA waves; the GroupNorm-affine + SiLU + hi / lo split of the input halo and the
+// split of the gradient rows cost ~450 of them per K tile against a 3.5k-cycle MFMA phase -- and every block repeats the
+// gradient split for its 32 input channels (cin / 32 times per element) and the input transform for its 128 output
+// channels (cout / 128 times).  The two element-wise kernels here do that arithmetic ONCE per element, into 16-bit hi / lo
+// planes ([row][channel], 2 + 2 bytes per element: the size of the fp32 tensor); the loaders then only copy.
+// Measured on the C2 training step (bs 80): the transforms cost 11.5 of the 22.5 ms of weight-gradient time.
+// ---------------------------------------------------------------------------------------------
+template <int PREC>
+__global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict__ g, long rows, int c, int ld,
+                                                         typename Split<PREC>::T* __restrict__ hi,
+                                                         typename Split<PREC>::T* __restrict__ lo, int chunks,
+                                                         float* __restrict__ colsum) {
+    // block = 128 channels (32 quads) x 8 row lanes over the rows of chunk blockIdx.y; colsum[chunk][c] = column sums of
+    // the chunk (the bias gradient's partial sums, same layout as sgd_wgrad's bias_slabs), or NULL
+    typedef typename Split<PREC>::T T;
+    typedef T T4 __attribute__((ext_vector_type(4)));
+    const int q = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const int col = blockIdx.x * 128 + q * 4;
+    const long per = (rows + chunks - 1) / chunks;
+    const long r0 = blockIdx.y * per, r1 = (r0 + per < rows) ? r0 + per : rows;
+    f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+    if (col < c) {
+        for (long r = r0 + rl; r < r1; r += 32) {
+            f32x4 v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const long rr = r + 8 * j < r1 ? r + 8 * j : r1 - 1;
+                v[j] = ld4(g + rr * ld + col);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (r + 8 * j >= r1) break;
+                sum += v[j];
+                T* hp = hi + (r + 8 * j) * c + col;
+                T* lp = lo + (r + 8 * j) * c + col;
+                if constexpr (PREC == SGD_PREC_F16X3) {
+                    u32x2 h, l;
+                    split4_f16(v[j], h, l);
+                    *reinterpret_cast<u32x2*>(hp) = h;
+                    *reinterpret_cast<u32x2*>(lp) = l;
+                } else {
+                    T4 h, l;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { T he, le; Split<PREC>::split(v[j][e], he, le); h[e] = he; l[e] = le; }
+                    *reinterpret_cast<T4*>(hp) = h;
+                    *reinterpret_cast<T4*>(lp) = l;
+                }
+            }
+        }
+    }
+    if (colsum) {
+        __shared__ float red[8][128];
+        *reinterpret_cast<f32x4*>(&red[rl][q * 4]) = sum;
+        __syncthreads();
+        if (threadIdx.x < 128 && blockIdx.x * 128 + threadIdx.x < c) {
+            float t = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t += red[k][threadIdx.x];
+            colsum[(long)blockIdx.y * c + blockIdx.x * 128 + threadIdx.x] = t;
+        }
+    }
+}
+
+// bslab[0][c] = sum over chunks of part[chunk][c] (fixed order), bslab[1 .. ksplit-1][c] = 0
+// block = 32 columns x 8 chunk lanes (eight independent loads in flight per lane, fixed order of additions)
+__global__ __launch_bounds__(256) void colsum_fold_rows_kernel(const float* __restrict__ part, int chunks, int c,
+                                                              float* __restrict__ bslab, int ksplit) {
+    const int col = blockIdx.x * 32 + (threadIdx.x & 31), kl = threadIdx.x >> 5;
+    float t = 0.f;
+    if (col < c) {
+        int k = kl;
+        for (; k + 56 < chunks; k += 64) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = part[(long)(k + 8 * j) * c + col];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t += v[j];
+        }
+        for (; k < chunks; k += 8) t += part[(long)k * c + col];
+    }
+    __shared__ float red[8][32];
+    red[kl][threadIdx.x & 31] = t;
+    __syncthreads();
+    if (threadIdx.x < 32 && col < c) {
+        float u = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) u += red[j][threadIdx.x];
+        bslab[col] = u;
+        for (int k = 1; k < ksplit; ++k) bslab[(long)k * c + col] = 0.f;
+    }
+}
+
+// activated conv input (virtual concat x0 | x1, GroupNorm affine, SiLU, train-time dropout: apply_pro) as hi / lo planes
+// [source row][cin]; resampling stays in the consumer's index map
+template <int PREC>
+__global__ __launch_bounds__(256) void act_split_kernel(const sgd_igemm_args a, long rows, int rows_per_n,
+                                                        typename Split<PREC>::T* __restrict__ hi,
+                                                        typename Split<PREC>::T* __restrict__ lo) {
+    typedef typename Split<PREC>::T T;
+    typedef T T4 __attribute__((ext_vector_type(4)));
+    const int cin = a.c0 + a.c1, cq = cin >> 2;
+    const long total = rows * cq;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long row = i / cq;
+        const int c = (int)(i - row * cq) * 4;
+        const int n = (int)(row / rows_per_n);
+        const f32x4 v = apply_pro(a, load_raw<true>(a, row, c), load_coef<true>(a, n, row, c), c, row);
+        T* hp = hi + row * cin + c;
+        T* lp = lo + row * cin + c;
+        if constexpr (PREC == SGD_PREC_F16X3) {
+            u32x2 h, l;
+            split4_f16(v, h, l);
+            *reinterpret_cast<u32x2*>(hp) = h;
+            *reinterpret_cast<u32x2*>(lp) = l;
+        } else {
+            T4 h, l;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { T he, le; Split<PREC>::split(v[e], he, le); h[e] = he; l[e] = le; }
+            *reinterpret_cast<T4*>(hp) = h;
+            *reinterpret_cast<T4*>(lp) = l;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Wave-specialised form of the 3x3 weight-gradient kernel (round 3).  The kernel above stages a K tile, waits, runs
+// its 108 MFMAs per wave, waits, stages the next: the matrix pipe sat idle through two memory latencies and ~300
+// vector instructions per tile (27..40 % busy even with two blocks per CU taking turns).  Here a block is 8 waves on
+// one CU: waves 0-3 only multiply (tile i from LDS slot i & 1), waves 4-7 only stage (tile i + 1 into the other slot:
+// GroupNorm affine + SiLU, hi / lo split) with the raw rows of tile i + 2 already requested -- the conv kernel's
+// loader / compute structure, one s_barrier per tile, every load consumed a whole tile period after its issue.
+// Fast cases only (16-byte gradient rows of a full 128-channel block, stride 1, no avg-pool, GroupNorm-affine or no
+// prologue); everything else takes the kernel above.  Same arithmetic, same slab layout, same results bit for bit.
+// ---------------------------------------------------------------------------------------------
+template <int PREC, bool PLANES>
+__global__ __launch_bounds__(512) void wgrad_conv_ws_kernel(const WArgs w) {
+    typedef typename Split<PREC>::T T;
+    typedef T T4 __attribute__((ext_vector_type(4)));
+    typedef T T8 __attribute__((ext_vector_type(8)));
+    typedef short s4 __attribute__((ext_vector_type(4)));
+    constexpr int UPITCH = 32;
+    constexpr int SLOT = 2 * 64 * FGP + 2 * 100 * UPITCH;          // 16-bit elements of one K tile: Gh | Gl | Uh | Ul
+    const sgd_igemm_args& a = w.a;
+    extern __shared__ __attribute__((aligned(16))) unsigned char wsm[];
+    T* const base = reinterpret_cast<T*>(wsm);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    int bid = blockIdx.x;
+    const int ks = bid % w.ksplit; bid /= w.ksplit;
+    const int cit = bid % w.ci_tiles; bid /= w.ci_tiles;
+    const int cot = bid;
+    const int co0 = cot * WT, ci0 = cit * 32;
+    const int cin = a.c0 + a.c1;
+    const int pw = a.wo >> 3, ppi = pw * (a.ho >> 3);             // 8x8 patches per row / per image
+    const int nk = ks < w.ktiles ? (w.ktiles - ks + w.ksplit - 1) / w.ksplit : 0;     // K tiles of this block
+
+    if (tid >= 256) {
+        // =============================== loader waves: global -> transform -> LDS ===============================
+        const int lt = tid - 256;
+        auto split_store = [&](T* hp, T* lp, f32x4 v) {
+            if constexpr (PREC == SGD_PREC_F16X3) {
+                u32x2 h, l;
+                split4_f16(v, h, l);
+                *reinterpret_cast<u32x2*>(hp) = h;
+                *reinterpret_cast<u32x2*>(lp) = l;
+            } else {
+                T4 h, l;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { T hj, lj; Split<PREC>::split(v[j], hj, lj); h[j] = hj; l[j] = lj; }
+                *reinterpret_cast<T4*>(hp) = h;
+                *reinterpret_cast<T4*>(lp) = l;
+            }
+        };
+        // The loader waves share their SIMDs' vector issue with waves that always have an MFMA waiting: every vector
+        // instruction here costs ~16 cycles of the tile period (measured on the conv kernel's loaders), so the per-tile
+        // index arithmetic is hoisted -- a thread's rows inside a patch and its halo pixels never change.
+        __builtin_amdgcn_s_setprio(2);
+        // raw data of the tile being fetched (requested one period before it is transformed)
+        f32x4 gv[8], ur[4];
+        long rrs[4];
+        Coef ukq;
+        int rn = 0, ry0 = 0, rx0 = 0;                              // patch of the requested tile
+        const int gq = lt & 31, gr0 = lt >> 5;                    // gradient rows: channel quad, first row
+        const int uq = lt & 7, uc = ci0 + uq * 4, ucc = uc < cin ? uc : 0;
+        const float* gcol = w.gy + co0 + gq * 4;
+        // row j of this thread inside an 8x8 patch: patch row j (r = gr0 + 8 j -> r >> 3 = j), patch column gr0
+        const long gstep = (long)a.wo * w.gy_ld;                   // one patch row down
+        int hys[4], hxs[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int hp = (lt >> 3) + j * 32;
+            hys[j] = hp / 10 - 1;
+            hxs[j] = hp - (hp / 10) * 10 - 1;
+        }
+        // PLANES: the operands arrive already split (pre-pass kernels above): 8 + 8 bytes per item, copied as they are
+        u32x2 gph[8], gpl[8], uph[4], upl[4];
+        const T* const ghp = reinterpret_cast<const T*>(w.gh) + co0 + gq * 4;
+        const T* const glp = reinterpret_cast<const T*>(w.gl) + co0 + gq * 4;
+        const T* const uhp = reinterpret_cast<const T*>(w.uh) + ucc;
+        const T* const ulp = reinterpret_cast<const T*>(w.ul) + ucc;
+        auto request = [&](int i) {                                // i-th K tile of this block (clamped: harmless duplicates)
+            const int kt = ks + (i < nk ? i : nk - 1) * w.ksplit;
+            rn = kt / ppi;
+            const int pr = kt - rn * ppi;
+            ry0 = (pr / pw) * 8;
+            rx0 = (pr - (pr / pw) * pw) * 8;
+            if constexpr (PLANES) {
+                const long r0 = (((long)rn * a.ho + ry0) * a.wo + rx0 + gr0) * w.cout;
+                const long rstep = (long)a.wo * w.cout;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    gph[j] = *reinterpret_cast<const u32x2*>(ghp + r0 + j * rstep);
+                    gpl[j] = *reinterpret_cast<const u32x2*>(glp + r0 + j * rstep);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    int y = ry0 + hys[j], x = rx0 + hxs[j];
+                    y = y < 0 ? 0 : (y >= w.hc ? w.hc - 1 : y);
+                    x = x < 0 ? 0 : (x >= w.wc ? w.wc - 1 : x);
+                    const long rr = a.resample == SGD_RS_UP2 ? ((long)rn * a.hi + (y >> 1)) * a.wi + (x >> 1) : ((long)rn * a.hi + y) * a.wi + x;
+                    uph[j] = *reinterpret_cast<const u32x2*>(uhp + rr * cin);
+                    upl[j] = *reinterpret_cast<const u32x2*>(ulp + rr * cin);
+                }
+                return;
+            }
+            const float* g0 = gcol + (((long)rn * a.ho + ry0) * a.wo + rx0 + gr0) * w.gy_ld;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) gv[j] = ld4(g0 + j * gstep);
+            ukq = load_coef<true>(a, rn, 0, ucc);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                int y = ry0 + hys[j], x = rx0 + hxs[j];
+                y = y < 0 ? 0 : (y >= w.hc ? w.hc - 1 : y);
+                x = x < 0 ? 0 : (x >= w.wc ? w.wc - 1 : x);
+                rrs[j] = a.resample == SGD_RS_UP2 ? ((long)rn * a.hi + (y >> 1)) * a.wi + (x >> 1) : ((long)rn * a.hi + y) * a.wi + x;
+                ur[j] = load_raw<true>(a, rrs[j], ucc);
+            }
+        };
+        f32x4 bsum = {0.f, 0.f, 0.f, 0.f};                         // bias gradient: column sums of the staged gy rows
+        auto finish = [&](int slot, float live) {                  // transform the fetched tile into LDS slot `slot`
+            T* Gh = base + slot * SLOT;
+            T* Gl = Gh + 64 * FGP;
+            T* Uh = Gl + 64 * FGP;
+            T* Ul = Uh + 100 * UPITCH;
+            if constexpr (PLANES) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int r = gr0 + j * 8;
+                    *reinterpret_cast<u32x2*>(Gh + r * FGP + gq * 4) = gph[j];
+                    *reinterpret_cast<u32x2*>(Gl + r * FGP + gq * 4) = gpl[j];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int hp = (lt >> 3) + j * 32;
+                    if (hp >= 100) break;
+                    const int y = ry0 + hys[j], x = rx0 + hxs[j];
+                    const bool ok = uc < cin && y >= 0 && y < w.hc && x >= 0 && x < w.wc;     // zero padding of the conv
+                    u32x2 h = uph[j], l = upl[j];
+                    if (!ok) { h.x = h.y = 0; l.x = l.y = 0; }
+                    *reinterpret_cast<u32x2*>(Uh + hp * UPITCH + uq * 4) = h;
+                    *reinterpret_cast<u32x2*>(Ul + hp * UPITCH + uq * 4) = l;
+                }
+                (void)live;
+                return;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int r = gr0 + j * 8;
+#if defined(SGDM_WS_ABL) && (SGDM_WS_ABL & 1)      /* timing experiment: gradient rows stored without the split arithmetic */
+                *reinterpret_cast<float2*>(Gh + r * FGP + gq * 4) = float2{gv[j][0], gv[j][1]};
+                *reinterpret_cast<float2*>(Gl + r * FGP + gq * 4) = float2{gv[j][2], gv[j][3]};
+#else
+                split_store(Gh + r * FGP + gq * 4, Gl + r * FGP + gq * 4, gv[j]);
+                bsum += gv[j] * live;                              // (a clamped duplicate past the block's last tile: x 0)
+#endif
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int hp = (lt >> 3) + j * 32;
+                if (hp >= 100) break;
+                const int y = ry0 + hys[j], x = rx0 + hxs[j];
+#if defined(SGDM_WS_ABL) && (SGDM_WS_ABL & 2)      /* timing experiment: input rows stored without transform / split */
+                *reinterpret_cast<float2*>(Uh + hp * UPITCH + uq * 4) = float2{ur[j][0], ur[j][1]};
+                *reinterpret_cast<float2*>(Ul + hp * UPITCH + uq * 4) = float2{ur[j][2], ur[j][3]};
+                (void)y; (void)x;
+#else
+                f32x4 uv = apply_pro(a, ur[j], ukq, ucc, rrs[j]);
+                if (!(uc < cin && y >= 0 && y < w.hc && x >= 0 && x < w.wc)) uv = f32x4{0.f, 0.f, 0.f, 0.f};
+                split_store(Uh + hp * UPITCH + uq * 4, Ul + hp * UPITCH + uq * 4, uv);
+#endif
+            }
+        };
+        if (nk > 0) {
+            request(0);
+            finish(0, 1.f);
+            request(1);
+        }
+        __syncthreads();                                           // barrier 0: slot 0 holds tile 0
+        for (int i = 0; i < nk; ++i) {
+            finish((i + 1) & 1, i + 1 < nk ? 1.f : 0.f);           // tile i + 1 (fetched during the previous period)
+            request(i + 2);
+            __syncthreads();                                       // barrier i + 1
+        }
+        // bias gradient: fold the 8 row lanes of every co quad through LDS (the slots are free now)
+        float* red = reinterpret_cast<float*>(wsm);                // [8][128]
+        if (!PLANES && w.bslab && cit == 0) *reinterpret_cast<f32x4*>(red + (lt >> 5) * 128 + (lt & 31) * 4) = bsum;
+        __syncthreads();
+        if (!PLANES && w.bslab && cit == 0 && lt < 128) {         // (PLANES: the split pre-pass wrote the column sums)
+            float t = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t += red[k * 128 + lt];
+            if (co0 + lt < w.cout) w.bslab[(long)ks * w.cout + co0 + lt] = t;
+        }
+        return;
+    }
+
+    // =================================== compute waves: LDS -> MFMA ===================================
+    const int li = lane & 31, lh = lane >> 5;
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    const int gidx = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+    const int kbase = 8 * (gidx >> 1) + q;
+    const int chl = 16 * (gidx & 1) + 4 * pp;
+    auto trd = [&](const T* p) -> T4 {
+        s4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)p);
+        return __builtin_bit_cast(T4, v);
+    };
+    __syncthreads();                                               // barrier 0
+    for (int i = 0; i < nk; ++i) {
+        const T* Gh = base + (i & 1) * SLOT;
+        const T* Gl = Gh + 64 * FGP;
+        const T* Uh = Gl + 64 * FGP;
+        const T* Ul = Uh + 100 * UPITCH;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int k0 = 16 * s + kbase;
+            T8 ah, al;
+            {
+                const T* g0 = Gh + k0 * FGP + wave * 32 + chl;
+                const T* g1 = Gl + k0 * FGP + wave * 32 + chl;
+                const T4 h0 = trd(g0), h1 = trd(g0 + 4 * FGP), l0 = trd(g1), l1 = trd(g1 + 4 * FGP);
+                ah = T8{h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+                al = T8{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+            }
+            const int hb = ((k0 >> 3) + 1) * 10 + (k0 & 7) + 1;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int off = ((t / 3 - 1) * 10 + (t % 3 - 1)) * UPITCH;
+                const T* u0 = Uh + hb * UPITCH + off + chl;
+                const T* u1 = Ul + hb * UPITCH + off + chl;
+                const T4 h0 = trd(u0), h1 = trd(u0 + 4 * UPITCH), l0 = trd(u1), l1 = trd(u1 + 4 * UPITCH);
+                const T8 bh = T8{h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+                const T8 bl = T8{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+                if constexpr (PREC == SGD_PREC_F16X3) {
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[t], 0, 0, 0);
+                } else {
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[t], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();                                           // barrier i + 1
+    }
+    __syncthreads();                                               // pairs with the loaders' bias-reduction barrier
+    // ---- slab store: D rows = co (registers), cols = ci (lanes)
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int ci = ci0 + li;
+        if (ci >= cin) continue;
+        float* slab = w.slabs + ((long)ks * 9 + t) * w.cout * cin;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (co < w.cout) slab[(long)co * cin + ci] = acc[t][r];
+        }
+    }
+}
+
+template <int PREC, bool PLANES>
+static void launch_wgrad_ws(const WArgs& w, long grid, hipStream_t st) {
+    constexpr size_t smem = (size_t)2 * (2 * 64 * FGP + 2 * 100 * 32) * 2;         // two K-tile slots
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)wgrad_conv_ws_kernel<PREC, PLANES>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)smem);
+        attr = true;
+    }
+    hipLaunchKernelGGL((wgrad_conv_ws_kernel<PREC, PLANES>), dim3((unsigned)grid), dim3(512), smem, st, w);
+}
+
+// pre-passes + the planes form of the wave-specialised kernel.  scratch: [gh | gl | uh | ul], 2 bytes per element each
+template <int PREC>
+static void launch_wgrad_planes(WArgs& w, long grid, void* scratch, hipStream_t st) {
+    typedef typename Split<PREC>::T T;
+    const sgd_igemm_args& a = w.a;
+    const int cin = a.c0 + a.c1;
+    const long grows = w.rows, urows = (long)a.n * a.hi * a.wi;
+    T* gh = reinterpret_cast<T*>(scratch);
+    T* gl = gh + grows * w.cout;
+    T* uh = gl + grows * w.cout;
+    T* ul = uh + urows * cin;
+    // enough row chunks to fill the chip (the K split of the main kernel can be as small as 2); the bias gradient's column
+    // sums go through per-chunk partials behind the planes and one fold into row 0 of bslab (rows 1.. zeroed: the caller
+    // folds all ksplit rows)
+    const int coltiles = (w.cout + 127) / 128;
+    long chunks = (1024 + coltiles - 1) / coltiles;
+    if (chunks > (grows + 31) / 32) chunks = (grows + 31) / 32;
+    if (chunks < 1) chunks = 1;
+    float* part = w.bslab ? reinterpret_cast<float*>(ul + urows * cin) : nullptr;      // [chunks][cout]
+    hipLaunchKernelGGL((split_rows_kernel<PREC>), dim3(coltiles, (unsigned)chunks), dim3(256), 0, st, w.gy, grows, w.cout,
+                       w.gy_ld, gh, gl, (int)chunks, part);
+    if (w.bslab)
+        hipLaunchKernelGGL(colsum_fold_rows_kernel, dim3((w.cout + 31) / 32), dim3(256), 0, st, part, (int)chunks, w.cout,
+                           w.bslab, w.ksplit);
+    const long quads = urows * (cin / 4);
+    long ablk = (quads + 255) / 256;
+    if (ablk > 16384) ablk = 16384;
+    hipLaunchKernelGGL((act_split_kernel<PREC>), dim3((unsigned)ablk), dim3(256), 0, st, a, urows, a.hi * a.wi, uh, ul);
+    w.gh = gh; w.gl = gl; w.uh = uh; w.ul = ul;
+    launch_wgrad_ws<PREC, true>(w, grid, st);
+}
+
 template <int PREC, bool VEC, int TAPS>
 static void launch_wgrad_fast(const WArgs& w, long grid, hipStream_t st) {
     constexpr size_t smem = (2 * 64 * FGP + 2 * (TAPS == 9 ? 100 * 32 : 64 * FGP)) * 2;
@@ -759,8 +1192,8 @@ inline unsigned nblk(long total, int cap = 1 << 20) {
 
 }  // namespace
 
-extern "C" int sgd_wgrad(const sgd_igemm_args* fwd, const float* gy, int32_t gy_ld, int32_t cout, float* slabs,
-                         int32_t ksplit, float* bias_slabs, void* stream) {
+static int wgrad_impl(const sgd_igemm_args* fwd, const float* gy, int32_t gy_ld, int32_t cout, float* slabs,
+                      int32_t ksplit, float* bias_slabs, void* scratch, int64_t scratch_bytes, void* stream) {
     SGD_CLEAR_ERR();
     if (!fwd || !gy || !slabs || cout <= 0 || ksplit <= 0 || gy_ld < cout) return SGD_ERR_ARG;
     WArgs w;
@@ -804,8 +1237,17 @@ extern "C" int sgd_wgrad(const sgd_igemm_args* fwd, const float* gy, int32_t gy_
         if (fast_conv) w.ci_tiles = (cin + 31) / 32;
         const long fgrid = (long)w.co_tiles * w.ci_tiles * w.ksplit;
         if (fgrid > 0x7fffffffL) return SGD_ERR_ARG;
+        // wave-specialised kernel: 16-byte gradient rows of whole 128-channel blocks, whole rows (cout % 128 == 0), vector
+        // input rows, GroupNorm-affine / no prologue, no avg-pool, no dropout (its keep mask is recomputed by the other one)
+        const bool ws = fast_conv && vec && w.gvec && cout % WT == 0 && (a.resample == SGD_RS_NONE || a.resample == SGD_RS_UP2)
+                        && (a.pro == SGD_PRO_NONE || a.pro == SGD_PRO_AFFINE_NC) && !getenv("SGDM_WGRAD_OLD");
+        // ... and with a scratch buffer for the pre-split operand planes: the loaders only copy
+        const int64_t need = 4 * ((int64_t)w.rows * cout + (int64_t)a.n * a.hi * a.wi * cin) + 4 * 2048 * (int64_t)cout;
+        const bool planes = ws && scratch && scratch_bytes >= need && !getenv("SGDM_WGRAD_NOPLANES");
 #define SGD_WG(P, V)                                                             \
-        do { if (fast_conv) launch_wgrad_fast<P, V, 9>(w, fgrid, st); else launch_wgrad_fast<P, V, 1>(w, fgrid, st); } while (0)
+        do { if (planes) launch_wgrad_planes<P>(w, fgrid, scratch, st);           \
+             else if (ws) launch_wgrad_ws<P, false>(w, fgrid, st);               \
+             else if (fast_conv) launch_wgrad_fast<P, V, 9>(w, fgrid, st); else launch_wgrad_fast<P, V, 1>(w, fgrid, st); } while (0)
         if (a.prec == SGD_PREC_F16X3) { if (vec) SGD_WG(SGD_PREC_F16X3, true); else SGD_WG(SGD_PREC_F16X3, false); }
         else { if (vec) SGD_WG(SGD_PREC_BF16X3, true); else SGD_WG(SGD_PREC_BF16X3, false); }
 #undef SGD_WG
@@ -819,6 +1261,22 @@ extern "C" int sgd_wgrad(const sgd_igemm_args* fwd, const float* gy, int32_t gy_
     if (vec) hipLaunchKernelGGL((wgrad_kernel<true>), dim3((unsigned)grid), dim3(256), 0, st, w);
     else hipLaunchKernelGGL((wgrad_kernel<false>), dim3((unsigned)grid), dim3(256), 0, st, w);
     return sgd_check_launch();
+}
+
+extern "C" int sgd_wgrad(const sgd_igemm_args* fwd, const float* gy, int32_t gy_ld, int32_t cout, float* slabs,
+                         int32_t ksplit, float* bias_slabs, void* stream) {
+    return wgrad_impl(fwd, gy, gy_ld, cout, slabs, ksplit, bias_slabs, nullptr, 0, stream);
+}
+
+extern "C" int64_t sgd_wgrad_scratch_bytes(const sgd_igemm_args* fwd, int32_t cout) {
+    if (!fwd || fwd->mode != SGD_MODE_CONV3) return 0;
+    const int64_t rows = (int64_t)fwd->n * fwd->ho * fwd->wo, urows = (int64_t)fwd->n * fwd->hi * fwd->wi;
+    return 4 * (rows * cout + urows * (fwd->c0 + fwd->c1)) + 4 * 2048 * (int64_t)cout;   // planes + column-sum partials
+}
+
+extern "C" int sgd_wgrad_scratch(const sgd_igemm_args* fwd, const float* gy, int32_t gy_ld, int32_t cout, float* slabs,
+                                 int32_t ksplit, float* bias_slabs, void* scratch, int64_t scratch_bytes, void* stream) {
+    return wgrad_impl(fwd, gy, gy_ld, cout, slabs, ksplit, bias_slabs, scratch, scratch_bytes, stream);
 }
 
 extern "C" int sgd_wgrad_reduce(const float* slabs, int32_t ksplit, int32_t taps, int32_t cout, int32_t cin,

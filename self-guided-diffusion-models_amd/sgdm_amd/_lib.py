@@ -20,7 +20,7 @@ RS_NONE, RS_AVGPOOL2, RS_UP2, RS_ZEROUP2 = 0, 1, 2, 3
 PRO_NONE, PRO_AFFINE_NC, PRO_LN_ROW = 0, 1, 2
 PREC_F32, PREC_F16X3, PREC_BF16X3 = 0, 1, 2
 PREC_BY_NAME = {"f32": PREC_F32, "f16x3": PREC_F16X3, "bf16x3": PREC_BF16X3}
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
@@ -64,6 +64,8 @@ SIGNATURES = {
                               vp, vp, vp, vp]),
     "sgd_pack_weight_dgrad": (i32, [vp, vp, i32, i32, i32, i32, C.POINTER(i32), C.POINTER(i32), vp]),
     "sgd_wgrad": (i32, [C.POINTER(IgemmArgs), vp, i32, i32, vp, i32, vp, vp]),
+    "sgd_wgrad_scratch_bytes": (i64, [C.POINTER(IgemmArgs), i32]),
+    "sgd_wgrad_scratch": (i32, [C.POINTER(IgemmArgs), vp, i32, i32, vp, i32, vp, vp, i64, vp]),
     "sgd_colsum_fold": (i32, [vp, i32, i32, vp, i32, f32, vp]),
     "sgd_wgrad_reduce": (i32, [vp, i32, i32, i32, i32, vp, i32, f32, vp]),
     "sgd_colsum": (i32, [vp, i32, i32, i32, vp, i32, f32, vp, i32, vp]),

@@ -85,6 +85,27 @@ class _PackedAdj:
         self.sig = sig
 
 
+def wgrad_ksplit(taps, cout, cin, rows):
+    """K split of a weight-gradient launch (sgd_wgrad's grid = co tiles x ci tiles x ksplit).  3x3 convs run as ONE
+    512-thread block per CU (csrc/backward.hip: wgrad_conv_ws_kernel, 32 input channels per block): the split is chosen
+    so that the grid is as close as possible to a whole number of rounds of the 256 CUs with at least ~8 K tiles per
+    block; 1x1 / linear launches (256-thread blocks, two per CU, 128 input channels per block) keep the round-2 rule."""
+    ktiles = (rows + 63) // 64
+    if taps == 9:
+        per_k = ((cout + 127) // 128) * ((cin + 31) // 32)
+        best, best_cost = 1, None
+        for ks in range(1, min(ktiles, 512) + 1):
+            grid = per_k * ks
+            rounds = -(-grid // 256)
+            tiles = -(-ktiles // ks)
+            cost = rounds * (tiles + 3.0)              # + ~3 tile periods of prologue / slab store per block
+            if tiles >= 4 and (best_cost is None or cost < best_cost - 1e-9):
+                best, best_cost = ks, cost
+        return best
+    base = taps * ((cout + 127) // 128) * ((cin + 127) // 128)
+    return max(1, min(ktiles, 1024 // base))
+
+
 class Backward:
     """backward launch program of one engine (unet_fast)"""
 
@@ -178,14 +199,23 @@ class Backward:
         self.prog.add(tag, self.lib.sgd_igemm, C.byref(a))
 
     def wgrad(self, tag, fwd_args, gy, gy_ld, cout, cin, taps, rows, wname, bias_name=None, dw_view=None):
-        base = taps * ((cout + 127) // 128) * ((cin + 127) // 128)
         ktiles = (rows + 63) // 64
-        ksplit = max(1, min(ktiles, 1024 // base))
+        ksplit = wgrad_ksplit(taps, cout, cin, rows)
         slabs = self.buf(ksplit, taps, cout, cin)
         # the bias gradient (column sums of gy) comes out of the same launch: the kernel stages the gy rows anyway
         bslab = self.buf(ksplit, cout) if bias_name is not None else None
-        self.prog.add(tag + ".wgrad", self.lib.sgd_wgrad, C.byref(fwd_args), _ptr(gy), gy_ld, cout, _ptr(slabs), ksplit,
-                      _ptr(bslab) if bslab is not None else None)
+        # 3x3 convs: operands pre-split once into 16-bit planes (scratch shared by every launch of the program, grown to
+        # the largest request before the first run: sgd_wgrad_scratch)
+        need = int(self.lib.sgd_wgrad_scratch_bytes(C.byref(fwd_args), cout)) if taps == 9 else 0
+        self.wscratch_bytes = max(getattr(self, "wscratch_bytes", 0), need)
+        box = self
+
+        def wgrad_launch(stream, fwd_args=fwd_args, gy=gy, slabs=slabs, bslab=bslab):
+            ws = box._wscratch()
+            return box.lib.sgd_wgrad_scratch(C.byref(fwd_args), _ptr(gy), gy_ld, cout, _ptr(slabs), ksplit,
+                                             _ptr(bslab) if bslab is not None else None, _ptr(ws), ws.numel() * 4, stream)
+        wgrad_launch.__name__ = "sgd_wgrad"
+        self.prog.add(tag + ".wgrad", wgrad_launch)
         dw = dw_view if dw_view is not None else self.pg(wname)
         self.prog.add(tag + ".wred", self.lib.sgd_wgrad_reduce, _ptr(slabs), ksplit, taps, cout, cin, _ptr(dw), 0,
                       self.unscale)
@@ -195,6 +225,11 @@ class Backward:
             self.prog.add(tag + ".bias", self.lib.sgd_colsum_fold, _ptr(bslab), ksplit, cout, _ptr(self.pg(bias_name)), 0,
                           self.unscale)
             self.wrote(bias_name)
+
+    def _wscratch(self):
+        if getattr(self, "_wscratch_buf", None) is None or self._wscratch_buf.numel() * 4 < self.wscratch_bytes:
+            self._wscratch_buf = torch.empty(max(4, self.wscratch_bytes) // 4 + 4, dtype=torch.float32, device=self.dev)
+        return self._wscratch_buf
 
     def colsum(self, tag, g_ptr, rows, c, ld, pname):
         self.prog.add(tag, self.lib.sgd_colsum, g_ptr, rows, c, ld, _ptr(self.pg(pname)), 0, self.unscale,

@@ -51,10 +51,17 @@ def test_conv_dgrad_is_forward_kernel_on_adjoint_weights(shape, prec, tol):
     assert max_rel(out.cpu().permute(0, 3, 1, 2), x.grad) < tol
 
 
-def _wgrad(L, lib, fwd, gy, cout, cin, taps, ksplit):
+def _wgrad(L, lib, fwd, gy, cout, cin, taps, ksplit, scratch=False):
     slabs = torch.full((ksplit, taps, cout, cin), float("nan"), device="cuda")
     bsl = torch.full((ksplit, cout), float("nan"), device="cuda")
-    L.check(lib.sgd_wgrad(C.byref(fwd), _p(gy), gy.shape[-1], cout, _p(slabs), ksplit, _p(bsl), _stream()), "wgrad")
+    if scratch:          # operands pre-split into 16-bit planes by two element-wise passes (sgd_wgrad_scratch)
+        nbytes = int(lib.sgd_wgrad_scratch_bytes(C.byref(fwd), cout))
+        assert nbytes > 0
+        buf = torch.full((nbytes // 4 + 4,), float("nan"), device="cuda")
+        L.check(lib.sgd_wgrad_scratch(C.byref(fwd), _p(gy), gy.shape[-1], cout, _p(slabs), ksplit, _p(bsl), _p(buf), nbytes,
+                                      _stream()), "wgrad_scratch")
+    else:
+        L.check(lib.sgd_wgrad(C.byref(fwd), _p(gy), gy.shape[-1], cout, _p(slabs), ksplit, _p(bsl), _stream()), "wgrad")
     # the bias gradient rides along: partial column sums of gy, folded like sgd_colsum's second stage
     db = torch.full((cout,), float("nan"), device="cuda")
     L.check(lib.sgd_colsum_fold(_p(bsl), ksplit, cout, _p(db), 0, 1.0, _stream()), "fold")
@@ -102,9 +109,9 @@ def test_conv_wgrad(mode):
 
 
 def _train_ksplit(taps, cout, cin, rows):
-    """the split the training program uses (sgdm_amd/train.py: Backward.wgrad)"""
-    base = taps * ((cout + 127) // 128) * ((cin + 127) // 128)
-    return max(1, min((rows + 63) // 64, 1024 // base))
+    """the split the training program uses (sgdm_amd/train.py: wgrad_ksplit)"""
+    from sgdm_amd.train import wgrad_ksplit
+    return wgrad_ksplit(taps, cout, cin, rows)
 
 
 @pytest.mark.parametrize("prec,tol", [("f32", 5e-6), ("f16x3", 3e-5), ("bf16x3", 3e-4)])
@@ -130,9 +137,13 @@ def test_conv_wgrad_split_precision_at_production_shapes(shape, prec, tol):
     pad, pbd = pa.cuda(), pb.cuda()
     fwd = _igemm_args(L, x0d, x1d, conv=(n, h, h, h, h), pa=pad, pb=pbd, silu=1)
     fwd.prec = L.PREC_BY_NAME[prec]
-    dw = _wgrad(L, lib, fwd, _nhwc(gy).cuda(), cout, cin, 9, _train_ksplit(9, cout, cin, n * h * h))
+    gyd = _nhwc(gy).cuda()
+    dw = _wgrad(L, lib, fwd, gyd, cout, cin, 9, _train_ksplit(9, cout, cin, n * h * h))
     err = max_rel(dw.reshape(cout, cin, 3, 3), w.grad.float())
     assert err < tol, err
+    if prec != "f32":    # the planes form (what the training program launches): the same arithmetic, bit for bit
+        dw2 = _wgrad(L, lib, fwd, gyd, cout, cin, 9, _train_ksplit(9, cout, cin, n * h * h), scratch=True)
+        assert torch.equal(dw, dw2)
 
 
 @pytest.mark.parametrize("prec,tol", [("f16x3", 3e-5), ("bf16x3", 3e-4)])
