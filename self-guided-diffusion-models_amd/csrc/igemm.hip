@@ -60,6 +60,7 @@ struct Geo {
     int hc, wc;               // conv-input dims (after resample)
     int sparts;               // statistics slots per image (args.stats), 0: unsupported geometry
     int fast_a;               // 1: split-phase A loader (stride 1, no avg-pool, pix*8 <= JMAX*256)
+    int stagger;              // EXPERIMENT: start delay per phase step, in s_memtime ticks
 #ifdef SGDM_PROBE
     int dbg;                  // SGDM_DBG bits: 1 skip A staging, 2 skip B staging, 4 skip MFMA, 8 skip stores, 16 skip the epilogue, 256 skip its statistics
     unsigned long long* stamp;   // [block][wave][4]: total cycles, cycles inside barriers, barriers, epilogue cycles
@@ -186,6 +187,69 @@ template <int PREC, int NT> struct Frag {
         }
     }
 };
+// v_mfma_f32_16x16x32_{f16,bf16} form of the split-precision stage: one stage = a 16-row block x the WHOLE 32-channel K
+// step, multiplied into NCB 16-column accumulator tiles (4 registers each).  Same MFMA cycles per flop as the 32x32x16
+// form, but the chip holds a higher clock on this shape under load (MI355X_MICROARCH.md, DVFS give-back item 7: +12..15 %
+// on random data).  The weights are read from the SAME packed units as the 32x32 form -- a lane of this form needs
+// W[co = 16 c + (lane & 15)][ci = 8 (lane >> 4) + j], which sits at sub-step (lane >> 5), lane-half (lane >> 4) & 1 of the
+// 32x32 fragment order: only the per-lane offset inside the 4 KiB unit differs (`p` carries it).
+template <int PREC, int NCB> struct Frag16 {
+    typedef typename Split<PREC>::T T;
+    typedef T T8 __attribute__((ext_vector_type(8)));
+    static constexpr int NREADS = 2;              // ds_read_b128 per stage
+    static constexpr int NWLOADS = 2 * NCB;       // 16-byte global loads per K step
+    static constexpr int NMMA = 3 * NCB;          // MFMAs per stage
+    struct AU {
+        T8 h, l;
+        __device__ __forceinline__ void load(const float* rowp, int kg) {      // kg = lane >> 4: this lane's 8-channel group
+            h = *reinterpret_cast<const T8*>(rowp + kg * 8);
+            l = *reinterpret_cast<const T8*>(rowp + kg * 8 + 4);
+        }
+    };
+    struct B {
+        T8 h[NCB], l[NCB];
+        __device__ __forceinline__ void load(const char* p) {
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) {
+                h[cb] = *reinterpret_cast<const T8*>(p + (cb >> 1) * WUNIT + (cb & 1) * 256);
+                l[cb] = *reinterpret_cast<const T8*>(p + (cb >> 1) * WUNIT + (cb & 1) * 256 + 1024);
+            }
+        }
+    };
+    static __device__ __forceinline__ f32x4 mma1(f32x4 acc, const AU& a, const B& b) {      // column block 0 only
+        if constexpr (PREC == SGD_PREC_F16X3) {
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(b.h[0], a.l, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(b.l[0], a.h, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(b.h[0], a.h, acc, 0, 0, 0);
+        } else {
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b.h[0], a.l, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b.l[0], a.h, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b.h[0], a.h, acc, 0, 0, 0);
+        }
+        return acc;
+    }
+    static __device__ __forceinline__ void mma(f32x4 (&acc)[NCB], const AU& a, const B& b) {
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) {
+            if constexpr (PREC == SGD_PREC_F16X3) {
+                acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b.h[cb], a.l, acc[cb], 0, 0, 0);
+                acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b.l[cb], a.h, acc[cb], 0, 0, 0);
+                acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b.h[cb], a.h, acc[cb], 0, 0, 0);
+            } else {
+                acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b.h[cb], a.l, acc[cb], 0, 0, 0);
+                acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b.l[cb], a.h, acc[cb], 0, 0, 0);
+                acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b.h[cb], a.h, acc[cb], 0, 0, 0);
+            }
+        }
+    }
+};
+template <int NCB> struct Frag16<SGD_PREC_F32, NCB> {     // never used (the exact mode keeps v_mfma_f32_32x32x2_f32)
+    static constexpr int NREADS = 1, NWLOADS = 1, NMMA = 1;
+    struct AU { __device__ __forceinline__ void load(const float*, int) {} };
+    struct B { __device__ __forceinline__ void load(const char*) {} };
+    static __device__ __forceinline__ void mma(f32x4 (&)[NCB], const AU&, const B&) {}
+    static __device__ __forceinline__ f32x4 mma1(f32x4 acc, const AU&, const B&) { return acc; }
+};
 template <int NT> struct Frag<SGD_PREC_F32, NT> {
     static constexpr int NKS = KC / 8;            // 8 channels per sub-step (4 MFMA k-pairs)
     static constexpr int NREADS = 1;
@@ -238,6 +302,14 @@ template <int N, class F> __device__ __forceinline__ void static_for(F&& f) {
     static_for_impl(f, std::make_integer_sequence<int, N>());
 }
 
+// sum over the 16 lanes of a DPP row; every lane of the row ends with the total
+__device__ __forceinline__ float row16_sum(float v) {
+    v = dpp_add<0xB1, 0xF>(v);       // quad_perm [1,0,3,2]
+    v = dpp_add<0x4E, 0xF>(v);       // quad_perm [2,3,0,1]
+    v = dpp_add<0x141, 0xF>(v);      // row_half_mirror
+    return dpp_add<0x140, 0xF>(v);   // row_mirror
+}
+
 struct Tile {
     int n0c;                 // first output column
     int img0, ty0, tx0;      // CONV3 origin
@@ -258,7 +330,7 @@ __device__ __forceinline__ Tile tile_at(const Geo& g, int lin, int bn, int tw, i
 }
 
 
-template <int BN, int PREC, bool VEC, int TAPS>
+template <int BN, int PREC, bool VEC, int TAPS, bool DEFER = false>
 __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
     const sgd_igemm_args& a = ka.a;
     const Geo& g = ka.g;
@@ -274,6 +346,23 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
     constexpr int MT = WM / 32, NT = WN / 32;
     constexpr int WAVES_N = BN / WN;
     typedef Frag<PREC, NT> FragT;
+    // 16x16x32 MFMA form (split modes, 128- and 32-column tiles; the 64-column wave tile has no registers left for the
+    // double-buffered weight fragments this form needs): accumulators are [RB row blocks of RBH rows][CBN column blocks]
+    // Measured (round 3, tools/ab_conv.py, UNet batch 80, against the 32x32x16 form of the same kernel): +4 % on
+    // 128-channel 3x3 layers, +7..9 % at 256..384 input channels, +13..16 % at 512..1024, 1x1 launches unchanged; the
+    // sampling step 19.5 -> 18.4 ms.  Same matrix-pipe cycles per flop, but the chip is power-limited under this load
+    // and the smaller MFMA sustains a higher clock.  -DSGDM_NO_MFMA16 builds the 32x32x16 form (A/B runs); the loader-side
+    // epilogue (DEFER) keeps it.
+#ifdef SGDM_NO_MFMA16
+    constexpr bool M16 = false;
+#else
+    constexpr bool M16 = PREC != SGD_PREC_F32 && BN <= 128 && !DEFER;
+#endif
+    constexpr int RB = M16 ? WM / 16 : MT, RBH = M16 ? 16 : 32;
+    constexpr int CBN = M16 ? WN / 16 : NT, CBW = M16 ? 16 : 32;      // column blocks of a wave tile and their width
+    constexpr int QPB = M16 ? 1 : 4;                                  // 4-channel quads a lane holds per (row block, column block)
+    typedef Frag16<PREC, CBN> Frag16T;
+    typedef std::conditional_t<M16, f32x4, f32x16> AccV;
     constexpr int NKS = FragT::NKS;
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -285,6 +374,17 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
     // bias-only epilogue of a conv without residual)
     float* bias_s = smem + (size_t)NA * a_floats + (size_t)g.pix * 8;       // [cout_p]
     const bool bias_lds = a.cout_p <= BIAS_LDS_MAX;        // very wide layers (all FiLM projections as one GEMM) read it from global
+    // DEFER kernels (3x3, 128-column tiles, 16-byte outputs, no or same-row residual, bias in LDS): the epilogue of every
+    // tile but a block's last runs on the LOADER waves.  Measured (round 3, compile-time ablations at UNet batch 80): the
+    // epilogue costs a compute wave 8..10 us per tile -- 30..40 % of a 128-channel 3x3 layer, 12..14 % of a 512-channel
+    // one -- and nearly all of it is waiting: vmcnt counts loads and stores in issue order, so the residual loads cost a
+    // round trip per batch and the next tile's first weight wait sits behind the acknowledgement of all 16 stores, with
+    // the matrix pipe idle (moving the epilogue into the next K loop of the SAME wave moves the stall, it does not remove
+    // it: tried).  So the compute waves copy their accumulators to an LDS staging tile (stg, [BM][BN + 4] floats: 0.3 us)
+    // and go on; the loaders, whose own waits have a whole chunk period of slack, drain it slice by slice.
+    constexpr int STG_LD = BN + 4;
+    float* stg = bias_s + a.cout_p;                         // [BM][STG_LD], DEFER only (sgd_igemm sizes the allocation)
+    static_assert(!DEFER || (BN == 128 && TAPS == 9 && VEC && !M16), "loader-side epilogue: 3x3, 128-column tiles");
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
@@ -330,6 +430,11 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
         }
     }
     if (ntiles == 0) return;
+    if (g.stagger > 0) {      // EXPERIMENT: phase-shift the blocks of an XCD (N neighbours of an M tile keep one phase)
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+        const unsigned long long d = (unsigned long long)(((blockIdx.x >> 3) / (g.nt > 0 ? g.nt : 1)) & 7) * g.stagger;
+        while (__builtin_amdgcn_s_memtime() - t0 < d) __builtin_amdgcn_s_sleep(32);
+    }
     auto lin_of = [&](int k) { return (rem_lin >= 0 && k == ntiles - 1) ? rem_lin : xbeg + loc + k * nloc; };
     // chunk range of the block's k-th tile: only the last one can be partial
     auto cbeg = [&](int k) { return k == ntiles - 1 ? last_c0 : 0; };
@@ -389,6 +494,109 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
 #ifndef SGDM_NO_LOADER_PRIO
         __builtin_amdgcn_s_setprio(2);
 #endif
+        // ---- loader-side epilogue (DEFER) ----------------------------------------------------------------------------
+        // Period q (between barriers q and q+1) belongs to tile dk; tile dk - 1 was staged in its first period.  Its 128 x 32
+        // quads are 16 per loader thread (thread = channel quad dcq, rows drg + 8 i), drained in dnck - 1 slices of <= 8:
+        // period j of the tile FINISHES slice j - 1 (staged sums * scale + bias + residual -> store, GroupNorm partial sums)
+        // and REQUESTS the residual quads of slice j.  Every period issues exactly 8 + 2 buffer stores and 8 buffer loads --
+        // slots without work carry an out-of-range offset, which the hardware drops -- so the loader stays branch-free
+        // around its vector memory operations and the compiler's counted waits stay exact: the input loads of the chunk
+        // pipeline are never waited for behind this period's stores.
+        const int dlt = tid - NCOMP;
+        const int dcq = (dlt >> 6) * 8 + (dlt & 7), drg = (dlt & 63) >> 3;
+        int dk = 0, dqs = 0, dnck = cend(0) - cbeg(0);
+        Tile dT = tile_at(g, lin_of(0), BN, TW, TH);       // tile dk - 1
+        int dcol = 0;                                      // first output channel of this thread's quad in tile dk - 1
+        unsigned dsoff = 0xFFFFFFFFu;                      // statistics slot of tile dk - 1 (byte offset), this thread's quad
+        f32x4 dres[8], ds1 = {0.f, 0.f, 0.f, 0.f}, ds2 = ds1;
+        unsigned dyoff[8];
+        int di0 = 0;                                       // first item of the slice requested one period ago
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { dres[j] = f32x4{0.f, 0.f, 0.f, 0.f}; dyoff[j] = 0xFFFFFFFFu; }
+        const float dwsi = (DEFER && a.w_scale_inv) ? *a.w_scale_inv : 1.f;
+        const long drows = (long)a.n * a.ho * a.wo;
+        const __amdgpu_buffer_rsrc_t dy_rs = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, (int)(drows * a.y_ld * 4), 0x00020000);
+        const __amdgpu_buffer_rsrc_t dr_rs = __builtin_amdgcn_make_buffer_rsrc(a.res ? const_cast<float*>(a.res) : a.y, 0,
+                                                                               a.res ? (int)(drows * a.cout * 4) : 0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t ds_rs = __builtin_amdgcn_make_buffer_rsrc(a.stats ? a.stats : a.y, 0,
+                                                 a.stats ? (int)((long)a.n * g.sparts * 2 * a.cout * 4) : 0, 0x00020000);
+        // slots per period, one value per launch (whole tiles have nchunks - 1 slices; a block's last, possibly partial tile
+        // has at least as many periods as MIN_PART_STEPS / 9 = 3): the period loops below are instantiated per value
+        const int dnq = !DEFER ? 0 : (nchunks - 1 >= 8 && cend(ntiles - 1) - cbeg(ntiles - 1) - 1 >= 8) ? 2
+                                   : (nchunks - 1 >= 4 && cend(ntiles - 1) - cbeg(ntiles - 1) - 1 >= 4) ? 4 : 8;
+        auto with_nq = [&](auto&& f) __attribute__((always_inline)) {
+            if (dnq == 2) f(std::integral_constant<int, 2>());
+            else if (dnq == 4) f(std::integral_constant<int, 4>());
+            else if (dnq == 8) f(std::integral_constant<int, 8>());
+            else f(std::integral_constant<int, 0>());
+        };
+        auto drain = [&](int q, auto nqc) __attribute__((always_inline)) {
+            constexpr int NQ = decltype(nqc)::value;     // quad slots per period: >= ceil(16 / (chunks per tile - 1))
+            if constexpr (DEFER && NQ > 0) {
+                if (q >= dqs + dnck) {                     // first period of the next tile: the one before it is pending
+                    dqs += dnck;
+                    ++dk;
+                    dnck = cend(dk) - cbeg(dk);
+                }
+                const int j = q - dqs, nsl = dnck - 1;
+                // ---- finish the slice requested one period ago
+                const f32x4 bq = *reinterpret_cast<const f32x4*>(bias_s + (dcol < a.cout_p ? dcol : 0));
+#pragma unroll
+                for (int jj = 0; jj < NQ; ++jj) {
+                    const int frow = drg + 8 * (di0 + jj < 16 ? di0 + jj : 15);
+                    f32x4 v = *reinterpret_cast<const f32x4*>(stg + (size_t)frow * STG_LD + dcq * 4);
+                    v = v * dwsi + bq + dres[jj];
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), dy_rs, dyoff[jj], 0, 0);
+                    if (dyoff[jj] != 0xFFFFFFFFu) {
+                        ds1 += v;
+                        ds2 += v * v;
+                    }
+                }
+                // ---- GroupNorm partial sums of the tile: after its last slice
+                const bool last = dk > 0 && j == nsl;
+                f32x4 t1 = ds1, t2 = ds2;
+                if (last) {
+#pragma unroll
+                    for (int o = 8; o < 64; o <<= 1)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            t1[e] += __shfl_xor(t1[e], o, 64);
+                            t2[e] += __shfl_xor(t2[e], o, 64);
+                        }
+                    ds1 = ds2 = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+                const unsigned so = (last && drg == 0) ? dsoff : 0xFFFFFFFFu;
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, t1), ds_rs, so, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, t2), ds_rs,
+                                                       so == 0xFFFFFFFFu ? so : so + (unsigned)a.cout * 4u, 0, 0);
+                // ---- request slice j of tile dk - 1
+                const bool req = dk > 0 && j < nsl;
+                int i0 = 0, i1 = 0;
+                if (req) { i0 = (16 * j) / nsl; i1 = (16 * (j + 1)) / nsl; }
+                di0 = i0;
+                if (dk > 0 && j == 0) {                    // per tile: its first channel / statistics slot for this thread
+                    dT = tile_at(g, lin_of(dk - 1), BN, TW, TH);
+                    const Tile& T = dT;
+                    dcol = T.n0c + dcq * 4;
+                    const int part = (T.ty0 >> g.th_l2) * g.tiles_x + (T.tx0 >> g.tw_l2);
+                    dsoff = (a.stats && dcol < a.cout) ? (unsigned)((((long)T.img0 * g.sparts + part) * 2 * a.cout + dcol) * 4) : 0xFFFFFFFFu;
+                }
+                const Tile& T = dT;
+#pragma unroll
+                for (int jj = 0; jj < NQ; ++jj) {
+                    const int i = i0 + jj;
+                    const int row = drg + 8 * (i < 16 ? i : 15);
+                    const int tx = row & (TW - 1), ty = (row >> g.tw_l2) & (TH - 1), nb = row >> (g.tw_l2 + g.th_l2);
+                    const int n = T.img0 + nb;
+                    const bool ok = i < i1 && nb < g.nb && n < a.n && dcol < a.cout;
+                    const int orow = (n * a.ho + T.ty0 + ty) * a.wo + T.tx0 + tx;
+                    dyoff[jj] = ok ? (unsigned)(((long)orow * a.y_ld + dcol) * 4) : 0xFFFFFFFFu;
+                    const unsigned ro = ok ? (unsigned)(((long)orow * a.cout + dcol) * 4) : 0xFFFFFFFFu;
+                    dres[jj] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(dr_rs, ro, 0, 0));
+                }
+            }
+            (void)q;
+        };
         if constexpr (CONV) {
             // =================================================================================
             // lean loader (the sampler's ResBlock convs: stride 1, per-image GroupNorm affine (+SiLU) or no prologue,
@@ -410,7 +618,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
                 const int lt = tid - NCOMP;
                 const int c4 = lt & 7;                                   // channel quad (inputs and weights alike)
                 const int items = g.pix * 8;
-                auto go = [&](auto unic, auto poolc) {
+                auto go = [&](auto unic, auto poolc) __attribute__((always_inline)) {
                     constexpr bool uni = decltype(unic)::value;          // true: GN affine + SiLU, false: raw input
                     constexpr bool LATE = false;
                     constexpr int NS = decltype(poolc)::value ? 4 : 1;   // source pixels per item (fused 2x2 average pool)
@@ -428,7 +636,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
                         pixj[j] = (live[j] ? idx : items - 1) >> 3;
                     }
                     unsigned valid1 = 0, valid2 = 0;
-                    auto load_rows = [&](int k) {
+                    auto load_rows = [&](int k) __attribute__((always_inline)) {
                         const int2* tab = pixtab + (size_t)(k & 3) * g.pix;
                         valid2 = 0;
 #pragma unroll
@@ -439,7 +647,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
                         }
                     };
                     struct S { int k, chunk, img0; const float* src; int stride; const float* ka; const float* kb; };
-                    auto fill = [&](S& c) {
+                    auto fill = [&](S& c) __attribute__((always_inline)) {
                         const int ch = c.chunk * KC;
                         if (ch < a.c0) { c.src = a.x0 + ch; c.stride = a.c0; }
                         else { c.src = a.x1 + (ch - a.c0); c.stride = a.c1; }
@@ -447,7 +655,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
                         c.ka = uni ? a.pa + ko : a.x0;   // no prologue: 32 harmless bytes instead of a branch around the load
                         c.kb = uni ? a.pb + ko : a.x0;
                     };
-                    auto advance = [&](S c) {
+                    auto advance = [&](S c) __attribute__((always_inline)) {
                         if (++c.chunk == cend(c.k)) {
                             if (c.k + 1 < ntiles) {      // tile index math (integer divisions) once per tile, not per chunk
                                 ++c.k; c.chunk = cbeg(c.k);
@@ -460,7 +668,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
                     };
                     f32x4 araw[AJ][NS];
                     Coef kq;
-                    auto transform = [&](f32x4 v, bool ok) {
+                    auto transform = [&](f32x4 v, bool ok) __attribute__((always_inline)) {
                         if (ABL(256)) return v;
                         if constexpr (uni) {
                             // SiLU with the padding mask folded into the denominator: t / (den + e^-t), den = 1 or +inf
@@ -474,7 +682,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
                         }
                         return v;
                     };
-                    auto issue_item = [&](const S& c, int j) {
+                    auto issue_item = [&](const S& c, int j) __attribute__((always_inline)) {
                         const float* p0 = c.src + (long)rows2[j] * c.stride + c4 * 4;
                         if (ABL(512)) { KEEP_LIVE(p0); return; }
                         araw[j][0] = ld4(p0);
@@ -484,7 +692,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
                             araw[j][3] = ld4(p0 + (long)(a.wi + 1) * c.stride);
                         }
                     };
-                    auto issue_coef = [&](const S& c) {
+                    auto issue_coef = [&](const S& c) __attribute__((always_inline)) {
                         if constexpr (uni) { kq.p = ld4(c.ka + c4 * 4); kq.q = ld4(c.kb + c4 * 4); }
                     };
                     // Branch-free: an item slot past the end of the tile is a DUPLICATE of the tile's last pixel (same source
@@ -492,7 +700,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
                     // branch per item made six separate basic blocks: the six dependency chains (affine -> exp -> rcp -> split)
                     // ran one after the other, and next to an MFMA wave a single serial chain gets ~2 issue slots per MFMA
                     // (measured 7.9k cycles for ~400 instructions per chunk -- the loaders paced the whole block).
-                    auto finish = [&](int slot, int j) {
+                    auto finish = [&](int slot, int j) __attribute__((always_inline)) {
                         const bool ok = (valid1 >> j) & 1u;
                         f32x4 v = transform(araw[j][0], ok);
                         if constexpr (NS == 4)
@@ -504,7 +712,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
                     // and three ahead in global memory: in period q they transform chunk q+2 (requested in period q-1) into
                     // slot (q+2) % 3 and request chunk q+3.  Prologue: chunks 0 and 1 staged before barrier 0.
                     S s2;                                               // chunk whose raw rows are in flight / in registers
-                    auto stage = [&](int slot) {                        // transform the chunk under s2, request the next one
+                    auto stage = [&](int slot) __attribute__((always_inline)) {                        // transform the chunk under s2, request the next one
                         valid1 = valid2;
                         auto finish_all = [&]() {
 #pragma unroll
@@ -530,12 +738,18 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
                     stage(1);                                           // chunk 1 -> slot 1, request chunk 2
                     SYNC();                                             // barrier 0: the compute waves' fragment
                                                                         // prefetch runs DEPTH stages into the next chunk
-                    for (int q = 0; q < Q; ++q) {
-                        stage((q + 2) % NA);                            // chunk q+2 -> slot (q+2) % 3, request chunk q+3
-                        // table of the tile that chunk q+4 opens (read by load_rows one period later)
-                        if (q + 4 < Q && (q + 4) % nchunks == 0) build_pixtab((q + 4) / nchunks, lt, LT);
-                        SYNC();                                         // barrier q+1
-                    }
+                    auto periods = [&](auto nqc) __attribute__((always_inline)) {
+                        for (int q = 0; q < Q; ++q) {
+                            drain(q, nqc);                              // DEFER: a slice of the previous tile's epilogue
+                            stage((q + 2) % NA);                        // chunk q+2 -> slot (q+2) % 3, request chunk q+3
+                            // table of the tile that chunk q+4 opens (read by load_rows one period later)
+                            if (q + 4 < Q && (q + 4) % nchunks == 0) build_pixtab((q + 4) / nchunks, lt, LT);
+                            SYNC();                                     // barrier q+1
+                        }
+                    };
+                    // (sgd_igemm never pairs the fused average pool -- 96 registers of raw rows -- with the loader-side epilogue)
+                    if constexpr (NS == 4) periods(std::integral_constant<int, 0>());
+                    else with_nq(periods);
                 };
                 if (uni_rt) {
                     if (a.resample == SGD_RS_AVGPOOL2) go(std::true_type(), std::true_type());
@@ -718,14 +932,14 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
             lds_store_act<PREC>(abuf + (size_t)pix * LDA, c4, v);
         };
         // everything at once: first chunk of the stream, avg-pool, big halo tiles
-        auto stage_A_sync = [&](int slot, int q) {
+        auto stage_A_sync = [&](int slot, int q) __attribute__((always_inline)) {
             q = q < Q ? q : Q - 1;
             const int k = q / nchunks, chunk = q - k * nchunks + cbeg(k);
             float* abuf = As + (size_t)(slot % NA) * a_floats;
             const TabRef tab = tabref(k);
             for (int idx = lt; idx < items; idx += A_THREADS) item_sync(abuf, tab, idx, chunk * KC);
         };
-        auto finish_item = [&](int slot, const TabRef& tab, int chunk, int idx, f32x4 raw, const Coef* kuni) {
+        auto finish_item = [&](int slot, const TabRef& tab, int chunk, int idx, f32x4 raw, const Coef* kuni) __attribute__((always_inline)) {
             float* abuf = As + (size_t)(slot % NA) * a_floats;
             const int c = chunk * KC + c4 * 4;
             if (idx < items) {
@@ -771,7 +985,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
                     return cx;
                 };
                 Ctx cx = ctx_of(1);
-                auto request = [&]() {
+                auto request = [&]() __attribute__((always_inline)) {
                     TabRef tr;
                     tr.tab = cx.tab;
                     tr.m0 = 0;
@@ -781,7 +995,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
 #pragma unroll
                     for (int j = 0; j < AJ; ++j) araw[j] = raw_item(tr, lt + j * A_THREADS, cx.c);
                 };
-                auto stage = [&](int slot, int qnext) {
+                auto stage = [&](int slot, int qnext) __attribute__((always_inline)) {
                     TabRef tr;
                     tr.tab = cx.tab;
                     tr.m0 = 0;
@@ -794,19 +1008,25 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
                 request();
                 stage(1, 2);
                 SYNC();                                                  // barrier 0 (chunks 0 and 1 staged)
-                for (int q = 0; q < Q; ++q) {
-                    stage(q + 2, q + 3);
-                    if (q + 4 < Q && (q + 4) % nchunks == 0) build_pixtab((q + 4) / nchunks, lt, A_THREADS);
-                    SYNC();
-                }
+                with_nq([&](auto nqc) __attribute__((always_inline)) {
+                    for (int q = 0; q < Q; ++q) {
+                        drain(q, nqc);
+                        stage(q + 2, q + 3);
+                        if (q + 4 < Q && (q + 4) % nchunks == 0) build_pixtab((q + 4) / nchunks, lt, A_THREADS);
+                        SYNC();
+                    }
+                });
             } else {
                 stage_A_sync(1, 1);
                 SYNC();                                                  // barrier 0 (chunks 0 and 1 staged)
-                for (int q = 0; q < Q; ++q) {
-                    stage_A_sync(q + 2, q + 2);
-                    if (q + 4 < Q && (q + 4) % nchunks == 0) build_pixtab((q + 4) / nchunks, lt, A_THREADS);
-                    SYNC();
-                }
+                with_nq([&](auto nqc) __attribute__((always_inline)) {
+                    for (int q = 0; q < Q; ++q) {
+                        drain(q, nqc);
+                        stage_A_sync(q + 2, q + 2);
+                        if (q + 4 < Q && (q + 4) % nchunks == 0) build_pixtab((q + 4) / nchunks, lt, A_THREADS);
+                        SYNC();
+                    }
+                });
             }
             PROBE_END(1);
             return;
@@ -884,10 +1104,18 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
         else if (li < 28) pli = li + 2;
         else pli = li < 30 ? li - 8 : li;
     }
-    int aoff[MT];
+    if constexpr (M16) {
+        // 16-row blocks: lane l reads row prow(l & 15), channel group l >> 4 (32 bytes further per group).  ds_read_b128
+        // serves {0-3,12-15,20-27} / {4-11,16-19,28-31} per LDS cycle: 8 lanes at group g and 8 at g + 1; with the 36-float
+        // pixel pitch the quad bank is 9 * pixel + 2 * group mod 16, conflict-free iff the rows read at the odd group all
+        // have one parity: lanes 4..11 take the odd rows, lanes 0..3 / 12..15 the even ones
+        const int i16 = lane & 15;
+        pli = i16 < 4 ? 2 * i16 : (i16 < 12 ? 2 * (i16 - 4) + 1 : 2 * i16 - 16);
+    }
+    int aoff[RB];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        int r = wm * WM + mt * 32 + pli;
+    for (int mt = 0; mt < RB; ++mt) {
+        int r = wm * WM + mt * RBH + pli;
         int p;
         if (CONV) {
             int tx = r & (TW - 1), ty = (r >> g.tw_l2) & (TH - 1), nb = r >> (g.tw_l2 + g.th_l2);
@@ -900,11 +1128,15 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
     // weight fragments: wave (wm, wn) needs N blocks wn*NT .. wn*NT+NT-1 of its tile; consecutive K steps of the stream
     // [chunk][tap] are `wstep` bytes apart (all N blocks of the layer for that step)
     const size_t wstep = (size_t)(a.cout_p >> 5) * WUNIT;
-    const char* const wlane = reinterpret_cast<const char*>(a.w) + (size_t)(wn * NT) * WUNIT + lane * 16;
+    const char* const wlane = reinterpret_cast<const char*>(a.w) + (size_t)(wn * NT) * WUNIT
+                              + (M16 ? (lane >> 5) * 2048 + (((lane >> 4) & 1) * 32 + (lane & 15)) * 16 : lane * 16);
     auto wtile_of = [&](int k) { return wlane + (size_t)(tile_at(g, lin_of(k), BN, TW, TH).n0c >> 5) * WUNIT; };
 
-    f32x16 acc[MT][NT];
-    const float wsi = a.w_scale_inv ? *a.w_scale_inv : 1.f;        // 2^-k of the packed weights (exact); once per block
+    AccV acc[RB][CBN];
+    // 2^-k of the packed weights (exact); once per block, held in a SCALAR register: as a vector register it was the value the
+    // allocator spilled, and its reload in front of every output quad waited (vmcnt is in order) for the previous store
+    const float wsi = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(
+        __builtin_bit_cast(int, a.w_scale_inv ? *a.w_scale_inv : 1.f)));
 
     // The K loop is a software pipeline over STAGES: a stage = (K sub-step ks, 32-row block mt) multiplies ONE input
     // fragment unit (2 ds_read_b128) into the wave's NT accumulator tiles (3 NT MFMAs).  The units live in a register
@@ -914,36 +1146,55 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
     // The weight fragments of sub-step ks are reloaded (for the next K step) right after their last use in this one:
     // they have (NKS - 1) * MT stages (>= 768 matrix-pipe cycles) to return from L2.  All waits are the compiler's
     // (plain loads: exact counted s_waitcnt); the sched_group_barriers only pin the issue order.
-    constexpr int STAGES = NKS * MT;               // per K step
-    constexpr int RING = STAGES >= 4 ? 4 : 2;      // STAGES % RING == 0: a K step always starts at ring slot 0
+    // M16 (16x16x32 MFMA): a K step is ONE MFMA deep, so its stages run column block by column block over ALL row blocks:
+    // stage (cb, rb) = 3 MFMAs.  The RB input units of the step stay in registers (64 for the 128-row wave tile); unit rb
+    // is reloaded for the NEXT step right after its last use (column block CBN - 1), the weights of column block cb right
+    // after stage (cb, RB - 1): every reload has RB - 1 .. RB stages (>= 336 matrix-pipe cycles) to land, with single
+    // buffers and compile-time register indices.
+    constexpr int STAGES = M16 ? RB * CBN : NKS * MT;    // per K step
+    constexpr int RING = M16 ? RB : (STAGES >= 4 ? 4 : 2);   // STAGES % RING == 0: a K step always starts at ring slot 0
     constexpr int DEPTH = RING - 1;
     static_assert(STAGES % RING == 0, "ring position must be a compile-time constant inside a K step");
-    typename FragT::AU ring[RING];
+    std::conditional_t<M16, typename Frag16<PREC, 1>::AU, typename FragT::AU> ring[RING];
     typename FragT::B fb[NKS];
+    typename Frag16<PREC, 1>::B fb16[CBN];         // M16: weights of one 16-column block each
     const int rowstep = g.hw * LDA;                // LDS floats between halo rows
+
     auto tap_off = [&](int tap) { return CONV ? (tap / 3) * rowstep + (tap % 3) * LDA : 0; };
     // one K step: `acur` holds this step's chunk, `anext` the chunk the prefetches run into when `seam` (last tap)
-    auto do_step = [&](const float* acur, const float* anext, auto tapc, const char* wnext) {
+    auto do_step = [&](const float* acur, const float* anext, auto tapc, auto parc, const char* wnext) {
         constexpr int tap = decltype(tapc)::value;
+        constexpr int PAR = decltype(parc)::value;
         constexpr bool seam = tap + 1 == TAPS;
         static_for<STAGES>([&](auto stc) {
             constexpr int st = decltype(stc)::value;
-            constexpr int ks = st / MT, mt = st % MT;
+            constexpr int ks = M16 ? 0 : st / MT, mt = M16 ? st % RB : st % MT;
             // the unit of stage st + DEPTH: this step, or the first stages of the next one (next tap / next chunk)
             constexpr int pst = (st + DEPTH) % STAGES;
             constexpr bool wrap = st + DEPTH >= STAGES;
             const float* pbase = (wrap && seam) ? anext : acur;
             constexpr int ptap = wrap ? (seam ? 0 : tap + 1) : tap;
-            if (!ABL(64)) ring[(st + DEPTH) % RING].load(pbase + tap_off(ptap) + aoff[pst % MT], pst / MT, lh);
-            if (!ABL(16)) FragT::mma(acc[mt], ring[st % RING], fb[ks]);
-            if (mt == MT - 1 && !ABL(32)) fb[ks].load(wnext, ks);
+            if constexpr (M16) {
+                constexpr int cbi = st / RB;
+                const float* nbase = seam ? anext : acur;                  // next step: next tap of this chunk / next chunk
+                constexpr int ntap = seam ? 0 : tap + 1;
+                if (!ABL(16)) acc[mt][cbi] = Frag16<PREC, 1>::mma1(acc[mt][cbi], ring[mt], fb16[cbi]);
+                if (cbi == CBN - 1 && !ABL(64)) ring[mt].load(nbase + tap_off(ntap) + aoff[mt], lane >> 4);
+                if (mt == RB - 1 && !ABL(32)) fb16[cbi].load(wnext + (cbi >> 1) * WUNIT + (cbi & 1) * 256);
+                (void)pbase; (void)ptap; (void)pst; (void)wrap;
+            } else {
+                if (!ABL(64)) ring[(st + DEPTH) % RING].load(pbase + tap_off(ptap) + aoff[pst % MT], pst / MT, lh);
+                if (!ABL(16)) FragT::mma(acc[mt], ring[st % RING], fb[ks]);
+                if (mt == MT - 1 && !ABL(32)) fb[ks].load(wnext, ks);
+            }
             // issue order: one MFMA, ONE LDS read, ... then one MFMA, ONE weight load, ...; the remaining MFMAs last
             // (a burst of reads in front of the MFMAs fills the LDS queue and the in-order wave cannot issue its MFMAs
             // until they are accepted)
             {
-                constexpr int NM = FragT::NMMA;
-                constexpr int P1 = FragT::NREADS < NM ? FragT::NREADS : NM;
-                constexpr int nw = (mt == MT - 1) ? FragT::NWLOADS : 0;
+                constexpr int NM = M16 ? 3 : FragT::NMMA;
+                constexpr int NR = M16 ? (st / RB == CBN - 1 ? 2 : 0) : FragT::NREADS;
+                constexpr int P1 = NR < NM ? NR : NM;
+                constexpr int nw = M16 ? (st % RB == RB - 1 ? 2 : 0) : ((mt == MT - 1) ? FragT::NWLOADS : 0);
                 constexpr int P2 = nw < NM - P1 ? nw : NM - P1;
 #pragma unroll
                 for (int i = 0; i < P1; ++i) {
@@ -965,11 +1216,19 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
     // first K step of the block's k-th tile (the last tile may start in the middle of its K range: balanced tail)
     auto wstart_of = [&](int k) { return wtile_of(k) + (size_t)cbeg(k) * TAPS * wstep; };
     const char* wp = wstart_of(0);                 // weight fragments of the CURRENT step
+    if constexpr (M16) {
 #pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) fb[ks].load(wp, ks);
+        for (int cb = 0; cb < CBN; ++cb) fb16[cb].load(wp + (cb >> 1) * WUNIT + (cb & 1) * 256);
+    } else {
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) fb[ks].load(wp, ks);
+    }
     SYNC();                               // pairs with the loaders' prologue barrier: chunks 0 AND 1 are staged
 #pragma unroll
-    for (int st = 0; st < DEPTH; ++st) ring[st].load(As + aoff[st % MT], st / MT, lh);
+    for (int st = 0; st < (M16 ? RB : DEPTH); ++st) {
+        if constexpr (M16) ring[st].load(As + aoff[st], lane >> 4);
+        else ring[st].load(As + aoff[st % MT], st / MT, lh);
+    }
     int aslot = 0;                                 // ring position of the current chunk
     // CONV: ONE barrier per 32-channel chunk (9 K steps).  The weights never pass through LDS and the input tile of a
     // chunk is immutable while its 9 taps run, so nothing inside a chunk needs the loaders: period q (between barriers
@@ -978,11 +1237,11 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
     // loaders fill slot (q+2) % 3 (last read in period q-1).
     for (int k = 0; k < ntiles; ++k) {
 #pragma unroll
-        for (int i = 0; i < MT; ++i)
+        for (int i = 0; i < RB; ++i)
 #pragma unroll
-            for (int j = 0; j < NT; ++j)
+            for (int j = 0; j < CBN; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+                for (int r = 0; r < (M16 ? 4 : 16); ++r) acc[i][j][r] = 0.f;
         const char* const wseam = k + 1 < ntiles ? wstart_of(k + 1) : nullptr;   // first step of the next tile
         const int c_end = cend(k);
         for (int chunk = cbeg(k); chunk < c_end; ++chunk) {
@@ -992,19 +1251,46 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
             // step after this chunk's last one: next chunk, next tile, or (end of the stream) the same slice again
             const char* const wlast = chunk + 1 == c_end ? (wseam ? wseam : wp + (TAPS - 1) * wstep) : nullptr;
             // taps fully unrolled: tap offsets are compile-time, so no scalar index math sits between the MFMA blocks
-            auto step = [&](auto tapc) {
+            static_for<TAPS>([&](auto tapc) {
                 constexpr int tap = decltype(tapc)::value;
                 const char* wnext = wp + wstep;
                 if (tap + 1 == TAPS && wlast) wnext = wlast;
-                do_step(acur, anext, tapc, wnext);
+                do_step(acur, anext, tapc, std::integral_constant<int, tap & 1>(), wnext);
                 wp = wnext;
-            };
-            static_for<TAPS>(step);
+            });
             aslot = naslot;
+        }
+        if constexpr (DEFER) {
+            if (k + 1 < ntiles) {
+                // Every tile but the block's last leaves through LDS: the accumulators go to the staging tile as they are
+                // (tile-local row, channel) and the LOADER waves run the epilogue during the next tile's K loop (drain,
+                // above).  This wave is past barrier qe (the last chunk's), the loaders finished reading the previous
+                // staged tile before it, and they read this one after the next barrier.
+                int plie = pli;
+                asm volatile("" : "+v"(plie));             // recompute the staging addresses per tile (see the epilogue)
+#pragma unroll
+                for (int mt = 0; mt < RB; ++mt) {
+                    float* sp = stg + (size_t)(wm * WM + mt * RBH + plie) * STG_LD + wn * WN + 4 * lh;
+#pragma unroll
+                    for (int q = 0; q < QPB; ++q) {
+                        f32x4 v;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = acc[mt][0][q * 4 + j];
+                        *reinterpret_cast<f32x4*>(sp + q * 8) = v;
+                    }
+                }
+                continue;
+            }
         }
 
         // ---- balanced tail: this tile's K range is shared with other blocks (see the schedule at the top) ----
-        constexpr size_t SLAB = (size_t)MT * NT * 4 * NCOMP * 16;      // bytes of one block's partial accumulators
+        constexpr size_t SLAB = (size_t)RB * CBN * QPB * NCOMP * 16;   // bytes of one block's partial accumulators
+        auto accq = [&](int mt, int nt, int q) {                       // quad q of a lane's (row block, column block) tile
+            f32x4 v;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = acc[mt][nt][(M16 ? 0 : q * 4) + j];
+            return v;
+        };
         const char* part_base = nullptr;                               // finisher: this thread's quads in the producers' slabs
         int nparts = 0;
         int* part_cnt = nullptr;
@@ -1022,17 +1308,13 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
                 // write-back of the L2's other dirty lines --, every storing wave drains its stores, then signals for itself
                 __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(slab0 + (size_t)rem_part * SLAB, 0, (int)SLAB, 0x00020000);
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
+                for (int mt = 0; mt < RB; ++mt)
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt)
+                    for (int nt = 0; nt < CBN; ++nt)
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            f32x4 v;
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) v[j] = acc[mt][nt][q * 4 + j];
-                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rs,
-                                                                   (((mt * NT + nt) * 4 + q) * NCOMP + tid) * 16, 0, 16 /* sc1 */);
-                        }
+                        for (int q = 0; q < QPB; ++q)
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, accq(mt, nt, q)), rs,
+                                                                   (((mt * CBN + nt) * QPB + q) * NCOMP + tid) * 16, 0, 16 /* sc1 */);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 if (lane == 0) __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 break;                                                     // no epilogue; the split tile is the block's last
@@ -1058,17 +1340,22 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
         // of 4 consecutive channels (8g + 4*(lane>>5) + 0..3).  => 16-byte residual loads / stores, and the
         // row index math runs twice per lane instead of 32 times.
         const Tile T = tile_at(g, lin_of(k), BN, TW, TH);
-        const int cb = T.n0c + wn * WN + 4 * lh;          // first channel of this lane's g = 0 run (nt = 0)
+        const int cb = T.n0c + wn * WN + 4 * (M16 ? lane >> 4 : lh);   // first channel of this lane's first quad (nt = 0)
         auto epilogue = [&](auto resmode, auto partc) {
             constexpr int RES = decltype(resmode)::value;     // 0 none, 1 same rows, 2 avg-pool of 2x map, 3 nearest of 1/2 map
             constexpr bool PART = decltype(partc)::value;     // balanced tail: add the other blocks' partial accumulators
             // per M block: output row / residual row of this lane's pixel
-            bool okm[MT];
-            float* ypm[MT];
-            const float* rpm[MT];
+            bool okm[RB];
+            float* ypm[RB];
+            const float* rpm[RB];
+            // the lane's pixel goes through an opaque register: its tile-invariant row arithmetic (tx, ty, image of every row
+            // block) is then redone per tile -- ~20 integer instructions -- instead of living in ~10 registers across the
+            // K loop, which the allocator spilled and reloaded behind the stores (vmcnt is in order)
+            int plie = pli;
+            asm volatile("" : "+v"(plie));
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                const int row = wm * WM + mt * 32 + pli;
+            for (int mt = 0; mt < RB; ++mt) {
+                const int row = wm * WM + mt * RBH + plie;
                 int orow, n = 0, oy = 0, ox = 0;
                 if (CONV) {
                     const int tx = row & (TW - 1), ty = (row >> g.tw_l2) & (TH - 1), nb = row >> (g.tw_l2 + g.th_l2);
@@ -1107,69 +1394,84 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
                     sp = a.stats + ((long)n_img * g.sparts + part) * 2 * a.cout;
                 }
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    // load phase: bias + residual of the four quads of this 32-channel block for both rows -- 12 independent
-                    // loads in flight (the compiler may not hoist them itself: y and res could alias), then the stores
-                    constexpr int QB = (RES == 2 || NT > 1) ? 1 : 2;   // quads per batch, bounded by the register budget
+                for (int nt = 0; nt < CBN; ++nt) {
+                    // load phase: bias + residual of the quads of this column block for all row blocks -- independent loads in
+                    // flight (the compiler may not hoist them itself: y and res could alias), then the stores
+                    constexpr int QB = (RES == 2 || NT > 1 || M16) ? 1 : 2;   // quads per batch, bounded by the register budget
+                    constexpr int RBB = M16 ? (RES == 2 ? 2 : 4) : RB;        // row blocks per batch (M16: 8 row blocks of 16)
 #pragma unroll
-                    for (int q0 = 0; q0 < 4; q0 += QB) {
-                    f32x4 rv[4][MT];
-                    f32x4 pv[4][MT];
+                    for (int q0 = 0; q0 < QPB; q0 += QB) {
+                    f32x4 s1[QB], s2[QB];
+#pragma unroll
+                    for (int i = 0; i < QB; ++i) s1[i] = s2[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int mb0 = 0; mb0 < RB; mb0 += RBB) {
+                    f32x4 rv[QB][RBB];
+                    f32x4 pv[QB][RBB];
                     if constexpr (PART) {
 #pragma unroll
                         for (int gq = q0; gq < q0 + QB; ++gq)
 #pragma unroll
-                            for (int mt = 0; mt < MT; ++mt) {
-                                const char* pp = part_base + (size_t)(((mt * NT + nt) * 4 + gq) * NCOMP) * 16;
+                            for (int mt = mb0; mt < mb0 + RBB; ++mt) {
+                                const char* pp = part_base + (size_t)(((mt * CBN + nt) * QPB + gq) * NCOMP) * 16;
                                 f32x4 sum = *reinterpret_cast<const f32x4*>(pp);
                                 for (int pi = 1; pi < nparts; ++pi) sum += *reinterpret_cast<const f32x4*>(pp + pi * SLAB);
-                                pv[gq][mt] = sum;
+                                pv[gq - q0][mt - mb0] = sum;
                             }
                     }
 #pragma unroll
                     for (int gq = q0; gq < q0 + QB; ++gq) {
-                        const int c = cb + nt * 32 + gq * 8;
+                        const int c = cb + nt * CBW + gq * 8;
                         const int cl = c < a.cout ? c : 0;    // clamped: the quad is skipped below
                         f32x4 bv = {0.f, 0.f, 0.f, 0.f};
                         if (bias_lds) bv = *reinterpret_cast<const f32x4*>(bias_s + cl);
                         else if (a.bias && !ABL(2)) bv = ld4(a.bias + cl);
 #pragma unroll
-                        for (int mt = 0; mt < MT; ++mt) {
-                            rv[gq][mt] = bv;
-                            if ((RES == 1 || RES == 3) && !ABL(2)) rv[gq][mt] += ld4(rpm[mt] + cl);
+                        for (int mt = mb0; mt < mb0 + RBB; ++mt) {
+                            f32x4& r = rv[gq - q0][mt - mb0];
+                            r = bv;
+                            if ((RES == 1 || RES == 3) && !ABL(2)) r += ld4(rpm[mt] + cl);
                             if (RES == 2 && !ABL(2)) {
                                 const long rw = (long)a.wo * 2 * a.cout;
                                 const float* rp = rpm[mt];
-                                rv[gq][mt] += 0.25f * (ld4(rp + cl) + ld4(rp + a.cout + cl) + ld4(rp + rw + cl) + ld4(rp + rw + a.cout + cl));
+                                r += 0.25f * (ld4(rp + cl) + ld4(rp + a.cout + cl) + ld4(rp + rw + cl) + ld4(rp + rw + a.cout + cl));
                             }
                         }
                     }
 #pragma unroll
                     for (int gq = q0; gq < q0 + QB; ++gq) {
-                        const int c = cb + nt * 32 + gq * 8;
-                        if (c >= a.cout) continue;            // uniform within a lane half
-                        f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = s1;
+                        const int c = cb + nt * CBW + gq * 8;
+                        if (c >= a.cout) continue;            // uniform within a lane half / a row of 16 lanes
 #pragma unroll
-                        for (int mt = 0; mt < MT; ++mt) {
-                            f32x4 v;
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) v[j] = acc[mt][nt][gq * 4 + j];
-                            if constexpr (PART) v += pv[gq][mt];
-                            v = v * wsi + rv[gq][mt];
+                        for (int mt = mb0; mt < mb0 + RBB; ++mt) {
+                            f32x4 v = accq(mt, nt, gq);
+                            if constexpr (PART) v += pv[gq - q0][mt - mb0];
+                            v = v * wsi + rv[gq - q0][mt - mb0];
                             if (okm[mt]) {
                                 if (!(DBG(8)) && !ABL(1)) *reinterpret_cast<f32x4*>(ypm[mt] + c) = v;
                                 else KEEP_LIVE(v);
-                                s1 += v;
-                                s2 += v * v;
+                                s1[gq - q0] += v;
+                                s2[gq - q0] += v * v;
                             }
                         }
-                        if (sp && !DBG(256) && !ABL(4)) {
-                            // sum over the 32 pixel lanes of this lane half: 4 DPP steps inside a row of 16, then across rows
+                    }
+                    }
+                    if (sp && !DBG(256) && !ABL(4)) {
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) { s1[j] = half_wave_sum_hi(s1[j]); s2[j] = half_wave_sum_hi(s2[j]); }
-                            if (li == 16) {
-                                *reinterpret_cast<f32x4*>(sp + c) = s1;
-                                *reinterpret_cast<f32x4*>(sp + a.cout + c) = s2;
+                        for (int gq = q0; gq < q0 + QB; ++gq) {
+                            const int c = cb + nt * CBW + gq * 8;
+                            if (c >= a.cout) continue;
+                            // sum over the pixel lanes that share this lane's channels: the 32 lanes of a lane half (4 DPP steps
+                            // inside a row of 16, then across rows) or, M16, the 16 lanes of a DPP row
+                            f32x4 t1 = s1[gq - q0], t2 = s2[gq - q0];
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                t1[j] = M16 ? row16_sum(t1[j]) : half_wave_sum_hi(t1[j]);
+                                t2[j] = M16 ? row16_sum(t2[j]) : half_wave_sum_hi(t2[j]);
+                            }
+                            if (M16 ? (lane & 15) == 0 : li == 16) {
+                                *reinterpret_cast<f32x4*>(sp + c) = t1;
+                                *reinterpret_cast<f32x4*>(sp + a.cout + c) = t2;
                             }
                         }
                     }
@@ -1177,21 +1479,21 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
                 }
             } else {
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
+                for (int mt = 0; mt < RB; ++mt) {
                     if (!okm[mt]) continue;
                     float* yp = ypm[mt];
                     const float* rp = rpm[mt];
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt)
+                    for (int nt = 0; nt < CBN; ++nt)
 #pragma unroll
-                        for (int gq = 0; gq < 4; ++gq)
+                        for (int gq = 0; gq < QPB; ++gq)
 #pragma unroll
                             for (int j = 0; j < 4; ++j) {
-                                const int c = cb + nt * 32 + gq * 8 + j;
+                                const int c = cb + nt * CBW + gq * 8 + j;
                                 if (c >= a.cout) continue;
-                                float x = acc[mt][nt][gq * 4 + j];
+                                float x = acc[mt][nt][(M16 ? 0 : gq * 4) + j];
                                 if constexpr (PART) {
-                                    const float* pp = reinterpret_cast<const float*>(part_base + (size_t)(((mt * NT + nt) * 4 + gq) * NCOMP) * 16) + j;
+                                    const float* pp = reinterpret_cast<const float*>(part_base + (size_t)(((mt * CBN + nt) * QPB + gq) * NCOMP) * 16) + j;
                                     for (int pi = 0; pi < nparts; ++pi) x += pp[pi * (SLAB / 4)];
                                 }
                                 x = x * wsi + (bias_lds ? bias_s[c] : (a.bias ? a.bias[c] : 0.f));
@@ -1207,9 +1509,9 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
         };
         auto keep_acc = [&]() {                     // ablation builds: the accumulators stay live without an epilogue
 #pragma unroll
-            for (int i = 0; i < MT; ++i)
+            for (int i = 0; i < RB; ++i)
 #pragma unroll
-                for (int j = 0; j < NT; ++j) KEEP_LIVE(acc[i][j]);
+                for (int j = 0; j < CBN; ++j) KEEP_LIVE(acc[i][j]);
         };
         auto run_epilogue = [&](auto partc) {
             if (DBG(16) || ABL(8)) keep_acc();
@@ -1232,16 +1534,24 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
         } else {
             PROBE_EPI(run_epilogue(std::false_type()));
         }
-        if constexpr (NT > 1) {
-            // 64-column wave tile: 128 accumulator registers.  The operands prefetched for the next tile (weights of its
-            // first step, DEPTH input units) are NOT carried across the epilogue -- 56 registers the epilogue needs --
-            // but requested again here: one L2 round trip per tile (~1 % of a tile's K loop).
+        if constexpr (NT > 1 || M16) {
+            // 64-column wave tile (128 accumulator registers) or 16x16x32 MFMAs (all RB input units resident: 80 operand
+            // registers).  The operands prefetched for the next tile (weights of its first step, the first input units)
+            // are NOT carried across the epilogue -- registers the epilogue needs -- but requested again here: one L2
+            // round trip per tile (~1 % of a tile's K loop).
             if (k + 1 < ntiles) {
-#pragma unroll
-                for (int ks = 0; ks < NKS; ++ks) fb[ks].load(wp, ks);
                 const float* a0 = As + (size_t)aslot * a_floats;
+                if constexpr (M16) {
 #pragma unroll
-                for (int st = 0; st < DEPTH; ++st) ring[st].load(a0 + aoff[st % MT], st / MT, lh);
+                    for (int cb = 0; cb < CBN; ++cb) fb16[cb].load(wp + (cb >> 1) * WUNIT + (cb & 1) * 256);
+#pragma unroll
+                    for (int st = 0; st < RB; ++st) ring[st].load(a0 + aoff[st], lane >> 4);
+                } else {
+#pragma unroll
+                    for (int ks = 0; ks < NKS; ++ks) fb[ks].load(wp, ks);
+#pragma unroll
+                    for (int st = 0; st < DEPTH; ++st) ring[st].load(a0 + aoff[st % MT], st / MT, lh);
+                }
             }
         }
     }
@@ -1358,11 +1668,11 @@ __global__ void pack_weight_kernel(const float* __restrict__ src, float* __restr
 inline int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 inline bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 
-template <int BN, int PREC, bool VEC, int TAPS>
+template <int BN, int PREC, bool VEC, int TAPS, bool DEFER = false>
 int launch1(const KArgs& ka, size_t smem, hipStream_t st) {
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute((const void*)igemm_kernel<BN, PREC, VEC, TAPS>,
+        (void)hipFuncSetAttribute((const void*)igemm_kernel<BN, PREC, VEC, TAPS, DEFER>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr = true;
     }
@@ -1370,12 +1680,20 @@ int launch1(const KArgs& ka, size_t smem, hipStream_t st) {
     int grid = ((total + 7) / 8) * 8;
     if (grid > 256) grid = 256;                   // persistent: one block per CU walks its tiles
     if (ka.a.work && total >= 8) grid = 256;      // balanced tail: blocks without a whole tile take K parts of the last ones
-    hipLaunchKernelGGL((igemm_kernel<BN, PREC, VEC, TAPS>), dim3(grid), dim3(NTHREADS), smem, st, ka);
+    if (const char* e = getenv("SGDM_MAX_GRID")) {     // tests: few blocks, so that small problems walk many tiles per block
+        const int cap = atoi(e) & ~7;
+        if (cap >= 8 && grid > cap) grid = cap;
+    }
+    hipLaunchKernelGGL((igemm_kernel<BN, PREC, VEC, TAPS, DEFER>), dim3(grid), dim3(NTHREADS), smem, st, ka);
     return sgd_check_launch();
 }
 
+// vec: 0 scalar inputs, 1 16-byte inputs, 2 16-byte inputs + the loader-side epilogue (DEFER: 3x3, 128-column tiles, split modes)
 template <int BN, int PREC>
-int launch(const KArgs& ka, bool vec, bool conv, size_t smem, hipStream_t st) {
+int launch(const KArgs& ka, int vec, bool conv, size_t smem, hipStream_t st) {
+    if constexpr (BN == 128 && PREC != SGD_PREC_F32) {
+        if (conv && vec == 2) return launch1<BN, PREC, true, 9, true>(ka, smem, st);
+    }
     if (conv) return vec ? launch1<BN, PREC, true, 9>(ka, smem, st) : launch1<BN, PREC, false, 9>(ka, smem, st);
     return vec ? launch1<BN, PREC, true, 1>(ka, smem, st) : launch1<BN, PREC, false, 1>(ka, smem, st);
 }
@@ -1385,21 +1703,27 @@ int launch(const KArgs& ka, bool vec, bool conv, size_t smem, hipStream_t st) {
 // One translation unit per arithmetic mode (build.py compiles this file with -DSGDM_IGEMM_PREC=0 / 1 / 2, in parallel: the
 // kernel template has 12 instances per mode and eight epilogue variants each): the mode's launch dispatcher has external
 // linkage, everything else lives in the host unit (no -DSGDM_IGEMM_PREC).  The argument block crosses as bytes.
-int sgd_igemm_dispatch_f32(const void* ka, int bn, bool vec, bool conv, size_t smem, hipStream_t st);
-int sgd_igemm_dispatch_f16x3(const void* ka, int bn, bool vec, bool conv, size_t smem, hipStream_t st);
-int sgd_igemm_dispatch_bf16x3(const void* ka, int bn, bool vec, bool conv, size_t smem, hipStream_t st);
+int sgd_igemm_dispatch_f32(const void* ka, int bn, int vec, bool conv, size_t smem, hipStream_t st);
+int sgd_igemm_dispatch_f16x3(const void* ka, int bn, int vec, bool conv, size_t smem, hipStream_t st);
+int sgd_igemm_dispatch_bf16x3(const void* ka, int bn, int vec, bool conv, size_t smem, hipStream_t st);
 
 #ifdef SGDM_IGEMM_PREC
+#ifdef SGDM_DEV_ONE      /* development: compile ONE kernel instance (register / asm inspection), never linked */
+#define SGD_DISPATCH_BODY(P)                                                                                        \
+    const KArgs& ka = *reinterpret_cast<const KArgs*>(kap); (void)bn; (void)vec; (void)conv;                         \
+    return launch1<128, P, true, SGDM_DEV_ONE, SGDM_DEV_DEFER>(ka, smem, st);
+#else
 #define SGD_DISPATCH_BODY(P)                                                                                        \
     const KArgs& ka = *reinterpret_cast<const KArgs*>(kap);                                                         \
     return bn == 256 ? (conv ? launch1<256, P, true, 9>(ka, smem, st) : launch1<256, P, true, 1>(ka, smem, st))     \
                      : (bn == 128 ? launch<128, P>(ka, vec, conv, smem, st) : launch<32, P>(ka, vec, conv, smem, st));
+#endif
 #if SGDM_IGEMM_PREC == 0
-int sgd_igemm_dispatch_f32(const void* kap, int bn, bool vec, bool conv, size_t smem, hipStream_t st) { SGD_DISPATCH_BODY(SGD_PREC_F32) }
+int sgd_igemm_dispatch_f32(const void* kap, int bn, int vec, bool conv, size_t smem, hipStream_t st) { SGD_DISPATCH_BODY(SGD_PREC_F32) }
 #elif SGDM_IGEMM_PREC == 1
-int sgd_igemm_dispatch_f16x3(const void* kap, int bn, bool vec, bool conv, size_t smem, hipStream_t st) { SGD_DISPATCH_BODY(SGD_PREC_F16X3) }
+int sgd_igemm_dispatch_f16x3(const void* kap, int bn, int vec, bool conv, size_t smem, hipStream_t st) { SGD_DISPATCH_BODY(SGD_PREC_F16X3) }
 #else
-int sgd_igemm_dispatch_bf16x3(const void* kap, int bn, bool vec, bool conv, size_t smem, hipStream_t st) { SGD_DISPATCH_BODY(SGD_PREC_BF16X3) }
+int sgd_igemm_dispatch_bf16x3(const void* kap, int bn, int vec, bool conv, size_t smem, hipStream_t st) { SGD_DISPATCH_BODY(SGD_PREC_BF16X3) }
 #endif
 #else   // ---------------------------------------------------------------------------------- host unit
 
@@ -1579,6 +1903,7 @@ extern "C" int sgd_igemm(const sgd_igemm_args* args, void* stream) {
     }
     if (a.stats && g.sparts == 0) return SGD_ERR_ARG;
     g.nt = a.cout_p / bn;
+    { const char* e = getenv("SGDM_STAGGER"); g.stagger = e ? atoi(e) : 0; }
     {
         const char* e = getenv("SGDM_BALANCE");   // 0: plain schedule even with a workspace (A/B runs)
         if ((a.work && a.work_bytes < sgd_igemm_work_bytes()) || (e && atoi(e) == 0)) a.work = nullptr;
@@ -1604,10 +1929,31 @@ extern "C" int sgd_igemm(const sgd_igemm_args* args, void* stream) {
     if (smem > 160 * 1024) return SGD_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     const bool conv = a.mode == SGD_MODE_CONV3;
+    // Loader-side epilogue (igemm_kernel<.., DEFER>): 3x3 launches with 128-column tiles in a split mode, 16-byte inputs
+    // and outputs, no or same-row residual, bias in LDS, at least 3 chunks per tile (the slices of a tile's epilogue ride
+    // on the periods of the next one), buffers addressable with 32-bit byte offsets, and room for the staging tile
+    int variant = vec ? 1 : 0;
+    size_t smem_launch = smem;
+    {
+        // Opt-in (SGDM_DEFER=1).  Measured (round 3, UNet batch 80): correct, the compute waves' epilogue time drops from
+        // 8..10 us per tile to 0.3 us -- and the launches are 3..7 % SLOWER: the chip is power-limited, the idle wait cost
+        // little energy, and the staging copy plus the loaders' extra instructions cost more than the wait saved.
+        const char* e = getenv("SGDM_DEFER");
+        const int nchunks = (cin + KC - 1) / KC;
+        const long rows_out = (long)a.n * a.ho * a.wo;
+        const size_t smem_defer = smem + (size_t)BM * (128 + 4) * sizeof(float);
+        if (conv && vec && bn == 128 && a.prec != SGD_PREC_F32 && ((a.cout | a.y_ld) & 3) == 0
+            && (!a.res || a.res_mode == SGD_RS_NONE) && a.resample != SGD_RS_AVGPOOL2 && a.cout_p <= BIAS_LDS_MAX && nchunks >= 3
+            && rows_out * a.y_ld * 4 < (1L << 32) && (!a.stats || (long)a.n * g.sparts * 2 * a.cout * 4 < (1L << 32))
+            && smem_defer <= 160 * 1024 && e && atoi(e) == 1) {
+            variant = 2;
+            smem_launch = smem_defer;
+        }
+    }
     switch (a.prec) {
-        case SGD_PREC_F32: return sgd_igemm_dispatch_f32(&ka, bn, vec, conv, smem, st);
-        case SGD_PREC_F16X3: return sgd_igemm_dispatch_f16x3(&ka, bn, vec, conv, smem, st);
-        case SGD_PREC_BF16X3: return sgd_igemm_dispatch_bf16x3(&ka, bn, vec, conv, smem, st);
+        case SGD_PREC_F32: return sgd_igemm_dispatch_f32(&ka, bn, variant, conv, smem_launch, st);
+        case SGD_PREC_F16X3: return sgd_igemm_dispatch_f16x3(&ka, bn, variant, conv, smem_launch, st);
+        case SGD_PREC_BF16X3: return sgd_igemm_dispatch_bf16x3(&ka, bn, variant, conv, smem_launch, st);
         default: return SGD_ERR_ARG;
     }
 }

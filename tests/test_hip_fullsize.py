@@ -365,6 +365,55 @@ def test_balanced_tail_equals_plain_schedule(case, prec, tol):
 
 
 # --------------------------------------------------------------------------------------------------------------------
+# loader-side epilogue (igemm_kernel<.., DEFER>): every tile but a block's last leaves through the LDS staging tile and is
+# finished by the loader waves during the next tile's K loop.  SGDM_MAX_GRID=8 makes small problems walk many tiles per
+# block; SGDM_DEFER=0 is the immediate epilogue of the same library.
+# --------------------------------------------------------------------------------------------------------------------
+# n, cin, cout, hw, residual
+DEFER_CASES = [(6, 96, 128, 16, True),       # 3 chunks: the minimum (two slices of 8 quads)
+               (5, 128, 256, 16, False),     # 4 chunks, two N tiles per M tile, no residual
+               (9, 160, 128, 8, True),       # 8x8 maps: two images per tile, ragged last tile
+               (3, 256, 128, 32, True),      # 8 chunks: slices of 2..3 quads
+               (2, 544, 128, 16, False)]     # 17 chunks: one quad per period
+
+
+@pytest.mark.parametrize("prec,tol", [k for k in KPRECS if k[0] != "f32"])
+@pytest.mark.parametrize("grid", ["8", "24"])
+@pytest.mark.parametrize("case", DEFER_CASES, ids=["x".join(map(str, c)) for c in DEFER_CASES])
+def test_loader_side_epilogue_equals_immediate(case, grid, prec, tol, monkeypatch):
+    n, cin, cout, h, with_res = case
+    L, lib = _lib()
+    p = L.PREC_BY_NAME[prec]
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(n, cin, h, h, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(cin * 9)
+    b = torch.randn(cout, generator=g)
+    pa, pb = 1 + 0.3 * torch.randn(n, cin, generator=g), 0.3 * torch.randn(n, cin, generator=g)
+    res = torch.randn(n, cout, h, h, generator=g) if with_res else None
+    act = F.silu(x.double() * pa.double()[:, :, None, None] + pb.double()[:, :, None, None])
+    ref = F.conv2d(act, w.double(), b.double(), padding=1) + (res.double() if with_res else 0)
+    wbuf, cp, op = _pack(w.cuda(), 3, p)
+    xd, pad, pbd, bd = _nhwc(x).cuda(), pa.cuda(), pb.cuda(), b.cuda()
+    rd = _nhwc(res).cuda() if with_res else None
+    monkeypatch.setenv("SGDM_MAX_GRID", grid)
+
+    def run(defer):
+        monkeypatch.setenv("SGDM_DEFER", "1" if defer else "0")
+        return _conv(L, lib, p, xd, None, wbuf, cp, op, cout, (n, h, h, h, h), bias=bd, pa=pad, pb=pbd, silu=1, res=rd,
+                     stats=(h * h) % 128 == 0)
+
+    y0, s0 = run(False)
+    for rep in range(2):
+        y1, s1 = run(True)
+        assert not torch.isnan(y1).any()
+        assert max_rel(y1.cpu().permute(0, 3, 1, 2), ref) < tol
+        assert max_rel(y1, y0) < 2e-6
+        if s0 is not None:
+            assert max_rel(s1, s0) < 2e-6
+    assert max_rel(y0.cpu().permute(0, 3, 1, 2), ref) < tol
+
+
+# --------------------------------------------------------------------------------------------------------------------
 # (b) whole model at the benchmarked batch
 # --------------------------------------------------------------------------------------------------------------------
 def _bench_model(workload, prec):
