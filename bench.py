@@ -191,7 +191,7 @@ def pmc_traffic(args, B):
     WRITE_SIZE in separate rocprofv3 --pmc runs of this same bench command, gfx950 FETCH_SIZE x2 correction).
     PMC collection needs the profiler around the process, so it cannot be taken live inside this run; null when no
     committed pass matches the workload/precision/batch being benchmarked."""
-    for rnd in ("r2", "r1"):
+    for rnd in ("r3", "r2", "r1"):
         path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_hbm_{args.workload}.json")
         if os.path.exists(path):
             break
@@ -438,6 +438,17 @@ def main():
         if not args.no_train:
             extra["c5"]["train_step"] = train_step_bench(m5, diff5, d5, k5["cond"], k5["layout"], w5["batch"], world, barrier, w5)
         del m5, diff5
+        # ---- the headline workload at C5's batch (bs=80, UNet batch 160): C2 and C5 side by side at one batch size
+        if B != w5["batch"]:
+            m2, _, d2 = build_model(wl, dev, args.prec, w5["batch"])
+            diff2 = LatentDiffusion(device=str(dev), **MODEL_PARAMS)
+            diff2.set_denoise_fn(m2.forward, m2.forward_with_cond_scale)
+            k2 = dict(cond=d2["cond"].to(dev), layout=None, cond_scale=2.0)
+            ms2 = time_sampling(m2, diff2, w5["batch"], S, k2, 5, 2, skw)
+            extra["c2_bs80"] = dict(workload=wl["desc"].replace("bs=40/GPU (UNet batch 80)", "bs=80/GPU (UNet batch 160)"),
+                                    ms_per_step=round(ms2, 3), value=round(w5["batch"] / ms2, 4), unit="images/s",
+                                    tflops_per_s=round(2 * w5["batch"] * wl["gflop_per_eval_img"] / ms2, 1), steps=5, warmup=2)
+            del m2, diff2
         # ---- BASELINE.json configs[0] (C1) at its true shape on the GPU: 10-step DDIM, bs=8 -- ~140 small launches per
         # step, so the host launch path matters: eager ctypes launches vs the hipGraph-captured step
         m1, _, d1 = build_model(C1, dev, args.prec, C1["batch"])

@@ -60,7 +60,6 @@ struct Geo {
     int hc, wc;               // conv-input dims (after resample)
     int sparts;               // statistics slots per image (args.stats), 0: unsupported geometry
     int fast_a;               // 1: split-phase A loader (stride 1, no avg-pool, pix*8 <= JMAX*256)
-    int stagger;              // EXPERIMENT: start delay per phase step, in s_memtime ticks
 #ifdef SGDM_PROBE
     int dbg;                  // SGDM_DBG bits: 1 skip A staging, 2 skip B staging, 4 skip MFMA, 8 skip stores, 16 skip the epilogue, 256 skip its statistics
     unsigned long long* stamp;   // [block][wave][4]: total cycles, cycles inside barriers, barriers, epilogue cycles
@@ -430,11 +429,6 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
         }
     }
     if (ntiles == 0) return;
-    if (g.stagger > 0) {      // EXPERIMENT: phase-shift the blocks of an XCD (N neighbours of an M tile keep one phase)
-        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-        const unsigned long long d = (unsigned long long)(((blockIdx.x >> 3) / (g.nt > 0 ? g.nt : 1)) & 7) * g.stagger;
-        while (__builtin_amdgcn_s_memtime() - t0 < d) __builtin_amdgcn_s_sleep(32);
-    }
     auto lin_of = [&](int k) { return (rem_lin >= 0 && k == ntiles - 1) ? rem_lin : xbeg + loc + k * nloc; };
     // chunk range of the block's k-th tile: only the last one can be partial
     auto cbeg = [&](int k) { return k == ntiles - 1 ? last_c0 : 0; };
@@ -1398,7 +1392,8 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
                     // load phase: bias + residual of the quads of this column block for all row blocks -- independent loads in
                     // flight (the compiler may not hoist them itself: y and res could alias), then the stores
                     constexpr int QB = (RES == 2 || NT > 1 || M16) ? 1 : 2;   // quads per batch, bounded by the register budget
-                    constexpr int RBB = M16 ? (RES == 2 ? 2 : 4) : RB;        // row blocks per batch (M16: 8 row blocks of 16)
+                    constexpr int RBB = M16 ? (RES == 2 || RB < 4 ? 2 : 4) : RB;   // row blocks per batch (M16: 8 or 2 row blocks of 16)
+                    static_assert(RB % RBB == 0, "row-block batches must tile the wave's rows");
 #pragma unroll
                     for (int q0 = 0; q0 < QPB; q0 += QB) {
                     f32x4 s1[QB], s2[QB];
@@ -1860,6 +1855,10 @@ static bool want_bn256(const sgd_igemm_args& a) {
     const long mt = (rows + BM - 1) / BM;
     const long t256 = mt * (a.cout_p / 256), t128 = mt * (a.cout_p / 128);
     if (t256 <= 256 && t128 > 256) return true;    // one round of bigger tiles instead of a second, partly empty one
+    // 3x3 launches in a split mode: the 128-column tile runs the 16x16x32 MFMA form, which the 64-column wave tile has no
+    // registers for, and wins wherever it fills the chip (measured, round 3: +4..14 % on every layer of more than one
+    // round); below one round (8x8 maps at UNet batch 80: 160 tiles) the bigger tile still does (+6..21 %)
+    if (a.mode == SGD_MODE_CONV3 && a.prec != SGD_PREC_F32) return t128 <= 256;
     const long r256 = (t256 + 255) / 256, r128 = (t128 + 255) / 256;
     return r256 * 2.0 < r128 * 1.07;
 }
@@ -1903,7 +1902,6 @@ extern "C" int sgd_igemm(const sgd_igemm_args* args, void* stream) {
     }
     if (a.stats && g.sparts == 0) return SGD_ERR_ARG;
     g.nt = a.cout_p / bn;
-    { const char* e = getenv("SGDM_STAGGER"); g.stagger = e ? atoi(e) : 0; }
     {
         const char* e = getenv("SGDM_BALANCE");   // 0: plain schedule even with a workspace (A/B runs)
         if ((a.work && a.work_bytes < sgd_igemm_work_bytes()) || (e && atoi(e) == 0)) a.work = nullptr;

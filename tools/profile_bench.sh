@@ -1,0 +1,12 @@
+#!/bin/bash
+# rocprofv3 kernel statistics of a bench.py command (run on the GPU box, from the repo root):
+#   tools/profile_bench.sh gpurun_out/r3_sampling  bench.py --steps 20 --warmup 3 --no-train --no-extra
+# writes <prefix>_kernel_stats.csv (the --stats summary) and <prefix>_bench.json (the bench line of that same process).
+R=${GRAFT_REPO_ROOT:-/root/repo}
+PFX="$R/$1"; shift
+cd /tmp && export TMPDIR=/tmp
+rm -rf /tmp/prof_bench
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_bench -o p -- python3 "$R/$1" "${@:2}" > /tmp/prof_bench.log 2>&1
+grep '^{"metric"' /tmp/prof_bench.log | tail -1 > "${PFX}_bench.json"
+cp "$(find /tmp/prof_bench -name '*kernel_stats.csv' | head -1)" "${PFX}_kernel_stats.csv"
+head -8 "${PFX}_kernel_stats.csv" | cut -c1-200
