@@ -385,7 +385,8 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
     float* stg = bias_s + a.cout_p;                         // [BM][STG_LD], DEFER only (sgd_igemm sizes the allocation)
     static_assert(!DEFER || (BN == 128 && TAPS == 9 && VEC && !M16), "loader-side epilogue: 3x3, 128-column tiles");
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform by construction: keeps its arithmetic scalar
 
     // XCD-aware persistent schedule: blocks b, b+8, .. share an XCD (and its L2).  XCD x owns the tile
     // range [x*xchunk, (x+1)*xchunk); its blocks stride through it together, so tiles in flight on one
@@ -1340,8 +1341,9 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
             constexpr bool PART = decltype(partc)::value;     // balanced tail: add the other blocks' partial accumulators
             // per M block: output row / residual row of this lane's pixel
             bool okm[RB];
-            float* ypm[RB];
-            const float* rpm[RB];
+            // rows as 32-bit indices, addresses formed at the use: as 64-bit pointers the 16 (M16) row pointers were the
+            // epilogue's spill traffic, and a kernel with scratch costs small launches ~3 us each (C1: 29 -> 25 ms)
+            int orw[RB], rrw[RB];
             // the lane's pixel goes through an opaque register: its tile-invariant row arithmetic (tx, ty, image of every row
             // block) is then redone per tile -- ~20 integer instructions -- instead of living in ~10 registers across the
             // K loop, which the allocator spilled and reloaded behind the stores (vmcnt is in order)
@@ -1368,8 +1370,8 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
                 if (!CONV && a.orows_in > 0)
                     orow = (int)((unsigned)orow / (unsigned)a.orows_in) * a.orows_out + a.orow_off
                            + (int)((unsigned)orow % (unsigned)a.orows_in);
-                ypm[mt] = a.y + (long)orow * a.y_ld;
-                rpm[mt] = RES ? a.res + (long)rrow * a.cout : nullptr;
+                orw[mt] = orow;
+                rrw[mt] = rrow;
             }
             const bool vec = ((a.cout | a.y_ld) & 3) == 0;
             if (vec) {
@@ -1401,6 +1403,9 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
                     for (int i = 0; i < QB; ++i) s1[i] = s2[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int mb0 = 0; mb0 < RB; mb0 += RBB) {
+                    // (opaque per batch: the addresses of a batch's rows are formed here, not hoisted as RB 64-bit values)
+#pragma unroll
+                    for (int mt = mb0; mt < mb0 + RBB; ++mt) asm volatile("" : "+v"(orw[mt]), "+v"(rrw[mt]));
                     f32x4 rv[QB][RBB];
                     f32x4 pv[QB][RBB];
                     if constexpr (PART) {
@@ -1425,10 +1430,10 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
                         for (int mt = mb0; mt < mb0 + RBB; ++mt) {
                             f32x4& r = rv[gq - q0][mt - mb0];
                             r = bv;
-                            if ((RES == 1 || RES == 3) && !ABL(2)) r += ld4(rpm[mt] + cl);
+                            if ((RES == 1 || RES == 3) && !ABL(2)) r += ld4(a.res + (long)rrw[mt] * a.cout + cl);
                             if (RES == 2 && !ABL(2)) {
                                 const long rw = (long)a.wo * 2 * a.cout;
-                                const float* rp = rpm[mt];
+                                const float* rp = a.res + (long)rrw[mt] * a.cout;
                                 r += 0.25f * (ld4(rp + cl) + ld4(rp + a.cout + cl) + ld4(rp + rw + cl) + ld4(rp + rw + a.cout + cl));
                             }
                         }
@@ -1443,7 +1448,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
                             if constexpr (PART) v += pv[gq - q0][mt - mb0];
                             v = v * wsi + rv[gq - q0][mt - mb0];
                             if (okm[mt]) {
-                                if (!(DBG(8)) && !ABL(1)) *reinterpret_cast<f32x4*>(ypm[mt] + c) = v;
+                                if (!(DBG(8)) && !ABL(1)) *reinterpret_cast<f32x4*>(a.y + (long)orw[mt] * a.y_ld + c) = v;
                                 else KEEP_LIVE(v);
                                 s1[gq - q0] += v;
                                 s2[gq - q0] += v * v;
@@ -1476,8 +1481,8 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
 #pragma unroll
                 for (int mt = 0; mt < RB; ++mt) {
                     if (!okm[mt]) continue;
-                    float* yp = ypm[mt];
-                    const float* rp = rpm[mt];
+                    float* yp = a.y + (long)orw[mt] * a.y_ld;
+                    const float* rp = RES ? a.res + (long)rrw[mt] * a.cout : nullptr;
 #pragma unroll
                     for (int nt = 0; nt < CBN; ++nt)
 #pragma unroll
