@@ -442,6 +442,7 @@ def main():
                     barrier()
                     ts_.append(1000.0 * (time.perf_counter() - t0_))
                 c1[name + "_ms_per_trajectory"] = round(sorted(ts_)[len(ts_) // 2], 3)
+                c1[name + "_ms_min"] = round(min(ts_), 3)
         c1.update(workload=C1["desc"], images_per_s=round(C1["batch"] / (c1["graph_ms_per_trajectory"] * 1e-3), 1),
                   graph_speedup=round(c1["eager_ms_per_trajectory"] / c1["graph_ms_per_trajectory"], 2),
                   note="whole p_sample_loop (10 steps, all of them snapshot steps, uint8 conversion); the captured step is cached on the model, capture cost excluded by the warm-up call")
