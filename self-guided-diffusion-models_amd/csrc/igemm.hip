@@ -1389,15 +1389,18 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
                     }
                     sp = a.stats + ((long)n_img * g.sparts + part) * 2 * a.cout;
                 }
+                {
+                    // Column slots cs = (column block nt, quad gq) of the lane's output: c = cb + nt * CBW + gq * 8.
+                    // load phase: bias + residual of a batch of slots x row blocks -- independent loads in flight (the compiler
+                    // may not hoist them itself: y and res could alias) -- then the stores.  Every batch is one exposed memory
+                    // round trip for a wave that has nothing else to issue, so batches are as big as the registers allow: with
+                    // the 16x16x32 form (operands not carried across the epilogue) ALL of a tile's 16 residual quads.
+                    constexpr int CS = CBN * QPB;                                      // column slots per lane
+                    constexpr int QB = M16 ? ((RES == 2 || PART) ? 1 : CBN) : ((RES == 2 || NT > 1) ? 1 : 2);   // slots per batch
+                    constexpr int RBB = M16 ? (RES == 2 || RB < 4 ? 2 : (PART ? 4 : RB)) : RB;   // row blocks per batch
+                    static_assert(RB % RBB == 0 && CS % QB == 0, "batches must tile the wave's rows and columns");
 #pragma unroll
-                for (int nt = 0; nt < CBN; ++nt) {
-                    // load phase: bias + residual of the quads of this column block for all row blocks -- independent loads in
-                    // flight (the compiler may not hoist them itself: y and res could alias), then the stores
-                    constexpr int QB = (RES == 2 || NT > 1 || M16) ? 1 : 2;   // quads per batch, bounded by the register budget
-                    constexpr int RBB = M16 ? (RES == 2 || RB < 4 ? 2 : 4) : RB;   // row blocks per batch (M16: 8 or 2 row blocks of 16)
-                    static_assert(RB % RBB == 0, "row-block batches must tile the wave's rows");
-#pragma unroll
-                    for (int q0 = 0; q0 < QPB; q0 += QB) {
+                    for (int q0 = 0; q0 < CS; q0 += QB) {
                     f32x4 s1[QB], s2[QB];
 #pragma unroll
                     for (int i = 0; i < QB; ++i) s1[i] = s2[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1410,25 +1413,25 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
                     f32x4 pv[QB][RBB];
                     if constexpr (PART) {
 #pragma unroll
-                        for (int gq = q0; gq < q0 + QB; ++gq)
+                        for (int cs = q0; cs < q0 + QB; ++cs)
 #pragma unroll
                             for (int mt = mb0; mt < mb0 + RBB; ++mt) {
-                                const char* pp = part_base + (size_t)(((mt * CBN + nt) * QPB + gq) * NCOMP) * 16;
+                                const char* pp = part_base + (size_t)((mt * CS + cs) * NCOMP) * 16;
                                 f32x4 sum = *reinterpret_cast<const f32x4*>(pp);
                                 for (int pi = 1; pi < nparts; ++pi) sum += *reinterpret_cast<const f32x4*>(pp + pi * SLAB);
-                                pv[gq - q0][mt - mb0] = sum;
+                                pv[cs - q0][mt - mb0] = sum;
                             }
                     }
 #pragma unroll
-                    for (int gq = q0; gq < q0 + QB; ++gq) {
-                        const int c = cb + nt * CBW + gq * 8;
+                    for (int cs = q0; cs < q0 + QB; ++cs) {
+                        const int c = cb + (cs / QPB) * CBW + (cs % QPB) * 8;
                         const int cl = c < a.cout ? c : 0;    // clamped: the quad is skipped below
                         f32x4 bv = {0.f, 0.f, 0.f, 0.f};
                         if (bias_lds) bv = *reinterpret_cast<const f32x4*>(bias_s + cl);
                         else if (a.bias && !ABL(2)) bv = ld4(a.bias + cl);
 #pragma unroll
                         for (int mt = mb0; mt < mb0 + RBB; ++mt) {
-                            f32x4& r = rv[gq - q0][mt - mb0];
+                            f32x4& r = rv[cs - q0][mt - mb0];
                             r = bv;
                             if ((RES == 1 || RES == 3) && !ABL(2)) r += ld4(a.res + (long)rrw[mt] * a.cout + cl);
                             if (RES == 2 && !ABL(2)) {
@@ -1439,31 +1442,31 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
                         }
                     }
 #pragma unroll
-                    for (int gq = q0; gq < q0 + QB; ++gq) {
-                        const int c = cb + nt * CBW + gq * 8;
+                    for (int cs = q0; cs < q0 + QB; ++cs) {
+                        const int c = cb + (cs / QPB) * CBW + (cs % QPB) * 8;
                         if (c >= a.cout) continue;            // uniform within a lane half / a row of 16 lanes
 #pragma unroll
                         for (int mt = mb0; mt < mb0 + RBB; ++mt) {
-                            f32x4 v = accq(mt, nt, gq);
-                            if constexpr (PART) v += pv[gq - q0][mt - mb0];
-                            v = v * wsi + rv[gq - q0][mt - mb0];
+                            f32x4 v = accq(mt, cs / QPB, cs % QPB);
+                            if constexpr (PART) v += pv[cs - q0][mt - mb0];
+                            v = v * wsi + rv[cs - q0][mt - mb0];
                             if (okm[mt]) {
                                 if (!(DBG(8)) && !ABL(1)) *reinterpret_cast<f32x4*>(a.y + (long)orw[mt] * a.y_ld + c) = v;
                                 else KEEP_LIVE(v);
-                                s1[gq - q0] += v;
-                                s2[gq - q0] += v * v;
+                                s1[cs - q0] += v;
+                                s2[cs - q0] += v * v;
                             }
                         }
                     }
                     }
                     if (sp && !DBG(256) && !ABL(4)) {
 #pragma unroll
-                        for (int gq = q0; gq < q0 + QB; ++gq) {
-                            const int c = cb + nt * CBW + gq * 8;
+                        for (int cs = q0; cs < q0 + QB; ++cs) {
+                            const int c = cb + (cs / QPB) * CBW + (cs % QPB) * 8;
                             if (c >= a.cout) continue;
                             // sum over the pixel lanes that share this lane's channels: the 32 lanes of a lane half (4 DPP steps
                             // inside a row of 16, then across rows) or, M16, the 16 lanes of a DPP row
-                            f32x4 t1 = s1[gq - q0], t2 = s2[gq - q0];
+                            f32x4 t1 = s1[cs - q0], t2 = s2[cs - q0];
 #pragma unroll
                             for (int j = 0; j < 4; ++j) {
                                 t1[j] = M16 ? row16_sum(t1[j]) : half_wave_sum_hi(t1[j]);
