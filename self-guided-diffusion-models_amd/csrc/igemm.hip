@@ -1545,8 +1545,9 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
             if (k + 1 < ntiles) {
                 const float* a0 = As + (size_t)aslot * a_floats;
                 if constexpr (M16) {
-#pragma unroll
-                    for (int cb = 0; cb < CBN; ++cb) fb16[cb].load(wp + (cb >> 1) * WUNIT + (cb & 1) * 256);
+                    // the WEIGHTS of the next tile's first step (requested by the last step, 16 registers) are carried: asked
+                    // for again here they would sit behind the acknowledgement of the epilogue's 16 stores (vmcnt is in
+                    // order); the input units come from LDS
 #pragma unroll
                     for (int st = 0; st < RB; ++st) ring[st].load(a0 + aoff[st], lane >> 4);
                 } else {
