@@ -15,7 +15,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIBDIR = os.path.join(HERE, "sgdm_amd", "lib")
-LIB = os.path.join(LIBDIR, "libsgdm_hip.so")
+# tools: SGDM_BUILD_TAG=_x SGDM_EXTRA_FLAGS="-D..." builds libsgdm_hip_x.so from objects *_x.o next to the product library
+TAG = os.environ.get("SGDM_BUILD_TAG", "")
+LIB = os.path.join(LIBDIR, f"libsgdm_hip{TAG}.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
          "-ffp-contract=fast"]
@@ -51,12 +53,13 @@ def _units():
 
 def _compile(unit, force):
     src, suffix, extra = unit
-    obj = os.path.join(OBJ, src[:-4] + suffix + ".o")
+    obj = os.path.join(OBJ, src[:-4] + suffix + TAG + ".o")
     sp = os.path.join(CSRC, src)
     if (not force and os.path.exists(obj)
             and os.path.getmtime(obj) >= max(os.path.getmtime(sp), _deps_mtime())):
         return obj
-    cmd = [HIPCC, *FLAGS, *FILE_FLAGS.get(src, []), *extra, "-c", sp, "-o", obj]
+    cmd = [HIPCC, *FLAGS, *FILE_FLAGS.get(src, []), *extra, *(os.environ.get("SGDM_EXTRA_FLAGS", "").split() if TAG else []),
+           "-c", sp, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")

@@ -1293,11 +1293,15 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
             // workspace: [WORK_TILES] {arrived, consumed} counters, then one slab per (split tile, producing part);
             // slab element (mt, nt, quad q) of compute thread tid at (((mt * NT + nt) * 4 + q) * NCOMP + tid) * 16 bytes:
             // every store / load instruction of a wave moves 1 KiB of consecutive bytes
-            // split tile of this launch, numbered densely: an XCD has at most nloc / split of them, so the slabs of a
-            // launch number at most 8 * (nloc / split) * (split - 1) <= 192 (sgd_igemm_work_bytes)
-            const int gi = xcd * (nloc / split) + loc / split;
+            // Every XCD owns a fixed range of counters and slabs: its `split` depends on ITS remainder (the last XCD of a
+            // launch usually has fewer tiles), and ranges sized by the XCD's own split overlapped between XCDs of different
+            // splits -- two split tiles on one counter: sums of the wrong tile, then a finisher polling forever (round 3:
+            // 1 evaluation in ~20 of the ch=224 model at batch 1).  An XCD has at most nloc / 2 split tiles and
+            // (nloc / split) * (split - 1) <= 3 nloc / 4 producer slabs: 8 * 24 = 192 at 256 blocks (sgd_igemm_work_bytes).
+            const int gi = xcd * (nloc >> 1) + loc / split;
             int* const cnt = reinterpret_cast<int*>(a.work) + gi * 2;
-            char* const slab0 = reinterpret_cast<char*>(a.work) + WORK_HEAD + (size_t)gi * (split - 1) * SLAB;
+            char* const slab0 = reinterpret_cast<char*>(a.work) + WORK_HEAD
+                                + ((size_t)xcd * ((nloc * 3) >> 2) + (size_t)(loc / split) * (split - 1)) * SLAB;
             if (rem_part + 1 < split) {
                 // PRODUCER (R1 of the guide's publish recipe): write-through (sc1) 16-byte stores -- no release fence, no
                 // write-back of the L2's other dirty lines --, every storing wave drains its stores, then signals for itself

@@ -303,6 +303,8 @@ BALANCE_CASES = [(80, 512, 512, 16, 9),     # 640 tiles: 2 whole rounds + 16 per
                  (12, 256, 128, 16, 9),     # 24 tiles: 3 per XCD split in 4 (8 chunks)
                  (5, 96, 128, 16, 9),       # 10 tiles, 3 chunks: split capped by the chunk count
                  (9, 64, 32, 8, 9),         # BN = 32 instance, 8x8 maps (two images per tile, ragged), 2 chunks
+                 (2, 672, 672, 16, 9),      # 84 tiles of 32 columns: XCDs 0..6 split their 11 tiles in 2, XCD 7 its 7 in 4 --
+                 (42, 672, 128, 16, 9),     # ... and of 128 columns: per-XCD counter / slab ranges must not depend on the split
                  (80, 512, 1536, 16, 1),    # qkv: FLAT, 160 x 12 = 1920 tiles: 7 rounds + 16 per XCD
                  (3, 384, 128, 32, 1)]      # FLAT, 24 tiles, 12 chunks
 
