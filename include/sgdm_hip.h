@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define SGD_ABI_VERSION 10
+#define SGD_ABI_VERSION 11
 int sgd_abi_version(void);
 
 /* --------------------------------------------------------------------------------------
@@ -104,6 +104,11 @@ typedef struct sgd_igemm_args {
     int64_t work_bytes;
 } sgd_igemm_args;
 int64_t sgd_igemm_work_bytes(void);
+/* Host-only test hook (no launch): the balanced-tail workspace layout of a launch of `total_tiles` tiles with `nchunks`
+ * 32-channel chunks per tile and `taps` (9 / 1) K steps per chunk on `grid` persistent blocks.  out[4*b .. 4*b+3] =
+ * {K split of block b's last tile (0: none), index of its arrival counter, first producer slab, producer slabs}.
+ * Two split tiles of one launch must never share a counter or a slab (tests/test_boundary_cpu.py). */
+int sgd_igemm_tail_layout(int32_t total_tiles, int32_t nchunks, int32_t taps, int32_t grid, int32_t* out);
 
 /* the keep/drop hash, shared by device code and host tests:
  *   h = seed ^ (lo * 0x9E3779B1) ^ (hi * 0x632BE5AB); h ^= h>>16; h *= 0x85EBCA6B; h ^= h>>13; h *= 0xC2B2AE35; h ^= h>>16;

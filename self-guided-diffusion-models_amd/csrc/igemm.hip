@@ -48,6 +48,28 @@ constexpr int MIN_PART_STEPS = 27;   // K steps (tap x 32 channels) of the small
 constexpr int SPLIT_MAX = 4;   // K parts of a tile of the balanced tail (sgd_igemm_args.work)
 constexpr int WORK_TILES = 256;                        // split tiles of one launch: < blocks
 constexpr int WORK_HEAD = WORK_TILES * 8;              // bytes: per split tile {arrived, consumed} wave counters
+
+// Balanced-tail arithmetic shared by the kernel and sgd_igemm_tail_layout (the CPU test of the workspace layout).
+// K parts of the `xrem` tiles an XCD has left after its whole rounds (0: no split): a part must be worth its hand-off
+// (publish + poll + acquire + the slab reads of the finisher, ~10 us): at least MIN_PART_STEPS K steps.  Measured
+// (tools/ab_conv.py, UNet batch 80): 3x3 convs of >= 256 input channels gain 4..7 %, 128-channel ones (2 chunks per
+// part) and every 1x1 launch lose 5..15 %.
+__host__ __device__ inline int tail_split(int xrem, int nloc, int nchunks, int taps) {
+    if (xrem <= 0 || nchunks < 2) return 0;
+    int split = nloc / xrem;
+    if (split > SPLIT_MAX) split = SPLIT_MAX;
+    while (split >= 2 && (nchunks / split) * taps < MIN_PART_STEPS) --split;
+    return split < 2 ? 0 : split;
+}
+// Every XCD owns a FIXED range of counters and slabs: its split depends on ITS remainder (the last XCD of a launch usually
+// has fewer tiles), and ranges sized by the XCD's own split overlapped between XCDs of different splits -- two split tiles
+// on one counter: sums of the wrong tile, then a finisher polling forever (round 3: 1 evaluation in ~20 of the ch=224
+// model at batch 1).  An XCD has at most nloc / 2 split tiles and (nloc / split) * (split - 1) <= 3 nloc / 4 producer
+// slabs: 8 * 24 = 192 at 256 blocks (sgd_igemm_work_bytes).
+__host__ __device__ inline int tail_counter(int xcd, int loc, int nloc, int split) { return xcd * (nloc >> 1) + loc / split; }
+__host__ __device__ inline int tail_slab(int xcd, int loc, int nloc, int split) {
+    return xcd * ((nloc * 3) >> 2) + (loc / split) * (split - 1);
+}
 constexpr int FAST_PIX = 192;  // halo tiles up to this many pixels (16x8 outputs + halo = 180) use the split-phase A loader
 
 struct Geo {
@@ -406,16 +428,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
     // LAST, after its whole tiles.
     const int xtiles = xend > xbeg ? xend - xbeg : 0;
     const int nfull = xtiles / nloc, xrem = xtiles - nfull * nloc;
-    int split = 0;
-    if (xrem > 0 && a.work && nchunks >= 2 && !ABL(2048)) {
-        split = nloc / xrem;
-        if (split > SPLIT_MAX) split = SPLIT_MAX;
-        // a part must be worth its hand-off (publish + poll + acquire + the slab reads of the finisher, ~10 us): at least
-        // MIN_PART_STEPS K steps.  Measured (tools/ab_conv.py, UNet batch 80): 3x3 convs of >= 256 input channels gain
-        // 4..7 %, 128-channel ones (2 chunks per part) and every 1x1 launch lose 5..15 %.
-        while (split >= 2 && (nchunks / split) * TAPS < MIN_PART_STEPS) --split;
-        if (split < 2) split = 0;
-    }
+    const int split = (a.work && !ABL(2048)) ? tail_split(xrem, nloc, nchunks, TAPS) : 0;
     int ntiles, rem_lin = -1, rem_part = 0, last_c0 = 0, last_c1 = nchunks;
     if (!split) {
         ntiles = loc < xtiles ? (xtiles - loc + nloc - 1) / nloc : 0;
@@ -1293,15 +1306,9 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
             // workspace: [WORK_TILES] {arrived, consumed} counters, then one slab per (split tile, producing part);
             // slab element (mt, nt, quad q) of compute thread tid at (((mt * NT + nt) * 4 + q) * NCOMP + tid) * 16 bytes:
             // every store / load instruction of a wave moves 1 KiB of consecutive bytes
-            // Every XCD owns a fixed range of counters and slabs: its `split` depends on ITS remainder (the last XCD of a
-            // launch usually has fewer tiles), and ranges sized by the XCD's own split overlapped between XCDs of different
-            // splits -- two split tiles on one counter: sums of the wrong tile, then a finisher polling forever (round 3:
-            // 1 evaluation in ~20 of the ch=224 model at batch 1).  An XCD has at most nloc / 2 split tiles and
-            // (nloc / split) * (split - 1) <= 3 nloc / 4 producer slabs: 8 * 24 = 192 at 256 blocks (sgd_igemm_work_bytes).
-            const int gi = xcd * (nloc >> 1) + loc / split;
+            const int gi = tail_counter(xcd, loc, nloc, split);
             int* const cnt = reinterpret_cast<int*>(a.work) + gi * 2;
-            char* const slab0 = reinterpret_cast<char*>(a.work) + WORK_HEAD
-                                + ((size_t)xcd * ((nloc * 3) >> 2) + (size_t)(loc / split) * (split - 1)) * SLAB;
+            char* const slab0 = reinterpret_cast<char*>(a.work) + WORK_HEAD + (size_t)tail_slab(xcd, loc, nloc, split) * SLAB;
             if (rem_part + 1 < split) {
                 // PRODUCER (R1 of the guide's publish recipe): write-through (sc1) 16-byte stores -- no release fence, no
                 // write-back of the L2's other dirty lines --, every storing wave drains its stores, then signals for itself
@@ -1874,6 +1881,30 @@ static bool want_bn256(const sgd_igemm_args& a) {
     if (a.mode == SGD_MODE_CONV3 && a.prec != SGD_PREC_F32) return t128 <= 256;
     const long r256 = (t256 + 255) / 256, r128 = (t128 + 255) / 256;
     return r256 * 2.0 < r128 * 1.07;
+}
+
+// Test hook (tests/test_boundary_cpu.py, no GPU): the balanced-tail workspace layout of a launch of `total_tiles` tiles with
+// `nchunks` channel chunks per tile on `grid` blocks -- per block {split, counter index, first slab, slabs} (split 0: the
+// block has no split tile) -- from the same functions the kernel uses.
+extern "C" int sgd_igemm_tail_layout(int32_t total_tiles, int32_t nchunks, int32_t taps, int32_t grid, int32_t* out) {
+    if (!out || grid < 8 || (grid & 7) || total_tiles < 0) return SGD_ERR_ARG;
+    const int xchunk = (total_tiles + 7) >> 3, nloc = grid >> 3;
+    for (int b = 0; b < grid; ++b) {
+        const int xcd = b & 7, loc = b >> 3;
+        const int xbeg = xcd * xchunk, xend = (xbeg + xchunk < total_tiles) ? xbeg + xchunk : total_tiles;
+        const int xtiles = xend > xbeg ? xend - xbeg : 0;
+        const int nfull = xtiles / nloc, xrem = xtiles - nfull * nloc;
+        const int split = tail_split(xrem, nloc, nchunks, taps);
+        int32_t* o = out + 4 * b;
+        o[0] = o[1] = o[2] = o[3] = 0;
+        if (split && loc < xrem * split) {
+            o[0] = split;
+            o[1] = tail_counter(xcd, loc, nloc, split);
+            o[2] = tail_slab(xcd, loc, nloc, split);
+            o[3] = split - 1;
+        }
+    }
+    return SGD_OK;
 }
 
 extern "C" int64_t sgd_igemm_work_bytes(void) {

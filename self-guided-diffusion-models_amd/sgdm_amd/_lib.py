@@ -20,7 +20,7 @@ RS_NONE, RS_AVGPOOL2, RS_UP2, RS_ZEROUP2 = 0, 1, 2, 3
 PRO_NONE, PRO_AFFINE_NC, PRO_LN_ROW = 0, 1, 2
 PREC_F32, PREC_F16X3, PREC_BF16X3 = 0, 1, 2
 PREC_BY_NAME = {"f32": PREC_F32, "f16x3": PREC_F16X3, "bf16x3": PREC_BF16X3}
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
@@ -45,6 +45,7 @@ SIGNATURES = {
     "sgd_igemm": (i32, [C.POINTER(IgemmArgs), vp]),
     "sgd_igemm_stats_parts": (i32, [C.POINTER(IgemmArgs)]),
     "sgd_igemm_work_bytes": (i64, []),
+    "sgd_igemm_tail_layout": (i32, [i32, i32, i32, i32, C.POINTER(i32)]),
     "sgd_stats_reduce": (i32, [vp, i32, i32, i32, vp, i32, i32, vp]),
     "sgd_packed_weight_bytes": (i64, [i32, i32, i32, i32]),
     "sgd_pack_weight": (i32, [vp, vp, i32, i32, i32, i32, C.POINTER(i32), C.POINTER(i32), vp]),

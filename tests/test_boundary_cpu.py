@@ -175,12 +175,16 @@ def test_optimizer_chunk_table():
     assert chunk_table([]) == [0]
 
 
-@pytest.mark.parametrize("fname", ["r1_bench_c2_f16x3.json", "r2_bench_c2_f16x3_final.json", "r2_bench_c2_f16x3_final_b.json"])
+@pytest.mark.parametrize("fname", ["r1_bench_c2_f16x3.json", "r2_bench_c2_f16x3_final.json", "r2_bench_c2_f16x3_final_b.json",
+                                   "r3_bench_c2_f16x3.json"])
 def test_committed_bench_line_has_the_contract_fields(fname):
     """the bench lines committed under profiles/ (produced by bench.py on the MI355X) carry every field of the contract"""
     import json
     line = json.loads(open(os.path.join(ROOT, "profiles", fname)).read().strip().splitlines()[-1])
-    if fname.startswith("r2_"):
+    if fname.startswith("r3_"):
+        assert "c2_bs80" in line and line["train_step"]["grad_checksums_equal"] is True
+        assert "r3_pmc_hbm" in line["roofline"]["traffic_source"]
+    if not fname.startswith("r1_"):
         # round 2: the line is self-sufficient (exact-fp32 figure, C5 and C1 legs, instantiation split, traffic label)
         for k in ("f32_exact", "c5", "c1"):
             assert k in line, k
@@ -230,3 +234,38 @@ def test_lost_box_corner_contract_matches_reference_pipeline_masks():
         ref = np.zeros((S, S), dtype=np.float32)
         ref[c[1]:c[3], c[0]:c[2]] = 1
         assert (ref == m[0]).all(), (b, c)
+
+
+def test_balanced_tail_workspace_layout_never_shares_a_counter_or_a_slab():
+    """sgd_igemm_tail_layout (the kernel's own schedule arithmetic, host side): in every launch geometry, the split tiles of
+    all XCDs -- whose K split differs when the last XCD holds fewer tiles -- own disjoint arrival counters and disjoint
+    producer slabs inside the workspace sgd_igemm_work_bytes() sizes.  (Round 3: ranges sized by the XCD's own split
+    overlapped: 1 NaN evaluation in ~20 of the ch=224 model at batch 1, then a hang.)"""
+    from sgdm_amd import _lib as L
+    lib = L.load()
+    slabs_total = (int(lib.sgd_igemm_work_bytes()) - 256 * 8) // (128 * 256 * 4)
+    mixed = 0
+    for grid in (256, 64, 8):
+        out = (ctypes.c_int32 * (4 * grid))()
+        for taps in (9, 1):
+            for nchunks in (2, 3, 4, 7, 8, 21, 32, 60):
+                for total in list(range(1, 700)) + [1280, 1920, 2560]:
+                    assert lib.sgd_igemm_tail_layout(total, nchunks, taps, grid, out) == 0
+                    tiles = {}
+                    for b in range(grid):
+                        split, cnt, slab0, ns = out[4 * b:4 * b + 4]
+                        if split:
+                            assert ns == split - 1 and 0 <= cnt < 256
+                            tiles.setdefault((b & 7, cnt), set()).add((split, slab0))
+                    counters = [c for (_, c) in tiles]
+                    assert len(counters) == len(set(counters)), (grid, taps, nchunks, total, "counter shared between XCDs")
+                    used = []
+                    for (xcd, cnt), v in tiles.items():
+                        assert len(v) == 1, "the blocks of one split tile agree on split and slab"
+                        (split, slab0), = v
+                        used += list(range(slab0, slab0 + split - 1))
+                    assert len(used) == len(set(used)), (grid, taps, nchunks, total, "slab shared")
+                    if grid == 256 and used:
+                        assert max(used) < slabs_total
+                    mixed += len({s for v in tiles.values() for (s, _) in v}) > 1
+    assert mixed > 100          # geometries where XCDs of one launch use different splits were actually covered
