@@ -166,9 +166,15 @@ def test_ddp_bucketed_allreduce_two_ranks(name, backend):
         procs = [ctx.Process(target=_ddp_rank, args=(r, 2, port, td, name, backend)) for r in range(2)]
         for p in procs:
             p.start()
-        for p in procs:
-            p.join(timeout=300)
-            assert p.exitcode == 0
+        try:
+            for p in procs:
+                p.join(timeout=600)         # a fresh box pages torch in for 1-2 minutes per spawned rank
+                assert p.exitcode == 0, f"rank process exit code {p.exitcode} (None: still running after 600 s)"
+        finally:
+            for p in procs:                 # never leave a rank behind on the GPU: it would time-slice every later test
+                if p.is_alive():
+                    p.kill()
+                    p.join(timeout=30)
         got = [torch.load(f"{td}/rank{r}.pt") for r in range(2)]
     ref0, ref1 = _grads_for_seed(100, ddp=False, name=name), _grads_for_seed(101, ddp=False, name=name)
     assert not any(k.startswith("to_cond_tokens_2d") for k in ref0)
