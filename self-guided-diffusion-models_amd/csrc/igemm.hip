@@ -947,14 +947,16 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
             const TabRef tab = tabref(k);
             for (int idx = lt; idx < items; idx += A_THREADS) item_sync(abuf, tab, idx, chunk * KC);
         };
-        auto finish_item = [&](int slot, const TabRef& tab, int chunk, int idx, f32x4 raw, const Coef* kuni) __attribute__((always_inline)) {
+        auto finish_item = [&](int slot, const TabRef& tab, int chunk, int idx, f32x4 raw, bool kuse, const Coef& kuni) __attribute__((always_inline)) {
+            // (coefficients by value + flag: a `cond ? &k : nullptr` pointer kept the struct in scratch memory, and a kernel
+            // with any scratch pays for it on every launch)
             float* abuf = As + (size_t)(slot % NA) * a_floats;
             const int c = chunk * KC + c4 * 4;
             if (idx < items) {
                 const int pix = idx >> 3;
                 const int2 e = entry(tab, pix);
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (c < cin && e.x >= 0) v = apply_pro(a, raw, kuni ? *kuni : load_coef<VEC>(a, e.y, e.x, c), c, e.x);
+                if (c < cin && e.x >= 0) v = apply_pro(a, raw, kuse ? kuni : load_coef<VEC>(a, e.y, e.x, c), c, e.x);
                 lds_store_act<PREC>(abuf + (size_t)pix * LDA, c4, v);
             }
         };
@@ -1009,7 +1011,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
                     tr.m0 = 0;
 #pragma unroll
                     for (int j = 0; j < AJ; ++j)
-                        finish_item(slot, tr, cx.chunk, lt + j * A_THREADS, araw[j], kshared ? &kq : nullptr);
+                        finish_item(slot, tr, cx.chunk, lt + j * A_THREADS, araw[j], kshared, kq);
                     cx = ctx_of(qnext);
                     request();
                 };
@@ -1062,7 +1064,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
                 knone.q = knone.p;
 #pragma unroll
                 for (int j = 0; j < AJ; ++j)
-                    finish_item(slot, tab, chunk, lt + j * A_THREADS, araw[R][j], a.pro == SGD_PRO_NONE ? &knone : nullptr);
+                    finish_item(slot, tab, chunk, lt + j * A_THREADS, araw[R][j], a.pro == SGD_PRO_NONE, knone);
             };
             typedef std::integral_constant<int, 0> R0;
             typedef std::integral_constant<int, 1> R1;
@@ -1103,23 +1105,30 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
     // 20-27} / {4-11,16-19,28-31}) meet pixels that collide mod 16 -> 2-way bank conflicts on every input fragment read.
     // The permutation gives each such lane group 16 pixels distinct mod 16 (36-float pixel pitch: bank = 9*pixel mod
     // 16 quads).  The epilogue uses the same map, so results are unchanged.
-    int pli = li;
-    if (CONV && g.tw_l2 == 4 && s == 1) {
-        if (li < 4) pli = li;
-        else if (li < 12) pli = li + 4;
-        else if (li < 16) pli = li - 8;
-        else if (li < 20) pli = li;
-        else if (li < 28) pli = li + 2;
-        else pli = li < 30 ? li - 8 : li;
-    }
-    if constexpr (M16) {
-        // 16-row blocks: lane l reads row prow(l & 15), channel group l >> 4 (32 bytes further per group).  ds_read_b128
-        // serves {0-3,12-15,20-27} / {4-11,16-19,28-31} per LDS cycle: 8 lanes at group g and 8 at g + 1; with the 36-float
-        // pixel pitch the quad bank is 9 * pixel + 2 * group mod 16, conflict-free iff the rows read at the odd group all
-        // have one parity: lanes 4..11 take the odd rows, lanes 0..3 / 12..15 the even ones
-        const int i16 = lane & 15;
-        pli = i16 < 4 ? 2 * i16 : (i16 < 12 ? 2 * (i16 - 4) + 1 : 2 * i16 - 16);
-    }
+    // (a function of the lane: the epilogue recomputes it from an opaque copy of `lane` instead of keeping it -- and what
+    // is derived from it -- in registers across the K loop)
+    auto pixel_of_lane = [&](int ln) __attribute__((always_inline)) {
+        const int l5 = ln & 31;
+        int px = l5;
+        if (CONV && g.tw_l2 == 4 && s == 1) {
+            if (l5 < 4) px = l5;
+            else if (l5 < 12) px = l5 + 4;
+            else if (l5 < 16) px = l5 - 8;
+            else if (l5 < 20) px = l5;
+            else if (l5 < 28) px = l5 + 2;
+            else px = l5 < 30 ? l5 - 8 : l5;
+        }
+        if constexpr (M16) {
+            // 16-row blocks: lane l reads row prow(l & 15), channel group l >> 4 (32 bytes further per group).  ds_read_b128
+            // serves {0-3,12-15,20-27} / {4-11,16-19,28-31} per LDS cycle: 8 lanes at group g and 8 at g + 1; with the
+            // 36-float pixel pitch the quad bank is 9 * pixel + 2 * group mod 16, conflict-free iff the rows read at the odd
+            // group all have one parity: lanes 4..11 take the odd rows, lanes 0..3 / 12..15 the even ones
+            const int i16 = ln & 15;
+            px = i16 < 4 ? 2 * i16 : (i16 < 12 ? 2 * (i16 - 4) + 1 : 2 * i16 - 16);
+        }
+        return px;
+    };
+    const int pli = pixel_of_lane(lane);
     int aoff[RB];
 #pragma unroll
     for (int mt = 0; mt < RB; ++mt) {
@@ -1136,9 +1145,14 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
     // weight fragments: wave (wm, wn) needs N blocks wn*NT .. wn*NT+NT-1 of its tile; consecutive K steps of the stream
     // [chunk][tap] are `wstep` bytes apart (all N blocks of the layer for that step)
     const size_t wstep = (size_t)(a.cout_p >> 5) * WUNIT;
-    const char* const wlane = reinterpret_cast<const char*>(a.w) + (size_t)(wn * NT) * WUNIT
-                              + (M16 ? (lane >> 5) * 2048 + (((lane >> 4) & 1) * 32 + (lane & 15)) * 16 : lane * 16);
-    auto wtile_of = [&](int k) { return wlane + (size_t)(tile_at(g, lin_of(k), BN, TW, TH).n0c >> 5) * WUNIT; };
+    // (the lane's offset inside a unit is re-derived per tile from the hardware lane index: as a 64-bit per-lane pointer held
+    // from here on it was the kernel's last spilled value, and a kernel with any scratch pays ~3 us on every launch)
+    auto wtile_of = [&](int k) __attribute__((always_inline)) {
+        int l;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+        const int loff = M16 ? (l >> 5) * 2048 + (((l >> 4) & 1) * 32 + (l & 15)) * 16 : l * 16;
+        return reinterpret_cast<const char*>(a.w) + (size_t)(wn * NT + (tile_at(g, lin_of(k), BN, TW, TH).n0c >> 5)) * WUNIT + loff;
+    };
 
     AccV acc[RB][CBN];
     // 2^-k of the packed weights (exact); once per block, held in a SCALAR register: as a vector register it was the value the
@@ -1335,7 +1349,11 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             // the producers' slabs are read by the epilogue, next to the residual (the accumulator registers themselves are
             // not touched here: modifying 64..128 live registers under a branch costs a copy / spill storm at the join)
-            part_base = slab0 + (size_t)tid * 16;
+            {
+                int lane_p;                                  // (per tile: not a 64-bit lane pointer carried through the K loop)
+                asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_p));
+                part_base = slab0 + (size_t)(wave * 64 + lane_p) * 16;
+            }
             nparts = split - 1;
             part_cnt = cnt;
         }
@@ -1346,7 +1364,11 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
         // of 4 consecutive channels (8g + 4*(lane>>5) + 0..3).  => 16-byte residual loads / stores, and the
         // row index math runs twice per lane instead of 32 times.
         const Tile T = tile_at(g, lin_of(k), BN, TW, TH);
-        const int cb = T.n0c + wn * WN + 4 * (M16 ? lane >> 4 : lh);   // first channel of this lane's first quad (nt = 0)
+        // the lane index re-read from the hardware (all lanes are active here): what the epilogue derives from the lane is
+        // computed per tile -- neither it nor `lane` itself has to survive the K loop in a register
+        int lane_e;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
+        const int cb = T.n0c + wn * WN + 4 * (M16 ? lane_e >> 4 : lane_e >> 5);   // first channel of this lane's first quad (nt = 0)
         auto epilogue = [&](auto resmode, auto partc) {
             constexpr int RES = decltype(resmode)::value;     // 0 none, 1 same rows, 2 avg-pool of 2x map, 3 nearest of 1/2 map
             constexpr bool PART = decltype(partc)::value;     // balanced tail: add the other blocks' partial accumulators
@@ -1358,8 +1380,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
             // the lane's pixel goes through an opaque register: its tile-invariant row arithmetic (tx, ty, image of every row
             // block) is then redone per tile -- ~20 integer instructions -- instead of living in ~10 registers across the
             // K loop, which the allocator spilled and reloaded behind the stores (vmcnt is in order)
-            int plie = pli;
-            asm volatile("" : "+v"(plie));
+            const int plie = pixel_of_lane(lane_e);
 #pragma unroll
             for (int mt = 0; mt < RB; ++mt) {
                 const int row = wm * WM + mt * RBH + plie;
