@@ -176,7 +176,7 @@ def test_optimizer_chunk_table():
 
 
 @pytest.mark.parametrize("fname", ["r1_bench_c2_f16x3.json", "r2_bench_c2_f16x3_final.json", "r2_bench_c2_f16x3_final_b.json",
-                                   "r3_bench_c2_f16x3.json"])
+                                   "r3_bench_c2_f16x3.json", "r3_bench_c2_f16x3_final.json"])
 def test_committed_bench_line_has_the_contract_fields(fname):
     """the bench lines committed under profiles/ (produced by bench.py on the MI355X) carry every field of the contract"""
     import json
