@@ -759,69 +759,86 @@ __global__ __launch_bounds__(512) void wgrad_conv_ws_kernel(const WArgs w) {
     }
 
     // =================================== compute waves: LDS -> MFMA ===================================
-    const int li = lane & 31, lh = lane >> 5;
-    f32x16 acc[9];
+    // v_mfma_f32_16x16x32 (round 3): the same matrix-pipe cycles per flop as 32x32x16, and a measured +14..16 % clock under
+    // this load (profiles/r3_pmc_mfma_form_clock.txt).  The wave's [32 co x 32 ci] tile of a tap is 2 x 2 blocks of 16 x 16,
+    // a K step is 32 pixels of the 8x8 patch: lane group g = lane >> 4 addresses pixel rows 8 g + q (and + 4) of the step,
+    // the transposing read hands lane j of a group channel j of the 16-channel block, 4 + 4 consecutive pixels.
+    f32x4 acc[9][2][2];
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[t][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int gidx = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
-    const int kbase = 8 * (gidx >> 1) + q;
-    const int chl = 16 * (gidx & 1) + 4 * pp;
+    // one per-lane element offset per operand; everything else (K step, block, tap, plane) is a compile-time constant that
+    // folds into the read's immediate offset: pixel 32 s + 8 g + q of the patch sits at halo index
+    // (4 s + g + 1) * 10 + q + 1
+    const int goff = (8 * gidx + q) * FGP + wave * 32 + 4 * pp;
+    const int uoff = ((gidx + 1) * 10 + q + 1) * UPITCH + 4 * pp;
     auto trd = [&](const T* p) -> T4 {
         s4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)p);
         return __builtin_bit_cast(T4, v);
     };
+    auto rd8 = [&](const T* p, int pitch4) -> T8 {                 // 8 consecutive pixels of this lane's channel
+        const T4 x0 = trd(p), x1 = trd(p + pitch4);
+        return T8{x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+    };
     __syncthreads();                                               // barrier 0
     for (int i = 0; i < nk; ++i) {
-        const T* Gh = base + (i & 1) * SLOT;
+        const T* Gh = base + (i & 1) * SLOT + goff;
         const T* Gl = Gh + 64 * FGP;
-        const T* Uh = Gl + 64 * FGP;
+        const T* Uh = base + (i & 1) * SLOT + 2 * 64 * FGP + uoff;
         const T* Ul = Uh + 100 * UPITCH;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const int k0 = 16 * s + kbase;
-            T8 ah, al;
-            {
-                const T* g0 = Gh + k0 * FGP + wave * 32 + chl;
-                const T* g1 = Gl + k0 * FGP + wave * 32 + chl;
-                const T4 h0 = trd(g0), h1 = trd(g0 + 4 * FGP), l0 = trd(g1), l1 = trd(g1 + 4 * FGP);
-                ah = T8{h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
-                al = T8{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+        for (int s = 0; s < 2; ++s) {
+            T8 ah[2], al[2];
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) {
+                ah[cb] = rd8(Gh + 32 * s * FGP + cb * 16, 4 * FGP);
+                al[cb] = rd8(Gl + 32 * s * FGP + cb * 16, 4 * FGP);
             }
-            const int hb = ((k0 >> 3) + 1) * 10 + (k0 & 7) + 1;
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
-                const int off = ((t / 3 - 1) * 10 + (t % 3 - 1)) * UPITCH;
-                const T* u0 = Uh + hb * UPITCH + off + chl;
-                const T* u1 = Ul + hb * UPITCH + off + chl;
-                const T4 h0 = trd(u0), h1 = trd(u0 + 4 * UPITCH), l0 = trd(u1), l1 = trd(u1 + 4 * UPITCH);
-                const T8 bh = T8{h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
-                const T8 bl = T8{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
-                if constexpr (PREC == SGD_PREC_F16X3) {
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[t], 0, 0, 0);
-                } else {
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[t], 0, 0, 0);
+                const int off = (40 * s + (t / 3 - 1) * 10 + (t % 3 - 1)) * UPITCH;
+#pragma unroll
+                for (int cj = 0; cj < 2; ++cj) {
+                    const T8 bh = rd8(Uh + off + cj * 16, 4 * UPITCH);
+                    const T8 bl = rd8(Ul + off + cj * 16, 4 * UPITCH);
+#pragma unroll
+                    for (int cb = 0; cb < 2; ++cb) {
+                        f32x4& c = acc[t][cb][cj];
+                        if constexpr (PREC == SGD_PREC_F16X3) {
+                            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[cb], bl, c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[cb], bh, c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[cb], bh, c, 0, 0, 0);
+                        } else {
+                            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[cb], bl, c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[cb], bh, c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[cb], bh, c, 0, 0, 0);
+                        }
+                    }
                 }
             }
         }
         __syncthreads();                                           // barrier i + 1
     }
     __syncthreads();                                               // pairs with the loaders' bias-reduction barrier
-    // ---- slab store: D rows = co (registers), cols = ci (lanes)
+    // ---- slab store: D block [16 co x 16 ci]: rows 4 (lane >> 4) + r in registers, column lane & 15
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
-        const int ci = ci0 + li;
-        if (ci >= cin) continue;
         float* slab = w.slabs + ((long)ks * 9 + t) * w.cout * cin;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int co = co0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            if (co < w.cout) slab[(long)co * cin + ci] = acc[t][r];
+        for (int cj = 0; cj < 2; ++cj) {
+            const int ci = ci0 + cj * 16 + (lane & 15);
+            if (ci >= cin) continue;
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int co = co0 + wave * 32 + cb * 16 + 4 * gidx + r;
+                    if (co < w.cout) slab[(long)co * cin + ci] = acc[t][cb][cj][r];
+                }
         }
     }
 }
