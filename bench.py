@@ -214,6 +214,11 @@ def train_step_bench(model, diff, data, cond, layout, B, world, barrier, wl, ste
     model.train()
     diff.train()
     from sgdm_amd.optim import FusedAdamWEma
+    if world > 1:
+        # replicas start identical (torch DDP's construction-time broadcast; bench seeds make them so anyway): the model
+        # BEFORE its EMA shadows are cloned from it
+        from sgdm_amd.ddp import sync_initial_state
+        sync_initial_state(model)
     ema = LitEma(model)
     # optim/adamw.yaml + data lr/wd; AdamW and the LitEma shadow update run as ONE launch (sgd_adamw_ema_step)
     opt = FusedAdamWEma([p for p in model.parameters() if p.requires_grad], lr=1e-4, weight_decay=0.01, ema=ema,
@@ -265,7 +270,9 @@ def train_step_bench(model, diff, data, cond, layout, B, world, barrier, wl, ste
                 backend=(dist.get_backend() if world > 1 else None),
                 per_rank_ms=[round(1000.0 * float(t_.item()) / steps, 2) for t_ in per_rank],
                 grad_checksum_first_step=[[float(v[0]), float(v[1])] for v in sums],
-                grad_checksums_equal=bool(all(torch.equal(v, ref) for v in sums)))
+                # null on one rank: there is nothing to compare, and a trivially true flag reads as a verified exchange
+                grad_checksums_equal=(bool(all(torch.equal(v, ref) for v in sums)) if world > 1 else None),
+                reserved_cus=int(__import__("sgdm_amd.ddp", fromlist=["x"]).reserved_cus(model)))
 
 
 def main():
@@ -295,6 +302,8 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # "nccl" is RCCL on ROCm.  SGDM_DIST_BACKEND=gloo lets several ranks share ONE GPU to exercise this path on a
         # single-GPU box (tests only: the ranks then time-slice the device)
+        # the exchange's kernels get the CUs the training programs leave free (sgdm_amd.ddp.reserved_cus) and no more
+        os.environ.setdefault("NCCL_MAX_NCHANNELS", os.environ.get("SGDM_RESERVE_CUS", "16"))
         dist.init_process_group(os.environ.get("SGDM_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
     local_rank %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define SGD_ABI_VERSION 11
+#define SGD_ABI_VERSION 12
 int sgd_abi_version(void);
 
 /* --------------------------------------------------------------------------------------
@@ -102,8 +102,26 @@ typedef struct sgd_igemm_args {
      * for the summation order of the split tiles. */
     void* work;
     int64_t work_bytes;
+    /* Persistent-grid cap (round 4).  The kernel runs one 512-thread block per compute unit (all of a CU's registers), so a
+     * launch sized to the whole device cannot share it: while another stream's kernel holds CUs -- RCCL's all-reduce
+     * during the overlapped backward (config/pl/default.yaml:2) -- the blocks that find no CU start only
+     * when others exit, and with the static tile lists that is up to 2x the launch time.  grid_cap > 0 launches at most
+     * grid_cap (rounded down to a multiple of 8, >= 8) blocks and leaves the remaining CUs to the other stream; 0 = every
+     * CU of the device (hipDeviceProp.multiProcessorCount).  Results do not depend on it bit for bit, except for the
+     * summation order of the balanced tail's split tiles. */
+    int32_t grid_cap;
+    int32_t reserved0;     /* keep 0 */
 } sgd_igemm_args;
 int64_t sgd_igemm_work_bytes(void);
+/* Balanced-tail health word (DEVICE int32 inside the workspace, byte offset sgd_igemm_work_status_offset()): 0 after a
+ * clean run.  A finisher whose producers did not arrive within its bounded poll (~2 s; cannot happen when the launches
+ * that share the workspace are ordered on one stream) sets it to 1 and multiplies its outputs by NaN instead of spinning
+ * for ever: check it after a run that produced NaN, zero the whole workspace before using it again. */
+int64_t sgd_igemm_work_status_offset(void);
+/* Diagnostic (tests/test_hip_contention.py, tools/): occupy `blocks` compute units -- one 512-thread block with 150 KB of
+ * LDS each, so nothing else fits beside it -- for `milliseconds` of wall-clock time.  Stands in for RCCL's kernels on a
+ * side stream in the single-GPU contention tests. */
+int sgd_debug_occupy(int32_t blocks, float milliseconds, void* stream);
 /* Host-only test hook (no launch): the balanced-tail workspace layout of a launch of `total_tiles` tiles with `nchunks`
  * 32-channel chunks per tile and `taps` (9 / 1) K steps per chunk on `grid` persistent blocks.  out[4*b .. 4*b+3] =
  * {K split of block b's last tile (0: none), index of its arrival counter, first producer slab, producer slabs}.

@@ -48,6 +48,14 @@ constexpr int MIN_PART_STEPS = 27;   // K steps (tap x 32 channels) of the small
 constexpr int SPLIT_MAX = 4;   // K parts of a tile of the balanced tail (sgd_igemm_args.work)
 constexpr int WORK_TILES = 256;                        // split tiles of one launch: < blocks
 constexpr int WORK_HEAD = WORK_TILES * 8;              // bytes: per split tile {arrived, consumed} wave counters
+// Health word of the workspace (sgd_igemm_work_status_offset): the last int of the head.  Counter pairs use indices
+// < 8 * (nloc / 2) <= 128 of the 256 pairs, so the word is never a counter.
+constexpr int WORK_STATUS_INT = WORK_HEAD / 4 - 1;
+// Finisher poll bound: s_sleep 16 = 1024 cycles, 2^22 polls ~ 2 s.  Producers never wait and the launches that share a
+// workspace are ordered on one stream, so a finisher that is still waiting then is waiting for a block that will never
+// store (stale counters after a faulted launch, a second stream on the same workspace): it flags the workspace and
+// poisons its outputs with NaN instead of hanging the device.
+constexpr int FINISH_POLL_MAX = 1 << 22;
 
 // Balanced-tail arithmetic shared by the kernel and sgd_igemm_tail_layout (the CPU test of the workspace layout).
 // K parts of the `xrem` tiles an XCD has left after its whole rounds (0: no split): a part must be worth its hand-off
@@ -1315,6 +1323,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
         };
         const char* part_base = nullptr;                               // finisher: this thread's quads in the producers' slabs
         int nparts = 0;
+        float wsk = wsi;                                               // this tile's output scale (NaN: see the finisher's poll)
         int* part_cnt = nullptr;
         if (rem_lin >= 0 && k == ntiles - 1) {
             // workspace: [WORK_TILES] {arrived, consumed} counters, then one slab per (split tile, producing part);
@@ -1341,10 +1350,17 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
             }
             // FINISHER (last K range): every wave polls for itself (one lane, relaxed, sleeping), ONE agent-scope acquire
             // after the match, then plain loads of the producers' slabs (in the epilogue), added in part order
+            int late = 0;
             if (lane == 0) {
                 const int need = (split - 1) * (NCOMP / 64);
-                while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) __builtin_amdgcn_s_sleep(16);
+                int polls = 0;
+                while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+                    __builtin_amdgcn_s_sleep(16);
+                    if (++polls >= FINISH_POLL_MAX) { late = 1; break; }
+                }
+                if (late) __hip_atomic_store(reinterpret_cast<int*>(a.work) + WORK_STATUS_INT, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
+            if (__builtin_amdgcn_readfirstlane(late)) wsk = __builtin_nanf("");      // bounded poll expired: poison, do not hang
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             // the producers' slabs are read by the epilogue, next to the residual (the accumulator registers themselves are
@@ -1481,7 +1497,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
                         for (int mt = mb0; mt < mb0 + RBB; ++mt) {
                             f32x4 v = accq(mt, cs / QPB, cs % QPB);
                             if constexpr (PART) v += pv[cs - q0][mt - mb0];
-                            v = v * wsi + rv[cs - q0][mt - mb0];
+                            v = v * wsk + rv[cs - q0][mt - mb0];
                             if (okm[mt]) {
                                 if (!(DBG(8)) && !ABL(1)) *reinterpret_cast<f32x4*>(a.y + (long)orw[mt] * a.y_ld + c) = v;
                                 else KEEP_LIVE(v);
@@ -1531,7 +1547,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
                                     const float* pp = reinterpret_cast<const float*>(part_base + (size_t)(((mt * CBN + nt) * QPB + gq) * NCOMP) * 16) + j;
                                     for (int pi = 0; pi < nparts; ++pi) x += pp[pi * (SLAB / 4)];
                                 }
-                                x = x * wsi + (bias_lds ? bias_s[c] : (a.bias ? a.bias[c] : 0.f));
+                                x = x * wsk + (bias_lds ? bias_s[c] : (a.bias ? a.bias[c] : 0.f));
                                 if (RES == 1 || RES == 3) x += rp[c];
                                 if (RES == 2) {
                                     const long rw = (long)a.wo * 2 * a.cout;
@@ -1702,6 +1718,18 @@ __global__ void pack_weight_kernel(const float* __restrict__ src, float* __restr
 }
 
 inline int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
+// compute units of the current device in whole groups of 8, at most 256 (the balanced tail's workspace layout is sized for
+// 32 blocks per XCD); read once per process and translation unit
+inline int device_cus() {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256;
+        n &= ~7;
+        cus = n < 8 ? 8 : (n > 256 ? 256 : n);
+    }
+    return cus;
+}
 inline bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 
 template <int BN, int PREC, bool VEC, int TAPS, bool DEFER = false>
@@ -1713,15 +1741,23 @@ int launch1(const KArgs& ka, size_t smem, hipStream_t st) {
         attr = true;
     }
     const int total = ka.g.mt * ka.g.nt;
-    int grid = ((total + 7) / 8) * 8;
-    if (grid > 256) grid = 256;                   // persistent: one block per CU walks its tiles
-    if (ka.a.work && total >= 8) grid = 256;      // balanced tail: blocks without a whole tile take K parts of the last ones
+    // persistent: one block per CU walks its tiles.  The device's CU count (256 on MI355X), less what the caller keeps
+    // free for another stream (args.grid_cap), in whole groups of 8 (one block per XCD and group)
+    int full = device_cus();
+    if (ka.a.grid_cap > 0 && ka.a.grid_cap < full) full = ka.a.grid_cap >= 8 ? (ka.a.grid_cap & ~7) : 8;
     if (const char* e = getenv("SGDM_MAX_GRID")) {     // tests: few blocks, so that small problems walk many tiles per block
         const int cap = atoi(e) & ~7;
-        if (cap >= 8 && grid > cap) grid = cap;
+        if (cap >= 8 && full > cap) full = cap;
     }
+    int grid = ((total + 7) / 8) * 8;
+    if (grid > full) grid = full;
+    if (ka.a.work && total >= 8) grid = full;     // balanced tail: blocks without a whole tile take K parts of the last ones
     hipLaunchKernelGGL((igemm_kernel<BN, PREC, VEC, TAPS, DEFER>), dim3(grid), dim3(NTHREADS), smem, st, ka);
-    return sgd_check_launch();
+    const int rc = sgd_check_launch();
+    // a launch that did not start leaves nothing behind, but one that faulted may have left arrival counters half-way:
+    // never hand such a head to the next launch
+    if (rc != SGD_OK && ka.a.work) (void)hipMemsetAsync(ka.a.work, 0, WORK_HEAD, st);
+    return rc;
 }
 
 // vec: 0 scalar inputs, 1 16-byte inputs, 2 16-byte inputs + the loader-side epilogue (DEFER: 3x3, 128-column tiles, split modes)
@@ -1933,6 +1969,8 @@ extern "C" int64_t sgd_igemm_work_bytes(void) {
     // 128 x 256 tile (128 KiB of partial accumulators per slab): split = 4 -> 192 slabs
     return (int64_t)WORK_HEAD + 192 * (int64_t)(BM * 256 * 4);
 }
+
+extern "C" int64_t sgd_igemm_work_status_offset(void) { return (int64_t)WORK_STATUS_INT * 4; }
 
 extern "C" int sgd_igemm_stats_parts(const sgd_igemm_args* args) {
     if (!args) return 0;

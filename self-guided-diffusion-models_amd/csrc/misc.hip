@@ -637,3 +637,32 @@ extern "C" int sgd_linear_splitk(const float* x, int32_t x_ld, const float* w, c
                        m, n, ksplit, y, y_ld);
     return sgd_check_launch();
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Diagnostic: hold `blocks` compute units for a wall-clock interval (sgd_debug_occupy).  512 threads + 150 KB of LDS per
+// block: nothing of the persistent conv kernel (one block per CU) fits beside it, which is what a collective's kernels on
+// a side stream do to the backward's launches (tests/test_hip_contention.py).
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(512) void occupy_kernel(unsigned long long ticks) {
+    extern __shared__ float occ_lds[];
+    const unsigned long long t0 = wall_clock64();                 // constant 100 MHz counter
+    occ_lds[threadIdx.x] = (float)threadIdx.x;                    // touch the allocation so it is real
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+    if (occ_lds[threadIdx.x] < 0.f) __builtin_trap();
+}
+}  // namespace
+
+extern "C" int sgd_debug_occupy(int32_t blocks, float milliseconds, void* stream) {
+    SGD_CLEAR_ERR();
+    if (blocks <= 0 || blocks > 256 || !(milliseconds > 0.f) || milliseconds > 1000.f) return SGD_ERR_ARG;
+    static bool attr = false;
+    constexpr size_t LDS = 150 * 1024;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)occupy_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
+        attr = true;
+    }
+    hipLaunchKernelGGL(occupy_kernel, dim3(blocks), dim3(512), LDS, (hipStream_t)stream,
+                       (unsigned long long)(milliseconds * 1.0e5f));
+    return sgd_check_launch();
+}

@@ -20,7 +20,7 @@ RS_NONE, RS_AVGPOOL2, RS_UP2, RS_ZEROUP2 = 0, 1, 2, 3
 PRO_NONE, PRO_AFFINE_NC, PRO_LN_ROW = 0, 1, 2
 PREC_F32, PREC_F16X3, PREC_BF16X3 = 0, 1, 2
 PREC_BY_NAME = {"f32": PREC_F32, "f16x3": PREC_F16X3, "bf16x3": PREC_BF16X3}
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
@@ -35,7 +35,7 @@ class IgemmArgs(C.Structure):
         ("bias", vp), ("res", vp), ("res_mode", i32), ("y", vp), ("cout", i32), ("y_ld", i32),
         ("orows_in", i32), ("orows_out", i32), ("orow_off", i32), ("prec", i32),
         ("drop_p", f32), ("drop_seed", C.c_uint32), ("stats", vp), ("w_scale_inv", vp),
-        ("work", vp), ("work_bytes", i64),
+        ("work", vp), ("work_bytes", i64), ("grid_cap", i32), ("reserved0", i32),
     ]
 
 
@@ -45,6 +45,8 @@ SIGNATURES = {
     "sgd_igemm": (i32, [C.POINTER(IgemmArgs), vp]),
     "sgd_igemm_stats_parts": (i32, [C.POINTER(IgemmArgs)]),
     "sgd_igemm_work_bytes": (i64, []),
+    "sgd_igemm_work_status_offset": (i64, []),
+    "sgd_debug_occupy": (i32, [i32, f32, vp]),
     "sgd_igemm_tail_layout": (i32, [i32, i32, i32, i32, C.POINTER(i32)]),
     "sgd_stats_reduce": (i32, [vp, i32, i32, i32, vp, i32, i32, vp]),
     "sgd_packed_weight_bytes": (i64, [i32, i32, i32, i32]),

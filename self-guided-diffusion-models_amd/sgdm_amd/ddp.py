@@ -141,3 +141,63 @@ def exclude_from_torch_ddp(root, *modules):
     prev = list(getattr(root, "_ddp_params_and_buffers_to_ignore", []))
     root._ddp_params_and_buffers_to_ignore = prev + [n for n in names if n not in prev]
     return names
+
+
+def torch_ddp_ignores(wrapper, module):
+    """True iff torch's DistributedDataParallel `wrapper` ignores EVERY parameter of `module` (by tensor identity: names
+    of other submodules may share a suffix with ours)"""
+    ignored = set(getattr(wrapper, "parameters_to_ignore", None)
+                  or getattr(wrapper.module, "_ddp_params_and_buffers_to_ignore", []) or [])
+    if not ignored:
+        return False
+    ignored_ids = {id(t) for n, t in wrapper.module.named_parameters() if n in ignored}
+    return all(id(p) in ignored_ids for p in module.parameters())
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# what torch DDP does at construction and this path must do itself: identical replicas before the first step
+# ------------------------------------------------------------------------------------------------------------------
+def sync_initial_state(module, group=None, src=0):
+    """broadcast rank `src`'s parameters and buffers to every rank, ONCE per module (torch DDP's construction-time
+    `_sync_module_states`; the reference relies on it through pl.trainer.strategy=ddp, config/pl/default.yaml:2).
+    In-place copies that bump the tensors' versions, so packed weights follow.  Returns the number of tensors sent."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return 0
+    if getattr(module, "_hip_ddp_synced", False):
+        return 0
+    tensors = list(module.parameters()) + list(module.buffers())
+    # one flat buffer per dtype: a few large broadcasts instead of ~400 small ones.  The copies back are in-place writes on
+    # the parameters themselves (under no_grad): they bump the tensors' versions, which is what the packed-weight caches key on
+    by_dtype = {}
+    for t in tensors:
+        by_dtype.setdefault(t.dtype, []).append(t)
+    with torch.no_grad():
+        for dtype, ts in by_dtype.items():
+            flat = torch.cat([t.detach().reshape(-1) for t in ts])
+            dist.broadcast(flat, src=src, group=group)
+            off = 0
+            for t in ts:
+                n = t.numel()
+                t.copy_(flat[off:off + n].view_as(t))
+                off += n
+    module._hip_ddp_synced = True
+    return len(tensors)
+
+
+def reserved_cus(model=None):
+    """compute units the persistent conv kernels leave free during a data-parallel TRAINING step.
+
+    The conv kernel runs one block per CU with all of the CU's registers; RCCL's all-reduce kernels on the side stream
+    need CUs of their own.  Without a reserve the two fight launch by launch (tests/test_hip_contention.py: a launch
+    whose blocks do not all fit takes up to 2x).  With world == 1, or the exchange off, nothing is reserved.
+    `SGDM_RESERVE_CUS` (default 16 = two per XCD; RCCL's workgroups are dealt round-robin over the XCDs like everyone
+    else's) -- pair it with NCCL_MAX_NCHANNELS <= the reserve (bench.py does)."""
+    import os
+    forced = getattr(model, "hip_reserve_cus", None) if model is not None else None
+    if forced is not None:                           # tests / tuning: a reserve without a process group
+        return max(0, int(forced))
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return 0
+    if model is not None and not getattr(model, "hip_ddp", True):
+        return 0
+    return max(0, int(os.environ.get("SGDM_RESERVE_CUS", "16")))

@@ -194,6 +194,7 @@ class Backward:
             a.res, a.res_mode = y.data_ptr(), L.RS_NONE
         if self.e.work_bytes:                # the forward engine's balanced-tail scratch (same stream: launches are ordered)
             a.work, a.work_bytes = self.e.work.data_ptr(), self.e.work_bytes
+        a.grid_cap = getattr(self.e, "_grid_cap", 0)
         self.late.append((a, pk))
         self.keep.append(a)
         self.prog.add(tag, self.lib.sgd_igemm, C.byref(a))
@@ -647,12 +648,10 @@ class _UNetTrainFn(torch.autograd.Function):
             # the reference's own multi-GPU command wraps the LightningModule in torch DDP (pl.trainer.strategy=ddp): then
             # torch's reducer owns the exchange -- this path must hand it the gradients through autograd (its hooks sit
             # on the AccumulateGrad nodes) and must NOT all-reduce them a second time
-            from .ddp import find_torch_ddp_wrapper
+            from .ddp import find_torch_ddp_wrapper, torch_ddp_ignores
             model._torch_ddp_checked = True
             wrapper = find_torch_ddp_wrapper(model)
-            ignored = set(getattr(getattr(wrapper, "module", None), "_ddp_params_and_buffers_to_ignore", []) or [])
-            if wrapper is not None and not (ignored and all(
-                    any(n.endswith(k) for n in ignored) for k, _ in model.named_parameters())):
+            if wrapper is not None and not torch_ddp_ignores(wrapper, model):
                 import warnings
                 model.hip_ddp = False
                 model.hip_grad_alias = False
@@ -715,6 +714,13 @@ def forward_train(model, x, t, cond, layout, mask, n):
         raise NotImplementedError("training through the SpatialTransformer path is not built: the reference raises "
                                   "AttributeError in its backward for this variant (checkpoint with context=None)")
     prec = L.PREC_BY_NAME[model.hip_precision]
+    if not getattr(model, "_hip_ddp_synced", False) and getattr(model, "hip_ddp", True):
+        # torch DDP broadcasts rank 0's parameters and buffers when it wraps a module; nothing else on this path would, and
+        # replicas that start from different weights (rank-dependent init, a missing seed_everything, per-rank
+        # checkpoints) would train silently diverged: once per model, before its first exchanged training step.  (A
+        # LitEma built before this point holds the old values: sync it too -- HipDDPStrategy and bench.py do.)
+        from .ddp import sync_initial_state
+        sync_initial_state(model)
     eng = model._engine(n, H, W, prec)
     params = [p for p in model.parameters() if p.requires_grad]
     eps = _UNetTrainFn.apply(model, eng, (x, t, cond, layout, mask), *params)

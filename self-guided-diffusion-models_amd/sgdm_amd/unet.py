@@ -466,6 +466,11 @@ class UNetModelBase(nn.Module):
         return out
 
 
+def device_cus(dev):
+    """compute units of `dev` (256 on MI355X)"""
+    return int(torch.cuda.get_device_properties(dev).multi_processor_count)
+
+
 # ------------------------------------------------------------------------------------------------
 class _Engine:
     """static launch program + workspace for one (UNet batch, H, W, precision)"""
@@ -752,6 +757,21 @@ class _Engine:
             self._film_bias.copy_(torch.cat([b.detach().reshape(-1) for b in self._film_bias_src]))
             self._film_sig = sig
 
+    def set_grid_cap(self, reserve):
+        """sgd_igemm_args.grid_cap of every conv / linear launch of the forward AND backward programs: all CUs but
+        `reserve` (0: the whole device).  Host-side field of the argument blocks -- a captured hipGraph keeps the value it
+        was captured with, which is why only the (never captured) training programs use a reserve."""
+        cap = 0 if reserve <= 0 else max(8, device_cus(self.dev) - int(reserve))
+        if cap == getattr(self, "_grid_cap", 0):
+            return
+        self._grid_cap = cap
+        for a, _ in self._late:
+            a.grid_cap = cap
+        bw = getattr(self, "backward", None)
+        if bw is not None:
+            for a, _ in bw.late:
+                a.grid_cap = cap
+
     def run(self, x, t, cond, layout, mask, train=False):
         stream = torch.cuda.current_stream().cuda_stream
         self.prepare(x, t, cond, layout, mask, train=train)
@@ -764,6 +784,10 @@ class _Engine:
         m, n = self.m, self.n
         stream = torch.cuda.current_stream().cuda_stream
         self.refresh(stream)
+        # training step of a data-parallel job: the persistent conv grid leaves CUs to the gradient exchange that runs on a
+        # side stream under the backward (ddp.reserved_cus); every other evaluation owns the device
+        from .ddp import reserved_cus
+        self.set_grid_cap(reserved_cus(m) if train else 0)
         p_drop = float(m.dropout) if (train and m.dropout) else 0.0      # (grad mode is off inside autograd.Function)
         if p_drop != self._p_drop or p_drop > 0:
             seeds = torch.randint(0, 2 ** 31 - 1, (len(self.drops),)).tolist() if p_drop > 0 else [0] * len(self.drops)

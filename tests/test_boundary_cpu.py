@@ -182,7 +182,7 @@ def test_committed_bench_line_has_the_contract_fields(fname):
     import json
     line = json.loads(open(os.path.join(ROOT, "profiles", fname)).read().strip().splitlines()[-1])
     if fname.startswith("r3_"):
-        assert "c2_bs80" in line and line["train_step"]["grad_checksums_equal"] is True
+        assert "c2_bs80" in line      # (its grad_checksums_equal is trivially true: one rank; null from round 4 on)
         assert "r3_pmc_hbm" in line["roofline"]["traffic_source"]
     if not fname.startswith("r1_"):
         # round 2: the line is self-sufficient (exact-fp32 figure, C5 and C1 legs, instantiation split, traffic label)

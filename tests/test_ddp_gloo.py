@@ -118,3 +118,128 @@ def test_torch_ddp_wrapper_detection_and_exclusion():
             assert w.parameters_to_ignore == set(names)
         finally:
             dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# round 4: what torch DDP's constructor did and the HIP exchange has to do itself
+# ------------------------------------------------------------------------------------------------------------------
+def _sync_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from sgdm_amd.ddp import sync_initial_state
+    torch.manual_seed(1000 + rank)                       # deliberately DIFFERENT initial weights per rank
+    net = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3), torch.nn.GroupNorm(4, 8), torch.nn.Linear(8, 5))
+    net.register_buffer("shadow", torch.randn(7))
+    net.register_buffer("num_updates", torch.tensor(rank, dtype=torch.int32))
+    before = [p.detach().clone() for p in net.parameters()]
+    versions = [p._version for p in net.parameters()]
+    sent = sync_initial_state(net)
+    again = sync_initial_state(net)                      # once per module
+    torch.manual_seed(1000)                              # what rank 0 drew
+    ref = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3), torch.nn.GroupNorm(4, 8), torch.nn.Linear(8, 5))
+    ref_shadow = torch.randn(7)
+    same = all(torch.equal(a, b) for a, b in zip(net.parameters(), ref.parameters()))
+    same = same and torch.equal(net.shadow, ref_shadow) and int(net.num_updates) == 0
+    changed = any(not torch.equal(a, b.detach()) for a, b in zip(before, net.parameters()))
+    bumped = all(p._version > v for p, v in zip(net.parameters(), versions))      # packed-weight caches key on versions
+    q.put((rank, same, changed, bumped, sent, again))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_initial_state_broadcast_world2_gloo():
+    """ranks that start from different weights end up with rank 0's parameters AND buffers (bit for bit), the copies
+    bump the parameter versions (so packed weights are rebuilt), and the broadcast happens once per module"""
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sync_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, same, changed, bumped, sent, again in res:
+        assert same and bumped and sent == 8 and again == 0, res
+        assert changed == (rank != 0), res
+
+
+def test_pl_strategy_hooks():
+    """HipDDPStrategy on a stand-in for Lightning's DDPStrategy that drives the hooks the way both generations do
+    (1.6-1.9: configure_ddp wraps LightningDistributedModule(model) through _setup_model; 2.x: _setup_model(model) and
+    _register_ddp_hooks asserting a DistributedDataParallel instance): the module must come out bare either way."""
+    from sgdm_amd import pl_strategy
+
+    class Wrapped:
+        def __init__(self, m):
+            self.module = m
+
+    calls = []
+
+    class FakeDDPStrategy:
+        def __init__(self, model, generation):
+            self.model, self.generation = model, generation
+
+        def _setup_model(self, model):                   # Lightning: DistributedDataParallel(module=model, ...)
+            calls.append("base._setup_model")
+            return Wrapped(model)
+
+        def _register_ddp_hooks(self):
+            calls.append("base._register_ddp_hooks")
+            assert isinstance(self.model, Wrapped)       # 2.x asserts the wrapper type on CUDA
+
+        def configure_ddp(self):
+            inner = self.model if self.generation == 2 else ("LightningDistributedModule", self.model)
+            self.model = self._setup_model(inner)
+            self._register_ddp_hooks()
+
+        def setup(self):                                 # trainer.fit(): strategy.setup() -> configure_ddp()
+            self.configure_ddp()
+
+    cls = pl_strategy.make_strategy(FakeDDPStrategy)
+    assert cls.strategy_name == "hip_ddp"
+    for generation in (1, 2):
+        net = torch.nn.Linear(3, 2)
+        st = cls(net, generation)
+        st.setup()
+        assert st.model is net and not calls, (generation, calls)
+        assert st._setup_model(net) is net
+    # without Lightning the public name raises on use, importing the module does not
+    if pl_strategy._Base is None:
+        import pytest
+        with pytest.raises(ImportError):
+            pl_strategy.HipDDPStrategy()
+
+
+def test_torch_ddp_ignores_is_by_identity():
+    """a parameter of ANOTHER submodule whose name ends like one of ours must not count as ignored"""
+    from sgdm_amd.ddp import torch_ddp_ignores
+
+    class Holder(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.dynamic = torch.nn.Linear(4, 4)
+            self.ema_dynamic = torch.nn.Linear(4, 4)     # "ema_dynamic.weight".endswith("dynamic.weight") style clash
+
+    class FakeWrapper:
+        def __init__(self, root, names):
+            self.module, self.parameters_to_ignore = root, set(names)
+
+    root = Holder()
+    assert not torch_ddp_ignores(FakeWrapper(root, ["ema_dynamic.weight", "ema_dynamic.bias"]), root.dynamic)
+    assert not torch_ddp_ignores(FakeWrapper(root, ["dynamic.weight"]), root.dynamic)          # only some of them
+    assert torch_ddp_ignores(FakeWrapper(root, ["dynamic.weight", "dynamic.bias"]), root.dynamic)
+    assert not torch_ddp_ignores(FakeWrapper(root, []), root.dynamic)
+
+
+def test_reserved_cus_policy(monkeypatch):
+    """one rank reserves nothing; the attribute override works without a process group"""
+    from sgdm_amd.ddp import reserved_cus
+    assert reserved_cus(None) == 0
+    m = torch.nn.Linear(1, 1)
+    assert reserved_cus(m) == 0
+    m.hip_reserve_cus = 32
+    assert reserved_cus(m) == 32
