@@ -590,7 +590,10 @@ class DDIMSampler(object):
             gstep = _GraphedStep.get(runner, img, "ddim", clip, temperature=float(sk["temperature"]))
             img = gstep.img
             ts_dev = torch.tensor(np.ascontiguousarray(timesteps), dtype=torch.long, device=dev).view(-1, 1).expand(total, B).contiguous()
-        for i, step in enumerate(np.flip(timesteps)):
+        # step_indices (teacher-forced tests): visit only these table indices, in the order given
+        visit = kwargs.get("step_indices")
+        walk = list(enumerate(np.flip(timesteps))) if visit is None else [(total - int(ix) - 1, timesteps[int(ix)]) for ix in visit]
+        for i, step in walk:
             index = total - i - 1
             want = index in snaps
             if gstep is not None:
@@ -627,6 +630,8 @@ class DDIMSampler(object):
                 pred.append(x0.detach().cpu().unsqueeze(0))
         if gstep is not None:
             img = img.clone()                       # the static buffer belongs to the cached graph
+        if not pred:
+            return img, dict(x_inter=img.new_zeros((0,) + tuple(shape)).cpu(), pred_x0=img.new_zeros((0,) + tuple(shape)).cpu())
         return img, dict(x_inter=torch.cat(inter, 0), pred_x0=torch.cat(pred, 0))
 
 

@@ -197,7 +197,8 @@ class Backward:
         a.grid_cap = getattr(self.e, "_grid_cap", 0)
         self.late.append((a, pk))
         self.keep.append(a)
-        self.prog.add(tag, self.lib.sgd_igemm, C.byref(a))
+        rows = (a.n * a.ho * a.wo) if conv is not None else m
+        self.prog.add(tag, self.lib.sgd_igemm, C.byref(a), flops=2.0 * rows * cout_of_y * (9 if conv is not None else 1) * cin_of_gy)
 
     def wgrad(self, tag, fwd_args, gy, gy_ld, cout, cin, taps, rows, wname, bias_name=None, dw_view=None):
         ktiles = (rows + 63) // 64
@@ -216,7 +217,7 @@ class Backward:
             return box.lib.sgd_wgrad_scratch(C.byref(fwd_args), _ptr(gy), gy_ld, cout, _ptr(slabs), ksplit,
                                              _ptr(bslab) if bslab is not None else None, _ptr(ws), ws.numel() * 4, stream)
         wgrad_launch.__name__ = "sgd_wgrad"
-        self.prog.add(tag + ".wgrad", wgrad_launch)
+        self.prog.add(tag + ".wgrad", wgrad_launch, flops=2.0 * rows * cout * cin * taps)
         dw = dw_view if dw_view is not None else self.pg(wname)
         self.prog.add(tag + ".wred", self.lib.sgd_wgrad_reduce, _ptr(slabs), ksplit, taps, cout, cin, _ptr(dw), 0,
                       self.unscale)

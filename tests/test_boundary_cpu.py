@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(L.SIGNATURES), declared ^ set(L.SIGNATURES)
     lib = L.load()                                    # binds every symbol or raises
     assert lib.sgd_abi_version() == L.ABI_VERSION
-    assert ctypes.sizeof(L.IgemmArgs) == 208
+    assert ctypes.sizeof(L.IgemmArgs) == 216
     # argument validation needs no GPU: invalid descriptors are rejected before any launch
     assert lib.sgd_igemm(None, None) == 1
     assert lib.sgd_packed_weight_bytes(128, 128, 3, 0) == 9 * 128 * 128 * 4

@@ -433,9 +433,10 @@ def _oracle_cfg(wl):
                       resblock_updown=not ca, dropout=0.0)
 
 
-@pytest.mark.parametrize("workload", ["c2", "c5"])
+@pytest.mark.parametrize("workload", ["c2", "c5", "c4"])
 def test_cfg_evaluation_at_benchmark_batch_vs_oracle(workload):
-    """BASELINE.json configs[1] at UNet batch 80 and configs[4] at UNet batch 160: one CFG evaluation against the CPU
+    """BASELINE.json configs[1] at UNet batch 80, configs[4] and configs[3] (VOC-64 `unetca_fast`, box-mask layout,
+    cond 100) at UNet batch 160: one CFG evaluation against the CPU
     oracle, as a direct forward_with_cond_scale call and as one native sampler step -- eager launches and the
     hipGraph-captured step `bench.py` replays -- in exact f32 and in f16x3"""
     import bench
@@ -530,3 +531,62 @@ def test_train_step_at_batch_16_vs_oracle(prec, tol):
         got, want = params[name].grad.cpu(), w[name].grad
         err = max_rel(got, want)
         assert err < tol, (name, err)
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# (d) BASELINE.json configs[0] at its TRUE shape (the reduced-width fixtures are ch = 32 / 16x16)
+# --------------------------------------------------------------------------------------------------------------------
+def test_c1_true_shape_ddim10_teacher_forced_vs_oracle():
+    """cifar10 `unet_fast` ch = 64, 32x32, label K = 10, bs = 8, 10-step DDIM (eta 0), w = 2 -- every 64-channel layer on
+    the 32-column tile instance, GroupNorm at 2 channels per group, 8x8 maps at the bottom.  Every step is fed the
+    ORACLE's x_t (free-running DDIM decorrelates); the CFG eps and the DDIM update are held to the
+    north_star's 1e-4 per evaluation in exact f32 and in f16x3, through the eager step and the captured hipGraph step."""
+    import bench
+    from oracle import diffusion_ref as D
+    from oracle import unet_ref as U
+    from sgdm_amd.diffusion import LatentDiffusion
+    c1 = bench.C1
+    B, S, steps_n = c1["batch"], c1["image"], c1["ddim_steps"]
+    m, sd, data = bench.build_model(c1, torch.device("cuda"), "f32", B)
+    cfg = U.make_cfg("unet_fast", S, model_channels=c1["model_channels"], cond_dim=c1["cond_dim"], condition_method="label",
+                     resblock_updown=True)
+    assert [k for k, _, _ in U.param_manifest(cfg)] == list(m.state_dict().keys())
+    cond = data["cond"]
+    g = torch.Generator().manual_seed(41)
+    x = torch.randn(B, 3, S, S, generator=g)
+    zs = torch.randn(steps_n, B, 3, S, S, generator=g)
+    sched = D.make_schedule()
+    steps = D.make_ddim_timesteps(steps_n)
+    tabs = D.make_ddim_tables(sched["alphas_cumprod"], steps, 0.0)
+    diff = LatentDiffusion(device="cuda", **bench.MODEL_PARAMS)
+    diff.set_denoise_fn(m.forward, m.forward_with_cond_scale)
+    dkw = dict(cond=cond.cuda(), layout=None, cond_scale=2.0)
+    skw = dict(sampling_method="ddim", vis=None, num_timesteps=steps_n, ddim_eta=0.0, log_num_per_prog=10, clip_denoised=True, dtp=1,
+               temperature=1.0, noise_dropout=0, random_sample_condition=False, return_inter_dict=True)
+    worst = {}
+    for i, step in enumerate(reversed(steps.tolist())):
+        index = steps_n - i - 1
+        ts = torch.full((B,), int(step), dtype=torch.long)
+        with torch.no_grad():
+            eps_ref = U.forward_with_cond_scale(cfg, sd, x, ts, 2.0, cond, None)
+        x_ref, x0_ref = D.ddim_step(tabs, index, x, eps_ref, zs[i])
+        for prec, tol in (("f32", 2e-5), ("f16x3", 5e-5)):
+            m.hip_precision = prec
+            with torch.no_grad():
+                eps = m.forward_with_cond_scale(x.cuda(), ts.cuda(), **dkw)
+            err = max_rel(eps.cpu(), eps_ref)
+            assert err < tol, (prec, index, "eps", err)
+            worst[prec] = max(worst.get(prec, 0.0), err)
+            imgs = {}
+            for graph in (False, True):
+                with torch.no_grad():
+                    img, inter = diff.sampler_list["ddim"].sample(
+                        (B, 3, S, S), sampling_kwargs=dict(skw, hip_graph=graph, alphas_cumprod=diff.sampler.alphas_cumprod),
+                        denoise_sample_fn=diff.denoise_sample_fn, denoise_sample_fn_kwargs=dkw, x_T=x.cuda(),
+                        step_indices=[index], noise_fn=lambda j, i=i: zs[i])
+                imgs[graph] = img
+                serr = max_rel(img.cpu(), x_ref)
+                assert serr < 1e-4, (prec, index, "graph" if graph else "eager", serr)
+            assert torch.equal(imgs[False], imgs[True]), (prec, index)
+        x = x_ref                                                # teacher forcing
+    print("\nC1 true shape, worst eps max-rel per mode:", worst)

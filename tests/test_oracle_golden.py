@@ -73,12 +73,14 @@ def test_cfg_paths_match_reference(name):
 
 
 def test_cfg_full_width_instances():
-    for name in ("uf_cluster5000_c128_s64", "ca_stego_c128_s64", "ca_clusterlayout_c128_s64"):
+    # (the *_s64_* entries are the shipped config/dynamic/*_s64.yaml plans: tests/golden/make_golden_s64.py)
+    for name in ("uf_cluster5000_c128_s64", "ca_stego_c128_s64", "ca_clusterlayout_c128_s64", "ca_s64_c224", "ca_s64_c224_layout",
+                 "uf_s64_c256"):
         entry = INDEX[name]
         cfg = cfg_from_index(entry)
         v = load_npz(f"unet_{name}.npz")
         x, t, cond, layout = _inputs(v)
-        if cfg["kind"] == "unetca_fast":
+        if cfg["kind"] == "unetca_fast" and cond is not None:
             cond = cond.float()
         with torch.no_grad():
             e = U.forward_with_cond_scale(cfg, _weights(entry), x, t, 2.0, cond, layout)
