@@ -24,6 +24,9 @@ extern "C" {
 
 #define SGD_ABI_VERSION 12
 int sgd_abi_version(void);
+/* 16 hex digits identifying the sources and flags the library was compiled from (build.py: source_id()); static storage.
+ * __graft_entry__.build() and tests/test_boundary_cpu.py compare it with the tree on disk. */
+const char* sgd_build_id(void);
 
 /* --------------------------------------------------------------------------------------
  * Fused implicit-GEMM convolution / linear layer.

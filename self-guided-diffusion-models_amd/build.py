@@ -30,10 +30,30 @@ def _sources():
     return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
 
 
-def _deps_mtime():
-    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+def _headers():
+    hdrs = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h"))
     hdrs.append(os.path.join(os.path.dirname(HERE), "include", "sgdm_hip.h"))
-    return max(os.path.getmtime(h) for h in hdrs)
+    return hdrs
+
+
+def _digest(paths, extra=()):
+    import hashlib
+    h = hashlib.sha256()
+    for p in paths:
+        h.update(os.path.basename(p).encode() + b"\0")
+        with open(p, "rb") as f:
+            h.update(f.read())
+    for e in extra:
+        h.update(str(e).encode() + b"\0")
+    return h.hexdigest()
+
+
+def source_id():
+    """identity of what the library is built FROM: every .hip / .h under csrc/, the public header and the compile
+    flags.  Embedded in the library (sgd_build_id(), csrc/build_id.hip); __graft_entry__.build() compares the two, so a
+    stale or foreign libsgdm_hip.so cannot pass for a build of this tree."""
+    srcs = [os.path.join(CSRC, f) for f in _sources()]
+    return _digest(srcs + _headers(), [FLAGS, sorted(FILE_FLAGS.items()), sorted(VARIANTS.items())])[:16]
 
 
 # translation units compiled from ONE source with different defines (igemm.hip: the host unit + one unit per arithmetic
@@ -55,16 +75,23 @@ def _compile(unit, force):
     src, suffix, extra = unit
     obj = os.path.join(OBJ, src[:-4] + suffix + TAG + ".o")
     sp = os.path.join(CSRC, src)
-    if (not force and os.path.exists(obj)
-            and os.path.getmtime(obj) >= max(os.path.getmtime(sp), _deps_mtime())):
-        return obj
     cmd = [HIPCC, *FLAGS, *FILE_FLAGS.get(src, []), *extra, *(os.environ.get("SGDM_EXTRA_FLAGS", "").split() if TAG else []),
            "-c", sp, "-o", obj]
+    if src == "build_id.hip":
+        cmd.insert(1, f'-DSGDM_BUILD_ID="{source_id()}"')
+    # an object is reused only when the CONTENT it was compiled from (source, headers, command line) is unchanged: the
+    # digest sits next to it (mtimes say nothing after a checkout or a copy)
+    want = _digest([sp] + _headers(), [cmd])
+    stamp = obj + ".sha"
+    if not force and os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read().strip() == want:
+        return obj
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
     if r.stderr.strip():
         sys.stderr.write(r.stderr)
+    with open(stamp, "w") as f:
+        f.write(want)
     return obj
 
 
@@ -111,12 +138,15 @@ def build_lib(force=False):
     os.makedirs(LIBDIR, exist_ok=True)
     with ThreadPoolExecutor(max_workers=int(os.environ.get("SGDM_BUILD_JOBS", "6"))) as ex:
         objs = list(ex.map(lambda u: _compile(u, force), _units()))
-    if (force or not os.path.exists(LIB)
-            or os.path.getmtime(LIB) < max(os.path.getmtime(o) for o in objs)):
+    want = _digest([o + ".sha" for o in objs])
+    stamp = LIB + ".sha"
+    if force or not os.path.exists(LIB) or not os.path.exists(stamp) or open(stamp).read().strip() != want:
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+        with open(stamp, "w") as f:
+            f.write(want)
     return LIB
 
 

@@ -725,6 +725,12 @@ extern "C" int sgd_linear_attention(const float* q, int32_t q_ld, int32_t q_hs, 
     SGD_CLEAR_ERR();
     if (!q || !k || !v || !out || batch <= 0 || heads <= 0 || tq <= 0 || tk <= 0 || d <= 0 || d > 128) return SGD_ERR_ARG;
     const size_t smem = ((size_t)d * (d + 1) + 2 * d) * sizeof(float);
+    // d = 127 / 128 need 66-67 KB of dynamic LDS, above the 64 KB a kernel gets without asking
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)linear_attention_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        attr = true;
+    }
     hipLaunchKernelGGL(linear_attention_kernel, dim3(heads, batch), dim3(256), smem, (hipStream_t)stream, q, q_ld, q_hs, k,
                        v, kv_ld, kv_hs, tq, tk, d, scale, kmask, out, out_ld);
     return sgd_check_launch();

@@ -1255,7 +1255,8 @@ static int wgrad_impl(const sgd_igemm_args* fwd, const float* gy, int32_t gy_ld,
         const long fgrid = (long)w.co_tiles * w.ci_tiles * w.ksplit;
         if (fgrid > 0x7fffffffL) return SGD_ERR_ARG;
         // wave-specialised kernel: 16-byte gradient rows of whole 128-channel blocks, whole rows (cout % 128 == 0), vector
-        // input rows, GroupNorm-affine / no prologue, no avg-pool, no dropout (its keep mask is recomputed by the other one)
+        // input rows, GroupNorm-affine / no prologue, no avg-pool.  (Dropout does not exclude it: with pre-split planes
+        // act_split_kernel applies the keep mask through apply_pro, and the in-kernel loader does the same.)
         const bool ws = fast_conv && vec && w.gvec && cout % WT == 0 && (a.resample == SGD_RS_NONE || a.resample == SGD_RS_UP2)
                         && (a.pro == SGD_PRO_NONE || a.pro == SGD_PRO_AFFINE_NC) && !getenv("SGDM_WGRAD_OLD");
         // ... and with a scratch buffer for the pre-split operand planes: the loaders only copy

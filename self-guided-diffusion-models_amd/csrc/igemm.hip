@@ -51,11 +51,12 @@ constexpr int WORK_HEAD = WORK_TILES * 8;              // bytes: per split tile 
 // Health word of the workspace (sgd_igemm_work_status_offset): the last int of the head.  Counter pairs use indices
 // < 8 * (nloc / 2) <= 128 of the 256 pairs, so the word is never a counter.
 constexpr int WORK_STATUS_INT = WORK_HEAD / 4 - 1;
-// Finisher poll bound: s_sleep 16 = 1024 cycles, 2^22 polls ~ 2 s.  Producers never wait and the launches that share a
+// Finisher poll bound: s_sleep 16 = 1024 cycles + one L2 round trip per poll, 2^20 polls ~ 1-2 s (measured 2.1 s at 2^22 sleeps
+// only; a legitimate wait is a producer's K part: a few hundred microseconds).  Producers never wait and the launches that share a
 // workspace are ordered on one stream, so a finisher that is still waiting then is waiting for a block that will never
 // store (stale counters after a faulted launch, a second stream on the same workspace): it flags the workspace and
 // poisons its outputs with NaN instead of hanging the device.
-constexpr int FINISH_POLL_MAX = 1 << 22;
+constexpr int FINISH_POLL_MAX = 1 << 20;
 
 // Balanced-tail arithmetic shared by the kernel and sgd_igemm_tail_layout (the CPU test of the workspace layout).
 // K parts of the `xrem` tiles an XCD has left after its whole rounds (0: no split): a part must be worth its hand-off
@@ -364,7 +365,14 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
     const sgd_igemm_args& a = ka.a;
     const Geo& g = ka.g;
     constexpr bool CONV = TAPS == 9;
-    constexpr int NA = 3;                         // A tile ring depth (CONV: chunks, loaders two ahead; FLAT: K steps)
+    // FLAT with TAPS = FG > 1 (round 4): a "chunk" is FG consecutive 32-channel planes of the 128 input rows, staged side
+    // by side in one ring slot ([FG][128][LDA]) and consumed as FG K steps between two barriers -- the 1x1 / linear
+    // launches then run in the conv kernel's rhythm (one s_barrier per chunk, loaders two chunks ahead in LDS) instead of
+    // one barrier per K step, where the two roles took turns (measured round 2: 2.4k cycles of work + 1.2k in the barrier
+    // on BOTH sides per step).  The packed weights are unchanged: [32-channel plane][output block] is already the order.
+    constexpr int FG = CONV ? 1 : TAPS;
+    constexpr int KCC = KC * FG;                  // input channels per chunk
+    constexpr int NA = 3;                         // A tile ring depth (chunks; the loaders run two ahead)
     // wave tile: BN >= 128 -> every MFMA wave owns ALL 128 rows x its own BN / 4 columns, so the four waves of a block load
     // disjoint weight fragments (a 64 x 64 split made two waves fetch the same 8 KB per step: the per-CU vector memory
     // pipe was > 50 % busy and its full queue stalled the in-order MFMA waves at their loads); the input fragments they
@@ -385,8 +393,17 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
 #ifdef SGDM_NO_MFMA16
     constexpr bool M16 = false;
 #else
+#ifdef SGDM_M16_256   /* experiment: the 16x16x32 form for the 128 x 256 tile as well */
+    constexpr bool M16 = PREC != SGD_PREC_F32 && !DEFER;
+#else
     constexpr bool M16 = PREC != SGD_PREC_F32 && BN <= 128 && !DEFER;
 #endif
+#endif
+    // M16 on the 128 x 256 tile (64 columns per wave, 128 accumulator registers): no room for all 8 input units of a K
+    // step next to them, so the step runs as two PASSES over the row blocks -- column blocks {0,1}, then {2,3} -- and the
+    // input units come through a ring of 4 (each is read from LDS once per pass); weights stay single-buffered: a pair is
+    // reloaded for the next step right after its pass and has the other pass (768 matrix-pipe cycles) to land
+    constexpr bool W256 = M16 && BN == 256;
     constexpr int RB = M16 ? WM / 16 : MT, RBH = M16 ? 16 : 32;
     constexpr int CBN = M16 ? WN / 16 : NT, CBW = M16 ? 16 : 32;      // column blocks of a wave tile and their width
     constexpr int QPB = M16 ? 1 : 4;                                  // 4-channel quads a lane holds per (row block, column block)
@@ -427,7 +444,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
     const int xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
     const int xbeg = xcd * xchunk, xend = (xbeg + xchunk < total) ? xbeg + xchunk : total;
     const int cin = a.c0 + a.c1;
-    const int nchunks = (cin + KC - 1) / KC;
+    const int nchunks = (cin + KCC - 1) / KCC;
     // Balanced tail (args.work): the XCD's tiles are nfull whole rounds of its nloc blocks plus R < nloc tiles.  Instead of
     // a last round that keeps R blocks busy and nloc - R idle, each of those R tiles is split along K into `split` chunk
     // ranges computed by `split` different blocks at the same time: parts 0 .. split-2 store their partial accumulators to
@@ -816,14 +833,15 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
                     c.ka = tile_uni ? a.pa + ko + c4 * 4 : (ln ? a.pb + c4 * 4 : a.x0);
                     c.kb = tile_uni ? a.pb + ko + c4 * 4 : ((ln && a.pc) ? a.pc + c4 * 4 : a.x0);
                 };
+                // (the cursors count 32-channel PLANES: FG per chunk)
                 auto advance = [&](Cur& c) {
-                    if (++c.chunk == cend(c.k)) {
-                        if (c.k + 1 < ntiles) { ++c.k; c.chunk = cbeg(c.k); open_tile(c); }
-                        else c.chunk = cend(c.k) - 1;
+                    if (++c.chunk == cend(c.k) * FG) {
+                        if (c.k + 1 < ntiles) { ++c.k; c.chunk = cbeg(c.k) * FG; open_tile(c); }
+                        else c.chunk = cend(c.k) * FG - 1;
                     }
                 };
                 Cur ci, cf;
-                ci.k = 0; ci.chunk = cbeg(0); open_tile(ci);
+                ci.k = 0; ci.chunk = cbeg(0) * FG; open_tile(ci);
                 cf = ci;
                 auto issue = [&](auto rc) {                              // request the chunk under the issue cursor
                     constexpr int R = decltype(rc)::value;
@@ -845,7 +863,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
                     }
                     advance(ci);
                 };
-                auto finish = [&](int slot, auto rc) {                   // stage the chunk under the finish cursor
+                auto finish = [&](int slot, auto rc, int sub = 0) {      // stage the plane under the finish cursor
                     constexpr int R = decltype(rc)::value;
 #pragma unroll
                     for (int j = 0; j < AI; ++j) {
@@ -860,34 +878,64 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
                             for (int e = 0; e < 4; ++e) v[e] = sgd_silu(v[e]);
                         }
                         if (cf.m0 + arow + j * AROWS >= M) v = f32x4{0.f, 0.f, 0.f, 0.f};
-                        lds_store_act<PREC>(As + (size_t)slot * a_floats + (size_t)(arow + j * AROWS) * LDA, c4, v);
+                        lds_store_act<PREC>(As + (size_t)slot * a_floats + (size_t)(sub * BM + arow + j * AROWS) * LDA, c4, v);
                     }
                     advance(cf);
                 };
-                issue(R0());
-                issue(R1());
-                finish(0, R0());
-                finish(1, R1());
-                issue(R2());
-                issue(R0());
-                issue(R1());
-                SYNC();
-                auto body = [&](int slot, auto rc) {
-                    finish(slot, rc);
-                    issue(rc);
+                if constexpr (FG == 1) {
+                    issue(R0());
+                    issue(R1());
+                    finish(0, R0());
+                    finish(1, R1());
+                    issue(R2());
+                    issue(R0());
+                    issue(R1());
                     SYNC();
-                };
-                int step = 0;
-                for (; step + 3 <= S; step += 3) {
-                    body(2, R2());
-                    body(0, R0());
-                    body(1, R1());
-                }
-                if (step < S) {
-                    body(2, R2());
-                    if (step + 1 < S) body(0, R0());
+                    auto body = [&](int slot, auto rc) {
+                        finish(slot, rc);
+                        issue(rc);
+                        SYNC();
+                    };
+                    int step = 0;
+                    for (; step + 3 <= S; step += 3) {
+                        body(2, R2());
+                        body(0, R0());
+                        body(1, R1());
+                    }
+                    if (step < S) {
+                        body(2, R2());
+                        if (step + 1 < S) body(0, R0());
+                    }
+                } else {
+                    static_assert(FG <= 2, "two planes per chunk");
+                    // plane p = FG * chunk + sub lives in register set p % 3 (requested three planes before it is staged) and
+                    // goes to ring slot chunk % 3; chunks 0 and 1 are staged before barrier 0, period q stages chunk q + 2
+                    issue(R0());
+                    issue(R1());
+                    issue(R2());
+                    finish(0, R0(), 0); issue(R0());            // plane 0, request plane 3
+                    finish(0, R1(), 1); issue(R1());            // plane 1, request plane 4
+                    finish(1, R2(), 0); issue(R2());            // plane 2, request plane 5
+                    finish(1, R0(), 1); issue(R0());            // plane 3, request plane 6
+                    SYNC();                                     // barrier 0
+                    auto period = [&](int slot, auto ra, auto rb) {      // planes 2q + 4 (set ra) and 2q + 5 (set rb)
+                        finish(slot, ra, 0); issue(ra);
+                        finish(slot, rb, 1); issue(rb);
+                        SYNC();
+                    };
+                    int q = 0;
+                    for (; q + 3 <= Q; q += 3) {
+                        period(2, R1(), R2());
+                        period(0, R0(), R1());
+                        period(1, R2(), R0());
+                    }
+                    if (q < Q) {
+                        period(2, R1(), R2());
+                        if (q + 1 < Q) period(0, R0(), R1());
+                    }
                 }
             };
+            if (FG > 1 && !leanf) __builtin_trap();           // sgd_igemm picks the multi-plane instance for lean launches only
             if (leanf) {
                 typedef std::integral_constant<int, 0> M0;
                 typedef std::integral_constant<int, 1> M1;
@@ -1150,6 +1198,26 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
         }
         aoff[mt] = p * LDA;
     }
+    // W256 (128 accumulator registers): the 8 row-block offsets as ONE vector register + wave-uniform steps.  Row block
+    // mt covers tile rows 16 mt .. 16 mt + 15; inside an image the halo offset is linear in mt, and every `mpi` row blocks
+    // the next image of the tile starts (8x8 maps: two images per tile):  aoff[mt] = aoff[0] + mt * astep + (mt >> mpi_l2) * bstep
+    int astep = 16 * LDA, bstep = 0, mpi_l2 = 8;
+    if constexpr (W256 && CONV) {
+        const int rpi_l2 = g.tw_l2 + g.th_l2;                    // log2 of the tile rows of one image
+        if (rpi_l2 >= 4) {
+            const int u = TW >= 16 ? 1 : (16 >> g.tw_l2);        // image rows per 16-row block
+            astep = u * s * g.hw * LDA;
+            mpi_l2 = rpi_l2 - 4;
+            bstep = g.hh * g.hw * LDA - (astep << mpi_l2);
+        } else {
+            astep = (16 >> rpi_l2) * g.hh * g.hw * LDA;          // a row block spans whole images
+        }
+    }
+    const int aoff0 = aoff[0];
+    auto aoff_at = [&](int mt) __attribute__((always_inline)) {
+        if constexpr (W256) return aoff0 + mt * astep + (mt >> mpi_l2) * bstep;
+        else return aoff[mt];
+    };
     // weight fragments: wave (wm, wn) needs N blocks wn*NT .. wn*NT+NT-1 of its tile; consecutive K steps of the stream
     // [chunk][tap] are `wstep` bytes apart (all N blocks of the layer for that step)
     const size_t wstep = (size_t)(a.cout_p >> 5) * WUNIT;
@@ -1181,8 +1249,8 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
     // is reloaded for the NEXT step right after its last use (column block CBN - 1), the weights of column block cb right
     // after stage (cb, RB - 1): every reload has RB - 1 .. RB stages (>= 336 matrix-pipe cycles) to land, with single
     // buffers and compile-time register indices.
-    constexpr int STAGES = M16 ? RB * CBN : NKS * MT;    // per K step
-    constexpr int RING = M16 ? RB : (STAGES >= 4 ? 4 : 2);   // STAGES % RING == 0: a K step always starts at ring slot 0
+    constexpr int STAGES = W256 ? 2 * RB : (M16 ? RB * CBN : NKS * MT);    // per K step
+    constexpr int RING = W256 ? 4 : (M16 ? RB : (STAGES >= 4 ? 4 : 2));   // STAGES % RING == 0: a K step always starts at ring slot 0
     constexpr int DEPTH = RING - 1;
     static_assert(STAGES % RING == 0, "ring position must be a compile-time constant inside a K step");
     std::conditional_t<M16, typename Frag16<PREC, 1>::AU, typename FragT::AU> ring[RING];
@@ -1190,7 +1258,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
     typename Frag16<PREC, 1>::B fb16[CBN];         // M16: weights of one 16-column block each
     const int rowstep = g.hw * LDA;                // LDS floats between halo rows
 
-    auto tap_off = [&](int tap) { return CONV ? (tap / 3) * rowstep + (tap % 3) * LDA : 0; };
+    auto tap_off = [&](int tap) { return CONV ? (tap / 3) * rowstep + (tap % 3) * LDA : tap * (BM * LDA); };
     // one K step: `acur` holds this step's chunk, `anext` the chunk the prefetches run into when `seam` (last tap)
     auto do_step = [&](const float* acur, const float* anext, auto tapc, auto parc, const char* wnext) {
         constexpr int tap = decltype(tapc)::value;
@@ -1204,7 +1272,18 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
             constexpr bool wrap = st + DEPTH >= STAGES;
             const float* pbase = (wrap && seam) ? anext : acur;
             constexpr int ptap = wrap ? (seam ? 0 : tap + 1) : tap;
-            if constexpr (M16) {
+            if constexpr (W256) {
+                constexpr int half = st / RB;
+                if (!ABL(64)) ring[(st + DEPTH) % RING].load(pbase + tap_off(ptap) + aoff_at(pst % RB), lane >> 4);
+                if (!ABL(16)) {
+                    acc[mt][2 * half] = Frag16<PREC, 1>::mma1(acc[mt][2 * half], ring[st % RING], fb16[2 * half]);
+                    acc[mt][2 * half + 1] = Frag16<PREC, 1>::mma1(acc[mt][2 * half + 1], ring[st % RING], fb16[2 * half + 1]);
+                }
+                if (mt == RB - 1 && !ABL(32)) {
+                    fb16[2 * half].load(wnext + half * WUNIT);
+                    fb16[2 * half + 1].load(wnext + half * WUNIT + 256);
+                }
+            } else if constexpr (M16) {
                 constexpr int cbi = st / RB;
                 const float* nbase = seam ? anext : acur;                  // next step: next tap of this chunk / next chunk
                 constexpr int ntap = seam ? 0 : tap + 1;
@@ -1221,10 +1300,10 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
             // (a burst of reads in front of the MFMAs fills the LDS queue and the in-order wave cannot issue its MFMAs
             // until they are accepted)
             {
-                constexpr int NM = M16 ? 3 : FragT::NMMA;
-                constexpr int NR = M16 ? (st / RB == CBN - 1 ? 2 : 0) : FragT::NREADS;
+                constexpr int NM = W256 ? 6 : (M16 ? 3 : FragT::NMMA);
+                constexpr int NR = W256 ? 2 : (M16 ? (st / RB == CBN - 1 ? 2 : 0) : FragT::NREADS);
                 constexpr int P1 = NR < NM ? NR : NM;
-                constexpr int nw = M16 ? (st % RB == RB - 1 ? 2 : 0) : ((mt == MT - 1) ? FragT::NWLOADS : 0);
+                constexpr int nw = W256 ? (st % RB == RB - 1 ? 4 : 0) : (M16 ? (st % RB == RB - 1 ? 2 : 0) : ((mt == MT - 1) ? FragT::NWLOADS : 0));
                 constexpr int P2 = nw < NM - P1 ? nw : NM - P1;
 #pragma unroll
                 for (int i = 0; i < P1; ++i) {
@@ -1255,8 +1334,8 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
     }
     SYNC();                               // pairs with the loaders' prologue barrier: chunks 0 AND 1 are staged
 #pragma unroll
-    for (int st = 0; st < (M16 ? RB : DEPTH); ++st) {
-        if constexpr (M16) ring[st].load(As + aoff[st], lane >> 4);
+    for (int st = 0; st < ((M16 && !W256) ? RB : DEPTH); ++st) {
+        if constexpr (M16) ring[st].load(As + aoff_at(st % RB), lane >> 4);
         else ring[st].load(As + aoff[st % MT], st / MT, lh);
     }
     int aslot = 0;                                 // ring position of the current chunk
@@ -1444,8 +1523,8 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
                     // round trip for a wave that has nothing else to issue, so batches are as big as the registers allow: with
                     // the 16x16x32 form (operands not carried across the epilogue) ALL of a tile's 16 residual quads.
                     constexpr int CS = CBN * QPB;                                      // column slots per lane
-                    constexpr int QB = M16 ? ((RES == 2 || PART) ? 1 : CBN) : ((RES == 2 || NT > 1) ? 1 : 2);   // slots per batch
-                    constexpr int RBB = M16 ? (RES == 2 || RB < 4 ? 2 : (PART ? 4 : RB)) : RB;   // row blocks per batch
+                    constexpr int QB = M16 ? ((RES == 2 || PART) ? 1 : (CBN > 2 ? 2 : CBN)) : ((RES == 2 || NT > 1) ? 1 : 2);   // slots per batch
+                    constexpr int RBB = M16 ? (RES == 2 || RB < 4 ? 2 : ((PART || CBN > 2) ? 4 : RB)) : RB;   // row blocks per batch
                     static_assert(RB % RBB == 0 && CS % QB == 0, "batches must tile the wave's rows and columns");
 #pragma unroll
                     for (int q0 = 0; q0 < CS; q0 += QB) {
@@ -1597,7 +1676,11 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
                     // for again here they would sit behind the acknowledgement of the epilogue's 16 stores (vmcnt is in
                     // order); the input units come from LDS
 #pragma unroll
-                    for (int st = 0; st < RB; ++st) ring[st].load(a0 + aoff[st], lane >> 4);
+                    for (int st = 0; st < (W256 ? DEPTH : RB); ++st) ring[st].load(a0 + aoff_at(st % RB), lane >> 4);
+                    if constexpr (W256) {     // 128 accumulator registers: the 32 weight registers are not carried either
+#pragma unroll
+                        for (int cb = 0; cb < CBN; ++cb) fb16[cb].load(wp + (cb >> 1) * WUNIT + (cb & 1) * 256);
+                    }
                 } else {
 #pragma unroll
                     for (int ks = 0; ks < NKS; ++ks) fb[ks].load(wp, ks);
@@ -1761,13 +1844,23 @@ int launch1(const KArgs& ka, size_t smem, hipStream_t st) {
 }
 
 // vec: 0 scalar inputs, 1 16-byte inputs, 2 16-byte inputs + the loader-side epilogue (DEFER: 3x3, 128-column tiles, split modes)
+// taps: 9 conv, 1 flat (one 32-channel plane per barrier), 2 flat with two planes per chunk (lean 16-byte launches)
 template <int BN, int PREC>
-int launch(const KArgs& ka, int vec, bool conv, size_t smem, hipStream_t st) {
-    if constexpr (BN == 128 && PREC != SGD_PREC_F32) {
-        if (conv && vec == 2) return launch1<BN, PREC, true, 9, true>(ka, smem, st);
+int launch(const KArgs& ka, int vec, int taps, size_t smem, hipStream_t st) {
+    const bool conv = taps == 9;
+    if constexpr (BN == 256) {                    // chosen for 16-byte launches only
+        if (conv) return launch1<BN, PREC, true, 9>(ka, smem, st);
+        return taps == 2 ? launch1<BN, PREC, true, 2>(ka, smem, st) : launch1<BN, PREC, true, 1>(ka, smem, st);
+    } else {
+        if constexpr (BN == 128 && PREC != SGD_PREC_F32) {
+            if (conv && vec == 2) return launch1<BN, PREC, true, 9, true>(ka, smem, st);
+        }
+        if (conv) return vec ? launch1<BN, PREC, true, 9>(ka, smem, st) : launch1<BN, PREC, false, 9>(ka, smem, st);
+        if constexpr (BN == 128) {
+            if (taps == 2) return launch1<BN, PREC, true, 2>(ka, smem, st);
+        }
+        return vec ? launch1<BN, PREC, true, 1>(ka, smem, st) : launch1<BN, PREC, false, 1>(ka, smem, st);
     }
-    if (conv) return vec ? launch1<BN, PREC, true, 9>(ka, smem, st) : launch1<BN, PREC, false, 9>(ka, smem, st);
-    return vec ? launch1<BN, PREC, true, 1>(ka, smem, st) : launch1<BN, PREC, false, 1>(ka, smem, st);
 }
 
 }  // namespace
@@ -1775,27 +1868,27 @@ int launch(const KArgs& ka, int vec, bool conv, size_t smem, hipStream_t st) {
 // One translation unit per arithmetic mode (build.py compiles this file with -DSGDM_IGEMM_PREC=0 / 1 / 2, in parallel: the
 // kernel template has 12 instances per mode and eight epilogue variants each): the mode's launch dispatcher has external
 // linkage, everything else lives in the host unit (no -DSGDM_IGEMM_PREC).  The argument block crosses as bytes.
-int sgd_igemm_dispatch_f32(const void* ka, int bn, int vec, bool conv, size_t smem, hipStream_t st);
-int sgd_igemm_dispatch_f16x3(const void* ka, int bn, int vec, bool conv, size_t smem, hipStream_t st);
-int sgd_igemm_dispatch_bf16x3(const void* ka, int bn, int vec, bool conv, size_t smem, hipStream_t st);
+int sgd_igemm_dispatch_f32(const void* ka, int bn, int vec, int taps, size_t smem, hipStream_t st);
+int sgd_igemm_dispatch_f16x3(const void* ka, int bn, int vec, int taps, size_t smem, hipStream_t st);
+int sgd_igemm_dispatch_bf16x3(const void* ka, int bn, int vec, int taps, size_t smem, hipStream_t st);
 
 #ifdef SGDM_IGEMM_PREC
 #ifdef SGDM_DEV_ONE      /* development: compile ONE kernel instance (register / asm inspection), never linked */
 #define SGD_DISPATCH_BODY(P)                                                                                        \
-    const KArgs& ka = *reinterpret_cast<const KArgs*>(kap); (void)bn; (void)vec; (void)conv;                         \
-    return launch1<128, P, true, SGDM_DEV_ONE, SGDM_DEV_DEFER>(ka, smem, st);
+    const KArgs& ka = *reinterpret_cast<const KArgs*>(kap); (void)bn; (void)vec; (void)taps;                         \
+    return launch1<SGDM_DEV_BN, P, true, SGDM_DEV_ONE, SGDM_DEV_DEFER>(ka, smem, st);
 #else
 #define SGD_DISPATCH_BODY(P)                                                                                        \
     const KArgs& ka = *reinterpret_cast<const KArgs*>(kap);                                                         \
-    return bn == 256 ? (conv ? launch1<256, P, true, 9>(ka, smem, st) : launch1<256, P, true, 1>(ka, smem, st))     \
-                     : (bn == 128 ? launch<128, P>(ka, vec, conv, smem, st) : launch<32, P>(ka, vec, conv, smem, st));
+    return bn == 256 ? launch<256, P>(ka, 1, taps, smem, st)                                                         \
+                     : (bn == 128 ? launch<128, P>(ka, vec, taps, smem, st) : launch<32, P>(ka, vec, taps, smem, st));
 #endif
 #if SGDM_IGEMM_PREC == 0
-int sgd_igemm_dispatch_f32(const void* kap, int bn, int vec, bool conv, size_t smem, hipStream_t st) { SGD_DISPATCH_BODY(SGD_PREC_F32) }
+int sgd_igemm_dispatch_f32(const void* kap, int bn, int vec, int taps, size_t smem, hipStream_t st) { SGD_DISPATCH_BODY(SGD_PREC_F32) }
 #elif SGDM_IGEMM_PREC == 1
-int sgd_igemm_dispatch_f16x3(const void* kap, int bn, int vec, bool conv, size_t smem, hipStream_t st) { SGD_DISPATCH_BODY(SGD_PREC_F16X3) }
+int sgd_igemm_dispatch_f16x3(const void* kap, int bn, int vec, int taps, size_t smem, hipStream_t st) { SGD_DISPATCH_BODY(SGD_PREC_F16X3) }
 #else
-int sgd_igemm_dispatch_bf16x3(const void* kap, int bn, int vec, bool conv, size_t smem, hipStream_t st) { SGD_DISPATCH_BODY(SGD_PREC_BF16X3) }
+int sgd_igemm_dispatch_bf16x3(const void* kap, int bn, int vec, int taps, size_t smem, hipStream_t st) { SGD_DISPATCH_BODY(SGD_PREC_BF16X3) }
 #endif
 #else   // ---------------------------------------------------------------------------------- host unit
 
@@ -1864,7 +1957,7 @@ extern "C" int sgd_pack_weight_scaled(const float* w_src, void* w_dst, int32_t c
 }
 
 // tile geometry of a launch (everything that does not depend on the packed-weight dims)
-static int make_geo(const sgd_igemm_args& a, Geo& g, int bn, int& na) {
+static int make_geo(const sgd_igemm_args& a, Geo& g, int bn, int& na, int fg = 1) {
     if (a.c0 <= 0 || a.c1 < 0 || a.cout <= 0 || a.y_ld < a.cout) return SGD_ERR_ARG;
     if (a.mode == SGD_MODE_CONV3) {
         if (a.n <= 0 || a.hi <= 0 || a.wi <= 0 || (a.stride != 1 && a.stride != 2)) return SGD_ERR_ARG;
@@ -1900,7 +1993,7 @@ static int make_geo(const sgd_igemm_args& a, Geo& g, int bn, int& na) {
         if (a.pro == SGD_PRO_AFFINE_NC && a.rows_per_n <= 0) return SGD_ERR_ARG;
         if (a.res && a.res_mode != SGD_RS_NONE) return SGD_ERR_ARG;
         g.tw_l2 = g.th_l2 = 0; g.nb = 1; g.tiles_x = g.tiles_y = 1; g.hh = g.hw = 1; g.hc = g.wc = 1;
-        g.pix = BM;
+        g.pix = BM * fg;          // fg 32-channel planes of the 128 rows side by side in one ring slot
         g.mt = (a.m + BM - 1) / BM;
         g.fast_a = 1;
         na = 3;
@@ -1999,8 +2092,18 @@ extern "C" int sgd_igemm(const sgd_igemm_args* args, void* stream) {
     // not depend on the tile (units of 32 output channels), so this is a launch-time choice.
     if (bn == 128 && a.cout_p % 256 == 0 && vec && (!a.res || a.res_mode == SGD_RS_NONE) && want_bn256(a)) bn = 256;
     int na;
+    const bool conv = a.mode == SGD_MODE_CONV3;
+    // flat launches the lean loaders serve (16-byte rows, no / per-image GroupNorm / LayerNorm prologue, no dropout, whole
+    // 32-channel planes per source) with an even number of planes: two planes per chunk, one barrier per chunk
+    // (SGDM_FLAT2=0: the one-plane instance, A/B runs)
+    int taps = conv ? 9 : 1;
+    if (!conv && vec && bn >= 128 && a.drop_p == 0.f && cin % (2 * KC) == 0 && (a.c1 == 0 || a.c0 % KC == 0)
+        && (a.pro == SGD_PRO_NONE || a.pro == SGD_PRO_LN_ROW || (a.pro == SGD_PRO_AFFINE_NC && a.rows_per_n > 0 && a.rows_per_n % BM == 0))) {
+        const char* e = getenv("SGDM_FLAT2");
+        if (!(e && atoi(e) == 0)) taps = 2;
+    }
     {
-        const int rc = make_geo(a, g, bn, na);
+        const int rc = make_geo(a, g, bn, na, conv ? 1 : taps);
         if (rc != SGD_OK) return rc;
     }
     if (a.stats && g.sparts == 0) return SGD_ERR_ARG;
@@ -2029,7 +2132,6 @@ extern "C" int sgd_igemm(const sgd_igemm_args* args, void* stream) {
                         + (a.cout_p <= BIAS_LDS_MAX ? (size_t)a.cout_p * sizeof(float) : 0);
     if (smem > 160 * 1024) return SGD_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
-    const bool conv = a.mode == SGD_MODE_CONV3;
     // Loader-side epilogue (igemm_kernel<.., DEFER>): 3x3 launches with 128-column tiles in a split mode, 16-byte inputs
     // and outputs, no or same-row residual, bias in LDS, at least 3 chunks per tile (the slices of a tile's epilogue ride
     // on the periods of the next one), buffers addressable with 32-bit byte offsets, and room for the staging tile
@@ -2052,9 +2154,9 @@ extern "C" int sgd_igemm(const sgd_igemm_args* args, void* stream) {
         }
     }
     switch (a.prec) {
-        case SGD_PREC_F32: return sgd_igemm_dispatch_f32(&ka, bn, variant, conv, smem_launch, st);
-        case SGD_PREC_F16X3: return sgd_igemm_dispatch_f16x3(&ka, bn, variant, conv, smem_launch, st);
-        case SGD_PREC_BF16X3: return sgd_igemm_dispatch_bf16x3(&ka, bn, variant, conv, smem_launch, st);
+        case SGD_PREC_F32: return sgd_igemm_dispatch_f32(&ka, bn, variant, taps, smem_launch, st);
+        case SGD_PREC_F16X3: return sgd_igemm_dispatch_f16x3(&ka, bn, variant, taps, smem_launch, st);
+        case SGD_PREC_BF16X3: return sgd_igemm_dispatch_bf16x3(&ka, bn, variant, taps, smem_launch, st);
         default: return SGD_ERR_ARG;
     }
 }

@@ -42,6 +42,7 @@ class IgemmArgs(C.Structure):
 # name -> (restype, argtypes); every symbol include/sgdm_hip.h declares
 SIGNATURES = {
     "sgd_abi_version": (i32, []),
+    "sgd_build_id": (C.c_char_p, []),
     "sgd_igemm": (i32, [C.POINTER(IgemmArgs), vp]),
     "sgd_igemm_stats_parts": (i32, [C.POINTER(IgemmArgs)]),
     "sgd_igemm_work_bytes": (i64, []),

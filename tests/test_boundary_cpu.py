@@ -23,11 +23,17 @@ class AD(dict):
 def test_library_exports_every_declared_symbol():
     from sgdm_amd import _lib as L
     hdr = open(os.path.join(ROOT, "include", "sgdm_hip.h")).read()
-    declared = set(re.findall(r"^\s*(?:int|int64_t)\s+(sgd_\w+)\s*\(", hdr, flags=re.M))
+    declared = set(re.findall(r"^\s*(?:int|int64_t|const char\*)\s+(sgd_\w+)\s*\(", hdr, flags=re.M))
     assert declared == set(L.SIGNATURES), declared ^ set(L.SIGNATURES)
     lib = L.load()                                    # binds every symbol or raises
     assert lib.sgd_abi_version() == L.ABI_VERSION
     assert ctypes.sizeof(L.IgemmArgs) == 216
+    # the library is a build of THIS tree: the source digest it embeds equals the digest of the sources on disk
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("sgdm_build", os.path.join(ROOT, "self-guided-diffusion-models_amd", "build.py"))
+    bld = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bld)
+    assert lib.sgd_build_id().decode() == bld.source_id()
     # argument validation needs no GPU: invalid descriptors are rejected before any launch
     assert lib.sgd_igemm(None, None) == 1
     assert lib.sgd_packed_weight_bytes(128, 128, 3, 0) == 9 * 128 * 128 * 4

@@ -254,6 +254,47 @@ def test_conv1x1_at_unet_batch_80(case, prec, tol):
     assert gerr < tol, gerr
 
 
+@pytest.mark.parametrize("prec", ["f32", "f16x3", "bf16x3"])
+@pytest.mark.parametrize("case", sorted(FLAT_CASES) + ["odd_planes", "ragged_rows", "silu_only"])
+def test_two_plane_flat_instance_equals_one_plane(case, prec, monkeypatch):
+    """round 4: 1x1 / linear launches stage TWO 32-channel planes per barrier (igemm_kernel<.., TAPS = 2>).  The K order is
+    the one of the one-plane instance, so the two must agree BIT FOR BIT -- GroupNorm / no prologue, SiLU, two-source
+    concat, residual, a row count that is not a multiple of the tile, and (odd number of planes) the fallback itself."""
+    L, lib = _lib()
+    p = L.PREC_BY_NAME[prec]
+    g = torch.Generator().manual_seed(53)
+    silu = 0
+    if case == "odd_planes":
+        c0, c1, cout, hw, gn, resid, n = 96, 0, 128, 256, False, False, 8           # 3 planes: one-plane instance both times
+    elif case == "ragged_rows":
+        c0, c1, cout, hw, gn, resid, n = 128, 64, 256, 1000, False, True, 3         # 3000 rows: last tile partly empty
+    elif case == "silu_only":
+        c0, c1, cout, hw, gn, resid, n, silu = 512, 0, 1024, 1, False, False, 80, 1  # emb_layers-like: SiLU(emb) @ W
+    else:
+        c0, c1, cout, hw, gn, resid = FLAT_CASES[case]
+        n = NB
+    cin, m = c0 + c1, n * hw
+    x0 = torch.randn(m, c0, generator=g).cuda()
+    x1 = torch.randn(m, c1, generator=g).cuda() if c1 else None
+    w = torch.randn(cout, cin, generator=g) / math.sqrt(cin)
+    b = torch.randn(cout, generator=g).cuda()
+    pa, pb = (1 + 0.3 * torch.randn(n, cin, generator=g)).cuda(), (0.3 * torch.randn(n, cin, generator=g)).cuda()
+    res = torch.randn(m, cout, generator=g).cuda() if resid else None
+    outs = {}
+    for flat2 in ("0", "1"):
+        monkeypatch.setenv("SGDM_FLAT2", flat2)
+        outs[flat2] = _flat(L, lib, p, x0, x1, w, b, m, rows_per_n=hw if gn else 0, pa=pa if gn else None,
+                            pb=pb if gn else None, res=res, silu=silu)
+        assert torch.isfinite(outs[flat2]).all()
+    assert torch.equal(outs["0"], outs["1"])
+    xin = torch.cat([x0, x1], 1) if c1 else x0
+    if silu:
+        xin = F.silu(xin)
+    if not gn:
+        ref = xin.double() @ w.cuda().double().t() + b.double() + (res.double() if resid else 0)
+        assert max_rel(outs["1"].cpu(), ref.cpu()) < {"f32": 5e-6, "f16x3": 2e-5, "bf16x3": 1e-4}[prec]
+
+
 @pytest.mark.parametrize("prec,tol", KPRECS)
 def test_image_packed_tiles_ragged_batch(prec, tol):
     """8x8 maps (the 4-level `*_s64` plans): two images per 128-row tile and an odd batch, so the last M tile of the stream
