@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define SGD_ABI_VERSION 12
+#define SGD_ABI_VERSION 13
 int sgd_abi_version(void);
 /* 16 hex digits identifying the sources and flags the library was compiled from (build.py: source_id()); static storage.
  * __graft_entry__.build() and tests/test_boundary_cpu.py compare it with the tree on disk. */
@@ -153,6 +153,28 @@ int sgd_pack_weight_scaled(const float* w_src, void* w_dst, int32_t cout, int32_
                            int32_t transpose /* 1: dgrad operator, dims are the FORWARD weight's */,
                            const uint32_t* amax_bits, float* scale_inv_out, int32_t* cin_p, int32_t* cout_p /* HOST out */,
                            void* stream);
+
+/* Every weight of a model in three launches (the per-step re-pack of a training loop: one zero, one amax, one pack kernel
+ * instead of two launches per tensor).  jobs / the block tables are DEVICE arrays the caller builds once:
+ *   jobs[j]          one weight tensor: src (OIHW fp32), dst (packed buffer of sgd_packed_weight_bytes), dims of the FORWARD
+ *                    weight, transpose (1: the dgrad operator), amax_bits / scale_inv as in sgd_pack_weight_scaled (NULL in
+ *                    f32 mode), own_amax (0: amax_bits belongs to another job of the same tensor and is only read)
+ *   *_block_job[b]   the job block b works on;  *_first[j] the first block of job j (n_jobs + 1 entries, ascending);
+ *                    a job with own_amax == 0 has no amax blocks.  sgd_pack_job_blocks gives the block counts per job
+ *                    (what the single-tensor entry points would launch) and the padded dims the packed operator has. */
+typedef struct sgd_pack_job {
+    const float* src;
+    void* dst;
+    uint32_t* amax_bits;
+    float* scale_inv;
+    int32_t cout, cin, ksize, transpose;
+    int32_t own_amax, reserved0;
+} sgd_pack_job;
+int sgd_pack_job_blocks(int32_t cout, int32_t cin, int32_t ksize, int32_t prec, int32_t transpose, int32_t* amax_blocks,
+                        int32_t* pack_blocks, int32_t* cin_p, int32_t* cout_p /* HOST out */);
+int sgd_pack_weights_batched(const sgd_pack_job* jobs, int32_t n_jobs, const int32_t* amax_block_job, const int32_t* amax_first,
+                             int32_t n_amax_blocks, const int32_t* pack_block_job, const int32_t* pack_first,
+                             int32_t n_pack_blocks, int32_t prec, void* stream);
 
 /* Skinny linear with a long reduction (mlp_cond.0 of the cluster-k5000 config, openaimodel.py:597-607: [2B, 5000] x
  * [256, 5000]^T): exact fp32 FMA, the K range split over `ksplit` blocks per 64-column tile, partial sums in
@@ -405,6 +427,15 @@ int sgd_linear_attention(const float* q, int32_t q_ld, int32_t q_hs, const float
  * dq/dk/dv are written with the same row strides / head strides as q/k/v (i.e. into a gqkv tensor).
  * Multi-query (kv_hs == 0, crossattetion_lr.py:115-137): dk/dv are summed over the heads inside the kernel. */
 int sgd_attention_bwd(const float* q, int32_t q_ld, int32_t q_hs, const float* k, const float* v, int32_t kv_ld,
+                      int32_t kv_hs, const float* o /* forward output */, int32_t o_ld,
+                      const float* dout, int32_t dout_ld, const float* lse /* from sgd_attention */,
+                      float* dvec /* workspace [batch, heads, tq] */,
+                      int32_t batch, int32_t heads, int32_t tq, int32_t tk, int32_t d, float scale,
+                      float* dq, float* dk, float* dv, void* stream);
+/* sgd_attention_bwd in split precision (the f16x3 engine): every operand as hi + lo f16 halves, three
+ * v_mfma_f32_32x32x16_f16 products, fp32 accumulate; P carried x 2^14 and dS x a per-wave running power of two
+ * (csrc/attention.hip).  Same arguments, same outputs within the engine's tolerance; head dims 16 / 32 / 64. */
+int sgd_attention_bwd_split(const float* q, int32_t q_ld, int32_t q_hs, const float* k, const float* v, int32_t kv_ld,
                       int32_t kv_hs, const float* o /* forward output */, int32_t o_ld,
                       const float* dout, int32_t dout_ld, const float* lse /* from sgd_attention */,
                       float* dvec /* workspace [batch, heads, tq] */,

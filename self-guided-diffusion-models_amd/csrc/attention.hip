@@ -568,6 +568,254 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(
 }
 
 
+
+// =============================================================================================
+// split-precision backward (prec f16x3, round 4): the two sweeps of attention_bwd_kernel on v_mfma_f32_32x32x16_f16 with
+// every fp32 operand as hi + lo f16 halves and three products, fp32 accumulate -- per 32-row tile at D = 64, 24 MFMAs
+// for S^T and dP^T and 24 (q sweep) / 48 (kv sweep) for the gradient contractions, against 512 + 512 / 1024
+// v_mfma_f32_32x32x2_f32 with one scalar LDS read each in the exact kernel.
+//   * streamed rows U, W are staged twice: row-major planes (A operand of the score products: 8 consecutive channels of a
+//     row per lane) and TRANSPOSED planes [d][row] in the row order the accumulator-as-operand idiom imposes (A operand
+//     of the gradient products), exactly as attention_split_kernel stages K and V^T;
+//   * P is carried times 2^14 (its lo half would sit in fp16's subnormals), undone in dV;
+//   * dS = P (dP - D) has no a-priori range (it scales with the loss gradient): it is carried times a per-wave power of
+//     two chosen from the running maximum of |dS| -- when a tile raises the maximum the accumulator is rescaled by the
+//     (exact) ratio, as the online softmax does with its running maximum -- so the largest element sits in [2^13, 2^14)
+//     and neither half overflows or underflows for elements within 2^-13 of it.
+// =============================================================================================
+template <int D, int SWEEP>
+__global__ __launch_bounds__(256) void attention_bwd_split_kernel(
+    const float* __restrict__ q, int q_ld, int q_hs, const float* __restrict__ k, const float* __restrict__ v,
+    int kv_ld, int kv_hs, const float* __restrict__ dout, int dout_ld, const float* __restrict__ lse,
+    const float* __restrict__ dvec, int tq, int tk, float scale, float* __restrict__ dq, float* __restrict__ dk,
+    float* __restrict__ dv, int heads, int mq) {
+    constexpr int DT = (D + 31) / 32;
+    constexpr int DP = DT * 32;
+    constexpr int KS = (D + 15) / 16;
+    constexpr int TT = 32;                               // streamed rows per LDS tile
+    constexpr int LDK = KS * 16 + 8;                     // f16 per row-major row
+    constexpr int LDT = TT + 8;                          // f16 per transposed row
+    constexpr bool KV = SWEEP == 0;
+    __shared__ __attribute__((aligned(16))) _Float16 Uh[TT * LDK], Ul[TT * LDK], Wh[TT * LDK], Wl[TT * LDK];
+    __shared__ __attribute__((aligned(16))) _Float16 UTh[DP * LDT], UTl[DP * LDT];
+    __shared__ __attribute__((aligned(16))) _Float16 WTh[KV ? DP * LDT : 8], WTl[KV ? DP * LDT : 8];
+    __shared__ float Ls[TT], Ds[TT];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int b = blockIdx.z;
+    const int head0 = mq ? 0 : blockIdx.y, head1 = mq ? heads : blockIdx.y + 1;
+    const int own_n = KV ? tk : tq, str_n = KV ? tq : tk;
+    const int oi = blockIdx.x * 128 + wave * 32 + li;    // this lane's owned row (key or query)
+    const int oc = oi < own_n ? oi : own_n - 1;
+    constexpr float PS = 16384.0f;                       // 2^14
+
+    f32x16 accA[DT], accB[DT];        // kv: dK^T (x sc_run), dV^T (x 2^14)   q: dQ^T (x sc_run)
+#pragma unroll
+    for (int i = 0; i < DT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { accA[i][r] = 0.f; accB[i][r] = 0.f; }
+    float sc_run = 1.329227996e36f;                      // 2^120: any tile lowers it
+    if (DP > D) {                                        // rows of the transposed images no channel writes (D = 16)
+        for (int idx = tid; idx < (DP - D) * LDT; idx += 256) {
+            UTh[D * LDT + idx] = (_Float16)0.f; UTl[D * LDT + idx] = (_Float16)0.f;
+            if (KV) { WTh[D * LDT + idx] = (_Float16)0.f; WTl[D * LDT + idx] = (_Float16)0.f; }
+        }
+    }
+    for (int head = head0; head < head1; ++head) {
+        const float* qb = q + (long)b * tq * q_ld + head * q_hs;
+        const float* kb = k + (long)b * tk * kv_ld + head * kv_hs;
+        const float* vb = v + (long)b * tk * kv_ld + head * kv_hs;
+        const float* gb = dout + (long)b * tq * dout_ld + head * D;
+        const float* lseb = lse + ((long)b * heads + head) * tq;
+        const float* dvb = dvec + ((long)b * heads + head) * tq;
+        // owner fragments (B operands): k step s, lane half lh: channels 16 s + 8 lh .. + 7 of owned row li
+        f16x8 xh[KS], xl[KS], yh[KS], yl[KS];
+        {
+            const float* xp = KV ? kb + (long)oc * kv_ld : qb + (long)oc * q_ld;
+            const float* yp = KV ? vb + (long)oc * kv_ld : gb + (long)oc * dout_ld;
+#pragma unroll
+            for (int s = 0; s < KS; ++s)
+#pragma unroll
+                for (int j4 = 0; j4 < 2; ++j4) {
+                    const int c = s * 16 + lh * 8 + j4 * 4;
+                    f32x4 tx = {0.f, 0.f, 0.f, 0.f}, ty = tx;
+                    if (c < D) { tx = *reinterpret_cast<const f32x4*>(xp + c); ty = *reinterpret_cast<const f32x4*>(yp + c); }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        _Float16 h, l;
+                        split_f16(tx[j], h, l); xh[s][j4 * 4 + j] = h; xl[s][j4 * 4 + j] = l;
+                        split_f16(ty[j], h, l); yh[s][j4 * 4 + j] = h; yl[s][j4 * 4 + j] = l;
+                    }
+                }
+        }
+        float own_lse = 0.f, own_d = 0.f;
+        if (!KV) { own_lse = lseb[oc]; own_d = dvb[oc]; }
+
+        for (int t0 = 0; t0 < str_n; t0 += TT) {
+            __syncthreads();
+            // a thread stages two neighbouring rows (neighbours in the permuted order too) x 4 channels of U and of W
+            constexpr int VPR = D / 4;
+            constexpr int NI = ((TT / 2) * VPR + 255) / 256;
+            f32x4 u0[NI], u1[NI], w0[NI], w1[NI];
+            const long last = str_n - 1;
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                int idx = tid + i * 256;
+                idx = idx < (TT / 2) * VPR ? idx : (TT / 2) * VPR - 1;
+                const int row = (idx / VPR) * 2, c4 = idx % VPR;
+                const long r0 = t0 + row < str_n ? t0 + row : last, r1 = t0 + row + 1 < str_n ? t0 + row + 1 : last;
+                if (KV) {
+                    u0[i] = *reinterpret_cast<const f32x4*>(qb + r0 * q_ld + c4 * 4);
+                    u1[i] = *reinterpret_cast<const f32x4*>(qb + r1 * q_ld + c4 * 4);
+                    w0[i] = *reinterpret_cast<const f32x4*>(gb + r0 * dout_ld + c4 * 4);
+                    w1[i] = *reinterpret_cast<const f32x4*>(gb + r1 * dout_ld + c4 * 4);
+                } else {
+                    u0[i] = *reinterpret_cast<const f32x4*>(kb + r0 * kv_ld + c4 * 4);
+                    u1[i] = *reinterpret_cast<const f32x4*>(kb + r1 * kv_ld + c4 * 4);
+                    w0[i] = *reinterpret_cast<const f32x4*>(vb + r0 * kv_ld + c4 * 4);
+                    w1[i] = *reinterpret_cast<const f32x4*>(vb + r1 * kv_ld + c4 * 4);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int idx = tid + i * 256;
+                if (idx >= (TT / 2) * VPR) break;
+                const int row = (idx / VPR) * 2, c4 = idx % VPR;
+                f32x4 a0 = u0[i], a1 = u1[i], b0 = w0[i], b1 = w1[i];
+                if (t0 + row >= str_n) { a0 = f32x4{0.f, 0.f, 0.f, 0.f}; b0 = a0; }
+                if (t0 + row + 1 >= str_n) { a1 = f32x4{0.f, 0.f, 0.f, 0.f}; b1 = a1; }
+                const int kk = row & 15;
+                const int pos = (row & ~15) + (((kk >> 2) & 1) << 3) + ((kk >> 3) << 2) + (kk & 3);
+                typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+                f16x4 ah0, al0, ah1, al1, bh0, bl0, bh1, bl1;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    _Float16 h, l;
+                    split_f16(a0[j], h, l); ah0[j] = h; al0[j] = l;
+                    split_f16(a1[j], h, l); ah1[j] = h; al1[j] = l;
+                    split_f16(b0[j], h, l); bh0[j] = h; bl0[j] = l;
+                    split_f16(b1[j], h, l); bh1[j] = h; bl1[j] = l;
+                    // (row is even: pos is even, the pair is one aligned 4-byte store)
+                    *reinterpret_cast<f16x2*>(UTh + (c4 * 4 + j) * LDT + pos) = f16x2{ah0[j], ah1[j]};
+                    *reinterpret_cast<f16x2*>(UTl + (c4 * 4 + j) * LDT + pos) = f16x2{al0[j], al1[j]};
+                    if (KV) {
+                        *reinterpret_cast<f16x2*>(WTh + (c4 * 4 + j) * LDT + pos) = f16x2{bh0[j], bh1[j]};
+                        *reinterpret_cast<f16x2*>(WTl + (c4 * 4 + j) * LDT + pos) = f16x2{bl0[j], bl1[j]};
+                    }
+                }
+                *reinterpret_cast<f16x4*>(Uh + row * LDK + c4 * 4) = ah0;
+                *reinterpret_cast<f16x4*>(Ul + row * LDK + c4 * 4) = al0;
+                *reinterpret_cast<f16x4*>(Uh + (row + 1) * LDK + c4 * 4) = ah1;
+                *reinterpret_cast<f16x4*>(Ul + (row + 1) * LDK + c4 * 4) = al1;
+                *reinterpret_cast<f16x4*>(Wh + row * LDK + c4 * 4) = bh0;
+                *reinterpret_cast<f16x4*>(Wl + row * LDK + c4 * 4) = bl0;
+                *reinterpret_cast<f16x4*>(Wh + (row + 1) * LDK + c4 * 4) = bh1;
+                *reinterpret_cast<f16x4*>(Wl + (row + 1) * LDK + c4 * 4) = bl1;
+            }
+            if (KV && tid < TT) {
+                const int r = t0 + tid;
+                Ls[tid] = r < str_n ? lseb[r] : 0.f;
+                Ds[tid] = r < str_n ? dvb[r] : 0.f;
+            }
+            __syncthreads();
+
+            // scores / dP tiles: rows = streamed rows (registers), cols = owned rows (lanes)
+            f32x16 sacc, pacc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; pacc[r] = 0.f; }
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const f16x8 uh = *reinterpret_cast<const f16x8*>(Uh + li * LDK + s * 16 + lh * 8);
+                const f16x8 ul = *reinterpret_cast<const f16x8*>(Ul + li * LDK + s * 16 + lh * 8);
+                const f16x8 wh = *reinterpret_cast<const f16x8*>(Wh + li * LDK + s * 16 + lh * 8);
+                const f16x8 wl = *reinterpret_cast<const f16x8*>(Wl + li * LDK + s * 16 + lh * 8);
+                sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ul, xh[s], sacc, 0, 0, 0);
+                sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(uh, xl[s], sacc, 0, 0, 0);
+                sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(uh, xh[s], sacc, 0, 0, 0);
+                pacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, yh[s], pacc, 0, 0, 0);
+                pacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, yl[s], pacc, 0, 0, 0);
+                pacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, yh[s], pacc, 0, 0, 0);
+            }
+            // P (x 2^14) and dS (sacc <- P', pacc <- dS), and the wave's largest |dS|
+            float mx = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int srow = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const bool ok = (t0 + srow < str_n) && (oi < own_n);
+                const float l = KV ? Ls[srow] : own_lse;
+                const float dd = KV ? Ds[srow] : own_d;
+                const float p = ok ? __expf(sacc[r] * scale - l) : 0.f;
+                sacc[r] = p * PS;
+                pacc[r] = p * (pacc[r] - dd);
+                mx = fmaxf(mx, fabsf(pacc[r]));
+            }
+            mx = wave_max(mx);
+            // power of two that puts the running maximum into [2^13, 2^14); exponent clamped so tiny gradients stay finite
+            {
+                int e = (int)((__float_as_uint(mx) >> 23) & 255u) - 126;          // mx = f 2^e, f in [0.5, 1)
+                int se = 14 - e;
+                se = se > 100 ? 100 : (se < -100 ? -100 : se);
+                const float sc_new = __uint_as_float((uint32_t)(se + 127) << 23);
+                if (mx > 0.f && sc_new < sc_run) {                                // wave-uniform
+                    const float ratio = sc_new / sc_run;                          // exact: powers of two (0 on the first tile)
+#pragma unroll
+                    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) accA[dt][r] *= ratio;
+                    sc_run = sc_new;
+                }
+            }
+            const float sc = sc_run < 1.0e36f ? sc_run : 0.f;                     // no non-zero dS seen yet: dS is all zero
+            f16x8 ph[2], pl[2], dh[2], dl[2];
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    _Float16 h, l;
+                    split_f16(sacc[s2 * 8 + j], h, l); ph[s2][j] = h; pl[s2][j] = l;
+                    split_f16(pacc[s2 * 8 + j] * sc, h, l); dh[s2][j] = h; dl[s2][j] = l;
+                }
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const f16x8 th = *reinterpret_cast<const f16x8*>(UTh + (dt * 32 + li) * LDT + s2 * 16 + lh * 8);
+                    const f16x8 tl = *reinterpret_cast<const f16x8*>(UTl + (dt * 32 + li) * LDT + s2 * 16 + lh * 8);
+                    accA[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(tl, dh[s2], accA[dt], 0, 0, 0);
+                    accA[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(th, dl[s2], accA[dt], 0, 0, 0);
+                    accA[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(th, dh[s2], accA[dt], 0, 0, 0);
+                    if (KV) {
+                        const f16x8 gh = *reinterpret_cast<const f16x8*>(WTh + (dt * 32 + li) * LDT + s2 * 16 + lh * 8);
+                        const f16x8 gl = *reinterpret_cast<const f16x8*>(WTl + (dt * 32 + li) * LDT + s2 * 16 + lh * 8);
+                        accB[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gl, ph[s2], accB[dt], 0, 0, 0);
+                        accB[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gh, pl[s2], accB[dt], 0, 0, 0);
+                        accB[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gh, ph[s2], accB[dt], 0, 0, 0);
+                    }
+                }
+        }
+    }
+    if (oi < own_n) {
+        const int head = head0;
+        const float fa = sc_run < 1.0e36f ? scale / sc_run : 0.f, fb = 1.0f / PS;
+        float* pa = KV ? dk + ((long)b * tk + oi) * kv_ld + head * kv_hs : dq + ((long)b * tq + oi) * q_ld + head * q_hs;
+        float* pb = KV ? dv + ((long)b * tk + oi) * kv_ld + head * kv_hs : nullptr;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const int dd = dt * 32 + gq * 8 + 4 * lh;
+                if (dd >= D) continue;
+                f32x4 va, vb2;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { va[j] = accA[dt][gq * 4 + j] * fa; vb2[j] = accB[dt][gq * 4 + j] * fb; }
+                *reinterpret_cast<f32x4*>(pa + dd) = va;
+                if (KV) *reinterpret_cast<f32x4*>(pb + dd) = vb2;
+            }
+    }
+}
+
+
 // ---------------------------------------------------------------------------------------------
 // Linear attention core of attention_ldm.LinearCrossAttention (dynamic/attention_ldm.py:261-298): per (batch, head)
 //   q~ = softmax_d(q) * scale        k~ = softmax over the KEYS of k (column-wise)        out = q~ (k~^T v)
@@ -694,6 +942,36 @@ extern "C" int sgd_attention_bwd(const float* q, int32_t q_ld, int32_t q_hs, con
         default: return SGD_ERR_ARG;
     }
 #undef SGD_ATTN_BWD
+    return sgd_check_launch();
+}
+
+// the same contract as sgd_attention_bwd in split precision (the f16x3 engine; head dims 16 / 32 / 64)
+extern "C" int sgd_attention_bwd_split(const float* q, int32_t q_ld, int32_t q_hs, const float* k, const float* v,
+                                       int32_t kv_ld, int32_t kv_hs, const float* o, int32_t o_ld, const float* dout,
+                                       int32_t dout_ld, const float* lse, float* dvec, int32_t batch, int32_t heads,
+                                       int32_t tq, int32_t tk, int32_t d, float scale, float* dq, float* dk, float* dv,
+                                       void* stream) {
+    SGD_CLEAR_ERR();
+    if (!q || !k || !v || !o || !dout || !lse || !dvec || !dq || !dk || !dv || batch <= 0 || heads <= 0 || tq <= 0 ||
+        tk <= 0)
+        return SGD_ERR_ARG;
+    if ((q_ld & 3) || (q_hs & 3) || (kv_ld & 3) || (kv_hs & 3) || (o_ld & 3) || (dout_ld & 3)) return SGD_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const int mq = (kv_hs == 0 && heads > 1) ? 1 : 0;
+    dim3 gp((heads * tq + 255) / 256, batch), gkv((tk + 127) / 128, mq ? 1 : heads, batch), gq((tq + 127) / 128, heads, batch);
+#define SGD_ATTN_BWD_S(DD)                                                                                            \
+    hipLaunchKernelGGL((attn_bwd_prep_kernel<DD>), gp, dim3(256), 0, st, o, o_ld, dout, dout_ld, heads, tq, dvec);      \
+    hipLaunchKernelGGL((attention_bwd_split_kernel<DD, 0>), gkv, dim3(256), 0, st, q, q_ld, q_hs, k, v, kv_ld, kv_hs,   \
+                       dout, dout_ld, lse, dvec, tq, tk, scale, dq, dk, dv, heads, mq);                                \
+    hipLaunchKernelGGL((attention_bwd_split_kernel<DD, 1>), gq, dim3(256), 0, st, q, q_ld, q_hs, k, v, kv_ld, kv_hs,    \
+                       dout, dout_ld, lse, dvec, tq, tk, scale, dq, dk, dv, heads, 0);
+    switch (d) {
+        case 16: SGD_ATTN_BWD_S(16) break;
+        case 32: SGD_ATTN_BWD_S(32) break;
+        case 64: SGD_ATTN_BWD_S(64) break;
+        default: return SGD_ERR_ARG;
+    }
+#undef SGD_ATTN_BWD_S
     return sgd_check_launch();
 }
 

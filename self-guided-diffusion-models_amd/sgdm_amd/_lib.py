@@ -20,7 +20,7 @@ RS_NONE, RS_AVGPOOL2, RS_UP2, RS_ZEROUP2 = 0, 1, 2, 3
 PRO_NONE, PRO_AFFINE_NC, PRO_LN_ROW = 0, 1, 2
 PREC_F32, PREC_F16X3, PREC_BF16X3 = 0, 1, 2
 PREC_BY_NAME = {"f32": PREC_F32, "f16x3": PREC_F16X3, "bf16x3": PREC_BF16X3}
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
@@ -39,6 +39,12 @@ class IgemmArgs(C.Structure):
     ]
 
 
+class PackJob(C.Structure):
+    """mirror of ``struct sgd_pack_job`` (include/sgdm_hip.h)"""
+    _fields_ = [("src", vp), ("dst", vp), ("amax_bits", vp), ("scale_inv", vp), ("cout", i32), ("cin", i32), ("ksize", i32),
+                ("transpose", i32), ("own_amax", i32), ("reserved0", i32)]
+
+
 # name -> (restype, argtypes); every symbol include/sgdm_hip.h declares
 SIGNATURES = {
     "sgd_abi_version": (i32, []),
@@ -54,6 +60,8 @@ SIGNATURES = {
     "sgd_pack_weight": (i32, [vp, vp, i32, i32, i32, i32, C.POINTER(i32), C.POINTER(i32), vp]),
     "sgd_weight_amax": (i32, [vp, i64, vp, vp]),
     "sgd_pack_weight_scaled": (i32, [vp, vp, i32, i32, i32, i32, i32, vp, vp, C.POINTER(i32), C.POINTER(i32), vp]),
+    "sgd_pack_job_blocks": (i32, [i32, i32, i32, i32, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]),
+    "sgd_pack_weights_batched": (i32, [vp, i32, vp, vp, i32, vp, vp, i32, i32, vp]),
     "sgd_linear_splitk": (i32, [vp, i32, vp, vp, i32, i32, i32, vp, i32, vp, i32, vp]),
     "sgd_chan_stats": (i32, [vp, i32, i32, i32, vp, i32, i32, vp]),
     "sgd_gn_coef_parts": (i32, [vp, i32, i32, vp, i32, i32, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp, vp, vp]),
@@ -66,6 +74,8 @@ SIGNATURES = {
     "sgd_linear_attention": (i32, [vp, i32, i32, vp, vp, i32, i32, vp, i32, i32, i32, i32, i32, f32, vp, i32, vp]),
     "sgd_attention_bwd": (i32, [vp, i32, i32, vp, vp, i32, i32, vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, i32, f32,
                               vp, vp, vp, vp]),
+    "sgd_attention_bwd_split": (i32, [vp, i32, i32, vp, vp, i32, i32, vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, i32, f32,
+                                    vp, vp, vp, vp]),
     "sgd_pack_weight_dgrad": (i32, [vp, vp, i32, i32, i32, i32, C.POINTER(i32), C.POINTER(i32), vp]),
     "sgd_wgrad": (i32, [C.POINTER(IgemmArgs), vp, i32, i32, vp, i32, vp, vp]),
     "sgd_wgrad_scratch_bytes": (i64, [C.POINTER(IgemmArgs), i32]),

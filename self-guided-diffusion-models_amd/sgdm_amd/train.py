@@ -27,6 +27,7 @@ of different size).
 """
 import ctypes as C
 import math
+import os
 
 import torch
 
@@ -132,6 +133,13 @@ class Backward:
         self._build()
 
     # ---------------------------------------------------------------- helpers
+    def attention_bwd_fn(self):
+        """the attention backward in the engine's arithmetic: split-precision MFMA for f16x3 (head dims up to 64; the
+        forward's choice, unet._Engine.attention_fn), exact fp32 otherwise"""
+        if self.prec == L.PREC_F16X3 and os.environ.get("SGDM_ATTN_BWD_SPLIT", "1") != "0":
+            return self.lib.sgd_attention_bwd_split
+        return self.lib.sgd_attention_bwd
+
     def buf(self, *shape):
         t = torch.empty(*shape, dtype=torch.float32, device=self.dev)
         self.keep.append(t)
@@ -402,7 +410,7 @@ class Backward:
         qkv, gqkv = rec["qkv"], self.buf(n, T, 3 * ch)
         dvec = self.buf(n, heads, T)
         off = lambda t, k: C.c_void_p(t.data_ptr() + 4 * k)
-        self.prog.add(p + ".attn_bwd", self.lib.sgd_attention_bwd, _ptr(qkv), 3 * ch, 3 * d, off(qkv, d), off(qkv, 2 * d),
+        self.prog.add(p + ".attn_bwd", self.attention_bwd_fn(), _ptr(qkv), 3 * ch, 3 * d, off(qkv, d), off(qkv, 2 * d),
                       3 * ch, 3 * d, _ptr(rec["att"]), ch, _ptr(gatt), ch, _ptr(rec["lse"]), _ptr(dvec), n, heads, T, T, d,
                       1.0 / math.sqrt(d), _ptr(gqkv), off(gqkv, d), off(gqkv, 2 * d))
         wq = P(p + ".qkv.weight")
@@ -474,7 +482,7 @@ class Backward:
         q, kv = rec["q"], rec["kv"]
         gq, gkv = self.buf(n, T, inner), self.buf(n, J, 2 * dp)
         dvec = self.buf(n, heads, T)
-        self.prog.add(p + ".attn_bwd", lib.sgd_attention_bwd, _ptr(q), inner, dp, _ptr(kv),
+        self.prog.add(p + ".attn_bwd", self.attention_bwd_fn(), _ptr(q), inner, dp, _ptr(kv),
                       C.c_void_p(kv.data_ptr() + 4 * dp), 2 * dp, 0, _ptr(rec["att"]), inner, _ptr(gatt), inner,
                       _ptr(rec["lse"]), _ptr(dvec), n, heads, T, J, dp, d ** -0.5, _ptr(gq), _ptr(gkv),
                       C.c_void_p(gkv.data_ptr() + 4 * dp))
@@ -608,8 +616,10 @@ class Backward:
     def run(self, geps_nchw):
         lib = self.lib
         stream = torch.cuda.current_stream().cuda_stream
-        for pk in self.packs:
-            pk.refresh(stream)
+        if getattr(self, "_pack_batch", None) is None or len(self._pack_batch.packs) != len(self.packs):
+            from .unet import _PackBatch
+            self._pack_batch = _PackBatch(self.packs, self.prec, self.dev)
+        self._pack_batch.refresh(stream)
         for a, pk in self.late:
             a.cin_p, a.cout_p = pk.cin_p, pk.cout_p
         n, c = self.n, self.m.out_channels

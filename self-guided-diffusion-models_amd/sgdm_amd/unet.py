@@ -225,6 +225,90 @@ class _Packed:
         self.sig = sig
 
 
+class _PackBatch:
+    """the weight packs of one launch program refreshed together: when (almost) all of them are stale -- every step of a
+    training loop -- ONE sgd_pack_weights_batched call (zero + amax + pack kernels over a device-side job table) replaces
+    two launches per tensor (142 pack + 74 amax launches of ~6 us per step at C2).  Members are `_Packed` /
+    `train._PackedAdj` objects whose source is one whole contiguous fp32 parameter; the others (concatenated FiLM
+    projections, zero-padded head re-layouts, sliced sources) keep their own refresh."""
+
+    MIN_STALE = 8           # fewer stale packs than this: refresh them one by one
+
+    def __init__(self, packs, prec, dev):
+        self.packs, self.prec, self.dev = list(packs), prec, dev
+        self.lib = L.load()
+        self.members, self.table_sig = None, None
+
+    @staticmethod
+    def _source(pk):
+        """(parameter, forward cout, forward cin, transpose) of a batchable pack, else None"""
+        if hasattr(pk, "srcs"):                                   # unet._Packed
+            if len(pk.srcs) != 1 or pk.pad is not None:
+                return None
+            p, t = pk.srcs[0], 0
+            cout, cin = pk.cout, pk.cin
+        else:                                                     # train._PackedAdj
+            if len(pk.deps) != 1:
+                return None
+            p, t = pk.deps[0], 1
+            src = pk.src_fn()
+            if src.data_ptr() != p.data_ptr() or src.numel() != p.numel():
+                return None
+            cout, cin = pk.cout_fwd, pk.cin_fwd
+        if p.dtype != torch.float32 or not p.is_contiguous() or p.numel() != cout * cin * pk.ksize * pk.ksize:
+            return None
+        return p, cout, cin, t
+
+    def _build(self):
+        members, jobs = [], []
+        ab, pb = C.c_int32(), C.c_int32()
+        cp, op = C.c_int32(), C.c_int32()
+        a_job, a_first, p_job, p_first = [], [0], [], [0]
+        scaled = self.prec != L.PREC_F32
+        for pk in self.packs:
+            srcd = self._source(pk)
+            if srcd is None:
+                continue
+            p, cout, cin, t = srcd
+            L.check(self.lib.sgd_pack_job_blocks(cout, cin, pk.ksize, self.prec, t, C.byref(ab), C.byref(pb), C.byref(cp),
+                                                 C.byref(op)), "sgd_pack_job_blocks")
+            j = len(members)
+            jobs.append(L.PackJob(src=p.data_ptr(), dst=pk.buf.data_ptr(), amax_bits=pk.amax.data_ptr() if scaled else 0,
+                                  scale_inv=pk.scale_inv.data_ptr() if scaled else 0, cout=cout, cin=cin, ksize=pk.ksize,
+                                  transpose=t, own_amax=1 if scaled else 0))
+            members.append((pk, p, cp.value, op.value))
+            a_job += [j] * (ab.value if scaled else 0)
+            a_first.append(len(a_job))
+            p_job += [j] * pb.value
+            p_first.append(len(p_job))
+        self.members = members
+        self.table_sig = tuple(p.data_ptr() for _, p, _, _ in members)
+        if not members:
+            return
+        arr = (L.PackJob * len(jobs))(*jobs)
+        self.jobs = torch.frombuffer(bytearray(C.string_at(C.addressof(arr), C.sizeof(arr))), dtype=torch.uint8).to(self.dev)
+        i32t = lambda v: torch.tensor(v if v else [0], dtype=torch.int32, device=self.dev)
+        self.a_job, self.a_first, self.p_job, self.p_first = i32t(a_job), i32t(a_first), i32t(p_job), i32t(p_first)
+        self.n_a, self.n_p = len(a_job), len(p_job)
+        self.batched = {id(pk) for pk, _, _, _ in members}
+
+    def refresh(self, stream):
+        if self.members is None or self.table_sig != tuple(p.data_ptr() for _, p, _, _ in self.members):
+            self._build()                                          # first use, or a parameter moved (.to(), re-materialised)
+        stale = [(pk, p, cp, op) for pk, p, cp, op in self.members if pk.sig != ((p.data_ptr(), p._version),)]
+        if len(stale) >= self.MIN_STALE and os.environ.get("SGDM_BATCHED_PACK", "1") != "0":
+            L.check(self.lib.sgd_pack_weights_batched(_ptr(self.jobs), len(self.members), _ptr(self.a_job), _ptr(self.a_first),
+                                                      self.n_a, _ptr(self.p_job), _ptr(self.p_first), self.n_p, self.prec,
+                                                      stream), "sgd_pack_weights_batched")
+            for pk, p, cp, op in self.members:                     # (fresh members were re-packed too: same bytes)
+                pk.cin_p, pk.cout_p = cp, op
+                pk.sig = ((p.data_ptr(), p._version),)
+                if hasattr(pk, "srcs") and pk.scaled:
+                    AMAX_OF[p.data_ptr()] = (p._version, pk.amax, weakref.ref(p))
+        for pk in self.packs:                                      # the rest, and small stale sets, one by one
+            pk.refresh(stream)
+
+
 class _Program:
     def __init__(self):
         self.ops = []
@@ -746,8 +830,9 @@ class _Engine:
 
     # ---- execution
     def refresh(self, stream):
-        for pk in self.packed:
-            pk.refresh(stream)
+        if getattr(self, "_pack_batch", None) is None or len(self._pack_batch.packs) != len(self.packed):
+            self._pack_batch = _PackBatch(self.packed, self.prec, self.dev)
+        self._pack_batch.refresh(stream)
         for a, pk in self._late:
             a.cin_p, a.cout_p = pk.cin_p, pk.cout_p
         for hook in self.refresh_hooks:

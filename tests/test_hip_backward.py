@@ -230,9 +230,15 @@ def test_groupnorm_silu_backward(gu_mode, silu, film):
         assert max_rel(dfilm.cpu(), fl.grad) < 2e-5
 
 
+@pytest.mark.parametrize("core,gscale", [("exact", 1.0), ("split", 1.0), ("split", 1e-2), ("split", 1e3)])
 @pytest.mark.parametrize("b,heads,t,d", [(2, 8, 256, 64), (2, 4, 64, 32), (1, 8, 16, 16), (1, 2, 100, 64)])
-def test_attention_backward(b, heads, t, d):
+def test_attention_backward(b, heads, t, d, core, gscale):
+    """exact fp32 core and (round 4) the split-precision core of the f16x3 engine; the latter also with output gradients
+    of different magnitudes inside fp16's range (where the backward program's power-of-two loss scale keeps them, like
+    every gradient the f16x3 dgrad launches split): dS has no a-priori range, the kernel carries it times a running
+    power of two"""
     L, lib = _lib()
+    bwd = lib.sgd_attention_bwd if core == "exact" else lib.sgd_attention_bwd_split
     g = torch.Generator().manual_seed(15)
     ch = heads * d
     qkv = torch.randn(b, t, 3 * ch, generator=g).requires_grad_(True)        # channel-last legacy layout
@@ -240,7 +246,7 @@ def test_attention_backward(b, heads, t, d):
     q, k, v = x[:, :, :, 0].permute(0, 2, 1, 3), x[:, :, :, 1].permute(0, 2, 1, 3), x[:, :, :, 2].permute(0, 2, 1, 3)
     w = torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(d), -1)
     o = (w @ v).permute(0, 2, 1, 3).reshape(b, t, ch)
-    go = torch.randn(b, t, ch, generator=g)
+    go = torch.randn(b, t, ch, generator=g) * gscale
     o.backward(go)
     qd = qkv.detach().cuda()
     out = torch.empty(b, t, ch, device="cuda")
@@ -252,11 +258,15 @@ def test_attention_backward(b, heads, t, d):
     gqkv = torch.full((b, t, 3 * ch), float("nan"), device="cuda")
     dvec = torch.empty(b, heads, t, device="cuda")
     god = go.cuda()
-    L.check(lib.sgd_attention_bwd(_p(qd), 3 * ch, 3 * d, kp, vp, 3 * ch, 3 * d, _p(out), ch, _p(god), ch, _p(lse),
-                                  _p(dvec), b, heads, t, t, d, 1 / math.sqrt(d), _p(gqkv),
-                                  C.c_void_p(gqkv.data_ptr() + 4 * d), C.c_void_p(gqkv.data_ptr() + 8 * d), _stream()),
+    L.check(bwd(_p(qd), 3 * ch, 3 * d, kp, vp, 3 * ch, 3 * d, _p(out), ch, _p(god), ch, _p(lse),
+                _p(dvec), b, heads, t, t, d, 1 / math.sqrt(d), _p(gqkv),
+                C.c_void_p(gqkv.data_ptr() + 4 * d), C.c_void_p(gqkv.data_ptr() + 8 * d), _stream()),
             "attn_bwd")
-    assert max_rel(gqkv.cpu(), qkv.grad) < 1e-5
+    assert torch.isfinite(gqkv).all()
+    x3 = gqkv.cpu().reshape(b, t, heads, 3, d)
+    r3 = qkv.grad.reshape(b, t, heads, 3, d)
+    for i, nm in enumerate("qkv"):                       # each of dq / dk / dv against ITS OWN maximum
+        assert max_rel(x3[:, :, :, i], r3[:, :, :, i]) < 1e-5, (core, nm)
 
 
 def test_q_sample_and_mse_loss():
@@ -283,9 +293,11 @@ def test_q_sample_and_mse_loss():
     assert max_rel(ge.cpu().permute(0, 3, 1, 2), eps.grad) < 1e-6
 
 
-def test_attention_backward_multiquery():
+@pytest.mark.parametrize("core", ["exact", "split"])
+def test_attention_backward_multiquery(core):
     """Attention_LR core (crossattetion_lr.py:115-137): 8 heads share K/V of 16+1+256 rows; dK/dV summed over heads"""
     L, lib = _lib()
+    bwd = lib.sgd_attention_bwd if core == "exact" else lib.sgd_attention_bwd_split
     g = torch.Generator().manual_seed(17)
     b, heads, t, j, d = 2, 8, 256, 273, 64
     q = torch.randn(b, t, heads * d, generator=g).requires_grad_(True)
@@ -304,11 +316,12 @@ def test_attention_backward_multiquery():
     gq = torch.full((b, t, heads * d), float("nan"), device="cuda")
     gkv = torch.full((b, j, 2 * d), float("nan"), device="cuda")
     dvec = torch.empty(b, heads, t, device="cuda")
-    L.check(lib.sgd_attention_bwd(_p(qd), heads * d, d, _p(kvd), vp, 2 * d, 0, _p(out), heads * d, _p(god), heads * d,
-                                  _p(lse), _p(dvec), b, heads, t, j, d, d ** -0.5, _p(gq), _p(gkv),
-                                  C.c_void_p(gkv.data_ptr() + 4 * d), _stream()), "attn_bwd")
+    L.check(bwd(_p(qd), heads * d, d, _p(kvd), vp, 2 * d, 0, _p(out), heads * d, _p(god), heads * d,
+                _p(lse), _p(dvec), b, heads, t, j, d, d ** -0.5, _p(gq), _p(gkv),
+                C.c_void_p(gkv.data_ptr() + 4 * d), _stream()), "attn_bwd")
     assert max_rel(gq.cpu(), q.grad) < 1e-5
-    assert max_rel(gkv.cpu(), kv.grad) < 1e-5
+    assert max_rel(gkv.cpu()[..., :d], kv.grad[..., :d]) < 1e-5
+    assert max_rel(gkv.cpu()[..., d:], kv.grad[..., d:]) < 1e-5
 
 
 @pytest.mark.parametrize("rows,c", [(300, 512), (48, 32)])

@@ -257,9 +257,10 @@ def test_conv1x1_at_unet_batch_80(case, prec, tol):
 @pytest.mark.parametrize("prec", ["f32", "f16x3", "bf16x3"])
 @pytest.mark.parametrize("case", sorted(FLAT_CASES) + ["odd_planes", "ragged_rows", "silu_only"])
 def test_two_plane_flat_instance_equals_one_plane(case, prec, monkeypatch):
-    """round 4: 1x1 / linear launches stage TWO 32-channel planes per barrier (igemm_kernel<.., TAPS = 2>).  The K order is
-    the one of the one-plane instance, so the two must agree BIT FOR BIT -- GroupNorm / no prologue, SiLU, two-source
-    concat, residual, a row count that is not a multiple of the tile, and (odd number of planes) the fallback itself."""
+    """round 4, opt-in (SGDM_FLAT2=1): 1x1 / linear launches stage TWO 32-channel planes per barrier (igemm_kernel<..,
+    TAPS = 2>).  The K order is the one of the one-plane instance, so the two must agree BIT FOR BIT -- GroupNorm / no
+    prologue, SiLU, two-source concat, residual, a row count that is not a multiple of the tile, and (odd number of
+    planes) the fallback itself.  (Not a default: csrc/igemm.hip, sgd_igemm, explains why.)"""
     L, lib = _lib()
     p = L.PREC_BY_NAME[prec]
     g = torch.Generator().manual_seed(53)

@@ -659,3 +659,52 @@ def test_train_step_with_zero_padded_attention_heads_vs_oracle(prec, tol):
         assert err < tol, (name, err)
         checked += 1
     assert checked > 50 and any(".to_q." in k for k in trainable)
+
+
+@pytest.mark.parametrize("prec", ["f32", "f16x3"])
+def test_batched_weight_repack_equals_single_packs(prec, monkeypatch):
+    """round 4: the per-step re-pack of every conv / linear weight (forward operators and their adjoints) as ONE
+    sgd_pack_weights_batched call -- packed bytes and per-tensor scales must equal what the per-tensor launches write"""
+    from sgdm_amd.diffusion import LatentDiffusion
+    import bench
+
+    def one_step(batched):
+        monkeypatch.setenv("SGDM_BATCHED_PACK", "1" if batched else "0")
+        m, entry = build_model("ca_stego_c32_s16", prec)
+        m.train()
+        d = LatentDiffusion(device="cuda", **bench.MODEL_PARAMS).train()
+        d.set_denoise_fn(m.forward, m.forward_with_cond_scale)
+        from sgdm_amd.synth import synth_batch
+        kw = entry["ctor"]
+        batch = synth_batch(kw["condition_method"], 4, 16, kw["cond_dim"], entry["layout_dim"], seed=3)
+        g = torch.Generator().manual_seed(3)
+        t = torch.randint(0, 1000, (4,), generator=g).cuda()
+        noise = torch.randn(4, 3, 16, 16, generator=g).cuda()
+        mask = torch.tensor([False, True, False, False]).cuda()
+        for _ in range(2):                                   # second pass: every parameter version bumped -> all stale again
+            loss, _ = d.p_losses(batch["image"].cuda(), t, noise, cond=batch["cond"].float().cuda(),
+                                 layout=batch["layout"].cuda(), cond_drop_prob=0.5, cond_drop_mask=mask)
+            loss.backward()
+            with torch.no_grad():
+                for p in m.parameters():
+                    p.mul_(1.0009765625)                       # exact scaling, bumps ._version
+        loss, _ = d.p_losses(batch["image"].cuda(), t, noise, cond=batch["cond"].float().cuda(),
+                             layout=batch["layout"].cuda(), cond_drop_prob=0.5, cond_drop_mask=mask)
+        loss.backward()
+        eng = next(iter(m._engines.values()))
+        out = []
+        for pk in list(eng.packed) + list(eng.backward.packs):
+            out.append((pk.buf.clone(), pk.scale_inv.clone() if pk.scaled else None, pk.cin_p, pk.cout_p))
+        nb = (len(eng._pack_batch.members), len(eng.backward._pack_batch.members))
+        return out, float(loss), nb
+
+    ref, loss0, _ = one_step(False)
+    got, loss1, nb = one_step(True)
+    assert nb[0] > 20 and nb[1] > 20, nb                      # most packs are batchable
+    assert loss0 == loss1
+    assert len(ref) == len(got)
+    for (b0, s0, ci0, co0), (b1, s1, ci1, co1) in zip(ref, got):
+        assert (ci0, co0) == (ci1, co1)
+        assert torch.equal(b0, b1)
+        if s0 is not None:
+            assert torch.equal(s0, s1)

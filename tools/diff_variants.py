@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""Which launch of a UNet evaluation differs between two settings of an environment switch the library reads per call
+(SGDM_FLAT2, SGDM_BN256, SGDM_BALANCE ...)?  Runs the forward program launch by launch under both settings, on the same
+inputs, and compares the output tensor of every sgd_igemm launch.
+
+    python tools/diff_variants.py --env SGDM_FLAT2 --a 0 --b 1 [--workload c5] [--batch 8] [--prec f16x3]"""
+import argparse, ctypes as C, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "self-guided-diffusion-models_amd"))
+import torch
+import bench
+from sgdm_amd import _lib as L
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--env", default="SGDM_FLAT2"); ap.add_argument("--a", default="0"); ap.add_argument("--b", default="1")
+ap.add_argument("--workload", default="c5"); ap.add_argument("--batch", type=int, default=8); ap.add_argument("--prec", default="f16x3")
+a = ap.parse_args()
+wl = bench.WORKLOADS[a.workload]
+dev = torch.device("cuda", 0)
+os.environ[a.env] = a.a
+m, sd, data = bench.build_model(wl, dev, a.prec, a.batch)
+cond = data.get("cond"); cond = None if cond is None else (cond.to(dev) if wl["kind"] == "unet_fast" else cond.float().to(dev))
+layout = data["layout"].to(dev) if "layout" in data else None
+B = a.batch
+x = torch.randn(B, 3, wl["image"], wl["image"], device=dev); t = torch.full((B,), 500, device=dev, dtype=torch.long)
+with torch.no_grad():
+    m.forward_with_cond_scale(x, t, cond_scale=2.0, cond=cond, layout=layout)
+eng = m._engines[(2 * B, wl["image"], wl["image"], L.PREC_BY_NAME[a.prec])]
+st = torch.cuda.current_stream().cuda_stream
+bufs = {b.data_ptr(): b for b in eng.bufs}
+
+
+def owner(ptr):
+    for p0, b in bufs.items():
+        if p0 <= ptr < p0 + b.numel() * b.element_size():
+            return b
+    return None
+
+
+# run op by op; after each igemm, snapshot its output buffer under setting a, then rerun the SAME op under b
+bad = 0
+for name, fn, args in eng.prog.ops:
+    os.environ[a.env] = a.a
+    rc = fn(*args, st)
+    assert rc == 0, name
+    if getattr(fn, "__name__", "") != "sgd_igemm":
+        continue
+    ia = args[0]._obj
+    out = owner(ia.y)
+    if out is None:
+        continue
+    torch.cuda.synchronize()
+    ref = out.clone()
+    os.environ[a.env] = a.b
+    out.fill_(float("nan")) if ia.orows_in == 0 and ia.y_ld == ia.cout and not ia.res else None
+    assert fn(*args, st) == 0
+    torch.cuda.synchronize()
+    same = torch.equal(torch.nan_to_num(out), torch.nan_to_num(ref))
+    if not same:
+        d = (torch.nan_to_num(out) - torch.nan_to_num(ref)).abs().max().item()
+        print(f"DIFF {name:44s} m={ia.m} c0={ia.c0} c1={ia.c1} cout={ia.cout} y_ld={ia.y_ld} pro={ia.pro} silu={ia.pro_silu} "
+              f"orows=({ia.orows_in},{ia.orows_out},{ia.orow_off}) res={bool(ia.res)} stats={bool(ia.stats)} max|d|={d:.3e} ref max {ref.abs().max().item():.3e}")
+        bad += 1
+        os.environ[a.env] = a.a                       # restore the reference output for the layers behind it
+        fn(*args, st)
+print("differing igemm launches:", bad)
