@@ -536,10 +536,13 @@ __global__ __launch_bounds__(256) void colsum_fold_rows_kernel(const float* __re
 
 // activated conv input (virtual concat x0 | x1, GroupNorm affine, SiLU, train-time dropout: apply_pro) as hi / lo planes
 // [source row][cin]; resampling stays in the consumer's index map
+// pool: the conv reads avg_pool2d(act(x)) (ResBlock(down), openaimodel.py:301-306): the planes are written at the POOLED
+// resolution -- rows = n * (hi / 2) * (wi / 2) -- and the consumer sees an unresampled input of those dims (round 4: these
+// launches ran on the generic per-tap kernel at ~400 us each, seven times their share)
 template <int PREC>
 __global__ __launch_bounds__(256) void act_split_kernel(const sgd_igemm_args a, long rows, int rows_per_n,
                                                         typename Split<PREC>::T* __restrict__ hi,
-                                                        typename Split<PREC>::T* __restrict__ lo) {
+                                                        typename Split<PREC>::T* __restrict__ lo, int pool) {
     typedef typename Split<PREC>::T T;
     typedef T T4 __attribute__((ext_vector_type(4)));
     const int cin = a.c0 + a.c1, cq = cin >> 2;
@@ -548,7 +551,23 @@ __global__ __launch_bounds__(256) void act_split_kernel(const sgd_igemm_args a, 
         const long row = i / cq;
         const int c = (int)(i - row * cq) * 4;
         const int n = (int)(row / rows_per_n);
-        const f32x4 v = apply_pro(a, load_raw<true>(a, row, c), load_coef<true>(a, n, row, c), c, row);
+        f32x4 v;
+        if (pool) {
+            const int wp = a.wi >> 1;
+            const int pr = (int)(row - (long)n * rows_per_n), py = pr / wp, px = pr - py * wp;
+            const long r00 = ((long)n * a.hi + 2 * py) * a.wi + 2 * px;
+            v = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 2; ++dx) {
+                    const long r = r00 + dy * a.wi + dx;
+                    v += apply_pro(a, load_raw<true>(a, r, c), load_coef<true>(a, n, r, c), c, r);
+                }
+            v = v * 0.25f;
+        } else {
+            v = apply_pro(a, load_raw<true>(a, row, c), load_coef<true>(a, n, row, c), c, row);
+        }
         T* hp = hi + row * cin + c;
         T* lp = lo + row * cin + c;
         if constexpr (PREC == SGD_PREC_F16X3) {
@@ -861,7 +880,8 @@ static void launch_wgrad_planes(WArgs& w, long grid, void* scratch, hipStream_t 
     typedef typename Split<PREC>::T T;
     const sgd_igemm_args& a = w.a;
     const int cin = a.c0 + a.c1;
-    const long grows = w.rows, urows = (long)a.n * a.hi * a.wi;
+    const bool pool = a.resample == SGD_RS_AVGPOOL2;
+    const long grows = w.rows, urows = pool ? (long)a.n * (a.hi / 2) * (a.wi / 2) : (long)a.n * a.hi * a.wi;
     T* gh = reinterpret_cast<T*>(scratch);
     T* gl = gh + grows * w.cout;
     T* uh = gl + grows * w.cout;
@@ -882,8 +902,14 @@ static void launch_wgrad_planes(WArgs& w, long grid, void* scratch, hipStream_t 
     const long quads = urows * (cin / 4);
     long ablk = (quads + 255) / 256;
     if (ablk > 16384) ablk = 16384;
-    hipLaunchKernelGGL((act_split_kernel<PREC>), dim3((unsigned)ablk), dim3(256), 0, st, a, urows, a.hi * a.wi, uh, ul);
+    hipLaunchKernelGGL((act_split_kernel<PREC>), dim3((unsigned)ablk), dim3(256), 0, st, a, urows,
+                       pool ? (a.hi / 2) * (a.wi / 2) : a.hi * a.wi, uh, ul, pool ? 1 : 0);
     w.gh = gh; w.gl = gl; w.uh = uh; w.ul = ul;
+    if (pool) {                   // the main kernel sees the pooled planes as an unresampled input
+        w.a.hi /= 2;
+        w.a.wi /= 2;
+        w.a.resample = SGD_RS_NONE;
+    }
     launch_wgrad_ws<PREC, true>(w, grid, st);
 }
 
@@ -1257,11 +1283,15 @@ static int wgrad_impl(const sgd_igemm_args* fwd, const float* gy, int32_t gy_ld,
         // wave-specialised kernel: 16-byte gradient rows of whole 128-channel blocks, whole rows (cout % 128 == 0), vector
         // input rows, GroupNorm-affine / no prologue, no avg-pool.  (Dropout does not exclude it: with pre-split planes
         // act_split_kernel applies the keep mask through apply_pro, and the in-kernel loader does the same.)
-        const bool ws = fast_conv && vec && w.gvec && cout % WT == 0 && (a.resample == SGD_RS_NONE || a.resample == SGD_RS_UP2)
-                        && (a.pro == SGD_PRO_NONE || a.pro == SGD_PRO_AFFINE_NC) && !getenv("SGDM_WGRAD_OLD");
+        // the fused average pool (ResBlock(down)) only through the planes: act_split_kernel writes them pooled
+        const bool pooled = a.resample == SGD_RS_AVGPOOL2 && !getenv("SGDM_WGRAD_NOPOOL");
+        const bool ws0 = fast_conv && vec && w.gvec && cout % WT == 0
+                         && (a.resample == SGD_RS_NONE || a.resample == SGD_RS_UP2 || pooled)
+                         && (a.pro == SGD_PRO_NONE || a.pro == SGD_PRO_AFFINE_NC) && !getenv("SGDM_WGRAD_OLD");
         // ... and with a scratch buffer for the pre-split operand planes: the loaders only copy
         const int64_t need = 4 * ((int64_t)w.rows * cout + (int64_t)a.n * a.hi * a.wi * cin) + 4 * 2048 * (int64_t)cout;
-        const bool planes = ws && scratch && scratch_bytes >= need && !getenv("SGDM_WGRAD_NOPLANES");
+        const bool planes = ws0 && scratch && scratch_bytes >= need && !getenv("SGDM_WGRAD_NOPLANES");
+        const bool ws = ws0 && (planes || !pooled);
 #define SGD_WG(P, V)                                                             \
         do { if (planes) launch_wgrad_planes<P>(w, fgrid, scratch, st);           \
              else if (ws) launch_wgrad_ws<P, false>(w, fgrid, st);               \

@@ -147,6 +147,36 @@ def test_conv_wgrad_split_precision_at_production_shapes(shape, prec, tol):
 
 
 @pytest.mark.parametrize("prec,tol", [("f16x3", 3e-5), ("bf16x3", 3e-4)])
+@pytest.mark.parametrize("shape", [(20, 128, 128, 64), (40, 256, 256, 32)])
+def test_conv_wgrad_fused_avgpool_through_pooled_planes(shape, prec, tol, monkeypatch):
+    """ResBlock(down) first conv (openaimodel.py:301-306): the conv reads avg_pool2d(SiLU(GN(x))).  Round 4: its weight
+    gradient runs on the wave-specialised kernel -- act_split_kernel writes the operand planes at the POOLED resolution
+    -- instead of the generic per-tap kernel; both must agree with float64 autograd, and with each other to rounding"""
+    L, lib = _lib()
+    n, cin, cout, h = shape
+    g = torch.Generator().manual_seed(33)
+    x = torch.randn(n, cin, h, h, generator=g)
+    pa, pb = 1 + 0.3 * torch.randn(n, cin, generator=g), 0.3 * torch.randn(n, cin, generator=g)
+    ho = h // 2
+    gy = torch.randn(n, cout, ho, ho, generator=g) / (n * ho * ho) ** 0.5
+    w = (torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(cin * 9)).double().requires_grad_(True)
+    u = F.avg_pool2d(F.silu(x.double() * pa.double()[:, :, None, None] + pb.double()[:, :, None, None]), 2)
+    F.conv2d(u, w, padding=1).backward(gy.double())
+    xd, pad, pbd = _nhwc(x).cuda(), pa.cuda(), pb.cuda()
+    fwd = _igemm_args(L, xd, None, conv=(n, h, h, ho, ho), pa=pad, pb=pbd, silu=1, resample=1)
+    fwd.prec = L.PREC_BY_NAME[prec]
+    gyd = _nhwc(gy).cuda()
+    ks = _train_ksplit(9, cout, cin, n * ho * ho)
+    dw = _wgrad(L, lib, fwd, gyd, cout, cin, 9, ks, scratch=True)            # pooled planes + wave-specialised kernel
+    err = max_rel(dw.reshape(cout, cin, 3, 3), w.grad.float())
+    assert err < tol, err
+    monkeypatch.setenv("SGDM_WGRAD_NOPOOL", "1")
+    dw_old = _wgrad(L, lib, fwd, gyd, cout, cin, 9, ks, scratch=True)        # the generic kernel it replaces
+    assert max_rel(dw_old.reshape(cout, cin, 3, 3), w.grad.float()) < tol
+    assert max_rel(dw, dw_old) < tol
+
+
+@pytest.mark.parametrize("prec,tol", [("f16x3", 3e-5), ("bf16x3", 3e-4)])
 def test_linear_wgrad_split_precision_at_production_shapes(prec, tol):
     """1x1 / linear weight gradient in split precision: attention qkv (512 -> 1536 over 80*256 rows)"""
     L, lib = _lib()
