@@ -182,13 +182,23 @@ def test_optimizer_chunk_table():
 
 
 @pytest.mark.parametrize("fname", ["r1_bench_c2_f16x3.json", "r2_bench_c2_f16x3_final.json", "r2_bench_c2_f16x3_final_b.json",
-                                   "r3_bench_c2_f16x3.json", "r3_bench_c2_f16x3_final.json"])
+                                   "r3_bench_c2_f16x3.json", "r3_bench_c2_f16x3_final.json", "r4_bench_c2_f16x3.json"])
 def test_committed_bench_line_has_the_contract_fields(fname):
     """the bench lines committed under profiles/ (produced by bench.py on the MI355X) carry every field of the contract"""
     import json
     line = json.loads(open(os.path.join(ROOT, "profiles", fname)).read().strip().splitlines()[-1])
-    if fname.startswith("r3_"):
+    if fname.startswith("r4_"):
+        # round 4: the metric in full beside the K-step figure, the train step's per-kernel record, an honest checksum flag
+        ft = line["full_trajectory"]
+        assert ft["steps"] == 1000 and ft["images"] == line["n_gpus"] * line["config"]["batch_per_gpu"]
+        assert abs(ft["vs_k_step_extrapolation"] - 1.0) < 0.03
+        tr = line["train_step"]
+        assert tr["grad_checksums_equal"] is None and tr["world_size"] == 1 and tr["reserved_cus"] == 0
+        assert {"sgd_wgrad", "sgd_igemm(forward)", "sgd_igemm(dgrad)"} <= set(tr["roofline"]["per_kernel"])
+        assert "_pmc_hbm_c2.json" in line["roofline"]["traffic_source"]
+    if fname.startswith("r3_") or fname.startswith("r4_"):
         assert "c2_bs80" in line      # (its grad_checksums_equal is trivially true: one rank; null from round 4 on)
+    if fname.startswith("r3_"):
         assert "r3_pmc_hbm" in line["roofline"]["traffic_source"]
     if not fname.startswith("r1_"):
         # round 2: the line is self-sufficient (exact-fp32 figure, C5 and C1 legs, instantiation split, traffic label)
