@@ -368,6 +368,14 @@ int sgd_colsum_fold(const float* partial, int32_t chunks, int32_t c, float* out,
  * (`scale` undoes the power-of-two gradient scaling that keeps the split-f16 dgrad operands in range) */
 int sgd_wgrad_reduce(const float* slabs, int32_t ksplit, int32_t taps, int32_t cout, int32_t cin,
                      float* dw, int32_t accumulate, float scale, void* stream);
+/* sgd_wgrad_reduce + the bias gradient of the same layer in one launch: bias_slabs [ksplit, cout] are the partial column
+ * sums the weight-gradient kernel wrote; dbias[cout] = scale * their sum (fixed order, double accumulation). */
+int sgd_wgrad_reduce_bias(const float* slabs, int32_t ksplit, int32_t taps, int32_t cout, int32_t cin, float* dw,
+                          int32_t accumulate, float scale, const float* bias_slabs, float* dbias, void* stream);
+/* column sums of two [rows, c] matrices (row stride ld) in one launch, rows <= 256: GroupNorm's dgamma and dbeta from the
+ * per-sample tables of sgd_gn_bwd_coef. */
+int sgd_colsum_pair(const float* g1, const float* g2, int32_t rows, int32_t c, int32_t ld, float* out1, float* out2,
+                    int32_t accumulate, float scale, void* stream);
 /* out[c] = (accumulate ? out[c] : 0) + scale * sum_rows g[row, c]   (bias / norm-affine gradients).
  * Deterministic two-stage reduction through `work` [work_chunks, c] (caller-owned scratch, e.g. 256 chunks). */
 int sgd_colsum(const float* g, int32_t rows, int32_t c, int32_t ld, float* out, int32_t accumulate, float scale,

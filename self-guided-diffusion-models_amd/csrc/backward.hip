@@ -925,9 +925,33 @@ static void launch_wgrad_fast(const WArgs& w, long grid, hipStream_t st) {
     hipLaunchKernelGGL((wgrad_conv_kernel<PREC, VEC, TAPS>), dim3((unsigned)grid), dim3(256), smem, st, w);
 }
 
+// bslab / dbias (optional): the bias gradient rides on the same launch -- its [ksplit][cout] partial column sums (written
+// by the weight-gradient kernel) are folded by the first `cout` threads in the fixed order and double accumulation of
+// colsum_stage2_kernel (round 4: 71 sgd_colsum_fold launches of ~6.5 us per training step)
 __global__ void wgrad_reduce_kernel(const float* __restrict__ slabs, int ksplit, int taps, int cout, int cin,
-                                    float* __restrict__ dw, int accumulate, float scale) {
+                                    float* __restrict__ dw, int accumulate, float scale,
+                                    const float* __restrict__ bslab, float* __restrict__ dbias) {
     const long per = (long)taps * cout * cin;
+    if (bslab && blockIdx.x * 32 < cout) {
+        // block b folds columns 32 b .. 32 b + 31: 8 slab lanes x 32 columns, independent loads in flight, fixed order
+        // (colsum_stage2_kernel's scheme; a serial loop over up to 512 slabs in one thread was a 30 us tail of the launch)
+        const int col = blockIdx.x * 32 + (threadIdx.x & 31), rl = threadIdx.x >> 5;
+        double t = 0;
+        if (col < cout) {
+#pragma unroll 4
+            for (int k = rl; k < ksplit; k += 8) t += bslab[(long)k * cout + col];
+        }
+        __shared__ double red[8][32];
+        red[rl][threadIdx.x & 31] = t;
+        __syncthreads();
+        if (threadIdx.x < 32 && col < cout) {
+            double u = 0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) u += red[k][threadIdx.x];
+            u *= scale;
+            dbias[col] = accumulate ? dbias[col] + (float)u : (float)u;
+        }
+    }
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < per; i += (long)gridDim.x * blockDim.x) {
         // i indexes [tap][co][ci]
         const int ci = i % cin;
@@ -956,9 +980,13 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slabs, int ksplit,
 // With ONE row chunk (rows <= 256: the per-sample GroupNorm dgamma / dbeta tables, bias gradients of the embedding linears)
 // the fold of stage 2 is the identity on one float, so stage 1 writes the scaled result itself: one launch instead of two,
 // bit-identical (float row sums, then double * scale exactly as stage 2 does).
+// blockIdx.z == 1 (sgd_colsum_pair): the second matrix / output of a pair with the same shape (GroupNorm dgamma + dbeta)
 __global__ __launch_bounds__(256) void colsum_stage1_kernel(const float* __restrict__ g, int rows, int c, int ld,
                                                             int chunks, float* __restrict__ work,
-                                                            float* __restrict__ out, int accumulate, float scale) {
+                                                            float* __restrict__ out, int accumulate, float scale,
+                                                            const float* __restrict__ g2 = nullptr,
+                                                            float* __restrict__ out2 = nullptr) {
+    if (blockIdx.z == 1) { g = g2; out = out2; }
     const int col = blockIdx.x * 32 + (threadIdx.x & 31), rl = threadIdx.x >> 5;     // 8 row lanes
     const int chunk = blockIdx.y;
     const long per = ((long)rows + chunks - 1) / chunks;
@@ -1332,7 +1360,29 @@ extern "C" int sgd_wgrad_reduce(const float* slabs, int32_t ksplit, int32_t taps
     SGD_CLEAR_ERR();
     if (!slabs || !dw || ksplit <= 0 || taps <= 0 || cout <= 0 || cin <= 0) return SGD_ERR_ARG;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nblk((long)taps * cout * cin, 8192)), dim3(256), 0,
-                       (hipStream_t)stream, slabs, ksplit, taps, cout, cin, dw, accumulate, scale);
+                       (hipStream_t)stream, slabs, ksplit, taps, cout, cin, dw, accumulate, scale, (const float*)nullptr,
+                       (float*)nullptr);
+    return sgd_check_launch();
+}
+
+extern "C" int sgd_wgrad_reduce_bias(const float* slabs, int32_t ksplit, int32_t taps, int32_t cout, int32_t cin, float* dw,
+                                     int32_t accumulate, float scale, const float* bias_slabs, float* dbias, void* stream) {
+    SGD_CLEAR_ERR();
+    if (!slabs || !dw || !bias_slabs || !dbias || ksplit <= 0 || taps <= 0 || cout <= 0 || cin <= 0) return SGD_ERR_ARG;
+    unsigned grid = nblk((long)taps * cout * cin, 8192);
+    if (grid < (unsigned)((cout + 31) / 32)) grid = (cout + 31) / 32;        // one block per 32 bias columns
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, slabs, ksplit, taps, cout, cin, dw,
+                       accumulate, scale, bias_slabs, dbias);
+    return sgd_check_launch();
+}
+
+// two column sums of one shape in ONE launch, rows <= 256 (the per-sample GroupNorm dgamma / dbeta tables [n, c])
+extern "C" int sgd_colsum_pair(const float* g1, const float* g2, int32_t rows, int32_t c, int32_t ld, float* out1, float* out2,
+                               int32_t accumulate, float scale, void* stream) {
+    SGD_CLEAR_ERR();
+    if (!g1 || !g2 || !out1 || !out2 || rows <= 0 || rows > 256 || c <= 0 || ld < c) return SGD_ERR_ARG;
+    hipLaunchKernelGGL(colsum_stage1_kernel, dim3((c + 31) / 32, 1, 2), dim3(256), 0, (hipStream_t)stream, g1, rows, c, ld, 1,
+                       (float*)nullptr, out1, accumulate, scale, g2, out2);
     return sgd_check_launch();
 }
 

@@ -82,6 +82,8 @@ SIGNATURES = {
     "sgd_wgrad_scratch": (i32, [C.POINTER(IgemmArgs), vp, i32, i32, vp, i32, vp, vp, i64, vp]),
     "sgd_colsum_fold": (i32, [vp, i32, i32, vp, i32, f32, vp]),
     "sgd_wgrad_reduce": (i32, [vp, i32, i32, i32, i32, vp, i32, f32, vp]),
+    "sgd_wgrad_reduce_bias": (i32, [vp, i32, i32, i32, i32, vp, i32, f32, vp, vp, vp]),
+    "sgd_colsum_pair": (i32, [vp, vp, i32, i32, i32, vp, vp, i32, f32, vp]),
     "sgd_colsum": (i32, [vp, i32, i32, i32, vp, i32, f32, vp, i32, vp]),
     "sgd_gn_bwd_reduce": (i32, [vp, i32, i32, i32, i32, i32, i32, vp, vp, i32, vp, i32, i32, f32, C.c_uint32, vp, vp]),
     "sgd_gn_bwd_coef": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, vp, vp, vp, vp, vp, vp, vp]),

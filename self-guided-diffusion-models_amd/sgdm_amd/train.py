@@ -227,13 +227,16 @@ class Backward:
         wgrad_launch.__name__ = "sgd_wgrad"
         self.prog.add(tag + ".wgrad", wgrad_launch, flops=2.0 * rows * cout * cin * taps)
         dw = dw_view if dw_view is not None else self.pg(wname)
-        self.prog.add(tag + ".wred", self.lib.sgd_wgrad_reduce, _ptr(slabs), ksplit, taps, cout, cin, _ptr(dw), 0,
-                      self.unscale)
+        if bias_name is not None:
+            # weight and bias gradient of the layer folded by one launch
+            self.prog.add(tag + ".wred", self.lib.sgd_wgrad_reduce_bias, _ptr(slabs), ksplit, taps, cout, cin, _ptr(dw), 0,
+                          self.unscale, _ptr(bslab), _ptr(self.pg(bias_name)))
+        else:
+            self.prog.add(tag + ".wred", self.lib.sgd_wgrad_reduce, _ptr(slabs), ksplit, taps, cout, cin, _ptr(dw), 0,
+                          self.unscale)
         if dw_view is None:
             self.wrote(wname)
         if bias_name is not None:
-            self.prog.add(tag + ".bias", self.lib.sgd_colsum_fold, _ptr(bslab), ksplit, cout, _ptr(self.pg(bias_name)), 0,
-                          self.unscale)
             self.wrote(bias_name)
 
     def _wscratch(self):
@@ -289,11 +292,15 @@ class Backward:
         self.prog.add(tag + ".coef", lib.sgd_gn_bwd_coef, _ptr(S), _ptr(sums), _ptr(gamma), _ptr(beta),
                       C.c_void_p(film_ptr), film_ld, n, ct, GN_GROUPS, h * w, GN_EPS, _ptr(A), _ptr(B), _ptr(Cc),
                       _ptr(dg), _ptr(db), C.c_void_p(dfilm_ptr))
-        self.prog.add(tag + ".dgamma", lib.sgd_colsum, _ptr(dg), n, ct, ct, _ptr(self.pg(gname + ".weight")), 0,
-                      self.unscale, _ptr(self.cwork), self.CW)
+        if n <= 256:             # dgamma and dbeta from the per-sample tables in one launch
+            self.prog.add(tag + ".dgamma_dbeta", lib.sgd_colsum_pair, _ptr(dg), _ptr(db), n, ct, ct,
+                          _ptr(self.pg(gname + ".weight")), _ptr(self.pg(gname + ".bias")), 0, self.unscale)
+        else:
+            self.prog.add(tag + ".dgamma", lib.sgd_colsum, _ptr(dg), n, ct, ct, _ptr(self.pg(gname + ".weight")), 0,
+                          self.unscale, _ptr(self.cwork), self.CW)
+            self.prog.add(tag + ".dbeta", lib.sgd_colsum, _ptr(db), n, ct, ct, _ptr(self.pg(gname + ".bias")), 0,
+                          self.unscale, _ptr(self.cwork), self.CW)
         self.wrote(gname + ".weight")
-        self.prog.add(tag + ".dbeta", lib.sgd_colsum, _ptr(db), n, ct, ct, _ptr(self.pg(gname + ".bias")), 0,
-                      self.unscale, _ptr(self.cwork), self.CW)
         self.wrote(gname + ".bias")
         off = 0
         for t, c in srcs:
