@@ -925,6 +925,128 @@ static void launch_wgrad_fast(const WArgs& w, long grid, hipStream_t st) {
     hipLaunchKernelGGL((wgrad_conv_kernel<PREC, VEC, TAPS>), dim3((unsigned)grid), dim3(256), smem, st, w);
 }
 
+// =============================================================================================
+// weight gradients of the two convs with a handful of channels on one side (round 4): the stem (3 or 4 input channels,
+// input_blocks.0.0, openaimodel.py:531-537) and the output head (3 output channels, out.2, :830-835).  2 GFLOP against
+// 170 MB of gradient / activation rows each: HBM-bound, and ~0.4 ms apiece on the generic per-tap MFMA kernel.  Here a
+// lane owns one channel of the WIDE side and walks a slab of rows; the narrow side of a pixel neighbourhood is a
+// handful of wave-uniform scalars.  Pure fp32 FMA (every arithmetic mode), deterministic, same slab format as the
+// other kernels: slabs[k][tap][co][ci], bslab[k][cout].
+// =============================================================================================
+// One kernel for both: per pixel r a lane holds v(r) -- gy[r][co] (stem) or act(x)[r][ci] (head) -- and the block shares
+// the pixel's NARROW vector nv(r)[9 taps][NC] through LDS -- x[r + tap][ci] (stem: an im2col row) or gy[r - tap][co]
+// (head: the 9 output pixels input pixel r feeds) -- zero outside the image: acc[t][c] += v * nv[t][c], 9 NC FMAs for one
+// vector load and 9 NC / 4 broadcast LDS reads.  A block owns one slab of the rows and walks it in chunks of WN_ROWS.
+constexpr int WN_ROWS = 128;
+template <int NC, bool HEAD>
+__global__ __launch_bounds__(256) void wgrad_narrow_kernel(const float* __restrict__ x, const float* __restrict__ pa,
+                                                           const float* __restrict__ pb, int silu, const float* __restrict__ gy,
+                                                           int gy_ld, int n, int h, int w, int wide, int ksplit,
+                                                           float* __restrict__ slabs, float* __restrict__ bslab) {
+    constexpr int NV = 9 * NC;                                 // narrow values per pixel
+    constexpr int NVP = (NV + 3) & ~3;                         // padded to 16 bytes
+    __shared__ __attribute__((aligned(16))) float nvs[WN_ROWS * NVP];
+    __shared__ float red[256 * (NV + 1)];
+    const int lanes = wide < 256 ? wide : 256;                 // host: wide % 64 == 0, 256 % lanes == 0
+    const int rsub = 256 / lanes;                              // row interleave inside a chunk
+    const int ch = threadIdx.x % lanes;
+    const int sub = __builtin_amdgcn_readfirstlane(threadIdx.x / lanes);
+    const long rows = (long)n * h * w;
+    const long per = ((rows + ksplit - 1) / ksplit + WN_ROWS - 1) / WN_ROWS * WN_ROWS;     // rows of a slab: whole chunks
+    const long s0 = (long)blockIdx.x * per, s1 = s0 + per < rows ? s0 + per : rows;
+    // the narrow tensor: gy for the head (NC = cout channels per row), x for the stem (NC = cin)
+    const float* nar = HEAD ? gy : x;
+    const int nar_ld = HEAD ? gy_ld : NC;
+    float acc[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) acc[i] = 0.f;
+    float accb = 0.f;
+    for (long c0 = s0; c0 < s1; c0 += WN_ROWS) {
+        __syncthreads();
+        // narrow vectors of the chunk's pixels: (pixel, tap) items, NC values each
+        for (int it = threadIdx.x; it < WN_ROWS * 9; it += 256) {
+            const int pr = it / 9, t = it - pr * 9;
+            const long r = c0 + pr;
+            const int dy = t / 3 - 1, dx = t % 3 - 1;
+            float vals[NC];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) vals[c] = 0.f;
+            if (r < s1) {
+                const int px = (int)(r % w), py = (int)((r / w) % h);
+                const int yy = HEAD ? py - dy : py + dy, xx = HEAD ? px - dx : px + dx;
+                if (yy >= 0 && yy < h && xx >= 0 && xx < w) {
+                    const long rr = HEAD ? r - (long)dy * w - dx : r + (long)dy * w + dx;
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) vals[c] = nar[rr * nar_ld + c];
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < NC; ++c) nvs[pr * NVP + t * NC + c] = vals[c];
+        }
+        __syncthreads();
+        const int nr = (int)(s1 - c0 < WN_ROWS ? s1 - c0 : WN_ROWS);
+        for (int pb0 = sub; pb0 < nr; pb0 += 8 * rsub) {
+            // eight rows of this lane requested before the first is used
+            float vq[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int pr = pb0 + j * rsub;
+                const long r = c0 + (pr < nr ? pr : nr - 1);
+                vq[j] = HEAD ? x[r * wide + ch] : gy[r * gy_ld + ch];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int pr = pb0 + j * rsub;
+                if (pr >= nr) break;                                       // wave-uniform
+                float v = vq[j];
+                if (HEAD) {
+                    if (pa) {
+                        const long img = (c0 + pr) / ((long)h * w);
+                        v = v * pa[img * wide + ch] + pb[img * wide + ch];
+                    }
+                    if (silu) v = sgd_silu(v);
+                    if (ch < NC) accb += nvs[pr * NVP + 4 * NC + ch];    // centre tap = gy of this pixel: the bias gradient
+                } else {
+                    accb += v;
+                }
+                const f32x4* nq = reinterpret_cast<const f32x4*>(nvs + pr * NVP);
+#pragma unroll
+                for (int i4 = 0; i4 < NVP / 4; ++i4) {
+                    const f32x4 q4 = nq[i4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (i4 * 4 + e < NV) acc[i4 * 4 + e] += v * q4[e];
+                }
+            }
+        }
+    }
+    // the rsub row interleaves of the block are folded through LDS: ONE slab per block
+    float* mine = red + (size_t)threadIdx.x * (NV + 1);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) mine[i] = acc[i];
+    mine[NV] = accb;
+    __syncthreads();
+    if (threadIdx.x < lanes) {
+        for (int s2 = 1; s2 < rsub; ++s2) {
+            const float* o = red + (size_t)(s2 * lanes + ch) * (NV + 1);
+#pragma unroll
+            for (int i = 0; i < NV; ++i) acc[i] += o[i];
+            accb += o[NV];
+        }
+        // slab layout [tap][co][ci]: stem wide = co (cin = NC), head wide = ci (cout = NC)
+        float* sl = slabs + (size_t)blockIdx.x * NV * wide;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+                sl[HEAD ? ((size_t)t * NC + c) * wide + ch : ((size_t)t * wide + ch) * NC + c] = acc[t * NC + c];
+        if (bslab) {
+            if (!HEAD) bslab[(size_t)blockIdx.x * wide + ch] = accb;
+            else if (ch < NC) bslab[(size_t)blockIdx.x * NC + ch] = accb;
+        }
+    }
+}
+
 // bslab / dbias (optional): the bias gradient rides on the same launch -- its [ksplit][cout] partial column sums (written
 // by the weight-gradient kernel) are folded by the first `cout` threads in the fixed order and double accumulation of
 // colsum_stage2_kernel (round 4: 71 sgd_colsum_fold launches of ~6.5 us per training step)
@@ -1291,6 +1413,24 @@ static int wgrad_impl(const sgd_igemm_args* fwd, const float* gy, int32_t gy_ld,
         return SGD_ERR_ARG;
     }
     if (w.rows <= 0) return SGD_ERR_ARG;
+    // stem / head: a handful of channels on one side, a whole number of waves of lanes on the other (see the kernels)
+    if (a.mode == SGD_MODE_CONV3 && a.stride == 1 && a.resample == SGD_RS_NONE && a.c1 == 0 && a.drop_p == 0.f
+        && ksplit <= (w.rows + 63) / 64 && !getenv("SGDM_WGRAD_NOSMALL")) {
+        hipStream_t st0 = (hipStream_t)stream;
+        const bool lanes_co = cout % 64 == 0 && (cout == 256 || (cout < 256 && 256 % cout == 0));
+        const bool lanes_ci = cin % 64 == 0 && (cin == 256 || (cin < 256 && 256 % cin == 0));
+        if (cin <= 4 && cin >= 3 && a.pro == SGD_PRO_NONE && !a.pro_silu && lanes_co) {
+            if (cin == 3) hipLaunchKernelGGL((wgrad_narrow_kernel<3, false>), dim3(ksplit), dim3(256), 0, st0, a.x0, (const float*)nullptr, (const float*)nullptr, 0, gy, gy_ld, a.n, a.ho, a.wo, cout, ksplit, slabs, bias_slabs);
+            else hipLaunchKernelGGL((wgrad_narrow_kernel<4, false>), dim3(ksplit), dim3(256), 0, st0, a.x0, (const float*)nullptr, (const float*)nullptr, 0, gy, gy_ld, a.n, a.ho, a.wo, cout, ksplit, slabs, bias_slabs);
+            return sgd_check_launch();
+        }
+        if (cout == 3 && (a.pro == SGD_PRO_NONE || a.pro == SGD_PRO_AFFINE_NC) && lanes_ci) {
+            hipLaunchKernelGGL((wgrad_narrow_kernel<3, true>), dim3(ksplit), dim3(256), 0, st0, a.x0, a.pro == SGD_PRO_AFFINE_NC ? a.pa : nullptr,
+                               a.pro == SGD_PRO_AFFINE_NC ? a.pb : nullptr, a.pro_silu, gy, gy_ld, a.n, a.ho, a.wo, cin, ksplit, slabs,
+                               bias_slabs);
+            return sgd_check_launch();
+        }
+    }
     w.gy = gy; w.gy_ld = gy_ld; w.cout = cout; w.slabs = slabs; w.bslab = bias_slabs;
     w.co_tiles = (cout + WT - 1) / WT;
     w.ci_tiles = (cin + WT - 1) / WT;

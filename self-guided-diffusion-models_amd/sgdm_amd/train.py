@@ -92,6 +92,10 @@ def wgrad_ksplit(taps, cout, cin, rows):
     so that the grid is as close as possible to a whole number of rounds of the 256 CUs with at least ~8 K tiles per
     block; 1x1 / linear launches (256-thread blocks, two per CU, 128 input channels per block) keep the round-2 rule."""
     ktiles = (rows + 63) // 64
+    if taps == 9 and (cin <= 4 or cout == 3):
+        # stem / head (csrc/backward.hip: wgrad_narrow_kernel): HBM-bound row walks, one 256-thread block per slab in
+        # chunks of 128 rows -- two blocks per CU at bs 80 (~640 rows each)
+        return max(1, min(ktiles, 1024, -(-rows // 640)))
     if taps == 9:
         per_k = ((cout + 127) // 128) * ((cin + 31) // 32)
         best, best_cost = 1, None

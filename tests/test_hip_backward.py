@@ -146,6 +146,40 @@ def test_conv_wgrad_split_precision_at_production_shapes(shape, prec, tol):
         assert torch.equal(dw, dw2)
 
 
+@pytest.mark.parametrize("prec", ["f32", "f16x3"])
+@pytest.mark.parametrize("kind,n,h,ch", [("stem3", 5, 64, 128), ("stem4", 3, 32, 64), ("head", 5, 64, 128), ("head", 2, 16, 64),
+                                         ("stem3", 2, 16, 256)])
+def test_conv_wgrad_stem_and_head(kind, n, h, ch, prec, monkeypatch):
+    """round 4: the stem (3 / 4 input channels) and the output head (3 output channels, GroupNorm + SiLU prologue) have
+    weight-gradient kernels of their own (HBM-bound row walks in fp32 FMA, any arithmetic mode) instead of the generic
+    per-tap MFMA kernel: both against float64 autograd, bias gradient included (checked inside _wgrad)"""
+    L, lib = _lib()
+    g = torch.Generator().manual_seed(44)
+    if kind.startswith("stem"):
+        cin, cout, fused = int(kind[-1]), ch, False
+    else:
+        cin, cout, fused = ch, 3, True
+    x = torch.randn(n, cin, h, h, generator=g)
+    pa, pb = 1 + 0.3 * torch.randn(n, cin, generator=g), 0.3 * torch.randn(n, cin, generator=g)
+    gy = torch.randn(n, cout, h, h, generator=g)
+    w = (torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(cin * 9)).double().requires_grad_(True)
+    u = x.double()
+    if fused:
+        u = F.silu(u * pa.double()[:, :, None, None] + pb.double()[:, :, None, None])
+    F.conv2d(u, w, padding=1).backward(gy.double())
+    xd, pad, pbd = _nhwc(x).cuda(), pa.cuda(), pb.cuda()          # (kept alive: the descriptor holds raw pointers)
+    fwd = _igemm_args(L, xd, None, conv=(n, h, h, h, h), pa=pad if fused else None, pb=pbd if fused else None,
+                      silu=1 if fused else 0)
+    fwd.prec = L.PREC_BY_NAME[prec]
+    gyd = _nhwc(gy).cuda()
+    ks = _train_ksplit(9, cout, cin, n * h * h)
+    dw = _wgrad(L, lib, fwd, gyd, cout, cin, 9, ks)
+    assert max_rel(dw.reshape(cout, cin, 3, 3), w.grad.float()) < 5e-6
+    monkeypatch.setenv("SGDM_WGRAD_NOSMALL", "1")             # the generic kernel they replace, same slabs
+    dw_old = _wgrad(L, lib, fwd, gyd, cout, cin, 9, ks)
+    assert max_rel(dw_old.reshape(cout, cin, 3, 3), w.grad.float()) < (5e-6 if prec == "f32" else 3e-5)
+
+
 @pytest.mark.parametrize("prec,tol", [("f16x3", 3e-5), ("bf16x3", 3e-4)])
 @pytest.mark.parametrize("shape", [(20, 128, 128, 64), (40, 256, 256, 32)])
 def test_conv_wgrad_fused_avgpool_through_pooled_planes(shape, prec, tol, monkeypatch):
