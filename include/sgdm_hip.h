@@ -182,6 +182,11 @@ int sgd_pack_weights_batched(const sgd_pack_job* jobs, int32_t n_jobs, const int
  *   y[m, n] = x[m, :k] . w[n, :k] + bias[n]                                (bias may be NULL) */
 int sgd_linear_splitk(const float* x, int32_t x_ld, const float* w, const float* bias, int32_t m, int32_t n, int32_t k,
                       float* work, int32_t ksplit, float* y, int32_t y_ld, void* stream);
+/* y[m, n] = x[m, k] * w[k][n] (weight indexed [k][n], row stride w_ld; no bias): the INPUT gradient of a wide linear layer
+ * with few rows -- x = the output gradient [m, k = out_features], w = the nn.Linear weight as stored ([out, in]; a column
+ * window of it through w + offset).  Same split-K scheme and scratch as sgd_linear_splitk: work[ksplit, m, n], m <= 256. */
+int sgd_linear_splitk_t(const float* x, int32_t x_ld, const float* w, int32_t w_ld, int32_t m, int32_t n, int32_t k,
+                        float* work, int32_t ksplit, float* y, int32_t y_ld, void* stream);
 
 /* --------------------------------------------------------------------------------------
  * GroupNorm(32) as statistics + per-(n,c) affine coefficients consumed by sgd_igemm's

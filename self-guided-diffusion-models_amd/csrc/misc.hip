@@ -615,6 +615,58 @@ __global__ __launch_bounds__(256) void linear_splitk_kernel(const float* __restr
     }
 }
 
+// the same with the weight indexed [k][n] (row stride w_ld): y[m, n] = sum_k x[m, k] w[k][n] -- the input gradient of a wide
+// linear layer seen from its few rows, e.g. all ResBlocks' emb_layers as one GEMM (openaimodel.py:262-268): 80 rows x
+// 13,824 output features back to 768 embedding channels ran as 4 tiles of the conv kernel walking 432 K steps each
+// (0.75 ms per training step for 1.7 GFLOP)
+__global__ __launch_bounds__(256) void linear_splitk_t_kernel(const float* __restrict__ x, int x_ld,
+                                                              const float* __restrict__ w, int w_ld, int m, int n, int k,
+                                                              int ksplit, float* __restrict__ work) {
+    __shared__ float ws[64][33];
+    __shared__ float xs[32][33];
+    const int tn = threadIdx.x & 63, tm = threadIdx.x >> 6;
+    const int n0 = blockIdx.x * 64, ks = blockIdx.y;
+    const int kper = ((k + ksplit - 1) / ksplit + 31) / 32 * 32;
+    const int kb = ks * kper, ke = (kb + kper < k) ? kb + kper : k;
+    float acc[LS_MMAX / 32][8];
+#pragma unroll
+    for (int i = 0; i < LS_MMAX / 32; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = 0.f;
+    for (int k0 = kb; k0 < ke; k0 += 32) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < 64 * 32; i += 256) {
+            const int r = i & 63, c = i >> 6;                     // consecutive threads walk a weight row: coalesced
+            ws[r][c] = (n0 + r < n && k0 + c < ke) ? w[(long)(k0 + c) * w_ld + n0 + r] : 0.f;
+        }
+#pragma unroll
+        for (int mt = 0; mt < LS_MMAX / 32; ++mt) {
+            if (mt * 32 >= m) break;
+            __syncthreads();
+            for (int i = threadIdx.x; i < 32 * 32; i += 256) {
+                const int r = i >> 5, c = i & 31;
+                xs[r][c] = (mt * 32 + r < m && k0 + c < ke) ? x[(long)(mt * 32 + r) * x_ld + k0 + c] : 0.f;
+            }
+            __syncthreads();
+#pragma unroll 8
+            for (int c = 0; c < 32; ++c) {
+                const float wv = ws[tn][c];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[mt][j] = fmaf(xs[tm * 8 + j][c], wv, acc[mt][j]);
+            }
+        }
+    }
+    if (n0 + tn < n) {
+#pragma unroll
+        for (int mt = 0; mt < LS_MMAX / 32; ++mt)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int row = mt * 32 + tm * 8 + j;
+                if (row < m) work[((long)ks * m + row) * n + n0 + tn] = acc[mt][j];
+            }
+    }
+}
+
 __global__ void linear_splitk_fold_kernel(const float* __restrict__ work, const float* __restrict__ bias, int m, int n,
                                           int ksplit, float* __restrict__ y, int y_ld) {
     const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
@@ -664,5 +716,17 @@ extern "C" int sgd_debug_occupy(int32_t blocks, float milliseconds, void* stream
     }
     hipLaunchKernelGGL(occupy_kernel, dim3(blocks), dim3(512), LDS, (hipStream_t)stream,
                        (unsigned long long)(milliseconds * 1.0e5f));
+    return sgd_check_launch();
+}
+
+extern "C" int sgd_linear_splitk_t(const float* x, int32_t x_ld, const float* w, int32_t w_ld, int32_t m, int32_t n, int32_t k,
+                                   float* work, int32_t ksplit, float* y, int32_t y_ld, void* stream) {
+    SGD_CLEAR_ERR();
+    if (!x || !w || !work || !y || m <= 0 || m > LS_MMAX || n <= 0 || k <= 0 || ksplit <= 0 || x_ld < k || y_ld < n || w_ld < n)
+        return SGD_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(linear_splitk_t_kernel, dim3((n + 63) / 64, ksplit), dim3(256), 0, st, x, x_ld, w, w_ld, m, n, k, ksplit, work);
+    hipLaunchKernelGGL(linear_splitk_fold_kernel, dim3((unsigned)(((long)m * n + 255) / 256)), dim3(256), 0, st, work,
+                       (const float*)nullptr, m, n, ksplit, y, y_ld);
     return sgd_check_launch();
 }

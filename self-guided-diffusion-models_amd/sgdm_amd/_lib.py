@@ -63,6 +63,7 @@ SIGNATURES = {
     "sgd_pack_job_blocks": (i32, [i32, i32, i32, i32, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]),
     "sgd_pack_weights_batched": (i32, [vp, i32, vp, vp, i32, vp, vp, i32, i32, vp]),
     "sgd_linear_splitk": (i32, [vp, i32, vp, vp, i32, i32, i32, vp, i32, vp, i32, vp]),
+    "sgd_linear_splitk_t": (i32, [vp, i32, vp, i32, i32, i32, i32, vp, i32, vp, i32, vp]),
     "sgd_chan_stats": (i32, [vp, i32, i32, i32, vp, i32, i32, vp]),
     "sgd_gn_coef_parts": (i32, [vp, i32, i32, vp, i32, i32, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp, vp, vp]),
     "sgd_gn_coef": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, vp, vp, vp]),

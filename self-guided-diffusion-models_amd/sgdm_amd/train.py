@@ -582,10 +582,31 @@ class Backward:
             self.wrote(p + ".emb_layers.1.bias")
         cat = lambda: torch.cat([w.detach() for w in wparams], 0)
         parts = [(rec["emb_t"], 0, ted)] + ([(rec["emb_c"], ted, cc)] if cc else [])
+        # few rows (the batch), a very long reduction (all FiLM outputs, 13,824 at C2): split-K on the concatenated weight as
+        # stored -- the conv kernel walked it with 4 tiles (0.75 ms per step); the concatenation follows the parameters
+        skinny = n <= 256 and fw >= 2048 and os.environ.get("SGDM_SKINNY_DGRAD", "1") != "0"
+        if skinny:
+            wcat = self.buf(fw, ted + cc)
+            box = dict(sig=None)
+
+            def refresh_wcat(stream, wcat=wcat, box=box):
+                sig = tuple((w.data_ptr(), w._version) for w in wparams)
+                if sig != box["sig"]:
+                    torch.cat([w.detach().float() for w in wparams], 0, out=wcat)
+                    box["sig"] = sig
+                return 0
+            self.prog.add("emb_layers.wcat", refresh_wcat)
+            ksplit = max(1, min(128, fw // 128))          # ~4 blocks per CU: the kernel is latency-bound per K tile
         for t, o, c in parts:
             gact = self.buf(n, c)
-            self.dgrad(f"emb_layers.dgrad{o}", self.gfilm, fw, gact, c, wparams, lambda o=o, c=c: cat()[:, o:o + c], fw, c, 1,
-                       m=n)
+            if skinny:
+                work = self.buf(ksplit, n, c)
+                self.prog.add(f"emb_layers.dgrad{o}", self.lib.sgd_linear_splitk_t, _ptr(self.gfilm), fw,
+                              C.c_void_p(wcat.data_ptr() + 4 * o), ted + cc, n, c, fw, _ptr(work), ksplit, _ptr(gact), c,
+                              flops=2.0 * n * c * fw)
+            else:
+                self.dgrad(f"emb_layers.dgrad{o}", self.gfilm, fw, gact, c, wparams, lambda o=o, c=c: cat()[:, o:o + c], fw, c,
+                           1, m=n)
             g = self.buf(n, c)
             self.prog.add(f"emb.silu_bwd{o}", self.lib.sgd_silu_bwd, _ptr(t), _ptr(gact), n * c, _ptr(g))
             self.G[t.data_ptr()] = [g, True]
