@@ -2177,8 +2177,8 @@ extern "C" int sgd_igemm(const sgd_igemm_args* args, void* stream) {
     // pattern is a stale quarter-wave, not logic.  In that instance's code the ds_write2_b64 of a split quad is followed at
     // once by the next item's v_pk_mul_f32 into the store's data registers; keeping those registers live past the store
     // (an s_nop statement that names them) cut the failing row groups from ~50 % to ~30 % of the candidates, no further,
-    // so that window is at most part of it and the cause stays open (-DSGDM_FLAT2_LN builds the combination for whoever
-    // picks it up).  A 0.3 % gain does not buy an unexplained failure mode: the instance is not a default, and never
+    // so that window is at most part of it; replacing the beta select on a 64-bit scalar mask by arithmetic changed
+    // nothing either.  The cause stays open (-DSGDM_FLAT2_LN builds the combination for whoever picks it up).  A 0.3 % gain does not buy an unexplained failure mode: the instance is not a default, and never
     // serves the LayerNorm prologue.
     int taps = conv ? 9 : 1;
     if (!conv && vec && bn >= 128 && a.drop_p == 0.f && cin % (2 * KC) == 0 && (a.c1 == 0 || a.c0 % KC == 0)
