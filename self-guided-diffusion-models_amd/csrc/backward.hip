@@ -31,7 +31,9 @@ struct WArgs {
     // wave-specialised kernel with pre-split operands (split_rows_kernel / act_split_kernel): 16-bit hi / lo planes of the
     // gradient [rows][cout] and of the activated input [source rows][cin]
     const void* gh; const void* gl; const void* uh; const void* ul;
+    int no_flat_pipe;           // SGDM_WGRAD_NOPIPE=1 (A/B runs): the synchronous staging of the 1x1 / linear kernel
 };
+__device__ __forceinline__ bool getenv_flat_pipe_off(const WArgs& w) { return w.no_flat_pipe != 0; }
 
 template <bool VEC>
 __global__ __launch_bounds__(256) void wgrad_kernel(const WArgs w) {
@@ -257,6 +259,96 @@ __global__ __launch_bounds__(256, 2) void wgrad_conv_kernel(const WArgs w) {
     const bool gy_fast = w.gvec && co0 + WT <= w.cout && w.rows > 0;
     const bool u_fast = CONV && VEC && (a.resample == SGD_RS_NONE || a.resample == SGD_RS_UP2)
                         && (a.pro == SGD_PRO_NONE || a.pro == SGD_PRO_AFFINE_NC);
+    // 1x1 / linear, the common case (16-byte rows on both sides, whole 128-channel gradient block, GroupNorm affine of
+    // ONE image per K tile or no prologue, no dropout): the rows of K tile kt + ksplit are requested into registers before
+    // the MFMA phase of tile kt and transformed into LDS after it -- round 4: the staging below is synchronous (request ->
+    // wait -> split -> barrier -> 48 MFMAs), two exposed memory latencies per 1.5k-cycle MFMA phase, 150 TF
+    bool flat_pipe = false;
+    if constexpr (!CONV)
+        flat_pipe = VEC && gy_fast && a.drop_p == 0.f && !getenv_flat_pipe_off(w)
+                    && (a.pro == SGD_PRO_NONE || (a.pro == SGD_PRO_AFFINE_NC && a.rows_per_n % 64 == 0));
+    if (flat_pipe) {
+        const int qd = tid & 31, r0 = tid >> 5;
+        const int c = ci0 + qd * 4;
+        const int cc = c < cin ? c : 0;
+        const float* gcol = w.gy + co0 + qd * 4;
+        // pipelined at HALF-tile granularity (32 rows = two k-steps): while the MFMAs of one half run, the rows of the other
+        // half are in flight -- 4 + 4 row quads per thread in registers (a whole tile's 16 would spill next to the 64
+        // accumulators at two blocks per CU).  The two halves are disjoint LDS rows, so a half is overwritten while the
+        // other is being read; two barriers per tile, as before.
+        f32x4 gv[4], uv[4];
+        Coef kq;
+        auto request = [&](int kt, int half) __attribute__((always_inline)) {
+            const long base = (long)kt * 64;
+            const long rlast = w.rows - 1;
+            const long rfirst = base < w.rows ? base : rlast;
+            kq = load_coef<true>(a, a.pro == SGD_PRO_AFFINE_NC ? (int)(rfirst / a.rows_per_n) : 0, rfirst, cc);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                long row = base + r0 + (half * 4 + i) * 8;
+                row = row < w.rows ? row : rlast;
+                gv[i] = ld4(gcol + row * w.gy_ld);
+                uv[i] = load_raw<true>(a, row, cc);
+            }
+        };
+        auto store_half = [&](int kt, int half) __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = r0 + (half * 4 + i) * 8;
+                const long row = (long)kt * 64 + r;
+                f32x4 g4 = gv[i];
+                f32x4 u4 = apply_pro(a, uv[i], kq, cc, row < w.rows ? row : w.rows - 1);
+                if (row >= w.rows) { g4 = f32x4{0.f, 0.f, 0.f, 0.f}; u4 = g4; }
+                if (c >= cin) u4 = f32x4{0.f, 0.f, 0.f, 0.f};
+                split_store(Gh + r * FGP + qd * 4, Gl + r * FGP + qd * 4, g4);
+                split_store(Uh + r * UPITCH + qd * 4, Ul + r * UPITCH + qd * 4, u4);
+                bsum += g4;
+            }
+        };
+        auto mma_half = [&](int half) __attribute__((always_inline)) {
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const int k0 = 16 * (half * 2 + s2) + kbase;
+                T8 ah, al;
+                {
+                    const T* g0 = Gh + k0 * FGP + wave * 32 + chl;
+                    const T* g1 = Gl + k0 * FGP + wave * 32 + chl;
+                    const T4 h0 = trd(g0), h1 = trd(g0 + 4 * FGP), l0 = trd(g1), l1 = trd(g1 + 4 * FGP);
+                    ah = T8{h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+                    al = T8{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+                }
+#pragma unroll
+                for (int t = 0; t < NACC; ++t) {
+                    const T* u0 = Uh + k0 * UPITCH + t * 32 + chl;
+                    const T* u1 = Ul + k0 * UPITCH + t * 32 + chl;
+                    const T4 h0 = trd(u0), h1 = trd(u0 + 4 * UPITCH), l0 = trd(u1), l1 = trd(u1 + 4 * UPITCH);
+                    const T8 bh = T8{h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+                    const T8 bl = T8{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+                    if constexpr (PREC == SGD_PREC_F16X3) {
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[t], 0, 0, 0);
+                    } else {
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[t], 0, 0, 0);
+                    }
+                }
+            }
+        };
+        int kt = ks;
+        if (kt < w.ktiles) request(kt, 0);
+        for (; kt < w.ktiles; kt += w.ksplit) {
+            store_half(kt, 0);                                   // (every wave is past the previous tile's first half: barrier 2)
+            request(kt, 1);
+            __syncthreads();                                     // barrier 1: first half staged
+            mma_half(0);
+            store_half(kt, 1);                                   // (every wave is past the previous tile's second half: barrier 1)
+            if (kt + w.ksplit < w.ktiles) request(kt + w.ksplit, 0);
+            __syncthreads();                                     // barrier 2: second half staged
+            mma_half(1);
+        }
+    } else
     for (int kt = ks; kt < w.ktiles; kt += w.ksplit) {
         const int n = CONV ? kt / ppi : 0, pr = kt - n * ppi;
         const int y0 = CONV ? (pr / pw) * 8 : 0, x0 = CONV ? (pr - (pr / pw) * pw) * 8 : 0;
@@ -1391,6 +1483,7 @@ static int wgrad_impl(const sgd_igemm_args* fwd, const float* gy, int32_t gy_ld,
     if (!fwd || !gy || !slabs || cout <= 0 || ksplit <= 0 || gy_ld < cout) return SGD_ERR_ARG;
     WArgs w;
     w.a = *fwd;
+    w.no_flat_pipe = getenv("SGDM_WGRAD_NOPIPE") ? 1 : 0;
     const sgd_igemm_args& a = w.a;
     if (!a.x0 || a.c0 <= 0 || a.c1 < 0 || (a.c1 > 0 && !a.x1)) return SGD_ERR_ARG;
     if (a.pro != SGD_PRO_NONE && (!a.pa || !a.pb)) return SGD_ERR_ARG;

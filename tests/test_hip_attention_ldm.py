@@ -66,3 +66,36 @@ def test_masked_attention_core_equals_dropping_the_keys():
     L.check(lib.sgd_attention(p(q), heads * d, d, p(kv2), C.c_void_p(kv2.data_ptr() + 4 * heads * d), 2 * heads * d, d,
                               b, heads, t, kv2.shape[1], d, d ** -0.5, p(ref), heads * d, None, st), "plain")
     assert max_rel(out.cpu(), ref.cpu()) < 2e-6
+
+
+@pytest.mark.parametrize("d", [24, 64, 128])
+def test_linear_attention_core_head_dims(d):
+    """sgd_linear_attention (dynamic/attention_ldm.py:261-298: q softmax over d, k softmax over the keys, out = q~ (k~^T v))
+    against plain fp32 torch, including d = 128 -- 66 KB of dynamic LDS, above the 64 KB a kernel gets without asking
+    (the launch failed there)"""
+    import ctypes as C
+    from sgdm_amd import _lib as L
+    lib = L.load()
+    g = torch.Generator().manual_seed(9)
+    b, heads, t, j = 2, 3, 50, 9
+    q = torch.randn(b, t, heads * d, generator=g)
+    kv = torch.randn(b, j, 2 * heads * d, generator=g)
+    mask = torch.rand(b, j, generator=g) > 0.3
+    mask[:, 0] = True
+    scale = d ** -0.5
+    qh = q.reshape(b, t, heads, d).permute(0, 2, 1, 3)
+    kh = kv[..., :heads * d].reshape(b, j, heads, d).permute(0, 2, 1, 3)
+    vh = kv[..., heads * d:].reshape(b, j, heads, d).permute(0, 2, 1, 3)
+    m4 = mask[:, None, :, None]
+    kh = kh.masked_fill(~m4, -torch.finfo(torch.float32).max)
+    vh = vh.masked_fill(~m4, 0.0)
+    ref = torch.einsum("bhnd,bhde->bhne", qh.softmax(-1) * scale, torch.einsum("bhnd,bhne->bhde", kh.softmax(-2), vh))
+    ref = ref.permute(0, 2, 1, 3).reshape(b, t, heads * d)
+    qd, kvd, mk = q.cuda(), kv.cuda(), mask.to(torch.uint8).cuda()
+    out = torch.full((b, t, heads * d), float("nan"), device="cuda")
+    p = lambda t_: C.c_void_p(t_.data_ptr())
+    L.check(lib.sgd_linear_attention(p(qd), heads * d, d, p(kvd), C.c_void_p(kvd.data_ptr() + 4 * heads * d), 2 * heads * d, d,
+                                     p(mk), b, heads, t, j, d, scale, p(out), heads * d, torch.cuda.current_stream().cuda_stream),
+            "sgd_linear_attention")
+    torch.cuda.synchronize()
+    assert max_rel(out.cpu(), ref) < 2e-6

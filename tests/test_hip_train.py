@@ -140,6 +140,15 @@ def _grads_for_seed(seed, ddp, name="uf_clusterlayout_c32_s16", torch_ddp=False)
     loss, _ = d.p_losses(batch["image"].cuda(), t, noise, cond=batch["cond"].float().cuda(),
                          layout=batch["layout"].cuda(), cond_drop_prob=0.5, cond_drop_mask=mask)
     loss.backward()
+    import torch.distributed as dist
+    if ddp and not torch_ddp and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        # round 4: a data-parallel training step leaves CUs to the exchange -- every conv / linear launch of the forward and
+        # backward programs carries the cap -- and the replicas were synchronised once
+        eng = next(iter(m._engines.values()))
+        cus = torch.cuda.get_device_properties(0).multi_processor_count
+        assert eng._grid_cap == cus - 16, eng._grid_cap
+        assert all(a.grid_cap == eng._grid_cap for a, _ in eng._late) and all(a.grid_cap == eng._grid_cap for a, _ in eng.backward.late)
+        assert getattr(m, "_hip_ddp_synced", False)
     return {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}
 
 
