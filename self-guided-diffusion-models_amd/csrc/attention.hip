@@ -232,16 +232,16 @@ __global__ __launch_bounds__(256) void attention_split_kernel(const float* __res
         }
     }
 
-    for (int kt0 = 0; kt0 < tk; kt0 += KT) {
-        __syncthreads();
-        // Every K / V quad of the tile is requested (clamped addresses, no branch around a load) before the first one is
-        // split and stored: with the bounds check around the load each item was load -> s_waitcnt vmcnt(0) -> store, six
-        // memory latencies in a row per 64-key tile.
-        constexpr int VPR = D / 4;
-        constexpr int NKI = (KT * VPR + 255) / 256;                // K quads per thread
-        constexpr int NVI = ((KT / 2) * VPR + 255) / 256;          // V key-pair quads per thread
-        f32x4 kq[NKI], vq0[NVI], vq1[NVI];
-        const int klast = tk - 1;
+    // Every K / V quad of a tile is requested (clamped addresses, no branch around a load) before the first one is split
+    // and stored: with the bounds check around the load each item was load -> s_waitcnt vmcnt(0) -> store, six memory
+    // latencies in a row per 64-key tile.  Round 4: the requests of tile t + 1 go out BEFORE the MFMA phase of tile t and
+    // are split into LDS after it (8 row quads per thread in registers): the staging latency was exposed once per tile.
+    constexpr int VPR = D / 4;
+    constexpr int NKI = (KT * VPR + 255) / 256;                // K quads per thread
+    constexpr int NVI = ((KT / 2) * VPR + 255) / 256;          // V key-pair quads per thread
+    f32x4 kq[NKI], vq0[NVI], vq1[NVI];
+    const int klast = tk - 1;
+    auto request = [&](int kt0) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < NKI; ++i) {
             int idx = tid + i * 256;
@@ -258,6 +258,10 @@ __global__ __launch_bounds__(256) void attention_split_kernel(const float* __res
             vq0[i] = *reinterpret_cast<const f32x4*>(vb + (long)(key < tk ? key : klast) * kv_ld + c4 * 4);
             vq1[i] = *reinterpret_cast<const f32x4*>(vb + (long)(key + 1 < tk ? key + 1 : klast) * kv_ld + c4 * 4);
         }
+    };
+    request(0);
+    for (int kt0 = 0; kt0 < tk; kt0 += KT) {
+        __syncthreads();
         // K rows: one float4 -> 4 hi + 4 lo (8-byte stores)
 #pragma unroll
         for (int i = 0; i < NKI; ++i) {
@@ -300,6 +304,7 @@ __global__ __launch_bounds__(256) void attention_split_kernel(const float* __res
                 *reinterpret_cast<f16x2*>(Vl + (c4 * 4 + j) * LDV + pos) = ll;
             }
         }
+        if (kt0 + KT < tk) request(kt0 + KT);                 // in flight under this tile's MFMA phase
         __syncthreads();
 
 #pragma unroll
@@ -652,13 +657,13 @@ __global__ __launch_bounds__(256) void attention_bwd_split_kernel(
         float own_lse = 0.f, own_d = 0.f;
         if (!KV) { own_lse = lseb[oc]; own_d = dvb[oc]; }
 
-        for (int t0 = 0; t0 < str_n; t0 += TT) {
-            __syncthreads();
-            // a thread stages two neighbouring rows (neighbours in the permuted order too) x 4 channels of U and of W
-            constexpr int VPR = D / 4;
-            constexpr int NI = ((TT / 2) * VPR + 255) / 256;
-            f32x4 u0[NI], u1[NI], w0[NI], w1[NI];
-            const long last = str_n - 1;
+        // a thread stages two neighbouring rows (neighbours in the permuted order too) x 4 channels of U and of W; the rows
+        // of tile t + 1 are requested before the MFMA phase of tile t and split into LDS after it
+        constexpr int VPR = D / 4;
+        constexpr int NI = ((TT / 2) * VPR + 255) / 256;
+        f32x4 u0[NI], u1[NI], w0[NI], w1[NI];
+        const long last = str_n - 1;
+        auto request = [&](int t0) __attribute__((always_inline)) {
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
                 int idx = tid + i * 256;
@@ -677,6 +682,10 @@ __global__ __launch_bounds__(256) void attention_bwd_split_kernel(
                     w1[i] = *reinterpret_cast<const f32x4*>(vb + r1 * kv_ld + c4 * 4);
                 }
             }
+        };
+        request(0);
+        for (int t0 = 0; t0 < str_n; t0 += TT) {
+            __syncthreads();
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
                 const int idx = tid + i * 256;
@@ -718,6 +727,7 @@ __global__ __launch_bounds__(256) void attention_bwd_split_kernel(
                 Ls[tid] = r < str_n ? lseb[r] : 0.f;
                 Ds[tid] = r < str_n ? dvb[r] : 0.f;
             }
+            if (t0 + TT < str_n) request(t0 + TT);               // in flight under this tile's MFMA phase
             __syncthreads();
 
             // scores / dP tiles: rows = streamed rows (registers), cols = owned rows (lanes)
