@@ -1077,6 +1077,14 @@ __global__ __launch_bounds__(256) void wgrad_narrow_kernel(const float* __restri
         }
         __syncthreads();
         const int nr = (int)(s1 - c0 < WN_ROWS ? s1 - c0 : WN_ROWS);
+        // head: GroupNorm coefficients of the chunk's image once per chunk when a chunk cannot straddle two images
+        const bool one_img = HEAD && pa && ((long)h * w) % WN_ROWS == 0;
+        float pav = 1.f, pbv = 0.f;
+        if (one_img) {
+            const long img = c0 / ((long)h * w);
+            pav = pa[img * wide + ch];
+            pbv = pb[img * wide + ch];
+        }
         for (int pb0 = sub; pb0 < nr; pb0 += 8 * rsub) {
             // eight rows of this lane requested before the first is used
             float vq[8];
@@ -1092,7 +1100,9 @@ __global__ __launch_bounds__(256) void wgrad_narrow_kernel(const float* __restri
                 if (pr >= nr) break;                                       // wave-uniform
                 float v = vq[j];
                 if (HEAD) {
-                    if (pa) {
+                    if (one_img) {
+                        v = v * pav + pbv;
+                    } else if (pa) {
                         const long img = (c0 + pr) / ((long)h * w);
                         v = v * pa[img * wide + ch] + pb[img * wide + ch];
                     }
