@@ -843,15 +843,15 @@ class _Engine:
             self._film_sig = sig
 
     def set_grid_cap(self, reserve):
-        """sgd_igemm_args.grid_cap of every conv / linear launch of the forward AND backward programs: all CUs but
-        `reserve` (0: the whole device).  Host-side field of the argument blocks -- a captured hipGraph keeps the value it
+        """sgd_igemm_args.grid_cap of every conv / linear launch of the BACKWARD program: all CUs but `reserve` (0: the
+        whole device).  The gradient exchange runs under the backward only -- the optimizer waits for it, so the next
+        forward finds the device empty again and keeps the whole-device grid (a reserve there would cost its CU share
+        of every launch for nothing).  Host-side field of the argument blocks -- a captured hipGraph keeps the value it
         was captured with, which is why only the (never captured) training programs use a reserve."""
         cap = 0 if reserve <= 0 else max(8, device_cus(self.dev) - int(reserve))
         if cap == getattr(self, "_grid_cap", 0):
             return
         self._grid_cap = cap
-        for a, _ in self._late:
-            a.grid_cap = cap
         bw = getattr(self, "backward", None)
         if bw is not None:
             for a, _ in bw.late:

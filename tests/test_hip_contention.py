@@ -143,8 +143,9 @@ def test_sampling_evaluation_under_cu_contention():
 
 
 def test_training_step_with_reserve_under_cu_contention():
-    """a training step (forward + backward programs) with the reserve training uses when world > 1: same gradients bit for
-    bit with and without the stand-in on the side stream, and the contention costs (almost) nothing"""
+    """a training step with the reserve training uses when world > 1 -- on the BACKWARD program, which is what the exchange
+    overlaps; the forward keeps the whole device: same gradients bit for bit with and without the stand-in on the side
+    stream under the backward, and the contention costs (almost) nothing"""
     import bench
     from sgdm_amd.diffusion import LatentDiffusion
     from sgdm_amd.synth import synth_batch
@@ -165,10 +166,13 @@ def test_training_step_with_reserve_under_cu_contention():
     x0, cond = data["image"].cuda(), data["cond"].cuda()
     side = torch.cuda.Stream()
 
-    def step():
+    def step(occupy_ms=0.0):
         for p in model.parameters():
             p.grad = None
         loss, _ = diff.p_losses(x0, t, noise, cond=cond, cond_drop_prob=0.1, cond_drop_mask=mask)
+        if occupy_ms:                # where a bucket's all-reduce starts: behind the forward, under the backward
+            side.wait_stream(torch.cuda.current_stream())
+            _occupy(lib, side, OCC, occupy_ms)
         loss.backward()
         return loss
 
@@ -176,11 +180,11 @@ def test_training_step_with_reserve_under_cu_contention():
     torch.cuda.synchronize()
     eng = next(iter(model._engines.values()))
     assert eng._grid_cap == _cus() - OCC
-    assert all(a.grid_cap == eng._grid_cap for a, _ in eng._late) and all(a.grid_cap == eng._grid_cap for a, _ in eng.backward.late)
+    assert all(a.grid_cap == 0 for a, _ in eng._late) and all(a.grid_cap == eng._grid_cap for a, _ in eng.backward.late)
     alone = min(_timed(step, 2) for _ in range(2))
     ref = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
-    _occupy(lib, side, OCC, 400.0)
-    busy = _timed(step, 2)
+    # the stand-in holds its CUs for about half a step: it starts with the backward and is gone before the next forward
+    busy = _timed(lambda: step(0.5 * alone), 2)
     torch.cuda.synchronize()
     for k, p in model.named_parameters():
         if p.grad is not None:
