@@ -132,6 +132,14 @@ struct Geo {
 #define ABL(bit) false
 #endif
 
+// Hazard experiments (tools/ln_hazard.py, -DSGDM_EXP builds only): an instruction sequence switched on per launch by a bit
+// of the SGDM_EXP environment variable (host side -> args.reserved0).  Folds away in the shipped library.
+#ifdef SGDM_EXP
+#define EXP_HOOK(bit, text) do { if (a.reserved0 & (bit)) asm volatile(text ::: "memory"); } while (0)
+#else
+#define EXP_HOOK(bit, text) do { } while (0)
+#endif
+
 // keep a value live without using it (ablation builds); the "v" constraint exists in the device pass only
 #if defined(__HIP_DEVICE_COMPILE__)
 #define KEEP_LIVE(x) asm volatile("" :: "v"(x))
@@ -865,6 +873,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
                 };
                 auto finish = [&](int slot, auto rc, int sub = 0) {      // stage the plane under the finish cursor
                     constexpr int R = decltype(rc)::value;
+                    EXP_HOOK(2, "s_waitcnt vmcnt(0)");
 #pragma unroll
                     for (int j = 0; j < AI; ++j) {
                         f32x4 v = araw[R][j];
@@ -878,7 +887,10 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
                             for (int e = 0; e < 4; ++e) v[e] = sgd_silu(v[e]);
                         }
                         if (cf.m0 + arow + j * AROWS >= M) v = f32x4{0.f, 0.f, 0.f, 0.f};
+                        EXP_HOOK(8, "s_nop 7\n\ts_nop 7");
                         lds_store_act<PREC>(As + (size_t)slot * a_floats + (size_t)(sub * BM + arow + j * AROWS) * LDA, c4, v);
+                        EXP_HOOK(1, "s_nop 7\n\ts_nop 7");
+                        EXP_HOOK(4, "s_waitcnt lgkmcnt(0)");
                     }
                     advance(cf);
                 };
@@ -2171,21 +2183,22 @@ extern "C" int sgd_igemm(const sgd_igemm_args* args, void* stream) {
     // number of planes.  Measured (round 4, tools/ab_conv.py, UNet batch 80): bit-identical to the one-plane instance,
     // +3..6 % on proj_out / decoder skips with a prologue, 0..3 % on plain ones, 0 on qkv and the HBM-bound 64x64 skips
     // -- the barrier per K step was never these launches' cost.  With the LayerNorm-row prologue (Attention_LR's to_q /
-    // to_kv) in a split mode the same instance returned wrong rows -- always tile rows 6, 7 mod 8, i.e. lanes 48..63 of a
-    // loader wave, a different subset on every launch, whatever the statistics and gamma -- while exact f32 and every
-    // other prologue stayed bit-identical (tools/diff_variants.py found the launches, gpurun_out/r4_diff.txt).  The
-    // pattern is a stale quarter-wave, not logic.  In that instance's code the ds_write2_b64 of a split quad is followed at
-    // once by the next item's v_pk_mul_f32 into the store's data registers; keeping those registers live past the store
-    // (an s_nop statement that names them) cut the failing row groups from ~50 % to ~30 % of the candidates, no further,
-    // so that window is at most part of it; replacing the beta select on a 64-bit scalar mask by arithmetic changed
-    // nothing either.  The cause stays open (-DSGDM_FLAT2_LN builds the combination for whoever picks it up).  A 0.3 % gain does not buy an unexplained failure mode: the instance is not a default, and never
-    // serves the LayerNorm prologue.
+    // to_kv) in a split mode the same instance returns wrong rows -- always tile rows 6, 7 mod 8, i.e. lanes 48..63 of a
+    // loader wave, a different subset on every launch -- while exact f32 and every other prologue stay bit-identical.
+    // DESIGN.md section 4 (round 4) and profiles/r4_ln_hazard.txt hold what tools/ln_hazard.py established: the wrong
+    // cells hold exactly beta in the low lane of a packed-f32 pair (the LayerNorm value with a zero product), in three of
+    // the six unrolled copies of the staging code only; no wait or idle cycle around the loads or the LDS stores changes
+    // it, moving the surrounding code does.  Cause open (-DSGDM_FLAT2_LN -DSGDM_EXP builds the combination).  A 0.3 %
+    // gain does not buy an unexplained failure mode: the instance is not a default, and never serves that prologue.
     int taps = conv ? 9 : 1;
     if (!conv && vec && bn >= 128 && a.drop_p == 0.f && cin % (2 * KC) == 0 && (a.c1 == 0 || a.c0 % KC == 0)
         && (a.pro == SGD_PRO_NONE || (a.pro == SGD_PRO_AFFINE_NC && a.rows_per_n > 0 && a.rows_per_n % BM == 0))) {
         const char* e = getenv("SGDM_FLAT2");
         if (e && atoi(e) == 1) taps = 2;
     }
+#ifdef SGDM_EXP
+    { const char* e = getenv("SGDM_EXP"); a.reserved0 = e ? atoi(e) : 0; }
+#endif
 #ifdef SGDM_FLAT2_LN      /* diagnostic builds only: the LayerNorm prologue on the two-plane instance (see above) */
     if (!conv && vec && bn >= 128 && a.drop_p == 0.f && cin % (2 * KC) == 0 && a.pro == SGD_PRO_LN_ROW) {
         const char* e = getenv("SGDM_FLAT2");
