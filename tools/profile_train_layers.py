@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Per-launch table of one training step's backward program (HIP events around every launch), slowest first.
-    python tools/profile_train_layers.py [--batch 80] [--top 40] [--match wgrad]"""
+"""Per-launch table of one training step's backward (or, --forward, forward) program (HIP events around every launch),
+slowest first.
+    python tools/profile_train_layers.py [--batch 80] [--top 40] [--match wgrad] [--forward] [--dropout 0.0]"""
 import argparse, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "self-guided-diffusion-models_amd"))
@@ -11,11 +12,13 @@ from sgdm_amd.diffusion import LatentDiffusion
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=80); ap.add_argument("--top", type=int, default=40); ap.add_argument("--match", default="")
-ap.add_argument("--prec", default="f16x3")
+ap.add_argument("--prec", default="f16x3"); ap.add_argument("--forward", action="store_true")
+ap.add_argument("--dropout", type=float, default=-1.0, help="override the model dropout")
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
 wl = bench.WORKLOADS["c2"]
 m, sd, data = bench.build_model(wl, dev, a.prec, a.batch)
+if a.dropout >= 0: m.dropout = a.dropout
 m.train()
 d = LatentDiffusion(device="cuda", **bench.MODEL_PARAMS).train()
 d.set_denoise_fn(m.forward, m.forward_with_cond_scale)
@@ -28,7 +31,7 @@ eng = m._engines[(a.batch, 64, 64, L.PREC_BY_NAME[a.prec])]
 st = torch.cuda.current_stream().cuda_stream
 rows = None
 for _ in range(3):
-    r = eng.backward.prog.run_profiled(st)
+    r = (eng.prog if a.forward else eng.backward.prog).run_profiled(st)
     rows = r if rows is None else [(x0[0], x0[1], x0[2] + y[2], x0[3], x0[4]) for x0, y in zip(rows, r)]
 rows = [(t, s, ms / 3, fl) for t, s, ms, fl, nb in rows if a.match in t or a.match in s]
 print("total ms", sum(r[2] for r in rows))
