@@ -155,6 +155,213 @@ def test_linear_flat(m, k, nout, prec, tol):
     assert max_rel(y.cpu(), ref) < tol
 
 
+def _random_conv_cases(count, seed):
+    """random but valid conv launches: channel counts off the 4 / 32 grid, concat, prologue, every resample / residual mode,
+    few blocks (SGDM_MAX_GRID: many tiles per block, partial last rounds -> the balanced tail) and capped grids"""
+    import random
+    rnd = random.Random(seed)
+    cases = []
+    while len(cases) < count:
+        kind = rnd.choice(["plain", "plain", "res", "down", "up", "stride2", "upconv"])
+        n = rnd.randint(1, 5)
+        h, w_ = rnd.choice([4, 8, 16, 32]), rnd.choice([4, 8, 16, 32])      # (sgd_igemm: power-of-two output maps)
+        c0 = rnd.choice([3, 4, 20, 32, 33, 64, 96, 100, 128, 160, 200])
+        c1 = rnd.choice([0, 0, 0, 4, 32, 36]) if c0 % 32 == 0 else 0
+        cout = rnd.choice([3, 4, 30, 32, 64, 100, 128, 132, 256, 300])
+        pro = rnd.random() < 0.6
+        silu = int(rnd.random() < 0.6)
+        if kind in ("down", "up"):
+            c1 = 0
+            cout = c0                      # the resampled identity skip adds x itself
+            pro = True
+        if n * h * w_ * max(c0 + c1, cout) > 3_000_000:     # keep the float64 reference quick
+            continue
+        cases.append(dict(kind=kind, n=n, h=h, w=w_, c0=c0, c1=c1, cout=cout, pro=pro, silu=silu,
+                          max_grid=rnd.choice([0, 0, 8, 16, 24, 40]), grid_cap=rnd.choice([0, 0, 0, 8, 72, 200]),
+                          work=rnd.random() < 0.7, seed=rnd.randint(0, 1 << 30)))
+    return cases
+
+
+@pytest.mark.parametrize("prec,tol", [("f32", 4e-6), ("f16x3", 4e-5)])
+def test_conv3x3_random_configurations(monkeypatch, prec, tol):
+    """48 seeded random launches against float64: the schedule paths a fixed shape list does not reach (tiles per block,
+    partial rounds with and without the workspace, capped grids) crossed with the loader / epilogue modes"""
+    L, lib = _lib()
+    p = L.PREC_BY_NAME[prec]
+    work = torch.zeros(int(lib.sgd_igemm_work_bytes()) // 4, device="cuda")
+    for ci, cs in enumerate(_random_conv_cases(48, 20260104)):
+        g = torch.Generator().manual_seed(cs["seed"])
+        n, h, w_, c0, c1, cout, kind = cs["n"], cs["h"], cs["w"], cs["c0"], cs["c1"], cs["cout"], cs["kind"]
+        cin = c0 + c1
+        x = torch.randn(n, cin, h, w_, generator=g, dtype=torch.float64)
+        wt = torch.randn(cout, cin, 3, 3, generator=g, dtype=torch.float64) / math.sqrt(cin * 9)
+        b = torch.randn(cout, generator=g, dtype=torch.float64)
+        pa = torch.randn(n, cin, generator=g, dtype=torch.float64)
+        pb = torch.randn(n, cin, generator=g, dtype=torch.float64)
+        act = x
+        if cs["pro"]:
+            act = act * pa[:, :, None, None] + pb[:, :, None, None]
+        if cs["silu"]:
+            act = F.silu(act)
+        resample, stride, res, res_mode = 0, 1, None, 0
+        if kind == "down":
+            ref = F.conv2d(F.avg_pool2d(act, 2), wt, b, padding=1) + F.avg_pool2d(x, 2)
+            resample, res, res_mode = 1, x, 1
+        elif kind == "up":
+            ref = F.conv2d(F.interpolate(act, scale_factor=2, mode="nearest"), wt, b, padding=1) \
+                + F.interpolate(x, scale_factor=2, mode="nearest")
+            resample, res, res_mode = 2, x, 2
+        elif kind == "stride2":
+            ref = F.conv2d(act, wt, b, stride=2, padding=1)
+            stride = 2
+        elif kind == "upconv":
+            ref = F.conv2d(F.interpolate(act, scale_factor=2, mode="nearest"), wt, b, padding=1)
+            resample = 2
+        else:
+            ref = F.conv2d(act, wt, b, padding=1)
+            if kind == "res":
+                res = torch.randn(ref.shape, generator=g, dtype=torch.float64)
+                ref = ref + res
+        # ---- the launch
+        hc, wc = (h // 2, w_ // 2) if resample == 1 else ((h * 2, w_ * 2) if resample == 2 else (h, w_))
+        ho, wo = ((hc + 1) // 2, (wc + 1) // 2) if stride == 2 else (hc, wc)
+        assert ref.shape[2:] == (ho, wo), (cs, ref.shape)
+        buf, cin_p, cout_p = _pack(wt.float().cuda(), 3, p)
+        x0d = _nhwc(x[:, :c0].float()).cuda()
+        x1d = _nhwc(x[:, c0:].float()).cuda() if c1 else None
+        pad, pbd, bd = pa.float().cuda(), pb.float().cuda(), b.float().cuda()
+        rd = _nhwc(res.float()).cuda() if res is not None else None
+        y = torch.full((n, ho, wo, cout), float("nan"), device="cuda")
+        a = L.IgemmArgs()
+        a.x0, a.x1, a.c0, a.c1 = x0d.data_ptr(), (x1d.data_ptr() if c1 else 0), c0, c1
+        a.mode, a.n, a.hi, a.wi, a.ho, a.wo, a.stride, a.resample = L.MODE_CONV3, n, h, w_, ho, wo, stride, resample
+        if cs["pro"]:
+            a.pro, a.pa, a.pb = L.PRO_AFFINE_NC, pad.data_ptr(), pbd.data_ptr()
+        a.pro_silu = cs["silu"]
+        a.w, a.cin_p, a.cout_p, a.bias = buf.data_ptr(), cin_p, cout_p, bd.data_ptr()
+        a.res, a.res_mode = (rd.data_ptr() if rd is not None else 0), res_mode
+        a.y, a.cout, a.y_ld, a.prec = y.data_ptr(), cout, cout, p
+        a.grid_cap = cs["grid_cap"]
+        if cs["work"]:
+            a.work, a.work_bytes = work.data_ptr(), work.numel() * 4
+        if cs["max_grid"]:
+            monkeypatch.setenv("SGDM_MAX_GRID", str(cs["max_grid"]))
+        else:
+            monkeypatch.delenv("SGDM_MAX_GRID", raising=False)
+        L.check(lib.sgd_igemm(C.byref(a), _stream()), f"igemm case {ci}: {cs}")
+        torch.cuda.synchronize()
+        got = y.cpu().permute(0, 3, 1, 2).double()
+        err = float((got - ref).abs().max() / ref.abs().max())
+        assert err < tol, (ci, cs, err)
+    monkeypatch.delenv("SGDM_MAX_GRID", raising=False)
+    off = int(lib.sgd_igemm_work_status_offset())
+    assert int(work.view(torch.int32)[off // 4]) == 0, "a finisher's bounded poll expired"
+
+
+@pytest.mark.parametrize("prec,tol", [("f32", 4e-6), ("f16x3", 4e-5)])
+def test_linear_random_configurations(monkeypatch, prec, tol):
+    """48 seeded random 1x1 / linear launches against float64: no / per-image affine / LayerNorm-row prologue, SiLU,
+    concat, residual, strided and row-remapped outputs, few blocks and capped grids, with and without the workspace"""
+    import random
+    L, lib = _lib()
+    p = L.PREC_BY_NAME[prec]
+    work = torch.zeros(int(lib.sgd_igemm_work_bytes()) // 4, device="cuda")
+    rnd = random.Random(20260105)
+    for ci in range(48):
+        g = torch.Generator().manual_seed(rnd.randint(0, 1 << 30))
+        pro = rnd.choice(["none", "none", "affine", "affine", "ln"])
+        rows_per_n = rnd.choice([16, 64, 100, 128, 256])
+        n = rnd.randint(1, 6)
+        m = n * rows_per_n if pro == "affine" else rnd.choice([7, 80, 128, 333, 1024, 1500])
+        c0 = rnd.choice([4, 20, 32, 64, 96, 128, 200, 256, 512])
+        if pro == "ln" or rnd.random() < 0.3:
+            c0 = rnd.choice([32, 64, 128, 512])
+        c1 = rnd.choice([0, 0, 32, 36]) if (c0 % 32 == 0 and pro != "ln") else 0
+        cin = c0 + c1
+        cout = rnd.choice([3, 32, 64, 100, 128, 256, 384, 512, 1536])
+        silu = int(rnd.random() < 0.5)
+        x = torch.randn(m, cin, generator=g, dtype=torch.float64) * 1.5 + 0.2
+        wt = torch.randn(cout, cin, generator=g, dtype=torch.float64) / math.sqrt(cin)
+        b = torch.randn(cout, generator=g, dtype=torch.float64)
+        act = x
+        a = L.IgemmArgs()
+        keep = []
+        if pro == "affine":
+            pa = torch.randn(n, cin, generator=g, dtype=torch.float64)
+            pb = torch.randn(n, cin, generator=g, dtype=torch.float64)
+            act = (x.reshape(n, rows_per_n, cin) * pa[:, None] + pb[:, None]).reshape(m, cin)
+            pad, pbd = pa.float().cuda(), pb.float().cuda()
+            keep += [pad, pbd]
+            a.pro, a.pa, a.pb, a.rows_per_n = L.PRO_AFFINE_NC, pad.data_ptr(), pbd.data_ptr(), rows_per_n
+        elif pro == "ln":
+            gamma = torch.randn(cin, generator=g, dtype=torch.float64)
+            beta = torch.randn(cin, generator=g, dtype=torch.float64) if rnd.random() < 0.7 else None
+            act = F.layer_norm(x, (cin,), gamma, beta, 1e-5)
+        if silu:
+            act = F.silu(act)
+        ref = act @ wt.t() + b
+        res = torch.randn(m, cout, generator=g, dtype=torch.float64) if rnd.random() < 0.4 else None
+        if res is not None:
+            ref = ref + res
+        # ---- the launch
+        x0d = x[:, :c0].float().contiguous().cuda()
+        x1d = x[:, c0:].float().contiguous().cuda() if c1 else None
+        if pro == "ln":
+            st = torch.empty(m, 2, device="cuda")
+            L.check(lib.sgd_ln_stats(_p(x0d), m, cin, C.c_float(1e-5), _p(st), _stream()), "ln_stats")
+            gd = gamma.float().cuda()
+            btd = beta.float().cuda() if beta is not None else None
+            keep += [st, gd, btd]
+            a.pro, a.pa, a.pb, a.pc = L.PRO_LN_ROW, st.data_ptr(), gd.data_ptr(), (btd.data_ptr() if btd is not None else 0)
+        buf, cin_p, cout_p = _pack(wt.float().reshape(cout, cin, 1, 1).cuda(), 1, p)
+        bd = b.float().cuda()
+        rd = res.float().cuda() if res is not None else None
+        # output: leading dimension and column offset of a wider buffer, optionally rows re-mapped group by group
+        remap = rnd.random() < 0.3 and m % 16 == 0 and (cout % 4 == 0)
+        y_ld = cout + rnd.choice([0, 0, 4, 64]) if cout % 4 == 0 else cout
+        if remap:
+            rin, rout, roff = 16, 16 + rnd.choice([1, 3]), rnd.choice([0, 1])
+            yrows = m // rin * rout
+        else:
+            rin = rout = roff = 0
+            yrows = m
+        y = torch.full((yrows, y_ld), float("nan"), device="cuda")
+        a.x0, a.x1, a.c0, a.c1 = x0d.data_ptr(), (x1d.data_ptr() if c1 else 0), c0, c1
+        a.mode, a.m, a.stride, a.pro_silu = L.MODE_FLAT, m, 1, silu
+        if pro != "affine":
+            a.rows_per_n = 0
+        a.w, a.cin_p, a.cout_p, a.bias = buf.data_ptr(), cin_p, cout_p, bd.data_ptr()
+        a.res = rd.data_ptr() if rd is not None else 0
+        a.y, a.cout, a.y_ld, a.prec = y.data_ptr(), cout, y_ld, p
+        a.orows_in, a.orows_out, a.orow_off = rin, rout, roff
+        a.grid_cap = rnd.choice([0, 0, 0, 8, 72, 200])
+        if rnd.random() < 0.7:
+            a.work, a.work_bytes = work.data_ptr(), work.numel() * 4
+        mg = rnd.choice([0, 0, 8, 16, 40])
+        if mg:
+            monkeypatch.setenv("SGDM_MAX_GRID", str(mg))
+        else:
+            monkeypatch.delenv("SGDM_MAX_GRID", raising=False)
+        desc = f"case {ci}: pro={pro} m={m} c0={c0} c1={c1} cout={cout} silu={silu} res={res is not None} y_ld={y_ld} remap={(rin, rout, roff)} grid_cap={a.grid_cap} max_grid={mg} work={bool(a.work)}"
+        L.check(lib.sgd_igemm(C.byref(a), _stream()), desc)
+        torch.cuda.synchronize()
+        got = y.cpu().double()
+        if remap:
+            rows = (torch.arange(m) // rin) * rout + roff + torch.arange(m) % rin
+            out = got[rows, :cout]
+            untouched = torch.ones(yrows, dtype=torch.bool)
+            untouched[rows] = False
+            assert torch.isnan(got[untouched]).all(), desc
+        else:
+            out = got[:, :cout]
+        assert torch.isnan(got[:, cout:]).all(), desc
+        err = float((out - ref).abs().max() / ref.abs().max())
+        assert err < tol, (desc, err)
+    monkeypatch.delenv("SGDM_MAX_GRID", raising=False)
+    off = int(lib.sgd_igemm_work_status_offset())
+    assert int(work.view(torch.int32)[off // 4]) == 0, "a finisher's bounded poll expired"
+
+
 def test_igemm_rejects_bad_args():
     L, lib = _lib()
     a = L.IgemmArgs()
