@@ -146,6 +146,82 @@ def test_conv_wgrad_split_precision_at_production_shapes(shape, prec, tol):
         assert torch.equal(dw, dw2)
 
 
+@pytest.mark.parametrize("prec,tol", [("f32", 6e-6), ("f16x3", 4e-5)])
+def test_wgrad_random_configurations(prec, tol):
+    """40 seeded random weight-gradient launches (3x3: plain / fused prologue / concat / avg-pool / nearest-up / stride 2;
+    1x1 rows) against float64 autograd, through whichever kernel sgd_wgrad picks for the shape -- wave-specialised with
+    or without operand planes, pooled planes, the narrow stem / head kernels, the pipelined 1x1 kernel, the generic one --
+    with random K splits and a gradient buffer wider than cout"""
+    import random
+    L, lib = _lib()
+    p = L.PREC_BY_NAME[prec]
+    rnd = random.Random(20260106)
+    done = 0
+    while done < 40:
+        g = torch.Generator().manual_seed(rnd.randint(0, 1 << 30))
+        kind = rnd.choice(["plain", "fused", "concat", "down", "up", "stride2", "flat", "flat"])
+        n = rnd.randint(1, 6)
+        h = rnd.choice([4, 8, 16, 32])
+        c0 = rnd.choice([3, 4, 32, 64, 96, 128, 160, 256])
+        cout = rnd.choice([3, 32, 64, 100, 128, 192, 256])
+        c1 = rnd.choice([32, 64]) if (kind == "concat" and c0 % 32 == 0) else 0
+        cin = c0 + c1
+        if n * h * h * max(cin, cout) > 2_500_000:
+            continue
+        fused = kind in ("fused", "concat", "down", "up") or (kind == "flat" and rnd.random() < 0.5)
+        x = torch.randn(n, cin, h, h, generator=g, dtype=torch.float64)
+        pa = 1 + 0.3 * torch.randn(n, cin, generator=g, dtype=torch.float64)
+        pb = 0.3 * torch.randn(n, cin, generator=g, dtype=torch.float64)
+        u = F.silu(x * pa[:, :, None, None] + pb[:, :, None, None]) if fused else x
+        taps, stride, rs, ho = 9, 1, 0, h
+        if kind == "down":
+            u, ho, rs = F.avg_pool2d(u, 2), h // 2, 1
+        elif kind == "up":
+            u, ho, rs = F.interpolate(u, scale_factor=2, mode="nearest"), h * 2, 2
+        elif kind == "stride2":
+            stride, ho = 2, h // 2
+        if ho < 2:
+            continue
+        if kind == "flat":
+            taps = 1
+            w = (torch.randn(cout, cin, generator=g, dtype=torch.float64) / math.sqrt(cin)).requires_grad_(True)
+            ur = u.permute(0, 2, 3, 1).reshape(n * h * h, cin)
+            gy = torch.randn(n * h * h, cout, generator=g, dtype=torch.float64)
+            F.linear(ur, w).backward(gy)
+            gy_rows = gy
+        else:
+            w = (torch.randn(cout, cin, 3, 3, generator=g, dtype=torch.float64) / math.sqrt(cin * 9)).requires_grad_(True)
+            gy = torch.randn(n, cout, ho, ho, generator=g, dtype=torch.float64)
+            F.conv2d(u, w, stride=stride, padding=1).backward(gy)
+            gy_rows = gy.permute(0, 2, 3, 1).reshape(n * ho * ho, cout)
+        # ---- the launch
+        xr = x.float()
+        x0d = _nhwc(xr[:, :c0]).cuda()
+        x1d = _nhwc(xr[:, c0:]).cuda() if c1 else None
+        pad, pbd = pa.float().cuda(), pb.float().cuda()
+        if kind == "flat":
+            fwd = _igemm_args(L, x0d.reshape(n * h * h, c0), None, m=n * h * h, rows_per_n=h * h,
+                              pa=pad if fused else None, pb=pbd if fused else None, silu=1 if fused else 0)
+        else:
+            fwd = _igemm_args(L, x0d, x1d, conv=(n, h, h, ho, ho), pa=pad if fused else None, pb=pbd if fused else None,
+                              silu=1 if fused else 0, stride=stride, resample=rs)
+        fwd.prec = p
+        gy_ld = cout + rnd.choice([0, 0, 4, 32]) if cout % 4 == 0 else cout
+        gyd = torch.full((gy_rows.shape[0], gy_ld), float("nan"), device="cuda")
+        gyd[:, :cout] = gy_rows.float().cuda()
+        if gy_ld > cout:
+            gyd[:, cout:] = 7.0                                  # finite junk next to the gradient: must not be read as data
+        rows = gy_rows.shape[0]
+        ks = min(rnd.choice([1, 2, 3, _train_ksplit(taps, cout, cin, rows)]), (rows + 63) // 64)     # (<= K tiles of 64 rows)
+        scratch = int(lib.sgd_wgrad_scratch_bytes(C.byref(fwd), cout)) > 0 and rnd.random() < 0.6
+        desc = f"case {done}: {kind} n={n} h={h} c0={c0} c1={c1} cout={cout} fused={fused} gy_ld={gy_ld} ksplit={ks} scratch={scratch}"
+        dw = _wgrad(L, lib, fwd, gyd, cout, cin, taps, ks, scratch=scratch)
+        ref = w.grad.float().reshape(cout, cin, taps)
+        err = max_rel(dw, ref)
+        assert err < tol, (desc, err)
+        done += 1
+
+
 @pytest.mark.parametrize("prec", ["f32", "f16x3"])
 @pytest.mark.parametrize("kind,n,h,ch", [("stem3", 5, 64, 128), ("stem4", 3, 32, 64), ("head", 5, 64, 128), ("head", 2, 16, 64),
                                          ("stem3", 2, 16, 256)])
