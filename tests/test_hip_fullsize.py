@@ -524,6 +524,46 @@ def test_cfg_evaluation_at_benchmark_batch_vs_oracle(workload):
                 eager[prec] = img.clone()
 
 
+@pytest.mark.parametrize("workload", ["c2", "c5"])
+def test_cfg_evaluation_is_independent_of_the_batch_it_runs_in(workload):
+    """every launch's tile schedule (tiles per block, partial rounds, K-split tails, image-packed tiles) is a function of the
+    batch; a sample's result must not be.  The same 11 samples evaluated alone, in batches of 3 + 8, of 5 + 6 and of 11
+    (UNet batches 2 .. 22 under CFG): each against the single-sample evaluation, f32 and f16x3.  No oracle involved --
+    this is the property a schedule bug breaks first (the round-3 balanced-tail race was such a bug)."""
+    import bench
+    wl = bench.WORKLOADS[workload]
+    N, S = 11, wl["image"]
+    m, sd, data = bench.build_model(wl, torch.device("cuda"), "f32", N)
+    cond = data["cond"] if wl["kind"] == "unet_fast" else data["cond"].float()
+    layout = data.get("layout")
+    g = torch.Generator().manual_seed(91)
+    x = torch.randn(N, 3, S, S, generator=g).cuda()
+    t = torch.randint(0, 1000, (N,), generator=g).cuda()
+    cond = cond.cuda()
+    layout = None if layout is None else layout.cuda()
+
+    def run(idx):
+        sl = slice(idx[0], idx[-1] + 1)
+        with torch.no_grad():
+            return m.forward_with_cond_scale(x[sl], t[sl], cond=cond[sl], layout=None if layout is None else layout[sl],
+                                             cond_scale=2.0).clone()
+
+    # (different batches split K differently over blocks, so sums associate differently: the tolerances are the whole-model
+    # ones of the oracle test above, not bit equality)
+    for prec, tol in (("f32", 2e-5), ("f16x3", 5e-5)):
+        m.hip_precision = prec
+        single = torch.cat([run([i]) for i in range(N)])
+        assert torch.isfinite(single).all()
+        for split in ([3, 8], [5, 6], [11]):
+            outs, at = [], 0
+            for b in split:
+                outs.append(run(list(range(at, at + b))))
+                at += b
+            got = torch.cat(outs)
+            err = max_rel(got.cpu(), single.cpu())
+            assert err < tol, (prec, split, err)
+
+
 # --------------------------------------------------------------------------------------------------------------------
 # (c) one training step with > 256 tiles per launch
 # --------------------------------------------------------------------------------------------------------------------
