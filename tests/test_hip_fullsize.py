@@ -564,6 +564,51 @@ def test_cfg_evaluation_is_independent_of_the_batch_it_runs_in(workload):
             assert err < tol, (prec, split, err)
 
 
+@pytest.mark.parametrize("prec,tol", [("f32", 5e-5), ("f16x3", 1e-4)])
+def test_training_gradients_are_consistent_across_batch_splits(prec, tol):
+    """the loss is a batch mean, so the gradient of a batch of 7 is the size-weighted mean of the gradients of its first 3
+    and last 4 samples (same timesteps, noise and drop mask, dropout off): forward AND backward programs of three
+    different batch sizes -- three different tile schedules for every conv, weight-gradient and reduction launch --
+    against each other, every parameter"""
+    import bench
+    from sgdm_amd.diffusion import LatentDiffusion
+    from sgdm_amd.synth import synth_batch
+    wl = bench.WORKLOADS["c2"]
+    B = 7
+    model, _, _ = bench.build_model(wl, torch.device("cuda"), prec, B)
+    model.dropout = 0.0
+    model.train()
+    diff = LatentDiffusion(device="cuda", **bench.MODEL_PARAMS).train()
+    diff.set_denoise_fn(model.forward, model.forward_with_cond_scale)
+    data = synth_batch(wl["method"], B, 64, wl["cond_dim"], 0, seed=9)
+    g = torch.Generator().manual_seed(9)
+    t = torch.randint(0, 1000, (B,), generator=g).cuda()
+    noise = torch.randn(B, 3, 64, 64, generator=g).cuda()
+    mask = (torch.rand(B, generator=g) < 0.3).cuda()
+    x0, cond = data["image"].cuda(), data["cond"].cuda()
+
+    def grads(sl):
+        for p in model.parameters():
+            p.grad = None
+        loss, _ = diff.p_losses(x0[sl], t[sl], noise[sl], cond=cond[sl], cond_drop_prob=0.3, cond_drop_mask=mask[sl])
+        loss.backward()
+        torch.cuda.synchronize()
+        return {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}, float(loss.detach())
+
+    g7, l7 = grads(slice(0, 7))
+    g3, l3 = grads(slice(0, 3))
+    g4, l4 = grads(slice(3, 7))
+    assert abs(l7 - (3 * l3 + 4 * l4) / 7) < 1e-5 * abs(l7)
+    assert set(g7) == set(g3) == set(g4) and len(g7) > 200
+    worst = ("", 0.0)
+    for k in g7:
+        mix = (3 * g3[k] + 4 * g4[k]) / 7
+        err = max_rel(g7[k].cpu(), mix.cpu())
+        if err > worst[1]:
+            worst = (k, err)
+    assert worst[1] < tol, worst
+
+
 # --------------------------------------------------------------------------------------------------------------------
 # (c) one training step with > 256 tiles per launch
 # --------------------------------------------------------------------------------------------------------------------
