@@ -106,40 +106,56 @@ __global__ void gn_coef_kernel(const float* __restrict__ sums, const float* __re
 // Phase 1 folds the producers' partial statistics into sums[n, c, 2] (kept: the training backward reads them; a source
 // with parts == 0 already has its sums there, written by sgd_chan_stats); phase 2 is gn_coef_kernel's arithmetic on the
 // float-rounded sums, so both routes give bit-identical coefficients.
-__global__ __launch_bounds__(256) void gn_coef_parts_kernel(const float* __restrict__ p0, int parts0, int c0,
+__global__ __launch_bounds__(512) void gn_coef_parts_kernel(const float* __restrict__ p0, int parts0, int c0,
                                                             const float* __restrict__ p1, int parts1, int c1,
                                                             float* __restrict__ sums, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, const float* __restrict__ film,
                                                             int film_ld, int groups, int hw, float eps,
                                                             float* __restrict__ a, float* __restrict__ b) {
-    extern __shared__ float sh[];                     // [c][2]
-    const int nn = blockIdx.x, c = c0 + c1;
-    for (int ch = threadIdx.x; ch < c; ch += blockDim.x) {
+    extern __shared__ double shd[];                   // [G][c][2] partial sums of the part groups, then float sh[c][2]
+    const int nn = blockIdx.x, c = c0 + c1, nthr = blockDim.x;
+    // G threads per channel, each folding every G-th partial pair (round 4: with one thread per channel half of the block
+    // idled at 128 channels and a 64x64 map's 32 partials were four dependent round trips -- 6 us for a launch that runs
+    // 49 times per UNet evaluation); fixed assignment and fixed fold order: deterministic
+    const int G = c < nthr ? nthr / c : 1;
+    float* sh = reinterpret_cast<float*>(shd + (size_t)G * c * 2);
+    for (int it = threadIdx.x; it < c * G; it += nthr) {
+        const int ch = it % c, grp = it / c;
         const bool first = ch < c0;
         const float* p = first ? p0 : p1;
         const int parts = first ? parts0 : parts1, cs = first ? c0 : c1, cl = first ? ch : ch - c0;
-        float s, ss;
+        double t0 = 0, t1 = 0;
         if (parts > 0) {
             const float* q = p + (long)nn * parts * 2 * cs + cl;
-            // eight partial pairs in flight per thread, folded in index order (the unroll-by-4 loop still waited once per four)
-            double t0 = 0, t1 = 0;
-            int k = 0;
-            for (; k + 8 <= parts; k += 8) {
+            // up to eight partial pairs in flight per thread, folded in index order
+            int k = grp;
+            for (; k + 7 * G < parts; k += 8 * G) {
                 float v0[8], v1[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) { v0[j] = q[(long)(k + j) * 2 * cs]; v1[j] = q[(long)(k + j) * 2 * cs + cs]; }
+                for (int j = 0; j < 8; ++j) { v0[j] = q[(long)(k + j * G) * 2 * cs]; v1[j] = q[(long)(k + j * G) * 2 * cs + cs]; }
 #pragma unroll
                 for (int j = 0; j < 8; ++j) { t0 += v0[j]; t1 += v1[j]; }
             }
-            if (k + 4 <= parts) {
+            if (k + 3 * G < parts) {
                 float v0[4], v1[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { v0[j] = q[(long)(k + j) * 2 * cs]; v1[j] = q[(long)(k + j) * 2 * cs + cs]; }
+                for (int j = 0; j < 4; ++j) { v0[j] = q[(long)(k + j * G) * 2 * cs]; v1[j] = q[(long)(k + j * G) * 2 * cs + cs]; }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { t0 += v0[j]; t1 += v1[j]; }
-                k += 4;
+                k += 4 * G;
             }
-            for (; k < parts; ++k) { t0 += q[(long)k * 2 * cs]; t1 += q[(long)k * 2 * cs + cs]; }
+            for (; k < parts; k += G) { t0 += q[(long)k * 2 * cs]; t1 += q[(long)k * 2 * cs + cs]; }
+        }
+        shd[((size_t)grp * c + ch) * 2] = t0;
+        shd[((size_t)grp * c + ch) * 2 + 1] = t1;
+    }
+    __syncthreads();
+    for (int ch = threadIdx.x; ch < c; ch += nthr) {
+        const int parts = ch < c0 ? parts0 : parts1;
+        float s, ss;
+        if (parts > 0) {
+            double t0 = 0, t1 = 0;
+            for (int gi = 0; gi < G; ++gi) { t0 += shd[((size_t)gi * c + ch) * 2]; t1 += shd[((size_t)gi * c + ch) * 2 + 1]; }
             s = (float)t0;
             ss = (float)t1;
             sums[((long)nn * c + ch) * 2] = s;
@@ -148,7 +164,7 @@ __global__ __launch_bounds__(256) void gn_coef_parts_kernel(const float* __restr
             s = sums[((long)nn * c + ch) * 2];
             ss = sums[((long)nn * c + ch) * 2 + 1];
         }
-        sh[ch * 2] = s;
+        sh[ch * 2] = s;                               // (sh sits behind the partials: no overlay)
         sh[ch * 2 + 1] = ss;
     }
     __syncthreads();
@@ -312,8 +328,9 @@ extern "C" int sgd_gn_coef_parts(const float* p0, int32_t parts0, int32_t c0, co
         parts0 < 0 || parts1 < 0 || (parts0 > 0 && !p0) || (c1 > 0 && parts1 > 0 && !p1) || c > 8192)
         return SGD_ERR_ARG;
     if (film && film_ld < 2 * c) return SGD_ERR_ARG;
-    hipLaunchKernelGGL(gn_coef_parts_kernel, dim3(n), dim3(256), (size_t)c * 2 * sizeof(float), (hipStream_t)stream, p0,
-                       parts0, c0, p1, parts1, c1, sums, gamma, beta, film, film_ld, groups, hw, eps, a, b);
+    const int nthr = 512, G = c < nthr ? nthr / c : 1;
+    hipLaunchKernelGGL(gn_coef_parts_kernel, dim3(n), dim3(nthr), (size_t)G * c * 2 * sizeof(double) + (size_t)c * 2 * sizeof(float),
+                       (hipStream_t)stream, p0, parts0, c0, p1, parts1, c1, sums, gamma, beta, film, film_ld, groups, hw, eps, a, b);
     return sgd_check_launch();
 }
 

@@ -572,6 +572,63 @@ def test_epilogue_statistics_match_chan_stats(shape):
     assert float(sums[:, :8].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("n,c0,parts0,c1,parts1,film", [(3, 128, 32, 0, 0, True), (2, 256, 8, 128, 8, False), (4, 64, 128, 0, 0, False),
+                                                         (2, 512, 2, 512, 0, True), (1, 1024, 5, 0, 0, False), (3, 96, 37, 32, 3, True),
+                                                         (2, 128, 1, 0, 0, False)])
+def test_groupnorm_coefficients_from_partial_statistics(n, c0, parts0, c1, parts1, film):
+    """sgd_gn_coef_parts (partial statistics of up to two concatenated producers -> GroupNorm + FiLM coefficients in one
+    launch; several threads per channel since round 4) against float64, and against sgd_stats_reduce + sgd_gn_coef.
+    parts1 == 0 with c1 > 0: that source's sums are already in place (a sgd_chan_stats source)."""
+    L, lib = _lib()
+    g = torch.Generator().manual_seed(61)
+    c, hw, groups = c0 + c1, 4096, 32
+    x = torch.randn(n, hw, c, generator=g, dtype=torch.float64) * 1.7 + 0.4          # the tensor the statistics describe
+
+    def partials(xs, parts):          # [n, parts, 2, cs]: sums over `parts` row ranges of uneven length
+        cuts = sorted(torch.randperm(hw - 1, generator=g)[:parts - 1].add(1).tolist()) if parts > 1 else []
+        edges = [0] + cuts + [hw]
+        out = torch.empty(n, parts, 2, xs.shape[-1], dtype=torch.float64)
+        for k in range(parts):
+            seg = xs[:, edges[k]:edges[k + 1]]
+            out[:, k, 0], out[:, k, 1] = seg.sum(1), (seg * seg).sum(1)
+        return out.float().cuda()
+
+    p0 = partials(x[..., :c0], parts0)
+    p1 = partials(x[..., c0:], parts1) if (c1 and parts1) else None
+    gamma, beta = torch.randn(c, generator=g).cuda(), torch.randn(c, generator=g).cuda()
+    fl = torch.randn(n, 2 * c, generator=g).cuda() if film else None
+    sums = torch.full((n, c, 2), float("nan"), device="cuda")
+    if c1 and not parts1:              # second source: sums already in place
+        xs = x[..., c0:]
+        sums[:, c0:, 0], sums[:, c0:, 1] = xs.sum(1).float().cuda(), (xs * xs).sum(1).float().cuda()
+    sums_in = sums.clone()
+    a, b = torch.empty(n, c, device="cuda"), torch.empty(n, c, device="cuda")
+    L.check(lib.sgd_gn_coef_parts(_p(p0), parts0, c0, _p(p1), parts1 if p1 is not None else 0, c1, _p(sums), _p(gamma), _p(beta),
+                                  _p(fl), 2 * c, n, groups, hw, 1e-5, _p(a), _p(b), _stream()), "coef_parts")
+    torch.cuda.synchronize()
+    # float64 reference of the affine (a, b): y = a * x + b == (GroupNorm(x) * (1 + scale) + shift)
+    xg = x.reshape(n, hw, groups, c // groups)
+    mean = xg.mean(dim=(1, 3), keepdim=True)
+    var = xg.var(dim=(1, 3), unbiased=False, keepdim=True)
+    rstd = (1.0 / torch.sqrt(var + 1e-5)).expand(n, 1, groups, c // groups).reshape(n, c)
+    mu = mean.expand(n, 1, groups, c // groups).reshape(n, c)
+    ga = gamma.cpu().double()[None] * rstd
+    be = beta.cpu().double()[None] - mu * ga
+    if film:
+        sc, sh = 1 + fl.cpu().double()[:, :c], fl.cpu().double()[:, c:]
+        ga, be = ga * sc, be * sc + sh
+    assert max_rel(a.cpu().double(), ga) < 2e-5 and max_rel(b.cpu().double(), be) < 2e-5
+    assert torch.isfinite(sums).all()
+    # the two-launch route on the same partials
+    s2 = sums_in.clone()
+    L.check(lib.sgd_stats_reduce(_p(p0), n, parts0, c0, _p(s2), c, 0, _stream()), "reduce0")
+    if p1 is not None:
+        L.check(lib.sgd_stats_reduce(_p(p1), n, parts1, c1, _p(s2), c, c0, _stream()), "reduce1")
+    a2, b2 = torch.empty(n, c, device="cuda"), torch.empty(n, c, device="cuda")
+    L.check(lib.sgd_gn_coef(_p(s2), _p(gamma), _p(beta), _p(fl), 2 * c, n, c, groups, hw, 1e-5, _p(a2), _p(b2), _stream()), "coef")
+    assert max_rel(sums, s2) < 1e-6 and max_rel(a, a2) < 1e-6 and max_rel(b, b2) < 1e-6
+
+
 @pytest.mark.parametrize("m,n,k,ksplit", [(7, 100, 1234, 5), (160, 256, 5000, 39), (256, 64, 33, 1)])
 def test_linear_splitk(m, n, k, ksplit):
     """skinny split-K linear (mlp_cond.0 at K = 5000) vs float64; ragged m / n / k and a padded x row stride"""
