@@ -341,6 +341,9 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"launched with WORLD_SIZE={world} but --gpus {args.gpus}"
     import torch.distributed as dist
+    # bind the rank to its GPU BEFORE the process group exists: RCCL picks up the current device at its first collective
+    local_rank %= max(1, torch.cuda.device_count())
+    torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # "nccl" is RCCL on ROCm.  SGDM_DIST_BACKEND=gloo lets several ranks share ONE GPU to exercise this path on a
@@ -348,8 +351,6 @@ def main():
         # the exchange's kernels get the CUs the training programs leave free (sgdm_amd.ddp.reserved_cus) and no more
         os.environ.setdefault("NCCL_MAX_NCHANNELS", os.environ.get("SGDM_RESERVE_CUS", "16"))
         dist.init_process_group(os.environ.get("SGDM_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
-    local_rank %= max(1, torch.cuda.device_count())
-    torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
     from sgdm_amd.diffusion import LatentDiffusion
