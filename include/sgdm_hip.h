@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define SGD_ABI_VERSION 13
+#define SGD_ABI_VERSION 14
 int sgd_abi_version(void);
 /* 16 hex digits identifying the sources and flags the library was compiled from (build.py: source_id()); static storage.
  * __graft_entry__.build() and tests/test_boundary_cpu.py compare it with the tree on disk. */
@@ -459,6 +459,15 @@ int sgd_attention_bwd_split(const float* q, int32_t q_ld, int32_t q_hs, const fl
  *   x_noisy = sa[t]*x0 + s1ma[t]*noise      (NCHW in, NCHW out; tables are the float32 schedule buffers) */
 int sgd_q_sample(const float* x0, const float* noise, const int64_t* t, const float* sqrt_ac, const float* sqrt_1mac,
                  int32_t b, int64_t chw, float* out, void* stream);
+/* --------------------------------------------------------------------------------------
+ * The UNet stem (openaimodel.py:560-566, openaimodel_ca.py:735-741: a 3x3 convolution of the 3- or 4-channel input,
+ * stride 1, padding 1) as a plain fp32 kernel (ABI 14): x NHWC [n,h,w,cin], cin 3 or 4; w the PARAMETER itself,
+ * [cout][cin][3][3]; y NHWC with leading dimension y_ld; cout % 4 == 0, <= 1024.  stats (or NULL): the GroupNorm partial
+ * statistics of y in sgd_igemm_args.stats' layout, [n][parts][2][cout] with parts = sgd_conv3_narrow_in_parts(h, w). */
+int sgd_conv3_narrow_in_parts(int32_t h, int32_t w);
+int sgd_conv3_narrow_in(const float* x, const float* w, const float* bias, float* y, float* stats, int32_t n, int32_t h,
+                        int32_t wd, int32_t cin, int32_t cout, int32_t y_ld, void* stream);
+
 /* per_sample[b] = mean_chw (noise - eps)^2 ; geps_nhwc = d(mean_b per_sample)/d eps laid out NHWC for the backward
  * program (eps_nhwc is the UNet output in NHWC, noise NCHW) */
 int sgd_mse_loss(const float* eps_nhwc, const float* noise_nchw, int32_t b, int32_t c, int32_t hw,

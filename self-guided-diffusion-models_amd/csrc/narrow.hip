@@ -1,0 +1,128 @@
+// 3x3 convolution of a 3- or 4-channel map (the UNet stem, openaimodel.py:560-566 / openaimodel_ca.py:735-741:
+// conv_nd(dims, in_channels, model_channels, 3, padding=1)) as a plain fp32 FMA kernel.
+//
+// On the implicit-GEMM kernel this layer pads its 3 input channels to a 32-channel K step per tap: 9 K steps of which
+// 29/32 are zeros, 0.112 ms at 20 TF/s for a layer whose real work is writing 168 MB (UNet batch 80: 0.03 ms at the
+// HBM rate) with 27 multiply-adds per output.  Here a thread owns FOUR output channels and keeps their 27 x 4 weights in
+// registers; a block stages the input rows it needs (halo included, zero padding resolved once) in LDS and walks its
+// pixels: per pixel 9 broadcast 16-byte LDS reads, 108 FMAs, one 16-byte store -- 512 contiguous bytes per pixel across
+// the 32 threads that share it.  The GroupNorm statistics of the output (sum y, sum y^2 per image and channel) leave as
+// one partial pair per block, in the layout sgd_igemm's epilogue writes (include/sgdm_hip.h: sgd_igemm_args.stats).
+// Exact fp32 whatever the engine's arithmetic mode.
+#include <hip/hip_runtime.h>
+
+#include "sgdm_common.h"
+#include "../../include/sgdm_hip.h"
+
+namespace {
+
+__device__ __forceinline__ f32x4 ld4n(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+
+template <int CIN>
+__global__ __launch_bounds__(256) void conv3_narrow_in_kernel(const float* __restrict__ x, const float* __restrict__ wt,
+                                                              const float* __restrict__ bias, float* __restrict__ y,
+                                                              float* __restrict__ stats, int h, int w, int cout, int y_ld,
+                                                              int rows_per_block, int parts) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];       // [(R + 2) * (w + 2)][4] input, then [PL][Q][8] sums
+    const int Q = cout >> 2, PL = blockDim.x / Q;
+    const int q = threadIdx.x % Q, pl = threadIdx.x / Q;
+    const int n = blockIdx.x / parts, part = blockIdx.x % parts;
+    const int r0 = part * rows_per_block, r1 = min(h, r0 + rows_per_block);
+    const int wp = w + 2, hrows = r1 - r0 + 2;
+    // ---- input rows r0 - 1 .. r1 (zero outside the map), channel-padded to 4
+    for (int i = threadIdx.x; i < hrows * wp; i += blockDim.x) {
+        const int yy = r0 - 1 + i / wp, xx = i % wp - 1;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (yy >= 0 && yy < h && xx >= 0 && xx < w) {
+            const float* p = x + (((long)n * h + yy) * w + xx) * CIN;
+#pragma unroll
+            for (int c = 0; c < CIN; ++c) v[c] = p[c];
+        }
+        *reinterpret_cast<f32x4*>(lds + (size_t)i * 4) = v;
+    }
+    // ---- this thread's weights: W[co][ci][tap], co = 4 q .. 4 q + 3
+    float wr[9][CIN][4];
+    f32x4 bq = {0.f, 0.f, 0.f, 0.f};
+    const bool live = pl < PL && q < Q;                               // (blockDim is Q * PL: always true, kept for clarity)
+    if (live) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int c = 0; c < CIN; ++c)
+#pragma unroll
+                for (int t = 0; t < 9; ++t) wr[t][c][j] = wt[((long)(q * 4 + j) * CIN + c) * 9 + t];
+        if (bias) bq = ld4n(bias + q * 4);
+    }
+    __syncthreads();
+    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = s1;
+    const int npix = (r1 - r0) * w;
+    for (int p = pl; p < npix; p += PL) {
+        const int oy = p / w, ox = p - oy * w;
+        f32x4 acc = bq;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const f32x4 in = *reinterpret_cast<const f32x4*>(lds + (size_t)((oy + t / 3) * wp + ox + t % 3) * 4);
+#pragma unroll
+            for (int c = 0; c < CIN; ++c)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] = fmaf(in[c], wr[t][c][j], acc[j]);
+        }
+        *reinterpret_cast<f32x4*>(y + (((long)n * h + r0 + oy) * w + ox) * y_ld + q * 4) = acc;
+        s1 += acc;
+        s2 += acc * acc;
+    }
+    if (!stats) return;
+    // ---- GroupNorm partial sums of the block: fold the PL pixel lanes of every channel quad in lane order
+    __syncthreads();                                                  // the input tile is dead
+    float* red = lds;                                                 // [PL][Q][8]
+    *reinterpret_cast<f32x4*>(red + ((size_t)pl * Q + q) * 8) = s1;
+    *reinterpret_cast<f32x4*>(red + ((size_t)pl * Q + q) * 8 + 4) = s2;
+    __syncthreads();
+    if (pl == 0) {
+        f32x4 t1 = {0.f, 0.f, 0.f, 0.f}, t2 = t1;
+        for (int k = 0; k < PL; ++k) {
+            t1 += *reinterpret_cast<const f32x4*>(red + ((size_t)k * Q + q) * 8);
+            t2 += *reinterpret_cast<const f32x4*>(red + ((size_t)k * Q + q) * 8 + 4);
+        }
+        float* sp = stats + ((long)n * parts + part) * 2 * cout + q * 4;
+        *reinterpret_cast<f32x4*>(sp) = t1;
+        *reinterpret_cast<f32x4*>(sp + cout) = t2;
+    }
+}
+
+// output rows per block: about 256 pixels, whole rows
+inline int narrow_rows_per_block(int h, int w) {
+    int r = 256 / (w > 0 ? w : 1);
+    if (r < 1) r = 1;
+    return r > h ? h : r;
+}
+
+}  // namespace
+
+extern "C" int sgd_conv3_narrow_in_parts(int32_t h, int32_t w) {
+    if (h <= 0 || w <= 0) return 0;
+    const int r = narrow_rows_per_block(h, w);
+    return (h + r - 1) / r;
+}
+
+extern "C" int sgd_conv3_narrow_in(const float* x, const float* w, const float* bias, float* y, float* stats, int32_t n,
+                                   int32_t h, int32_t wd, int32_t cin, int32_t cout, int32_t y_ld, void* stream) {
+    SGD_CLEAR_ERR();
+    if (!x || !w || !y || n <= 0 || h <= 0 || wd <= 0 || (cin != 3 && cin != 4) || cout <= 0 || (cout & 3) || cout > 1024 ||
+        y_ld < cout || (y_ld & 3))
+        return SGD_ERR_ARG;
+    const int Q = cout / 4;
+    const int PL = 256 / Q > 0 ? 256 / Q : 1;
+    const int R = narrow_rows_per_block(h, wd), parts = (h + R - 1) / R;
+    const size_t in_bytes = (size_t)(R + 2) * (wd + 2) * 16, red_bytes = (size_t)PL * Q * 32;
+    const size_t smem = in_bytes > red_bytes ? in_bytes : red_bytes;
+    if (smem > 64 * 1024) return SGD_ERR_ARG;
+    const dim3 grid((unsigned)((long)n * parts)), block((unsigned)(Q * PL));
+    if (cin == 3)
+        hipLaunchKernelGGL((conv3_narrow_in_kernel<3>), grid, block, smem, (hipStream_t)stream, x, w, bias, y, stats, h, wd, cout,
+                           y_ld, R, parts);
+    else
+        hipLaunchKernelGGL((conv3_narrow_in_kernel<4>), grid, block, smem, (hipStream_t)stream, x, w, bias, y, stats, h, wd, cout,
+                           y_ld, R, parts);
+    return sgd_check_launch();
+}

@@ -20,7 +20,7 @@ RS_NONE, RS_AVGPOOL2, RS_UP2, RS_ZEROUP2 = 0, 1, 2, 3
 PRO_NONE, PRO_AFFINE_NC, PRO_LN_ROW = 0, 1, 2
 PREC_F32, PREC_F16X3, PREC_BF16X3 = 0, 1, 2
 PREC_BY_NAME = {"f32": PREC_F32, "f16x3": PREC_F16X3, "bf16x3": PREC_BF16X3}
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
@@ -64,6 +64,8 @@ SIGNATURES = {
     "sgd_pack_weights_batched": (i32, [vp, i32, vp, vp, i32, vp, vp, i32, i32, vp]),
     "sgd_linear_splitk": (i32, [vp, i32, vp, vp, i32, i32, i32, vp, i32, vp, i32, vp]),
     "sgd_linear_splitk_t": (i32, [vp, i32, vp, i32, i32, i32, i32, vp, i32, vp, i32, vp]),
+    "sgd_conv3_narrow_in_parts": (i32, [i32, i32]),
+    "sgd_conv3_narrow_in": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "sgd_chan_stats": (i32, [vp, i32, i32, i32, vp, i32, i32, vp]),
     "sgd_gn_coef_parts": (i32, [vp, i32, i32, vp, i32, i32, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp, vp, vp]),
     "sgd_gn_coef": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, vp, vp, vp]),

@@ -638,8 +638,15 @@ class _Engine:
         a.prec = self.prec
         if self.work_bytes:
             a.work, a.work_bytes = self.work.data_ptr(), self.work_bytes
+        # the stem (3 / 4 input channels, no prologue, no residual): a plain fp32 kernel of its own (csrc/narrow.hip) reading
+        # the PARAMETER -- on the implicit-GEMM kernel 29 of every 32 K lanes of this layer multiply zeros.  The descriptor
+        # `a` is still built (and the weight still packed): the backward's weight gradient reads both.
+        narrow = (conv is not None and launch and c1 == 0 and c0 in (3, 4) and pro == L.PRO_NONE and not silu and res is None
+                  and conv[5] == 1 and conv[6] == 0 and cout % 4 == 0 and cout <= 1024 and y_off == 0 and orows == (0, 0, 0)
+                  and len(pk.srcs) == 1 and pk.pad is None and pk.srcs[0].dtype == torch.float32 and pk.srcs[0].is_contiguous()
+                  and os.environ.get("SGDM_NARROW_CONV", "1") != "0")
         if stats and os.environ.get("SGDM_FUSED_STATS", "1") != "0":
-            parts = self.lib.sgd_igemm_stats_parts(C.byref(a))
+            parts = self.lib.sgd_conv3_narrow_in_parts(conv[3], conv[4]) if narrow else self.lib.sgd_igemm_stats_parts(C.byref(a))
             if parts > 0:
                 sbuf = self.buf(rows_n, parts, 2, cout)
                 a.stats = sbuf.data_ptr()
@@ -653,7 +660,10 @@ class _Engine:
         cin = c0 + c1
         flops = 2.0 * rows * cout * taps * cin
         nbytes = 4.0 * (rows_in * cin + rows * cout * (2 if res is not None else 1) + taps * cin * cout)
-        if launch:          # launch=False: descriptor only (the backward's weight gradient reads it)
+        if narrow:
+            self.prog.add(tag, self.lib.sgd_conv3_narrow_in, _ptr(x0), _ptr(pk.srcs[0]), C.c_void_p(a.bias or 0), C.c_void_p(a.y),
+                          C.c_void_p(a.stats or 0), conv[0], conv[3], conv[4], c0, cout, a.y_ld, flops=flops, nbytes=nbytes)
+        elif launch:        # launch=False: descriptor only (the backward's weight gradient reads it)
             self.prog.add(tag, self.lib.sgd_igemm, C.byref(a), flops=flops, nbytes=nbytes)
         return a
 

@@ -155,6 +155,42 @@ def test_linear_flat(m, k, nout, prec, tol):
     assert max_rel(y.cpu(), ref) < tol
 
 
+@pytest.mark.parametrize("n,h,w_,cin,cout,pad", [(5, 64, 64, 3, 128, 0), (2, 32, 32, 4, 224, 0), (3, 16, 16, 3, 256, 8), (2, 8, 8, 4, 1024, 0),
+                                                  (1, 4, 4, 3, 32, 4), (2, 16, 64, 3, 64, 0), (3, 6, 10, 4, 128, 0)])
+def test_stem_conv_narrow_kernel(n, h, w_, cin, cout, pad):
+    """sgd_conv3_narrow_in (round 4): the UNet stem as a plain fp32 kernel -- output against float64 conv2d, the GroupNorm
+    partial statistics against the exact sums of the output it wrote, a strided destination left untouched outside its
+    columns; maps that are not powers of two included (this kernel has no tile geometry to satisfy)"""
+    L, lib = _lib()
+    g = torch.Generator().manual_seed(71)
+    x = torch.randn(n, cin, h, w_, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(cin * 9)
+    b = torch.randn(cout, generator=g)
+    ref = F.conv2d(x.double(), wt.double(), b.double(), padding=1)
+    xd, wd, bd = _nhwc(x).cuda(), wt.cuda(), b.cuda()
+    y_ld = cout + pad
+    y = torch.full((n, h, w_, y_ld), float("nan"), device="cuda")
+    parts = lib.sgd_conv3_narrow_in_parts(h, w_)
+    assert parts >= 1
+    st = torch.full((n, parts, 2, cout), float("nan"), device="cuda")
+    L.check(lib.sgd_conv3_narrow_in(_p(xd), _p(wd), _p(bd), _p(y), _p(st), n, h, w_, cin, cout, y_ld, _stream()), "stem")
+    torch.cuda.synchronize()
+    got = y[..., :cout].cpu().permute(0, 3, 1, 2)
+    assert max_rel(got, ref) < 2e-6
+    if pad:
+        assert torch.isnan(y[..., cout:]).all()
+    yy = y[..., :cout].double().reshape(n, h * w_, cout).cpu()
+    exact = torch.stack([yy.sum(1), (yy * yy).sum(1)], 1)                     # [n, 2, cout]
+    folded = st.cpu().double().sum(1)
+    assert float((folded - exact).abs().max() / exact.abs().max()) < 2e-6
+    # without statistics and without bias
+    y2 = torch.full((n, h, w_, y_ld), float("nan"), device="cuda")
+    L.check(lib.sgd_conv3_narrow_in(_p(xd), _p(wd), None, _p(y2), None, n, h, w_, cin, cout, y_ld, _stream()), "stem")
+    ref2 = F.conv2d(x.double(), wt.double(), None, padding=1)
+    assert max_rel(y2[..., :cout].cpu().permute(0, 3, 1, 2), ref2) < 2e-6
+    assert lib.sgd_conv3_narrow_in(_p(xd), _p(wd), None, _p(y2), None, n, h, w_, 5, cout, y_ld, _stream()) == 1     # cin 3 / 4 only
+
+
 def _random_conv_cases(count, seed):
     """random but valid conv launches: channel counts off the 4 / 32 grid, concat, prologue, every resample / residual mode,
     few blocks (SGDM_MAX_GRID: many tiles per block, partial last rounds -> the balanced tail) and capped grids"""
