@@ -463,10 +463,12 @@ int sgd_q_sample(const float* x0, const float* noise, const int64_t* t, const fl
  * The UNet stem (openaimodel.py:560-566, openaimodel_ca.py:735-741: a 3x3 convolution of the 3- or 4-channel input,
  * stride 1, padding 1) as a plain fp32 kernel (ABI 14): x NHWC [n,h,w,cin], cin 3 or 4; w the PARAMETER itself,
  * [cout][cin][3][3]; y NHWC with leading dimension y_ld; cout % 4 == 0, <= 1024.  stats (or NULL): the GroupNorm partial
- * statistics of y in sgd_igemm_args.stats' layout, [n][parts][2][cout] with parts = sgd_conv3_narrow_in_parts(h, w). */
+ * statistics of y in sgd_igemm_args.stats' layout, [n][parts][2][cout] with parts = sgd_conv3_narrow_in_parts(h, w).
+ * adjoint != 0: the INPUT GRADIENT of a 3x3 conv with 3 / 4 output channels (the head, openaimodel.py:724-728): x is the
+ * output gradient [n,h,w,cin], w that conv's parameter [cin][cout][3][3] (taps flipped inside), y its input gradient. */
 int sgd_conv3_narrow_in_parts(int32_t h, int32_t w);
 int sgd_conv3_narrow_in(const float* x, const float* w, const float* bias, float* y, float* stats, int32_t n, int32_t h,
-                        int32_t wd, int32_t cin, int32_t cout, int32_t y_ld, void* stream);
+                        int32_t wd, int32_t cin, int32_t cout, int32_t y_ld, int32_t adjoint, void* stream);
 
 /* per_sample[b] = mean_chw (noise - eps)^2 ; geps_nhwc = d(mean_b per_sample)/d eps laid out NHWC for the backward
  * program (eps_nhwc is the UNet output in NHWC, noise NCHW) */

@@ -22,7 +22,7 @@ template <int CIN>
 __global__ __launch_bounds__(256) void conv3_narrow_in_kernel(const float* __restrict__ x, const float* __restrict__ wt,
                                                               const float* __restrict__ bias, float* __restrict__ y,
                                                               float* __restrict__ stats, int h, int w, int cout, int y_ld,
-                                                              int rows_per_block, int parts) {
+                                                              int rows_per_block, int parts, int adjoint) {
     extern __shared__ __attribute__((aligned(16))) float lds[];       // [(R + 2) * (w + 2)][4] input, then [PL][Q][8] sums
     const int Q = cout >> 2, PL = blockDim.x / Q;
     const int q = threadIdx.x % Q, pl = threadIdx.x / Q;
@@ -40,7 +40,8 @@ __global__ __launch_bounds__(256) void conv3_narrow_in_kernel(const float* __res
         }
         *reinterpret_cast<f32x4*>(lds + (size_t)i * 4) = v;
     }
-    // ---- this thread's weights: W[co][ci][tap], co = 4 q .. 4 q + 3
+    // ---- this thread's weights: W[co][ci][tap], co = 4 q .. 4 q + 3; adjoint (input gradient of a conv with 3 / 4
+    // OUTPUT channels, i.e. the head): the parameter is W[ci][co][tap] and the taps are flipped
     float wr[9][CIN][4];
     f32x4 bq = {0.f, 0.f, 0.f, 0.f};
     const bool live = pl < PL && q < Q;                               // (blockDim is Q * PL: always true, kept for clarity)
@@ -50,7 +51,8 @@ __global__ __launch_bounds__(256) void conv3_narrow_in_kernel(const float* __res
 #pragma unroll
             for (int c = 0; c < CIN; ++c)
 #pragma unroll
-                for (int t = 0; t < 9; ++t) wr[t][c][j] = wt[((long)(q * 4 + j) * CIN + c) * 9 + t];
+                for (int t = 0; t < 9; ++t)
+                    wr[t][c][j] = adjoint ? wt[((long)c * cout + q * 4 + j) * 9 + (8 - t)] : wt[((long)(q * 4 + j) * CIN + c) * 9 + t];
         if (bias) bq = ld4n(bias + q * 4);
     }
     __syncthreads();
@@ -106,7 +108,7 @@ extern "C" int sgd_conv3_narrow_in_parts(int32_t h, int32_t w) {
 }
 
 extern "C" int sgd_conv3_narrow_in(const float* x, const float* w, const float* bias, float* y, float* stats, int32_t n,
-                                   int32_t h, int32_t wd, int32_t cin, int32_t cout, int32_t y_ld, void* stream) {
+                                   int32_t h, int32_t wd, int32_t cin, int32_t cout, int32_t y_ld, int32_t adjoint, void* stream) {
     SGD_CLEAR_ERR();
     if (!x || !w || !y || n <= 0 || h <= 0 || wd <= 0 || (cin != 3 && cin != 4) || cout <= 0 || (cout & 3) || cout > 1024 ||
         y_ld < cout || (y_ld & 3))
@@ -120,9 +122,9 @@ extern "C" int sgd_conv3_narrow_in(const float* x, const float* w, const float* 
     const dim3 grid((unsigned)((long)n * parts)), block((unsigned)(Q * PL));
     if (cin == 3)
         hipLaunchKernelGGL((conv3_narrow_in_kernel<3>), grid, block, smem, (hipStream_t)stream, x, w, bias, y, stats, h, wd, cout,
-                           y_ld, R, parts);
+                           y_ld, R, parts, adjoint);
     else
         hipLaunchKernelGGL((conv3_narrow_in_kernel<4>), grid, block, smem, (hipStream_t)stream, x, w, bias, y, stats, h, wd, cout,
-                           y_ld, R, parts);
+                           y_ld, R, parts, adjoint);
     return sgd_check_launch();
 }

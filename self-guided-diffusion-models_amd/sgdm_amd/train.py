@@ -186,6 +186,16 @@ class Backward:
               y_ld=None, zero_up=False, acc=False):
         """y (+)= adjoint(W) applied to gy (gy has cout_fwd channels, y gets cin_fwd channels).
         zero_up: adjoint of a stride-2 conv (gy is zero-upsampled x2 inside the loader); acc: add into y."""
+        # the head (a conv with 3 / 4 OUTPUT channels): its input gradient is the stem's kernel on the flipped, transposed
+        # parameter (csrc/narrow.hip, adjoint mode) -- fp32 FMA straight from the weight, no adjoint pack
+        if (conv is not None and ksize == 3 and not zero_up and not acc and cin_of_gy in (3, 4) and cout_fwd == cin_of_gy
+                and cout_of_y % 4 == 0 and cout_of_y <= 1024 and len(deps) == 1 and deps[0].dtype == torch.float32
+                and deps[0].is_contiguous() and gy.shape[-1] == cin_of_gy and os.environ.get("SGDM_NARROW_CONV", "1") != "0"):
+            nimg, hh, ww = conv
+            self.prog.add(tag, self.lib.sgd_conv3_narrow_in, C.c_void_p(gy.data_ptr()), C.c_void_p(deps[0].data_ptr()),
+                          C.c_void_p(0), C.c_void_p(y.data_ptr()), C.c_void_p(0), nimg, hh, ww, cin_of_gy, cout_of_y,
+                          y_ld or cout_of_y, 1, flops=2.0 * nimg * hh * ww * cout_of_y * 9 * cin_of_gy)
+            return
         pk = _PackedAdj(deps, src_fn, cout_fwd, cin_fwd, ksize, self.prec, self.dev)
         self.packs.append(pk)
         a = L.IgemmArgs()

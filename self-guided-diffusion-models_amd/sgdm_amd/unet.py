@@ -662,7 +662,7 @@ class _Engine:
         nbytes = 4.0 * (rows_in * cin + rows * cout * (2 if res is not None else 1) + taps * cin * cout)
         if narrow:
             self.prog.add(tag, self.lib.sgd_conv3_narrow_in, _ptr(x0), _ptr(pk.srcs[0]), C.c_void_p(a.bias or 0), C.c_void_p(a.y),
-                          C.c_void_p(a.stats or 0), conv[0], conv[3], conv[4], c0, cout, a.y_ld, flops=flops, nbytes=nbytes)
+                          C.c_void_p(a.stats or 0), conv[0], conv[3], conv[4], c0, cout, a.y_ld, 0, flops=flops, nbytes=nbytes)
         elif launch:        # launch=False: descriptor only (the backward's weight gradient reads it)
             self.prog.add(tag, self.lib.sgd_igemm, C.byref(a), flops=flops, nbytes=nbytes)
         return a

@@ -173,7 +173,7 @@ def test_stem_conv_narrow_kernel(n, h, w_, cin, cout, pad):
     parts = lib.sgd_conv3_narrow_in_parts(h, w_)
     assert parts >= 1
     st = torch.full((n, parts, 2, cout), float("nan"), device="cuda")
-    L.check(lib.sgd_conv3_narrow_in(_p(xd), _p(wd), _p(bd), _p(y), _p(st), n, h, w_, cin, cout, y_ld, _stream()), "stem")
+    L.check(lib.sgd_conv3_narrow_in(_p(xd), _p(wd), _p(bd), _p(y), _p(st), n, h, w_, cin, cout, y_ld, 0, _stream()), "stem")
     torch.cuda.synchronize()
     got = y[..., :cout].cpu().permute(0, 3, 1, 2)
     assert max_rel(got, ref) < 2e-6
@@ -185,10 +185,18 @@ def test_stem_conv_narrow_kernel(n, h, w_, cin, cout, pad):
     assert float((folded - exact).abs().max() / exact.abs().max()) < 2e-6
     # without statistics and without bias
     y2 = torch.full((n, h, w_, y_ld), float("nan"), device="cuda")
-    L.check(lib.sgd_conv3_narrow_in(_p(xd), _p(wd), None, _p(y2), None, n, h, w_, cin, cout, y_ld, _stream()), "stem")
+    L.check(lib.sgd_conv3_narrow_in(_p(xd), _p(wd), None, _p(y2), None, n, h, w_, cin, cout, y_ld, 0, _stream()), "stem")
     ref2 = F.conv2d(x.double(), wt.double(), None, padding=1)
     assert max_rel(y2[..., :cout].cpu().permute(0, 3, 1, 2), ref2) < 2e-6
-    assert lib.sgd_conv3_narrow_in(_p(xd), _p(wd), None, _p(y2), None, n, h, w_, 5, cout, y_ld, _stream()) == 1     # cin 3 / 4 only
+    assert lib.sgd_conv3_narrow_in(_p(xd), _p(wd), None, _p(y2), None, n, h, w_, 5, cout, y_ld, 0, _stream()) == 1     # cin 3 / 4 only
+    # adjoint: the input gradient of a conv with `cin` OUTPUT channels (the head) -- x plays the output gradient
+    wh = (torch.randn(cin, cout, 3, 3, generator=g) / math.sqrt(cout * 9)).double()
+    u = torch.randn(n, cout, h, w_, generator=g, dtype=torch.float64, requires_grad=True)
+    F.conv2d(u, wh, padding=1).backward(x.double())
+    whd = wh.float().cuda()
+    y3 = torch.full((n, h, w_, y_ld), float("nan"), device="cuda")
+    L.check(lib.sgd_conv3_narrow_in(_p(xd), _p(whd), None, _p(y3), None, n, h, w_, cin, cout, y_ld, 1, _stream()), "head dgrad")
+    assert max_rel(y3[..., :cout].cpu().permute(0, 3, 1, 2), u.grad) < 2e-6
 
 
 def _random_conv_cases(count, seed):
