@@ -42,7 +42,8 @@ __global__ __launch_bounds__(256) void conv3_narrow_in_kernel(const float* __res
     }
     // ---- this thread's weights: W[co][ci][tap], co = 4 q .. 4 q + 3; adjoint (input gradient of a conv with 3 / 4
     // OUTPUT channels, i.e. the head): the parameter is W[ci][co][tap] and the taps are flipped
-    float wr[9][CIN][4];
+    typedef float f32x2 __attribute__((ext_vector_type(2)));          // pairs: v_pk_fma_f32, two FMAs per issue slot
+    f32x2 wr[9][CIN][2];
     f32x4 bq = {0.f, 0.f, 0.f, 0.f};
     const bool live = pl < PL && q < Q;                               // (blockDim is Q * PL: always true, kept for clarity)
     if (live) {
@@ -52,26 +53,35 @@ __global__ __launch_bounds__(256) void conv3_narrow_in_kernel(const float* __res
             for (int c = 0; c < CIN; ++c)
 #pragma unroll
                 for (int t = 0; t < 9; ++t)
-                    wr[t][c][j] = adjoint ? wt[((long)c * cout + q * 4 + j) * 9 + (8 - t)] : wt[((long)(q * 4 + j) * CIN + c) * 9 + t];
+                    wr[t][c][j >> 1][j & 1] = adjoint ? wt[((long)c * cout + q * 4 + j) * 9 + (8 - t)]
+                                                      : wt[((long)(q * 4 + j) * CIN + c) * 9 + t];
         if (bias) bq = ld4n(bias + q * 4);
     }
     __syncthreads();
     f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = s1;
     const int npix = (r1 - r0) * w;
+    // (row, column) of the thread's pixel advance by PL pixels per step: no division per pixel
+    int oy = pl / w, ox = pl - oy * w;
+    const int dy = PL / w, dx = PL - dy * w;
     for (int p = pl; p < npix; p += PL) {
-        const int oy = p / w, ox = p - oy * w;
-        f32x4 acc = bq;
+        f32x2 a0 = {bq[0], bq[1]}, a1 = {bq[2], bq[3]};
+        const float* tile = lds + (size_t)(oy * wp + ox) * 4;
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
-            const f32x4 in = *reinterpret_cast<const f32x4*>(lds + (size_t)((oy + t / 3) * wp + ox + t % 3) * 4);
+            const f32x4 in = *reinterpret_cast<const f32x4*>(tile + (size_t)((t / 3) * wp + t % 3) * 4);
 #pragma unroll
-            for (int c = 0; c < CIN; ++c)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[j] = fmaf(in[c], wr[t][c][j], acc[j]);
+            for (int c = 0; c < CIN; ++c) {
+                const f32x2 xi = {in[c], in[c]};
+                a0 = __builtin_elementwise_fma(xi, wr[t][c][0], a0);
+                a1 = __builtin_elementwise_fma(xi, wr[t][c][1], a1);
+            }
         }
+        const f32x4 acc = {a0[0], a0[1], a1[0], a1[1]};
         *reinterpret_cast<f32x4*>(y + (((long)n * h + r0 + oy) * w + ox) * y_ld + q * 4) = acc;
         s1 += acc;
         s2 += acc * acc;
+        oy += dy; ox += dx;
+        if (ox >= w) { ox -= w; ++oy; }
     }
     if (!stats) return;
     // ---- GroupNorm partial sums of the block: fold the PL pixel lanes of every channel quad in lane order
@@ -92,9 +102,10 @@ __global__ __launch_bounds__(256) void conv3_narrow_in_kernel(const float* __res
     }
 }
 
-// output rows per block: about 256 pixels, whole rows
+// output rows per block: about 512 pixels, whole rows (the 108 weight loads and the input staging of a block are its fixed
+// cost: 256 pixels 122 us, 512 pixels 107 us, 1024 pixels 112 us at UNet batch 160, tools/bench_narrow.py)
 inline int narrow_rows_per_block(int h, int w) {
-    int r = 256 / (w > 0 ? w : 1);
+    int r = 512 / (w > 0 ? w : 1);
     if (r < 1) r = 1;
     return r > h ? h : r;
 }
