@@ -192,9 +192,12 @@ class Backward:
                 and cout_of_y % 4 == 0 and cout_of_y <= 1024 and len(deps) == 1 and deps[0].dtype == torch.float32
                 and deps[0].is_contiguous() and gy.shape[-1] == cin_of_gy and os.environ.get("SGDM_NARROW_CONV", "1") != "0"):
             nimg, hh, ww = conv
-            self.prog.add(tag, self.lib.sgd_conv3_narrow_in, C.c_void_p(gy.data_ptr()), C.c_void_p(deps[0].data_ptr()),
-                          C.c_void_p(0), C.c_void_p(y.data_ptr()), C.c_void_p(0), nimg, hh, ww, cin_of_gy, cout_of_y,
-                          y_ld or cout_of_y, 1, flops=2.0 * nimg * hh * ww * cout_of_y * 9 * cin_of_gy)
+            wsrc, fn, gy_p, y_p, ld = deps[0], self.lib.sgd_conv3_narrow_in, C.c_void_p(gy.data_ptr()), C.c_void_p(y.data_ptr()), y_ld or cout_of_y
+
+            def sgd_conv3_narrow_in(stream):          # (the parameter's address is read at launch time)
+                return fn(gy_p, C.c_void_p(wsrc.data_ptr()), C.c_void_p(0), y_p, C.c_void_p(0), nimg, hh, ww, cin_of_gy, cout_of_y,
+                          ld, 1, stream)
+            self.prog.add(tag, sgd_conv3_narrow_in, flops=2.0 * nimg * hh * ww * cout_of_y * 9 * cin_of_gy)
             return
         pk = _PackedAdj(deps, src_fn, cout_fwd, cin_fwd, ksize, self.prec, self.dev)
         self.packs.append(pk)

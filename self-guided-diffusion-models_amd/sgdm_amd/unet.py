@@ -661,8 +661,13 @@ class _Engine:
         flops = 2.0 * rows * cout * taps * cin
         nbytes = 4.0 * (rows_in * cin + rows * cout * (2 if res is not None else 1) + taps * cin * cout)
         if narrow:
-            self.prog.add(tag, self.lib.sgd_conv3_narrow_in, _ptr(x0), _ptr(pk.srcs[0]), C.c_void_p(a.bias or 0), C.c_void_p(a.y),
-                          C.c_void_p(a.stats or 0), conv[0], conv[3], conv[4], c0, cout, a.y_ld, 0, flops=flops, nbytes=nbytes)
+            wsrc, fn = pk.srcs[0], self.lib.sgd_conv3_narrow_in
+            x_p, b_p, y_p, s_p = _ptr(x0), C.c_void_p(a.bias or 0), C.c_void_p(a.y), C.c_void_p(a.stats or 0)
+            nimg, ho, wo, y_ld = conv[0], conv[3], conv[4], a.y_ld
+
+            def sgd_conv3_narrow_in(stream):          # the parameter's address is read at launch time, like a repack would
+                return fn(x_p, C.c_void_p(wsrc.data_ptr()), b_p, y_p, s_p, nimg, ho, wo, c0, cout, y_ld, 0, stream)
+            self.prog.add(tag, sgd_conv3_narrow_in, flops=flops, nbytes=nbytes)
         elif launch:        # launch=False: descriptor only (the backward's weight gradient reads it)
             self.prog.add(tag, self.lib.sgd_igemm, C.byref(a), flops=flops, nbytes=nbytes)
         return a
