@@ -66,6 +66,8 @@ def explain(out, ref):
     per_thread = tb.sum(dim=1)                                  # wrong items per (tile, arow, plane)
     print(f"  wrong items per (tile, thread row, plane) that has any: {torch.bincount(per_thread[per_thread > 0].flatten(), minlength=5).tolist()[1:]} (1, 2, 3, 4 of 4)")
     print(f"  wrong cells per item index j: {tb.sum(dim=(0, 2, 3)).tolist()}")
+    # thread row lt >> 3 = 8 * (loader wave) + row of the wave: which of the four loader waves (one per SIMD) wrote them
+    print(f"  wrong cells per loader wave (SIMD): {tb.sum(dim=(0, 1, 3)).view(4, 8).sum(dim=1).tolist()}")
     el = (o != r).view(m, P, 8, 4)                              # [row, plane, quad, element]
     print(f"  wrong values per element of the quad: {el.sum(dim=(0, 1, 2)).tolist()}; per quad of the row: {el.sum(dim=(0, 1, 3)).tolist()}")
     kinds = {}
