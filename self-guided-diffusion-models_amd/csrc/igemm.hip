@@ -879,8 +879,20 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
                         f32x4 v = araw[R][j];
                         if constexpr (tile_uni) v = v * kq[R].p + kq[R].q;
                         if constexpr (ln) {
+#ifdef SGDM_EXP       /* bit 256: the normalised value (before gamma / beta) of element 0 to the side buffer; bit 512: x - mean */
+                            if ((a.reserved0 & 768) && a.x1 && cf.m0 + arow + j * AROWS < M) {
+                                const f32x4 d = v - rst[R][j].x;
+                                const f32x4 tn = d * rst[R][j].y;
+                                const_cast<float*>(a.x1)[(long)(cf.m0 + arow + j * AROWS) * (cin >> 2) + cf.chunk * 8 + c4] =
+                                    (a.reserved0 & 512) ? d[0] : tn[0];
+                                v = tn * kq[R].p;
+                                if (a.pc) v += kq[R].q;
+                            } else
+#endif
+                            {
                             v = (v - rst[R][j].x) * rst[R][j].y * kq[R].p;
                             if (a.pc) v += kq[R].q;
+                            }
                         }
                         if constexpr (SILU) {
 #pragma unroll
@@ -888,6 +900,10 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
                         }
                         if (cf.m0 + arow + j * AROWS >= M) v = f32x4{0.f, 0.f, 0.f, 0.f};
                         EXP_HOOK(8, "s_nop 7\n\ts_nop 7");
+#ifdef SGDM_EXP       /* bit 128: element 0 of the quad as the loader formed it, to a side buffer (args.x1, unused when c1 == 0) */
+                        if ((a.reserved0 & 128) && a.x1 && cf.m0 + arow + j * AROWS < M)
+                            const_cast<float*>(a.x1)[(long)(cf.m0 + arow + j * AROWS) * (cin >> 2) + cf.chunk * 8 + c4] = v[0];
+#endif
                         lds_store_act<PREC>(As + (size_t)slot * a_floats + (size_t)(sub * BM + arow + j * AROWS) * LDA, c4, v);
                         EXP_HOOK(1, "s_nop 7\n\ts_nop 7");
                         EXP_HOOK(4, "s_waitcnt lgkmcnt(0)");

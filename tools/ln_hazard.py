@@ -17,6 +17,8 @@ ap.add_argument("--cout", type=int, default=512); ap.add_argument("--prec", defa
 ap.add_argument("--reps", type=int, default=20); ap.add_argument("--masks", default="0,1,8,9,4,2")
 ap.add_argument("--nobeta", action="store_true")
 ap.add_argument("--identity", action="store_true", help="W = I: the output IS the staged input; say what the wrong rows hold")
+ap.add_argument("--select", type=int, default=-1, help="with --identity and cout < cin: W picks channels select .. select + cout (ONE N tile: one block per row tile)")
+ap.add_argument("--side", action="store_true", help="with --identity and mask bit 128: compare the loader's side copy of element 0 (before the split / LDS store) with what the MFMA saw")
 a = ap.parse_args()
 lib = L.load(); prec = L.PREC_BY_NAME[a.prec]
 dev = "cuda"
@@ -24,7 +26,11 @@ torch.manual_seed(0)
 m, cin, cout = a.m, a.cin, a.cout
 x = torch.randn(m, cin, device=dev)
 w = torch.randn(cout, cin, 1, 1, device=dev) / cin ** 0.5
-if a.identity:
+if a.identity and a.select >= 0:
+    w = torch.zeros(cout, cin, device=dev)
+    w[torch.arange(cout), a.select + torch.arange(cout)] = 1.0
+    w = w.reshape(cout, cin, 1, 1).contiguous()
+elif a.identity:
     assert cin == cout
     w = torch.eye(cin, device=dev).reshape(cout, cin, 1, 1).contiguous()
 gamma, beta = torch.randn(cin, device=dev), torch.randn(cin, device=dev)
@@ -41,6 +47,9 @@ g.mode, g.m, g.rows_per_n, g.stride = L.MODE_FLAT, m, m, 1
 g.pro, g.pa, g.pb = L.PRO_LN_ROW, stats.data_ptr(), gamma.data_ptr()
 if not a.nobeta: g.pc = beta.data_ptr()
 g.w, g.cin_p, g.cout_p = buf.data_ptr(), cp.value, op.value
+side_all = torch.full((m, cin // 4), float("nan"), device=dev)
+if a.side:
+    g.x1 = side_all.data_ptr()                      # (c1 stays 0: the kernel does not read it; -DSGDM_EXP bit 128 writes it)
 g.y, g.cout, g.y_ld, g.prec = y.data_ptr(), cout, cout, prec
 
 
@@ -118,5 +127,36 @@ for mask in [int(t) for t in a.masks.split(",")]:
             idx = bad.nonzero().flatten()
             for r8 in range(8): hist[r8] += int(((idx % 8) == r8).sum())
             worst = max(worst, float((out - ref).abs().max()))
-            if a.identity and bad_launches == 1: explain(out, ref)
+            if a.identity and a.select < 0 and bad_launches == 1: explain(out, ref)
+            if a.identity and a.side and bad_launches == 1:
+                torch.cuda.synchronize()
+                sel0 = max(a.select, 0)
+                side = side_all[:, sel0 // 4: sel0 // 4 + cout // 4]     # the quads W shows (one N tile: written by the same block)
+                beta_v = beta[sel0: sel0 + cout]
+                e0_out, e0_ref = out.view(m, cout // 4, 4)[..., 0], ref.view(m, cout // 4, 4)[..., 0]
+                wrong = e0_out != e0_ref                              # element 0 of a quad as the MFMA saw it
+                written = ~torch.isnan(side)
+                if mask & 768:        # the side buffer holds an intermediate: x - mean (512) or (x - mean) * rstd (256)
+                    xs = x[:, sel0: sel0 + cout].view(m, cout // 4, 4)[..., 0]
+                    inter = xs - stats[:, 0:1]
+                    if mask & 256: inter = inter * stats[:, 1:2]
+                    bad_i = (side - inter).abs() > 1e-5 * inter.abs().clamp_min(1e-2)
+                    print(f"  intermediate {'x - mean' if mask & 512 else '(x - mean) * rstd'} of element 0: wrong at the MFMA {int(wrong.sum())} quads; "
+                          f"of those the intermediate is wrong too: {int((wrong & bad_i).sum())}, right: {int((wrong & ~bad_i).sum())}; "
+                          f"intermediate wrong elsewhere: {int((~wrong & bad_i).sum())}")
+                    for r_, q_ in wrong.nonzero()[:6].tolist():
+                        print(f"    row {r_} channel {sel0 + 4 * q_}: intermediate {side[r_, q_].item():.7g} expected {inter[r_, q_].item():.7g} | "
+                              f"MFMA {e0_out[r_, q_].item():.7g} expected {e0_ref[r_, q_].item():.7g} beta {beta_v[4 * q_].item():.7g}")
+                    continue
+                sw = (side - e0_ref).abs() > 1e-3 * e0_ref.abs().clamp_min(1e-3)     # side copy is fp32, the output hi + lo
+                print(f"  (each row tile staged by {(cout + 127) // 128} block(s)) side copy written for {int(written.sum())} of {side.numel()} quads; element 0 wrong at the MFMA: {int(wrong.sum())}; "
+                      f"of those the loader's own fp32 copy is ALSO wrong: {int((wrong & sw).sum())}, right: {int((wrong & ~sw & written).sum())}; "
+                      f"side copy wrong where the MFMA saw the right value: {int((~wrong & sw & written).sum())}")
+                for title, sel in (("MFMA wrong, side copy right", wrong & ~sw & written), ("both wrong", wrong & sw),
+                                   ("side copy wrong, MFMA right", ~wrong & sw & written)):
+                    for r_, q_ in sel.nonzero()[:5].tolist():
+                        c_ = 4 * q_
+                        e0 = e0_ref[r_, q_].item()
+                        print(f"    {title}: row {r_} channel {sel0 + c_}: side {side[r_, q_].item():.7g}  MFMA {e0_out[r_, q_].item():.7g}  "
+                              f"expected {e0:.7g}  beta {beta_v[c_].item():.7g}  lo(expected) {e0 - float(torch.tensor(e0).half()):.3g}")
     print(f"SGDM_EXP={mask:2d}: {bad_launches}/{a.reps} launches differ, {rows_total} rows, rows mod 8 {hist}, max|d| {worst:.3g}")
