@@ -213,16 +213,17 @@ def pmc_traffic(args, B):
 def train_step_bench(model, diff, data, cond, layout, B, world, barrier, wl, steps=4, warmup=2):
     """train-step ms (max over ranks): forward_tao -> loss.backward() (bucketed all-reduce inside) -> AdamW -> EMA"""
     import torch.distributed as dist
+    from sgdm_amd import ddp
     from sgdm_amd.ema import LitEma
     dev = next(model.parameters()).device
     model.train()
     diff.train()
     from sgdm_amd.optim import FusedAdamWEma
-    if world > 1:
+    exchanging = ddp.exchange_active(model)          # world > 1, or a one-rank group with the exchange forced
+    if exchanging:
         # replicas start identical (torch DDP's construction-time broadcast; bench seeds make them so anyway): the model
         # BEFORE its EMA shadows are cloned from it
-        from sgdm_amd.ddp import sync_initial_state
-        sync_initial_state(model)
+        ddp.sync_initial_state(model)
     ema = LitEma(model)
     # optim/adamw.yaml + data lr/wd; AdamW and the LitEma shadow update run as ONE launch (sgd_adamw_ema_step)
     opt = FusedAdamWEma([p for p in model.parameters() if p.requires_grad], lr=1e-4, weight_decay=0.01, ema=ema,
@@ -266,17 +267,60 @@ def train_step_bench(model, diff, data, cond, layout, B, world, barrier, wl, ste
     model.eval()
     diff.eval()
     ref = sums[0]
+    # when did the exchange run relative to the backward program?  (HIP events on the streams the work ran on, last timed
+    # step; null when nothing was exchanged)
+    overlap = None
+    if exchanging:
+        for eng in model._engines.values():
+            red = getattr(getattr(eng, "backward", None), "reducer", None)
+            if eng.n == B and red is not None:
+                overlap = red.overlap_stats()
+    ov = overlap or {}
     return dict(ms=round(1000.0 * float(tt.item()) / steps, 2), batch_per_gpu=B, global_batch=B * world, steps=steps,
                 dropout=float(model.dropout), loss=round(float(loss.item()), 4),
-                includes="q_sample + UNet fwd/bwd + bucketed RCCL grad all-reduce (overlapped) + fused AdamW/EMA step",
+                includes="q_sample + UNet fwd/bwd + " + ("bucketed grad all-reduce on a side stream under the backward + "
+                                                          if exchanging else "") + "fused AdamW/EMA step (per-step weight re-pack inside)",
                 algorithmic_tflop=round(3 * B * wl["gflop_per_eval_img"] / 1e3, 3),
-                world_size=(dist.get_world_size() if world > 1 else 1),
-                backend=(dist.get_backend() if world > 1 else None),
+                world_size=(dist.get_world_size() if dist.is_initialized() else 1),
+                backend=(str(dist.get_backend()) if dist.is_initialized() else None),
+                exchange=("forced on one rank" if exchanging and world == 1 else bool(exchanging)),
                 per_rank_ms=[round(1000.0 * float(t_.item()) / steps, 2) for t_ in per_rank],
                 grad_checksum_first_step=[[float(v[0]), float(v[1])] for v in sums],
                 # null on one rank: there is nothing to compare, and a trivially true flag reads as a verified exchange
                 grad_checksums_equal=(bool(all(torch.equal(v, ref) for v in sums)) if world > 1 else None),
-                reserved_cus=int(__import__("sgdm_amd.ddp", fromlist=["x"]).reserved_cus(model)))
+                reserved_cus=int(ddp.reserved_cus(model)),
+                exchange_ms=ov.get("exchange_ms"), exposed_exchange_ms=ov.get("exposed_exchange_ms"),
+                first_bucket_at_frac_of_backward=ov.get("first_bucket_at_frac_of_backward"),
+                exchange_buckets=ov.get("per_bucket"), exchange_backward_ms=ov.get("backward_ms"))
+
+
+def exchange_probe(model, diff, data, cond, layout, B, barrier, wl):
+    """the data-parallel training step on ONE rank: a world-size-1 "nccl" (= RCCL) group, `hip_force_exchange` on the model.
+    Never fatal: what fails is reported as a string."""
+    import tempfile
+    import torch.distributed as dist
+    rec = None
+    try:
+        from sgdm_amd.ddp import cap_exchange_channels
+        cap_exchange_channels()
+        with tempfile.TemporaryDirectory() as td:
+            dist.init_process_group("nccl", init_method=f"file://{os.path.join(td, 'store')}", rank=0, world_size=1)
+            try:
+                for e in model._engines.values():
+                    e.backward = None                        # next backward: arena + bucket hooks
+                model.hip_force_exchange = True
+                model._hip_ddp_synced = False
+                rec = train_step_bench(model, diff, data, cond, layout, B, 1, barrier, wl, steps=3, warmup=2)
+            finally:
+                model.hip_force_exchange = False
+                for e in model._engines.values():
+                    e.backward = None
+                dist.destroy_process_group()
+    except Exception as exc:                                 # pragma: no cover - depends on the box
+        return dict(error=f"{type(exc).__name__}: {exc}"[:400])
+    keep = ("ms", "batch_per_gpu", "steps", "world_size", "backend", "exchange", "reserved_cus", "exchange_ms",
+            "exposed_exchange_ms", "first_bucket_at_frac_of_backward", "exchange_backward_ms", "exchange_buckets")
+    return {k: rec[k] for k in keep}
 
 
 def train_step_roofline(model, prec, B, S):
@@ -329,6 +373,9 @@ def main():
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-train", action="store_true")
     ap.add_argument("--train-batch", type=int, default=80, help="per-GPU batch of the train-step leg (metric: bs=80)")
+    ap.add_argument("--no-train40", action="store_true", help="skip the bs=40/GPU train-step leg (configs[2])")
+    ap.add_argument("--no-exchange-probe", action="store_true",
+                    help="skip the one-rank RCCL run of the data-parallel step (train_step.exchange_world1)")
     ap.add_argument("--no-extra", action="store_true", help="skip the f32_exact / c5 / c1 sub-records")
     ap.add_argument("--no-full", action="store_true", help="skip the complete 1000-step trajectory (full_trajectory)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of the hipGraph-captured step")
@@ -348,9 +395,13 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # "nccl" is RCCL on ROCm.  SGDM_DIST_BACKEND=gloo lets several ranks share ONE GPU to exercise this path on a
         # single-GPU box (tests only: the ranks then time-slice the device)
-        # the exchange's kernels get the CUs the training programs leave free (sgdm_amd.ddp.reserved_cus) and no more
-        os.environ.setdefault("NCCL_MAX_NCHANNELS", os.environ.get("SGDM_RESERVE_CUS", "16"))
-        dist.init_process_group(os.environ.get("SGDM_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
+        backend = os.environ.get("SGDM_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            # the exchange's kernels get the CUs the training programs leave free (sgdm_amd.ddp.reserved_cus) and no more:
+            # the PRODUCT's own rule (the same call HipDDPStrategy.setup_environment makes), before the group exists
+            from sgdm_amd.ddp import cap_exchange_channels
+            cap_exchange_channels()
+        dist.init_process_group(backend, rank=rank, world_size=world)
     dev = torch.device("cuda", local_rank)
 
     from sgdm_amd.diffusion import LatentDiffusion
@@ -464,7 +515,7 @@ def main():
 
     # ---- second half of BASELINE.json's metric: DDPM train-step time (q_sample + UNet fwd/bwd + RCCL gradient
     # all-reduce overlapped with backward + AdamW + EMA), per-GPU batch of the config, dropout as configured
-    train = None
+    train = train40 = None
     if not args.no_train:
         from sgdm_amd.synth import synth_batch
         TB = args.train_batch
@@ -476,6 +527,16 @@ def main():
         train = train_step_bench(model, diff, tdata, tcond, tlayout, TB, world, barrier, wl)
         if world == 1 and not args.no_profile:
             train["roofline"] = train_step_roofline(model, args.prec, TB, S)
+        # ---- BASELINE.json configs[2] (C3): the same model at bs=40 per GPU
+        if TB != 40 and not args.no_train40:
+            sl = lambda v: v[:40] if v is not None else None
+            t40 = {k: sl(v) for k, v in tdata.items()}
+            train40 = train_step_bench(model, diff, t40, sl(tcond), sl(tlayout), 40, world, barrier, wl)
+        # ---- one rank: the data-parallel step's own code on the hardware at hand -- a world-size-1 RCCL group with the
+        # exchange forced (arena, bucketed all-reduce through librccl on the side stream, CU reserve): what the N > 1 legs
+        # run, with its overlap record.  A record of the path, not a scaling number.
+        if world == 1 and not args.no_exchange_probe:
+            train["exchange_world1"] = exchange_probe(model, diff, tdata, tcond, tlayout, TB, barrier, wl)
 
     def time_sampling(mdl, dif, bsz, size, kw, steps, warm, skw_):
         """ms per CFG sampling step of `mdl` (setup outside, W untimed + K timed steps, barrier + sync around)"""
@@ -575,7 +636,8 @@ def main():
             "config": {"workload": wl["desc"], "batch_per_gpu": B, "unet_batch": 2 * B, "precision_mode": args.prec,
                        "algorithmic_tflop_per_step": round(2 * B * wl["gflop_per_eval_img"] / 1e3, 3),
                        "launch": "eager" if args.no_graph else "hipGraph-captured step"},
-            "roofline": roof, "cpu_baseline": cpu, "train_step": train, "full_trajectory": full,
+            "roofline": roof, "cpu_baseline": cpu, "train_step": train, "train_step_bs40": train40,
+            "full_trajectory": full,
         }
         out.update(extra)
         print(json.dumps(out), flush=True)

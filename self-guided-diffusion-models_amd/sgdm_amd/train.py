@@ -171,7 +171,7 @@ class Backward:
 
     def wrote(self, name):
         """program point right after the launch that completes parameter `name`: overlapped bucket send"""
-        if self.reducer is None or self.world == 1:
+        if self.reducer is None or not self.reducer.active:
             return
         bi = self.arena.bucket_of[name]
         if self.arena.buckets[bi][2] == name:
@@ -675,6 +675,7 @@ class Backward:
             self.reducer.start()
         self.prog.run(stream)
         if self.reducer is not None:
+            self.reducer.backward_done()     # (overlap record: everything the exchange could hide behind is issued)
             self.reducer.finish()            # flush the tail bucket, join the side stream
         return self.pgrad
 
@@ -700,22 +701,7 @@ class _UNetTrainFn(torch.autograd.Function):
                                "model (same batch/resolution) after the one being differentiated and overwrote its "
                                "activations; call backward() before the next forward")
         model = ctx.model
-        if not getattr(model, "_torch_ddp_checked", False):
-            # the reference's own multi-GPU command wraps the LightningModule in torch DDP (pl.trainer.strategy=ddp): then
-            # torch's reducer owns the exchange -- this path must hand it the gradients through autograd (its hooks sit
-            # on the AccumulateGrad nodes) and must NOT all-reduce them a second time
-            from .ddp import find_torch_ddp_wrapper, torch_ddp_ignores
-            model._torch_ddp_checked = True
-            wrapper = find_torch_ddp_wrapper(model)
-            if wrapper is not None and not torch_ddp_ignores(wrapper, model):
-                import warnings
-                model.hip_ddp = False
-                model.hip_grad_alias = False
-                warnings.warn("sgdm_amd: the model is wrapped in torch DistributedDataParallel -- gradients are handed to "
-                              "torch's reducer (one all-reduce, torch's buckets) and the HIP path's own overlapped RCCL "
-                              "exchange is off.  For the native exchange run one process per GPU WITHOUT the wrapper "
-                              "(sgdm_amd.pl_strategy.HipDDPStrategy) or call sgdm_amd.ddp.exclude_from_torch_ddp(root, "
-                              "unet, ema) before wrapping (INTEGRATION.md).")
+        _check_torch_ddp(model)
         if getattr(eng, "backward", None) is None:
             eng.backward = make_backward(eng)
         # The program writes every parameter gradient into a persistent buffer (a view of the DDP arena when there is one).
@@ -744,20 +730,41 @@ class _UNetTrainFn(torch.autograd.Function):
         return (None, None, None) + tuple(out)
 
 
+def _check_torch_ddp(model):
+    """once per model: the reference's own multi-GPU command wraps the LightningModule in torch DDP
+    (pl.trainer.strategy=ddp): then torch's reducer owns the exchange -- this path must hand it the gradients through
+    autograd (its hooks sit on the AccumulateGrad nodes) and must NOT all-reduce them a second time, nor broadcast the
+    parameters the wrapper's constructor has already broadcast"""
+    if getattr(model, "_torch_ddp_checked", False):
+        return
+    from .ddp import find_torch_ddp_wrapper, torch_ddp_ignores
+    model._torch_ddp_checked = True
+    wrapper = find_torch_ddp_wrapper(model)
+    if wrapper is not None and not torch_ddp_ignores(wrapper, model):
+        import warnings
+        model.hip_ddp = False
+        model.hip_grad_alias = False
+        warnings.warn("sgdm_amd: the model is wrapped in torch DistributedDataParallel -- gradients are handed to "
+                      "torch's reducer (one all-reduce, torch's buckets) and the HIP path's own overlapped RCCL "
+                      "exchange is off.  For the native exchange run one process per GPU WITHOUT the wrapper "
+                      "(sgdm_amd.pl_strategy.HipDDPStrategy) or call sgdm_amd.ddp.exclude_from_torch_ddp(root, "
+                      "unet, ema) before wrapping (INTEGRATION.md).")
+
+
 def make_backward(eng):
     """single process: plain gradient buffers.  torch.distributed initialised with world > 1: a dry build learns the
     order in which the backward produces the parameter gradients, then the real program writes them into a flat
     arena in that order and overlaps the bucketed RCCL all-reduce with the remaining launches."""
-    import torch.distributed as dist
-    world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
-    if world == 1 or not getattr(eng.m, "hip_ddp", True):
+    from .ddp import BucketReducer, GradArena, exchange_active, exchange_forced, exchange_group
+    if not exchange_active(eng.m):
         return Backward(eng)
-    from .ddp import BucketReducer, GradArena
     dry = Backward(eng)
     order = [(name, tuple(g.shape)) for name, g in dry.pgrad.items()]
     del dry
     arena = GradArena(order, eng.dev, bucket_bytes=getattr(eng.m, "hip_bucket_bytes", 64 << 20))
-    return Backward(eng, arena, BucketReducer(arena, average=False))
+    # RCCL: a communicator of the exchange's own, capped at the CU reserve (collective over all ranks: every rank builds
+    # its backward program at its first training step)
+    return Backward(eng, arena, BucketReducer(arena, group=exchange_group(), average=False, force=exchange_forced(eng.m)))
 
 
 def forward_train(model, x, t, cond, layout, mask, n):
@@ -773,10 +780,16 @@ def forward_train(model, x, t, cond, layout, mask, n):
     if not getattr(model, "_hip_ddp_synced", False) and getattr(model, "hip_ddp", True):
         # torch DDP broadcasts rank 0's parameters and buffers when it wraps a module; nothing else on this path would, and
         # replicas that start from different weights (rank-dependent init, a missing seed_everything, per-rank
-        # checkpoints) would train silently diverged: once per model, before its first exchanged training step.  (A
-        # LitEma built before this point holds the old values: sync it too -- HipDDPStrategy and bench.py do.)
-        from .ddp import sync_initial_state
-        sync_initial_state(model)
+        # checkpoints) would train silently diverged: once per model, before its first exchanged training step.  Every
+        # rank enters its first training forward together (it is a collective).  Under torch's own wrapper
+        # (strategy=ddp unchanged) the wrapper's constructor has done this already: look for it FIRST.  A LitEma built
+        # before this point holds the old values: sync the root module early instead -- HipDDPStrategy and bench.py do;
+        # this late call warns on a rank whose values it had to change.
+        from .ddp import exchange_active, sync_initial_state
+        if exchange_active(model):
+            _check_torch_ddp(model)
+        if getattr(model, "hip_ddp", True):
+            sync_initial_state(model, late=True)
     eng = model._engine(n, H, W, prec)
     params = [p for p in model.parameters() if p.requires_grad]
     eps = _UNetTrainFn.apply(model, eng, (x, t, cond, layout, mask), *params)

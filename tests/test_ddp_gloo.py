@@ -214,6 +214,81 @@ def test_pl_strategy_hooks():
             pl_strategy.HipDDPStrategy()
 
 
+def test_pl_strategy_step_dispatch():
+    """Lightning 1.6-1.9's DDPStrategy.training_step is `self.model(*args)` and relies on the
+    LightningDistributedModule wrapper to redirect forward -> training_step.  HipDDPStrategy keeps the bare module, so it
+    must dispatch the four step methods itself, under the precision plugin's context."""
+    import contextlib
+    from sgdm_amd import pl_strategy
+    entered = []
+
+    class Plugin:
+        def _ctx(self, name):
+            @contextlib.contextmanager
+            def cm():
+                entered.append(name)
+                yield
+            return cm
+
+        def __getattr__(self, name):
+            if name.endswith("_context"):
+                return self._ctx(name)
+            raise AttributeError(name)
+
+    class LM(torch.nn.Module):
+        def forward(self, *a, **k):
+            raise AssertionError("forward() reached: the step was not redirected")
+
+        def training_step(self, batch, batch_idx):
+            return ("train", batch, batch_idx)
+
+        def validation_step(self, batch, batch_idx):
+            return ("val", batch, batch_idx)
+
+        def test_step(self, batch, batch_idx):
+            return ("test", batch, batch_idx)
+
+        def predict_step(self, batch, batch_idx):
+            return ("predict", batch, batch_idx)
+
+    class OldDDPStrategy:                                # the 1.6-1.9 shape of the base class
+        def __init__(self, model):
+            self.model, self.precision_plugin = model, Plugin()
+            self.env_calls = 0
+
+        @property
+        def lightning_module(self):
+            return getattr(self.model, "module", self.model)
+
+        def setup_environment(self):
+            self.env_calls += 1
+
+        def training_step(self, *args, **kwargs):
+            return self.model(*args, **kwargs)
+
+        validation_step = test_step = predict_step = training_step
+
+    cls = pl_strategy.make_strategy(OldDDPStrategy)
+    st = cls(LM())
+    assert st.training_step("b", 3) == ("train", "b", 3)
+    assert st.validation_step("b", 4) == ("val", "b", 4)
+    assert st.test_step("b", 5) == ("test", "b", 5)
+    assert st.predict_step("b", 6) == ("predict", "b", 6)
+    assert entered == ["train_step_context", "val_step_context", "test_step_context", "predict_step_context"]
+    # setup_environment: RCCL's channel cap is in the environment before the base class creates the process group
+    old = os.environ.pop("NCCL_MAX_NCHANNELS", None)
+    try:
+        st.setup_environment()
+        assert st.env_calls == 1 and os.environ.get("NCCL_MAX_NCHANNELS") == os.environ.get("SGDM_RESERVE_CUS", "16")
+        os.environ["NCCL_MAX_NCHANNELS"] = "4"           # the user's own setting wins
+        st.setup_environment()
+        assert os.environ["NCCL_MAX_NCHANNELS"] == "4"
+    finally:
+        os.environ.pop("NCCL_MAX_NCHANNELS", None)
+        if old is not None:
+            os.environ["NCCL_MAX_NCHANNELS"] = old
+
+
 def test_torch_ddp_ignores_is_by_identity():
     """a parameter of ANOTHER submodule whose name ends like one of ours must not count as ignored"""
     from sgdm_amd.ddp import torch_ddp_ignores
@@ -236,10 +311,66 @@ def test_torch_ddp_ignores_is_by_identity():
 
 
 def test_reserved_cus_policy(monkeypatch):
-    """one rank reserves nothing; the attribute override works without a process group"""
-    from sgdm_amd.ddp import reserved_cus
+    """one rank reserves nothing; the attribute override works without a process group; a backend that launches no
+    kernels on the device (gloo) needs no compute units"""
+    import tempfile
+    from sgdm_amd.ddp import exchange_active, reserved_cus
     assert reserved_cus(None) == 0
     m = torch.nn.Linear(1, 1)
     assert reserved_cus(m) == 0
     m.hip_reserve_cus = 32
     assert reserved_cus(m) == 32
+    del m.hip_reserve_cus
+    with tempfile.TemporaryDirectory() as td:
+        dist.init_process_group("gloo", init_method=f"file://{os.path.join(td, 'store')}", rank=0, world_size=1)
+        try:
+            assert not exchange_active(m) and reserved_cus(m) == 0
+            m.hip_force_exchange = True                  # one rank, exchange forced: active, but gloo reserves nothing
+            assert exchange_active(m) and reserved_cus(m) == 0
+            m.hip_ddp = False
+            assert not exchange_active(m)
+        finally:
+            dist.destroy_process_group()
+
+
+def _forced_worker(q):
+    """one-rank group with the exchange forced: the collectives are issued, marks recorded, values unchanged"""
+    import tempfile
+    from sgdm_amd.ddp import BucketReducer, GradArena
+    with tempfile.TemporaryDirectory() as td:
+        dist.init_process_group("gloo", init_method=f"file://{os.path.join(td, 'store')}", rank=0, world_size=1)
+        shapes = [("c.weight", (64, 64, 3, 3)), ("b.weight", (64, 64, 3, 3)), ("a.weight", (8, 3))]
+        arena = GradArena(shapes, "cpu", bucket_bytes=64 * 1024)
+        idle = BucketReducer(arena)
+        forced = BucketReducer(arena, force=True)
+        assert not idle.active and forced.active and forced.world == 1
+        g = torch.Generator().manual_seed(1)
+        vals = {n: torch.randn(s, generator=g) for n, s in shapes}
+        forced.start()
+        for n, _ in shapes:
+            arena.grad(n).copy_(vals[n])
+            bi = arena.bucket_of[n]
+            if n == arena.buckets[bi][2]:
+                forced.bucket_ready(bi)
+        forced.backward_done()
+        forced.finish()
+        st = forced.overlap_stats()
+        ok = all(torch.equal(arena.grad(n), vals[n]) for n, _ in shapes)
+        q.put((ok, st))
+        dist.destroy_process_group()
+
+
+def test_forced_exchange_one_rank_records_overlap():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_forced_worker, args=(q,))
+    p.start()
+    ok, st = q.get(timeout=120)
+    p.join(timeout=60)
+    assert p.exitcode == 0 and ok
+    assert st["buckets"] == 3 and len(st["per_bucket"]) == 3
+    assert st["exchange_ms"] >= 0 and st["exposed_exchange_ms"] >= 0 and st["backward_ms"] > 0
+    assert 0.0 <= st["first_bucket_at_frac_of_backward"] <= 1.0
+    # buckets are enqueued in production order and each completes after it was enqueued
+    enq = [b["enqueued_at_ms"] for b in st["per_bucket"]]
+    assert enq == sorted(enq) and all(b["complete_at_ms"] >= b["enqueued_at_ms"] for b in st["per_bucket"])

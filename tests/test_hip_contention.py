@@ -259,5 +259,10 @@ def test_bench_two_ranks_gloo_on_one_gpu():
     assert tr["world_size"] == 2 and tr["backend"] == "gloo" and tr["global_batch"] == 160
     assert len(tr["per_rank_ms"]) == 2 and all(v > 0 for v in tr["per_rank_ms"])
     assert len(tr["grad_checksum_first_step"]) == 2 and tr["grad_checksums_equal"] is True
-    assert tr["reserved_cus"] == 16
+    assert tr["reserved_cus"] == 0                  # gloo launches no kernels on the device: nothing to reserve
+    # the overlap record of the exchange (host-ordered under gloo, HIP events all the same)
+    assert tr["exchange"] is True and tr["exchange_ms"] is not None and tr["exposed_exchange_ms"] is not None
+    assert 0.0 < tr["first_bucket_at_frac_of_backward"] < 1.0
+    assert len(tr["exchange_buckets"]) >= 3
+    assert line["train_step_bs40"]["batch_per_gpu"] == 40 and line["train_step_bs40"]["global_batch"] == 80
     assert line["roofline"]["frac"] > 0 and line["cpu_baseline"] is None
