@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define SGD_ABI_VERSION 14
+#define SGD_ABI_VERSION 15
 int sgd_abi_version(void);
 /* 16 hex digits identifying the sources and flags the library was compiled from (build.py: source_id()); static storage.
  * __graft_entry__.build() and tests/test_boundary_cpu.py compare it with the tree on disk. */
@@ -113,8 +113,25 @@ typedef struct sgd_igemm_args {
      * CU of the device (hipDeviceProp.multiProcessorCount).  Results do not depend on it bit for bit, except for the
      * summation order of the balanced tail's split tiles. */
     int32_t grid_cap;
-    int32_t reserved0;     /* keep 0 */
+    /* Per-call schedule overrides, SGD_TUNE_* bits (0 = the launcher's own rules, which is what the product passes).  They
+     * select among code paths that all return the same result (bit for bit, except where a flag changes the summation order
+     * of split tiles or slabs): parity tests pin one path against another, A/B tools time them.  A field of the call --
+     * the library reads NO environment variable and keeps no global state. */
+    int32_t tune;
 } sgd_igemm_args;
+enum {
+    SGD_TUNE_BN128 = 1,            /* sgd_igemm: the 128-column tile even where the launcher would take 128 x 256 */
+    SGD_TUNE_BN256 = 2,            /* sgd_igemm: the 128 x 256 tile wherever the shape allows */
+    SGD_TUNE_FLAT2 = 4,            /* sgd_igemm, 1x1 / linear: two 32-channel planes per barrier (never with PRO_LN_ROW) */
+    SGD_TUNE_DEFER = 8,            /* sgd_igemm, 3x3 split modes: the epilogue on the loader waves */
+    SGD_TUNE_PLAIN_SCHEDULE = 16,  /* sgd_igemm: no balanced tail even with a workspace */
+    SGD_TUNE_WGRAD_GENERIC_NARROW = 256,  /* sgd_wgrad: stem / head on the generic kernels instead of wgrad_narrow_kernel */
+    SGD_TUNE_WGRAD_NO_POOLED_PLANES = 512,/* sgd_wgrad: fused-average-pool convs on the per-tap kernel (no pooled planes) */
+    SGD_TUNE_WGRAD_F32 = 1024,            /* sgd_wgrad: the exact-f32 per-tap kernel in every mode */
+    SGD_TUNE_WGRAD_NO_WS = 2048,          /* sgd_wgrad: the round-2 all-taps kernel instead of the wave-specialised one */
+    SGD_TUNE_WGRAD_NO_PLANES = 4096,      /* sgd_wgrad: no pre-split operand planes even with scratch */
+    SGD_TUNE_WGRAD_NO_PIPE = 8192         /* sgd_wgrad, 1x1 / linear: synchronous staging (no register pipelining) */
+};
 int64_t sgd_igemm_work_bytes(void);
 /* Balanced-tail health word (DEVICE int32 inside the workspace, byte offset sgd_igemm_work_status_offset()): 0 after a
  * clean run.  A finisher whose producers did not arrive within its bounded poll (~2 s; cannot happen when the launches

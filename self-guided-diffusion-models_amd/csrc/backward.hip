@@ -31,9 +31,9 @@ struct WArgs {
     // wave-specialised kernel with pre-split operands (split_rows_kernel / act_split_kernel): 16-bit hi / lo planes of the
     // gradient [rows][cout] and of the activated input [source rows][cin]
     const void* gh; const void* gl; const void* uh; const void* ul;
-    int no_flat_pipe;           // SGDM_WGRAD_NOPIPE=1 (A/B runs): the synchronous staging of the 1x1 / linear kernel
+    int no_flat_pipe;           // SGD_TUNE_WGRAD_NO_PIPE (A/B runs): the synchronous staging of the 1x1 / linear kernel
 };
-__device__ __forceinline__ bool getenv_flat_pipe_off(const WArgs& w) { return w.no_flat_pipe != 0; }
+__device__ __forceinline__ bool flat_pipe_off(const WArgs& w) { return w.no_flat_pipe != 0; }
 
 template <bool VEC>
 __global__ __launch_bounds__(256) void wgrad_kernel(const WArgs w) {
@@ -265,7 +265,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_conv_kernel(const WArgs w) {
     // wait -> split -> barrier -> 48 MFMAs), two exposed memory latencies per 1.5k-cycle MFMA phase, 150 TF
     bool flat_pipe = false;
     if constexpr (!CONV)
-        flat_pipe = VEC && gy_fast && a.drop_p == 0.f && !getenv_flat_pipe_off(w)
+        flat_pipe = VEC && gy_fast && a.drop_p == 0.f && !flat_pipe_off(w)
                     && (a.pro == SGD_PRO_NONE || (a.pro == SGD_PRO_AFFINE_NC && a.rows_per_n % 64 == 0));
     if (flat_pipe) {
         const int qd = tid & 31, r0 = tid >> 5;
@@ -1493,7 +1493,7 @@ static int wgrad_impl(const sgd_igemm_args* fwd, const float* gy, int32_t gy_ld,
     if (!fwd || !gy || !slabs || cout <= 0 || ksplit <= 0 || gy_ld < cout) return SGD_ERR_ARG;
     WArgs w;
     w.a = *fwd;
-    w.no_flat_pipe = getenv("SGDM_WGRAD_NOPIPE") ? 1 : 0;
+    w.no_flat_pipe = (fwd->tune & SGD_TUNE_WGRAD_NO_PIPE) ? 1 : 0;
     const sgd_igemm_args& a = w.a;
     if (!a.x0 || a.c0 <= 0 || a.c1 < 0 || (a.c1 > 0 && !a.x1)) return SGD_ERR_ARG;
     if (a.pro != SGD_PRO_NONE && (!a.pa || !a.pb)) return SGD_ERR_ARG;
@@ -1518,7 +1518,7 @@ static int wgrad_impl(const sgd_igemm_args* fwd, const float* gy, int32_t gy_ld,
     if (w.rows <= 0) return SGD_ERR_ARG;
     // stem / head: a handful of channels on one side, a whole number of waves of lanes on the other (see the kernels)
     if (a.mode == SGD_MODE_CONV3 && a.stride == 1 && a.resample == SGD_RS_NONE && a.c1 == 0 && a.drop_p == 0.f
-        && ksplit <= (w.rows + 63) / 64 && !getenv("SGDM_WGRAD_NOSMALL")) {
+        && ksplit <= (w.rows + 63) / 64 && !(a.tune & SGD_TUNE_WGRAD_GENERIC_NARROW)) {
         hipStream_t st0 = (hipStream_t)stream;
         const bool lanes_co = cout % 64 == 0 && (cout == 256 || (cout < 256 && 256 % cout == 0));
         const bool lanes_ci = cin % 64 == 0 && (cin == 256 || (cin < 256 && 256 % cin == 0));
@@ -1546,7 +1546,7 @@ static int wgrad_impl(const sgd_igemm_args* fwd, const float* gy, int32_t gy_ld,
     const bool fast_conv = a.mode == SGD_MODE_CONV3 && a.stride == 1 && a.resample != SGD_RS_ZEROUP2 && a.ho % 8 == 0
                            && a.wo % 8 == 0;
     const bool fast_flat = a.mode == SGD_MODE_FLAT && a.pro != SGD_PRO_LN_ROW && cout >= 32 && cin >= 32;
-    if ((fast_conv || fast_flat) && a.prec != SGD_PREC_F32 && !getenv("SGDM_WGRAD_F32")) {
+    if ((fast_conv || fast_flat) && a.prec != SGD_PREC_F32 && !(a.tune & SGD_TUNE_WGRAD_F32)) {
         w.gvec = gy_ld % 4 == 0;
         if (fast_conv) w.ci_tiles = (cin + 31) / 32;
         const long fgrid = (long)w.co_tiles * w.ci_tiles * w.ksplit;
@@ -1555,13 +1555,13 @@ static int wgrad_impl(const sgd_igemm_args* fwd, const float* gy, int32_t gy_ld,
         // input rows, GroupNorm-affine / no prologue, no avg-pool.  (Dropout does not exclude it: with pre-split planes
         // act_split_kernel applies the keep mask through apply_pro, and the in-kernel loader does the same.)
         // the fused average pool (ResBlock(down)) only through the planes: act_split_kernel writes them pooled
-        const bool pooled = a.resample == SGD_RS_AVGPOOL2 && !getenv("SGDM_WGRAD_NOPOOL");
+        const bool pooled = a.resample == SGD_RS_AVGPOOL2 && !(a.tune & SGD_TUNE_WGRAD_NO_POOLED_PLANES);
         const bool ws0 = fast_conv && vec && w.gvec && cout % WT == 0
                          && (a.resample == SGD_RS_NONE || a.resample == SGD_RS_UP2 || pooled)
-                         && (a.pro == SGD_PRO_NONE || a.pro == SGD_PRO_AFFINE_NC) && !getenv("SGDM_WGRAD_OLD");
+                         && (a.pro == SGD_PRO_NONE || a.pro == SGD_PRO_AFFINE_NC) && !(a.tune & SGD_TUNE_WGRAD_NO_WS);
         // ... and with a scratch buffer for the pre-split operand planes: the loaders only copy
         const int64_t need = 4 * ((int64_t)w.rows * cout + (int64_t)a.n * a.hi * a.wi * cin) + 4 * 2048 * (int64_t)cout;
-        const bool planes = ws0 && scratch && scratch_bytes >= need && !getenv("SGDM_WGRAD_NOPLANES");
+        const bool planes = ws0 && scratch && scratch_bytes >= need && !(a.tune & SGD_TUNE_WGRAD_NO_PLANES);
         const bool ws = ws0 && (planes || !pooled);
 #define SGD_WG(P, V)                                                             \
         do { if (planes) launch_wgrad_planes<P>(w, fgrid, scratch, st);           \

@@ -132,14 +132,6 @@ struct Geo {
 #define ABL(bit) false
 #endif
 
-// Hazard experiments (tools/ln_hazard.py, -DSGDM_EXP builds only): an instruction sequence switched on per launch by a bit
-// of the SGDM_EXP environment variable (host side -> args.reserved0).  Folds away in the shipped library.
-#ifdef SGDM_EXP
-#define EXP_HOOK(bit, text) do { if (a.reserved0 & (bit)) asm volatile(text ::: "memory"); } while (0)
-#else
-#define EXP_HOOK(bit, text) do { } while (0)
-#endif
-
 // keep a value live without using it (ablation builds); the "v" constraint exists in the device pass only
 #if defined(__HIP_DEVICE_COMPILE__)
 #define KEEP_LIVE(x) asm volatile("" :: "v"(x))
@@ -396,22 +388,10 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
     // Measured (round 3, tools/ab_conv.py, UNet batch 80, against the 32x32x16 form of the same kernel): +4 % on
     // 128-channel 3x3 layers, +7..9 % at 256..384 input channels, +13..16 % at 512..1024, 1x1 launches unchanged; the
     // sampling step 19.5 -> 18.4 ms.  Same matrix-pipe cycles per flop, but the chip is power-limited under this load
-    // and the smaller MFMA sustains a higher clock.  -DSGDM_NO_MFMA16 builds the 32x32x16 form (A/B runs); the loader-side
-    // epilogue (DEFER) keeps it.
-#ifdef SGDM_NO_MFMA16
-    constexpr bool M16 = false;
-#else
-#ifdef SGDM_M16_256   /* experiment: the 16x16x32 form for the 128 x 256 tile as well */
-    constexpr bool M16 = PREC != SGD_PREC_F32 && !DEFER;
-#else
+    // and the smaller MFMA sustains a higher clock.  The loader-side epilogue (DEFER) and the 128 x 256 tile keep the
+    // 32x32x16 form (the 16x16 form on the wide tile was built and lost 0..14 % to the 128 x 128 tile on every shape:
+    // profiles/r4_ab_m16_256.txt; the code is profiles/r5_igemm_experiments.patch).
     constexpr bool M16 = PREC != SGD_PREC_F32 && BN <= 128 && !DEFER;
-#endif
-#endif
-    // M16 on the 128 x 256 tile (64 columns per wave, 128 accumulator registers): no room for all 8 input units of a K
-    // step next to them, so the step runs as two PASSES over the row blocks -- column blocks {0,1}, then {2,3} -- and the
-    // input units come through a ring of 4 (each is read from LDS once per pass); weights stay single-buffered: a pair is
-    // reloaded for the next step right after its pass and has the other pass (768 matrix-pipe cycles) to land
-    constexpr bool W256 = M16 && BN == 256;
     constexpr int RB = M16 ? WM / 16 : MT, RBH = M16 ? 16 : 32;
     constexpr int CBN = M16 ? WN / 16 : NT, CBW = M16 ? 16 : 32;      // column blocks of a wave tile and their width
     constexpr int QPB = M16 ? 1 : 4;                                  // 4-channel quads a lane holds per (row block, column block)
@@ -532,9 +512,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
         // vector instructions per chunk took 10k cycles and the compute waves waited 27 % of the time at the chunk
         // barrier).  An MFMA needs one issue slot per 32 cycles, so handing the loader the priority costs the matrix
         // pipe nothing as long as the loader's own stream has dependency gaps.
-#ifndef SGDM_NO_LOADER_PRIO
         __builtin_amdgcn_s_setprio(2);
-#endif
         // ---- loader-side epilogue (DEFER) ----------------------------------------------------------------------------
         // Period q (between barriers q and q+1) belongs to tile dk; tile dk - 1 was staged in its first period.  Its 128 x 32
         // quads are 16 per loader thread (thread = channel quad dcq, rows drg + 8 i), drained in dnck - 1 slices of <= 8:
@@ -759,9 +737,6 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
 #pragma unroll
                             for (int j = 0; j < AJ; ++j) finish(slot, j);
                         };
-#ifdef SGDM_PROBE_DRAIN
-                        __builtin_amdgcn_s_waitcnt(0x0F70);             // vmcnt(0): exclude the load wait from the phase time
-#endif
                         PROBE_EPI(finish_all());                        // probe build: cycles of the transform phase
                         const int kprev = s2.k;
                         s2 = advance(s2);
@@ -873,40 +848,20 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
                 };
                 auto finish = [&](int slot, auto rc, int sub = 0) {      // stage the plane under the finish cursor
                     constexpr int R = decltype(rc)::value;
-                    EXP_HOOK(2, "s_waitcnt vmcnt(0)");
 #pragma unroll
                     for (int j = 0; j < AI; ++j) {
                         f32x4 v = araw[R][j];
                         if constexpr (tile_uni) v = v * kq[R].p + kq[R].q;
                         if constexpr (ln) {
-#ifdef SGDM_EXP       /* bit 256: the normalised value (before gamma / beta) of element 0 to the side buffer; bit 512: x - mean */
-                            if ((a.reserved0 & 768) && a.x1 && cf.m0 + arow + j * AROWS < M) {
-                                const f32x4 d = v - rst[R][j].x;
-                                const f32x4 tn = d * rst[R][j].y;
-                                const_cast<float*>(a.x1)[(long)(cf.m0 + arow + j * AROWS) * (cin >> 2) + cf.chunk * 8 + c4] =
-                                    (a.reserved0 & 512) ? d[0] : tn[0];
-                                v = tn * kq[R].p;
-                                if (a.pc) v += kq[R].q;
-                            } else
-#endif
-                            {
                             v = (v - rst[R][j].x) * rst[R][j].y * kq[R].p;
                             if (a.pc) v += kq[R].q;
-                            }
                         }
                         if constexpr (SILU) {
 #pragma unroll
                             for (int e = 0; e < 4; ++e) v[e] = sgd_silu(v[e]);
                         }
                         if (cf.m0 + arow + j * AROWS >= M) v = f32x4{0.f, 0.f, 0.f, 0.f};
-                        EXP_HOOK(8, "s_nop 7\n\ts_nop 7");
-#ifdef SGDM_EXP       /* bit 128: element 0 of the quad as the loader formed it, to a side buffer (args.x1, unused when c1 == 0) */
-                        if ((a.reserved0 & 128) && a.x1 && cf.m0 + arow + j * AROWS < M)
-                            const_cast<float*>(a.x1)[(long)(cf.m0 + arow + j * AROWS) * (cin >> 2) + cf.chunk * 8 + c4] = v[0];
-#endif
                         lds_store_act<PREC>(As + (size_t)slot * a_floats + (size_t)(sub * BM + arow + j * AROWS) * LDA, c4, v);
-                        EXP_HOOK(1, "s_nop 7\n\ts_nop 7");
-                        EXP_HOOK(4, "s_waitcnt lgkmcnt(0)");
                     }
                     advance(cf);
                 };
@@ -1226,26 +1181,6 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
         }
         aoff[mt] = p * LDA;
     }
-    // W256 (128 accumulator registers): the 8 row-block offsets as ONE vector register + wave-uniform steps.  Row block
-    // mt covers tile rows 16 mt .. 16 mt + 15; inside an image the halo offset is linear in mt, and every `mpi` row blocks
-    // the next image of the tile starts (8x8 maps: two images per tile):  aoff[mt] = aoff[0] + mt * astep + (mt >> mpi_l2) * bstep
-    int astep = 16 * LDA, bstep = 0, mpi_l2 = 8;
-    if constexpr (W256 && CONV) {
-        const int rpi_l2 = g.tw_l2 + g.th_l2;                    // log2 of the tile rows of one image
-        if (rpi_l2 >= 4) {
-            const int u = TW >= 16 ? 1 : (16 >> g.tw_l2);        // image rows per 16-row block
-            astep = u * s * g.hw * LDA;
-            mpi_l2 = rpi_l2 - 4;
-            bstep = g.hh * g.hw * LDA - (astep << mpi_l2);
-        } else {
-            astep = (16 >> rpi_l2) * g.hh * g.hw * LDA;          // a row block spans whole images
-        }
-    }
-    const int aoff0 = aoff[0];
-    auto aoff_at = [&](int mt) __attribute__((always_inline)) {
-        if constexpr (W256) return aoff0 + mt * astep + (mt >> mpi_l2) * bstep;
-        else return aoff[mt];
-    };
     // weight fragments: wave (wm, wn) needs N blocks wn*NT .. wn*NT+NT-1 of its tile; consecutive K steps of the stream
     // [chunk][tap] are `wstep` bytes apart (all N blocks of the layer for that step)
     const size_t wstep = (size_t)(a.cout_p >> 5) * WUNIT;
@@ -1277,8 +1212,8 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
     // is reloaded for the NEXT step right after its last use (column block CBN - 1), the weights of column block cb right
     // after stage (cb, RB - 1): every reload has RB - 1 .. RB stages (>= 336 matrix-pipe cycles) to land, with single
     // buffers and compile-time register indices.
-    constexpr int STAGES = W256 ? 2 * RB : (M16 ? RB * CBN : NKS * MT);    // per K step
-    constexpr int RING = W256 ? 4 : (M16 ? RB : (STAGES >= 4 ? 4 : 2));   // STAGES % RING == 0: a K step always starts at ring slot 0
+    constexpr int STAGES = M16 ? RB * CBN : NKS * MT;    // per K step
+    constexpr int RING = M16 ? RB : (STAGES >= 4 ? 4 : 2);   // STAGES % RING == 0: a K step always starts at ring slot 0
     constexpr int DEPTH = RING - 1;
     static_assert(STAGES % RING == 0, "ring position must be a compile-time constant inside a K step");
     std::conditional_t<M16, typename Frag16<PREC, 1>::AU, typename FragT::AU> ring[RING];
@@ -1300,18 +1235,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
             constexpr bool wrap = st + DEPTH >= STAGES;
             const float* pbase = (wrap && seam) ? anext : acur;
             constexpr int ptap = wrap ? (seam ? 0 : tap + 1) : tap;
-            if constexpr (W256) {
-                constexpr int half = st / RB;
-                if (!ABL(64)) ring[(st + DEPTH) % RING].load(pbase + tap_off(ptap) + aoff_at(pst % RB), lane >> 4);
-                if (!ABL(16)) {
-                    acc[mt][2 * half] = Frag16<PREC, 1>::mma1(acc[mt][2 * half], ring[st % RING], fb16[2 * half]);
-                    acc[mt][2 * half + 1] = Frag16<PREC, 1>::mma1(acc[mt][2 * half + 1], ring[st % RING], fb16[2 * half + 1]);
-                }
-                if (mt == RB - 1 && !ABL(32)) {
-                    fb16[2 * half].load(wnext + half * WUNIT);
-                    fb16[2 * half + 1].load(wnext + half * WUNIT + 256);
-                }
-            } else if constexpr (M16) {
+            if constexpr (M16) {
                 constexpr int cbi = st / RB;
                 const float* nbase = seam ? anext : acur;                  // next step: next tap of this chunk / next chunk
                 constexpr int ntap = seam ? 0 : tap + 1;
@@ -1328,10 +1252,10 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
             // (a burst of reads in front of the MFMAs fills the LDS queue and the in-order wave cannot issue its MFMAs
             // until they are accepted)
             {
-                constexpr int NM = W256 ? 6 : (M16 ? 3 : FragT::NMMA);
-                constexpr int NR = W256 ? 2 : (M16 ? (st / RB == CBN - 1 ? 2 : 0) : FragT::NREADS);
+                constexpr int NM = M16 ? 3 : FragT::NMMA;
+                constexpr int NR = M16 ? (st / RB == CBN - 1 ? 2 : 0) : FragT::NREADS;
                 constexpr int P1 = NR < NM ? NR : NM;
-                constexpr int nw = W256 ? (st % RB == RB - 1 ? 4 : 0) : (M16 ? (st % RB == RB - 1 ? 2 : 0) : ((mt == MT - 1) ? FragT::NWLOADS : 0));
+                constexpr int nw = M16 ? (st % RB == RB - 1 ? 2 : 0) : ((mt == MT - 1) ? FragT::NWLOADS : 0);
                 constexpr int P2 = nw < NM - P1 ? nw : NM - P1;
 #pragma unroll
                 for (int i = 0; i < P1; ++i) {
@@ -1362,8 +1286,8 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
     }
     SYNC();                               // pairs with the loaders' prologue barrier: chunks 0 AND 1 are staged
 #pragma unroll
-    for (int st = 0; st < ((M16 && !W256) ? RB : DEPTH); ++st) {
-        if constexpr (M16) ring[st].load(As + aoff_at(st % RB), lane >> 4);
+    for (int st = 0; st < (M16 ? RB : DEPTH); ++st) {
+        if constexpr (M16) ring[st].load(As + aoff[st % RB], lane >> 4);
         else ring[st].load(As + aoff[st % MT], st / MT, lh);
     }
     int aslot = 0;                                 // ring position of the current chunk
@@ -1465,7 +1389,13 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
                     __builtin_amdgcn_s_sleep(16);
                     if (++polls >= FINISH_POLL_MAX) { late = 1; break; }
                 }
-                if (late) __hip_atomic_store(reinterpret_cast<int*>(a.work) + WORK_STATUS_INT, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                int* const status = reinterpret_cast<int*>(a.work) + WORK_STATUS_INT;
+                if (late) __hip_atomic_store(status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // A workspace that has timed out once is not trusted again until the host has zeroed it: producers of the
+                // failed launch may still arrive and push a LATER launch's counters over their target early -- stale slabs,
+                // wrong values that are not NaN.  While the health word is up every split tile is poisoned (loud), and the
+                // host paths that own a workspace check the word at their sync points (unet._Engine.check_health).
+                else if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) late = 2;
             }
             if (__builtin_amdgcn_readfirstlane(late)) wsk = __builtin_nanf("");      // bounded poll expired: poison, do not hang
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -1704,11 +1634,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
                     // for again here they would sit behind the acknowledgement of the epilogue's 16 stores (vmcnt is in
                     // order); the input units come from LDS
 #pragma unroll
-                    for (int st = 0; st < (W256 ? DEPTH : RB); ++st) ring[st].load(a0 + aoff_at(st % RB), lane >> 4);
-                    if constexpr (W256) {     // 128 accumulator registers: the 32 weight registers are not carried either
-#pragma unroll
-                        for (int cb = 0; cb < CBN; ++cb) fb16[cb].load(wp + (cb >> 1) * WUNIT + (cb & 1) * 256);
-                    }
+                    for (int st = 0; st < RB; ++st) ring[st].load(a0 + aoff[st % RB], lane >> 4);
                 } else {
 #pragma unroll
                     for (int ks = 0; ks < NKS; ++ks) fb[ks].load(wp, ks);
@@ -1892,10 +1818,7 @@ int launch1(const KArgs& ka, size_t smem, hipStream_t st) {
     // free for another stream (args.grid_cap), in whole groups of 8 (one block per XCD and group)
     int full = device_cus();
     if (ka.a.grid_cap > 0 && ka.a.grid_cap < full) full = ka.a.grid_cap >= 8 ? (ka.a.grid_cap & ~7) : 8;
-    if (const char* e = getenv("SGDM_MAX_GRID")) {     // tests: few blocks, so that small problems walk many tiles per block
-        const int cap = atoi(e) & ~7;
-        if (cap >= 8 && full > cap) full = cap;
-    }
+    // (tests cap the grid the same way so that small problems walk many tiles per block)
     int grid = ((total + 7) / 8) * 8;
     if (grid > full) grid = full;
     if (ka.a.work && total >= 8) grid = full;     // balanced tail: blocks without a whole tile take K parts of the last ones
@@ -2114,12 +2037,10 @@ static int make_geo(const sgd_igemm_args& a, Geo& g, int bn, int& na, int fg = 1
     return SGD_OK;
 }
 
-// SGDM_BN256: 0 never, 1 whenever the shape allows, unset: when the launch has enough tiles to keep every CU busy
+// args.tune: SGD_TUNE_BN128 never, SGD_TUNE_BN256 whenever the shape allows; default: the rule below
 static bool want_bn256(const sgd_igemm_args& a) {
-    const char* e = getenv("SGDM_BN256");          // read per call: tools flip it between launches of one process
-    const int mode = e ? atoi(e) : -1;
-    if (mode == 0) return false;
-    if (mode == 1) return true;
+    if (a.tune & SGD_TUNE_BN128) return false;
+    if (a.tune & SGD_TUNE_BN256) return true;
     // whole rounds of 256 persistent blocks: a 128 x 256 tile costs 2 / 1.07 of a 128 x 128 one (measured, tools/ab_conv.py:
     // +5..9 % where both shapes fill the chip evenly), so it wins unless the coarser tiles quantise worse
     const long rows = a.mode == SGD_MODE_CONV3 ? (long)a.n * a.ho * a.wo : (long)a.m;
@@ -2194,7 +2115,7 @@ extern "C" int sgd_igemm(const sgd_igemm_args* args, void* stream) {
     if (bn == 128 && a.cout_p % 256 == 0 && vec && (!a.res || a.res_mode == SGD_RS_NONE) && want_bn256(a)) bn = 256;
     int na;
     const bool conv = a.mode == SGD_MODE_CONV3;
-    // Two planes per chunk (igemm_kernel<.., TAPS = 2>): OPT-IN, SGDM_FLAT2=1.  Flat launches the lean loaders serve
+    // Two planes per chunk (igemm_kernel<.., TAPS = 2>): OPT-IN, args.tune & SGD_TUNE_FLAT2.  Flat launches the lean loaders serve
     // (16-byte rows, no / per-image GroupNorm prologue, no dropout, whole 32-channel planes per source) with an even
     // number of planes.  Measured (round 4, tools/ab_conv.py, UNet batch 80): bit-identical to the one-plane instance,
     // +3..6 % on proj_out / decoder skips with a prologue, 0..3 % on plain ones, 0 on qkv and the HBM-bound 64x64 skips
@@ -2204,33 +2125,21 @@ extern "C" int sgd_igemm(const sgd_igemm_args* args, void* stream) {
     // DESIGN.md section 4 (round 4) and profiles/r4_ln_hazard.txt hold what tools/ln_hazard.py established: the wrong
     // cells hold exactly beta in the low lane of a packed-f32 pair (the LayerNorm value with a zero product), in three of
     // the six unrolled copies of the staging code only; no wait or idle cycle around the loads or the LDS stores changes
-    // it, moving the surrounding code does.  Cause open (-DSGDM_FLAT2_LN -DSGDM_EXP builds the combination).  A 0.3 %
-    // gain does not buy an unexplained failure mode: the instance is not a default, and never serves that prologue.
+    // it, moving the surrounding code does.  Cause open (profiles/r5_igemm_experiments.patch re-adds the diagnostic
+    // build of the combination).  A 0.3 % gain does not buy an unexplained failure mode: the instance is not a default,
+    // and never serves that prologue.
     int taps = conv ? 9 : 1;
     if (!conv && vec && bn >= 128 && a.drop_p == 0.f && cin % (2 * KC) == 0 && (a.c1 == 0 || a.c0 % KC == 0)
-        && (a.pro == SGD_PRO_NONE || (a.pro == SGD_PRO_AFFINE_NC && a.rows_per_n > 0 && a.rows_per_n % BM == 0))) {
-        const char* e = getenv("SGDM_FLAT2");
-        if (e && atoi(e) == 1) taps = 2;
-    }
-#ifdef SGDM_EXP
-    { const char* e = getenv("SGDM_EXP"); a.reserved0 = e ? atoi(e) : 0; }
-#endif
-#ifdef SGDM_FLAT2_LN      /* diagnostic builds only: the LayerNorm prologue on the two-plane instance (see above) */
-    if (!conv && vec && bn >= 128 && a.drop_p == 0.f && cin % (2 * KC) == 0 && a.pro == SGD_PRO_LN_ROW) {
-        const char* e = getenv("SGDM_FLAT2");
-        if (e && atoi(e) == 1) taps = 2;
-    }
-#endif
+        && (a.pro == SGD_PRO_NONE || (a.pro == SGD_PRO_AFFINE_NC && a.rows_per_n > 0 && a.rows_per_n % BM == 0))
+        && (a.tune & SGD_TUNE_FLAT2))
+        taps = 2;
     {
         const int rc = make_geo(a, g, bn, na, conv ? 1 : taps);
         if (rc != SGD_OK) return rc;
     }
     if (a.stats && g.sparts == 0) return SGD_ERR_ARG;
     g.nt = a.cout_p / bn;
-    {
-        const char* e = getenv("SGDM_BALANCE");   // 0: plain schedule even with a workspace (A/B runs)
-        if ((a.work && a.work_bytes < sgd_igemm_work_bytes()) || (e && atoi(e) == 0)) a.work = nullptr;
-    }
+    if ((a.work && a.work_bytes < sgd_igemm_work_bytes()) || (a.tune & SGD_TUNE_PLAIN_SCHEDULE)) a.work = nullptr;
     {
         // epilogue uses 32-bit row indices
         const long rows_out = a.mode == SGD_MODE_CONV3 ? (long)a.n * a.ho * a.wo : (long)a.m;
@@ -2257,17 +2166,16 @@ extern "C" int sgd_igemm(const sgd_igemm_args* args, void* stream) {
     int variant = vec ? 1 : 0;
     size_t smem_launch = smem;
     {
-        // Opt-in (SGDM_DEFER=1).  Measured (round 3, UNet batch 80): correct, the compute waves' epilogue time drops from
+        // Opt-in (args.tune & SGD_TUNE_DEFER).  Measured (round 3, UNet batch 80): correct, the compute waves' epilogue time drops from
         // 8..10 us per tile to 0.3 us -- and the launches are 3..7 % SLOWER: the chip is power-limited, the idle wait cost
         // little energy, and the staging copy plus the loaders' extra instructions cost more than the wait saved.
-        const char* e = getenv("SGDM_DEFER");
         const int nchunks = (cin + KC - 1) / KC;
         const long rows_out = (long)a.n * a.ho * a.wo;
         const size_t smem_defer = smem + (size_t)BM * (128 + 4) * sizeof(float);
         if (conv && vec && bn == 128 && a.prec != SGD_PREC_F32 && ((a.cout | a.y_ld) & 3) == 0
             && (!a.res || a.res_mode == SGD_RS_NONE) && a.resample != SGD_RS_AVGPOOL2 && a.cout_p <= BIAS_LDS_MAX && nchunks >= 3
             && rows_out * a.y_ld * 4 < (1L << 32) && (!a.stats || (long)a.n * g.sparts * 2 * a.cout * 4 < (1L << 32))
-            && smem_defer <= 160 * 1024 && e && atoi(e) == 1) {
+            && smem_defer <= 160 * 1024 && (a.tune & SGD_TUNE_DEFER)) {
             variant = 2;
             smem_launch = smem_defer;
         }

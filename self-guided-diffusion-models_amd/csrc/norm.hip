@@ -105,7 +105,9 @@ __global__ void gn_coef_kernel(const float* __restrict__ sums, const float* __re
 // sgd_stats_reduce (for up to two concatenated sources) + sgd_gn_coef in ONE launch: one block per image.
 // Phase 1 folds the producers' partial statistics into sums[n, c, 2] (kept: the training backward reads them; a source
 // with parts == 0 already has its sums there, written by sgd_chan_stats); phase 2 is gn_coef_kernel's arithmetic on the
-// float-rounded sums, so both routes give bit-identical coefficients.
+// float-rounded sums.  The partials are folded in DOUBLE in strided groups, sgd_stats_reduce folds them in index order: the
+// two routes agree wherever the double sums round to the same float -- in practice always, but the contract is the
+// tolerance of tests/test_hip_kernels.py::test_groupnorm_coefficients_from_partial_statistics (1e-6), not bit identity.
 __global__ __launch_bounds__(512) void gn_coef_parts_kernel(const float* __restrict__ p0, int parts0, int c0,
                                                             const float* __restrict__ p1, int parts1, int c1,
                                                             float* __restrict__ sums, const float* __restrict__ gamma,
@@ -329,7 +331,19 @@ extern "C" int sgd_gn_coef_parts(const float* p0, int32_t parts0, int32_t c0, co
         return SGD_ERR_ARG;
     if (film && film_ld < 2 * c) return SGD_ERR_ARG;
     const int nthr = 512, G = c < nthr ? nthr / c : 1;
-    hipLaunchKernelGGL(gn_coef_parts_kernel, dim3(n), dim3(nthr), (size_t)G * c * 2 * sizeof(double) + (size_t)c * 2 * sizeof(float),
+    // dynamic LDS: G partial double pairs per channel + the folded float pair: 24 bytes per channel from 512 channels on.
+    // Above the 64 KB default (c > 2730) the function attribute is raised once; what does not fit a CU's 160 KB is refused
+    // here instead of failing at launch (the guard used to be the 8-bytes-per-channel figure of the round-3 kernel)
+    const size_t lds = (size_t)G * c * 2 * sizeof(double) + (size_t)c * 2 * sizeof(float);
+    if (lds > 160 * 1024) return SGD_ERR_ARG;
+    if (lds > 64 * 1024) {
+        static bool raised = false;
+        if (!raised) {
+            (void)hipFuncSetAttribute((const void*)gn_coef_parts_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            raised = true;
+        }
+    }
+    hipLaunchKernelGGL(gn_coef_parts_kernel, dim3(n), dim3(nthr), lds,
                        (hipStream_t)stream, p0, parts0, c0, p1, parts1, c1, sums, gamma, beta, film, film_ld, groups, hw, eps, a, b);
     return sgd_check_launch();
 }

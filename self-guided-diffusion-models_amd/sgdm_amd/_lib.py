@@ -20,7 +20,12 @@ RS_NONE, RS_AVGPOOL2, RS_UP2, RS_ZEROUP2 = 0, 1, 2, 3
 PRO_NONE, PRO_AFFINE_NC, PRO_LN_ROW = 0, 1, 2
 PREC_F32, PREC_F16X3, PREC_BF16X3 = 0, 1, 2
 PREC_BY_NAME = {"f32": PREC_F32, "f16x3": PREC_F16X3, "bf16x3": PREC_BF16X3}
-ABI_VERSION = 14
+ABI_VERSION = 15
+
+# sgd_igemm_args.tune (include/sgdm_hip.h: SGD_TUNE_*): per-call schedule overrides for parity tests and A/B tools
+TUNE_BN128, TUNE_BN256, TUNE_FLAT2, TUNE_DEFER, TUNE_PLAIN_SCHEDULE = 1, 2, 4, 8, 16
+TUNE_WGRAD_GENERIC_NARROW, TUNE_WGRAD_NO_POOLED_PLANES, TUNE_WGRAD_F32 = 256, 512, 1024
+TUNE_WGRAD_NO_WS, TUNE_WGRAD_NO_PLANES, TUNE_WGRAD_NO_PIPE = 2048, 4096, 8192
 
 vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
@@ -35,7 +40,7 @@ class IgemmArgs(C.Structure):
         ("bias", vp), ("res", vp), ("res_mode", i32), ("y", vp), ("cout", i32), ("y_ld", i32),
         ("orows_in", i32), ("orows_out", i32), ("orow_off", i32), ("prec", i32),
         ("drop_p", f32), ("drop_seed", C.c_uint32), ("stats", vp), ("w_scale_inv", vp),
-        ("work", vp), ("work_bytes", i64), ("grid_cap", i32), ("reserved0", i32),
+        ("work", vp), ("work_bytes", i64), ("grid_cap", i32), ("tune", i32),
     ]
 
 

@@ -689,6 +689,12 @@ class LatentDiffusion(nn.Module):
             shape=shape, denoise_sample_fn=self.denoise_sample_fn, sampling_kwargs=sk, **kwargs)
         samples = to_uint8(samples)
         inter["pred_x0"] = to_uint8(inter["pred_x0"])
+        # end of a trajectory: the one place this path synchronises anyway -- a conv launch whose balanced tail timed out has
+        # poisoned its outputs with NaN and flagged its workspace; raise here instead of handing NaN images on
+        unet = _unet_of(getattr(self.denoise_sample_fn, "_sgdm_inner", self.denoise_sample_fn))
+        if unet is not None:
+            for eng in list(unet._engines.values()):
+                eng.check_health()
         return samples, inter
 
     def vis_schedule(self):

@@ -92,9 +92,13 @@ def wgrad_ksplit(taps, cout, cin, rows):
     so that the grid is as close as possible to a whole number of rounds of the 256 CUs with at least ~8 K tiles per
     block; 1x1 / linear launches (256-thread blocks, two per CU, 128 input channels per block) keep the round-2 rule."""
     ktiles = (rows + 63) // 64
-    if taps == 9 and (cin <= 4 or cout == 3):
-        # stem / head (csrc/backward.hip: wgrad_narrow_kernel): HBM-bound row walks, one 256-thread block per slab in
-        # chunks of 128 rows -- two blocks per CU at bs 80 (~640 rows each)
+    # stem / head (csrc/backward.hip, wgrad_impl: wgrad_narrow_kernel): 3 / 4 channels on one side and, on the other, a
+    # whole number of waves of lanes that divides (or equals) the 256-thread block -- the SAME predicate as the launcher's
+    # (`lanes_co` / `lanes_ci`); other widths (the ch = 224 plans) fall through to the generic kernels and their rules
+    lanes = lambda c: c % 64 == 0 and (c == 256 or (c < 256 and 256 % c == 0))
+    if taps == 9 and ((3 <= cin <= 4 and lanes(cout)) or (cout == 3 and lanes(cin))):
+        # HBM-bound row walks, one 256-thread block per slab in chunks of 128 rows -- two blocks per CU at bs 80 (~640
+        # rows each)
         return max(1, min(ktiles, 1024, -(-rows // 640)))
     if taps == 9:
         per_k = ((cout + 127) // 128) * ((cin + 31) // 32)
@@ -677,6 +681,7 @@ class Backward:
         if self.reducer is not None:
             self.reducer.backward_done()     # (overlap record: everything the exchange could hide behind is issued)
             self.reducer.finish()            # flush the tail bucket, join the side stream
+        self.e.note_health()                 # balanced-tail health word -> pinned host memory, read at the next step
         return self.pgrad
 
 

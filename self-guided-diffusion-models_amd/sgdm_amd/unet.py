@@ -857,6 +857,43 @@ class _Engine:
             self._film_bias.copy_(torch.cat([b.detach().reshape(-1) for b in self._film_bias_src]))
             self._film_sig = sig
 
+    # ---- balanced-tail health word (include/sgdm_hip.h: sgd_igemm_work_status_offset).  A finisher whose producers did not
+    # arrive within its bounded poll poisons its tile with NaN and raises the word; from then on every split tile on this
+    # workspace is poisoned until the host zeroes it.  The paths that own a workspace honour that contract here: the
+    # samplers at the end of a trajectory (check_health: one 4-byte read), the training step without a sync of its own
+    # (note_health after the backward program, looked at when the next step is prepared).
+    def _health_fail(self):
+        self.work.zero_()
+        raise RuntimeError("sgdm_amd: a conv launch's balanced tail timed out waiting for another block's partial sums "
+                           "(stale arrival counters: a faulted launch, or two streams on one engine); the affected outputs "
+                           "were poisoned with NaN.  The workspace has been re-zeroed: rerun the step.")
+
+    def check_health(self):
+        """synchronising check (end of a sampling trajectory, tests)"""
+        if self.work_bytes:
+            off = int(self.lib.sgd_igemm_work_status_offset()) // 4
+            if int(self.work.view(torch.int32)[off].item()) != 0:
+                self._health_fail()
+
+    def note_health(self):
+        """asynchronous: copy the word to pinned host memory behind the launches issued so far"""
+        if not self.work_bytes:
+            return
+        if getattr(self, "_health_host", None) is None:
+            self._health_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+            self._health_off = int(self.lib.sgd_igemm_work_status_offset()) // 4
+        self._health_host.copy_(self.work.view(torch.int32)[self._health_off:self._health_off + 1], non_blocking=True)
+        self._health_ev = torch.cuda.Event()
+        self._health_ev.record()
+
+    def poll_health(self):
+        """look at the last note_health() if its copy has landed (never waits)"""
+        ev = getattr(self, "_health_ev", None)
+        if ev is not None and ev.query():
+            self._health_ev = None
+            if int(self._health_host[0]) != 0:
+                self._health_fail()
+
     def set_grid_cap(self, reserve):
         """sgd_igemm_args.grid_cap of every conv / linear launch of the BACKWARD program: all CUs but `reserve` (0: the
         whole device).  The gradient exchange runs under the backward only -- the optimizer waits for it, so the next
@@ -883,6 +920,7 @@ class _Engine:
         the SAME buffers on every replay, so a caller that replays must update them in place."""
         m, n = self.m, self.n
         stream = torch.cuda.current_stream().cuda_stream
+        self.poll_health()
         self.refresh(stream)
         # training step of a data-parallel job: the persistent conv grid leaves CUs to the gradient exchange that runs on a
         # side stream under the backward (ddp.reserved_cus); every other evaluation owns the device

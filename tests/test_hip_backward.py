@@ -251,7 +251,7 @@ def test_conv_wgrad_stem_and_head(kind, n, h, ch, prec, monkeypatch):
     ks = _train_ksplit(9, cout, cin, n * h * h)
     dw = _wgrad(L, lib, fwd, gyd, cout, cin, 9, ks)
     assert max_rel(dw.reshape(cout, cin, 3, 3), w.grad.float()) < 5e-6
-    monkeypatch.setenv("SGDM_WGRAD_NOSMALL", "1")             # the generic kernel they replace, same slabs
+    fwd.tune = L.TUNE_WGRAD_GENERIC_NARROW                    # the generic kernel they replace, same slabs
     dw_old = _wgrad(L, lib, fwd, gyd, cout, cin, 9, ks)
     assert max_rel(dw_old.reshape(cout, cin, 3, 3), w.grad.float()) < (5e-6 if prec == "f32" else 3e-5)
 
@@ -280,7 +280,7 @@ def test_conv_wgrad_fused_avgpool_through_pooled_planes(shape, prec, tol, monkey
     dw = _wgrad(L, lib, fwd, gyd, cout, cin, 9, ks, scratch=True)            # pooled planes + wave-specialised kernel
     err = max_rel(dw.reshape(cout, cin, 3, 3), w.grad.float())
     assert err < tol, err
-    monkeypatch.setenv("SGDM_WGRAD_NOPOOL", "1")
+    fwd.tune = L.TUNE_WGRAD_NO_POOLED_PLANES
     dw_old = _wgrad(L, lib, fwd, gyd, cout, cin, 9, ks, scratch=True)        # the generic kernel it replaces
     assert max_rel(dw_old.reshape(cout, cin, 3, 3), w.grad.float()) < tol
     assert max_rel(dw, dw_old) < tol

@@ -64,7 +64,7 @@ def _tiles(rows, cout):
 
 
 def _conv(L, lib, prec, x0, x1, wbuf, cin_p, cout_p, cout, dims, bias=None, pa=None, pb=None, silu=0, resample=0, stride=1,
-          res=None, res_mode=0, stats=False):
+          res=None, res_mode=0, stats=False, tune=0, grid_cap=0):
     """x0/x1/res: NHWC device tensors; returns the NHWC output (and the folded statistics)"""
     n, hi, wi, ho, wo = dims
     a = L.IgemmArgs()
@@ -80,6 +80,7 @@ def _conv(L, lib, prec, x0, x1, wbuf, cin_p, cout_p, cout, dims, bias=None, pa=N
     a.res, a.res_mode = (res.data_ptr() if res is not None else 0), res_mode
     y = torch.full((n, ho, wo, cout), float("nan"), device="cuda")
     a.y, a.cout, a.y_ld, a.prec = y.data_ptr(), cout, cout, prec
+    a.tune, a.grid_cap = tune, grid_cap
     sums = None
     if stats:
         parts = lib.sgd_igemm_stats_parts(C.byref(a))
@@ -189,7 +190,7 @@ def test_conv3x3_dgrad_at_unet_batch_80(shape, prec, tol):
     _check(got, lambda idx: ref(torch.float64, idx), ref(torch.float32), tol)
 
 
-def _flat(L, lib, prec, x0, x1, w, bias, m, rows_per_n=0, pa=None, pb=None, silu=0, res=None, adjoint=False):
+def _flat(L, lib, prec, x0, x1, w, bias, m, rows_per_n=0, pa=None, pb=None, silu=0, res=None, adjoint=False, tune=0):
     wbuf, cp, op = _pack(w.cuda(), 1, prec, adjoint=adjoint)
     nout = w.shape[1] if adjoint else w.shape[0]
     a = L.IgemmArgs()
@@ -205,6 +206,7 @@ def _flat(L, lib, prec, x0, x1, w, bias, m, rows_per_n=0, pa=None, pb=None, silu
     a.res = res.data_ptr() if res is not None else 0
     y = torch.full((m, nout), float("nan"), device="cuda")
     a.y, a.cout, a.y_ld, a.prec = y.data_ptr(), nout, nout, prec
+    a.tune = tune
     L.check(lib.sgd_igemm(C.byref(a), _stream()), "igemm")
     torch.cuda.synchronize()
     return y
@@ -256,8 +258,8 @@ def test_conv1x1_at_unet_batch_80(case, prec, tol):
 
 @pytest.mark.parametrize("prec", ["f32", "f16x3", "bf16x3"])
 @pytest.mark.parametrize("case", sorted(FLAT_CASES) + ["odd_planes", "ragged_rows", "silu_only"])
-def test_two_plane_flat_instance_equals_one_plane(case, prec, monkeypatch):
-    """round 4, opt-in (SGDM_FLAT2=1): 1x1 / linear launches stage TWO 32-channel planes per barrier (igemm_kernel<..,
+def test_two_plane_flat_instance_equals_one_plane(case, prec):
+    """round 4, opt-in (sgd_igemm_args.tune & SGD_TUNE_FLAT2): 1x1 / linear launches stage TWO 32-channel planes per barrier (igemm_kernel<..,
     TAPS = 2>).  The K order is the one of the one-plane instance, so the two must agree BIT FOR BIT -- GroupNorm / no
     prologue, SiLU, two-source concat, residual, a row count that is not a multiple of the tile, and (odd number of
     planes) the fallback itself.  (Not a default: csrc/igemm.hip, sgd_igemm, explains why.)"""
@@ -283,9 +285,8 @@ def test_two_plane_flat_instance_equals_one_plane(case, prec, monkeypatch):
     res = torch.randn(m, cout, generator=g).cuda() if resid else None
     outs = {}
     for flat2 in ("0", "1"):
-        monkeypatch.setenv("SGDM_FLAT2", flat2)
         outs[flat2] = _flat(L, lib, p, x0, x1, w, b, m, rows_per_n=hw if gn else 0, pa=pa if gn else None,
-                            pb=pb if gn else None, res=res, silu=silu)
+                            pb=pb if gn else None, res=res, silu=silu, tune=L.TUNE_FLAT2 if flat2 == "1" else 0)
         assert torch.isfinite(outs[flat2]).all()
     assert torch.equal(outs["0"], outs["1"])
     xin = torch.cat([x0, x1], 1) if c1 else x0
@@ -410,8 +411,8 @@ def test_balanced_tail_equals_plain_schedule(case, prec, tol):
 
 # --------------------------------------------------------------------------------------------------------------------
 # loader-side epilogue (igemm_kernel<.., DEFER>): every tile but a block's last leaves through the LDS staging tile and is
-# finished by the loader waves during the next tile's K loop.  SGDM_MAX_GRID=8 makes small problems walk many tiles per
-# block; SGDM_DEFER=0 is the immediate epilogue of the same library.
+# finished by the loader waves during the next tile's K loop.  grid_cap = 8 makes small problems walk many tiles per
+# block; tune = 0 is the immediate epilogue of the same library, SGD_TUNE_DEFER the loader-side one.
 # --------------------------------------------------------------------------------------------------------------------
 # n, cin, cout, hw, residual
 DEFER_CASES = [(6, 96, 128, 16, True),       # 3 chunks: the minimum (two slices of 8 quads)
@@ -424,7 +425,7 @@ DEFER_CASES = [(6, 96, 128, 16, True),       # 3 chunks: the minimum (two slices
 @pytest.mark.parametrize("prec,tol", [k for k in KPRECS if k[0] != "f32"])
 @pytest.mark.parametrize("grid", ["8", "24"])
 @pytest.mark.parametrize("case", DEFER_CASES, ids=["x".join(map(str, c)) for c in DEFER_CASES])
-def test_loader_side_epilogue_equals_immediate(case, grid, prec, tol, monkeypatch):
+def test_loader_side_epilogue_equals_immediate(case, grid, prec, tol):
     n, cin, cout, h, with_res = case
     L, lib = _lib()
     p = L.PREC_BY_NAME[prec]
@@ -439,12 +440,10 @@ def test_loader_side_epilogue_equals_immediate(case, grid, prec, tol, monkeypatc
     wbuf, cp, op = _pack(w.cuda(), 3, p)
     xd, pad, pbd, bd = _nhwc(x).cuda(), pa.cuda(), pb.cuda(), b.cuda()
     rd = _nhwc(res).cuda() if with_res else None
-    monkeypatch.setenv("SGDM_MAX_GRID", grid)
 
     def run(defer):
-        monkeypatch.setenv("SGDM_DEFER", "1" if defer else "0")
         return _conv(L, lib, p, xd, None, wbuf, cp, op, cout, (n, h, h, h, h), bias=bd, pa=pad, pb=pbd, silu=1, res=rd,
-                     stats=(h * h) % 128 == 0)
+                     stats=(h * h) % 128 == 0, tune=L.TUNE_DEFER if defer else 0, grid_cap=int(grid))
 
     y0, s0 = run(False)
     for rep in range(2):

@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
 """A/B of the fused conv kernel across builds / launch modes IN ONE PROCESS (cdna_hip_programming.md rule 24): every
-variant is a (library path, environment overrides) pair; rounds are interleaved, median and min reported, outputs of
-all variants compared with the first.
+variant is a (library path, per-call overrides) pair -- `tune=<SGD_TUNE_* bits>` / `grid_cap=<n>` set the fields of
+sgd_igemm_args (the library reads no environment), anything else is put into the environment for libraries older than
+ABI 15; rounds are interleaved, median and min reported, outputs of all variants compared with the first.
 
-    python tools/ab_conv.py --variants base=lib/libsgdm_hip_base.so new=lib/libsgdm_hip.so new256=lib/libsgdm_hip.so:SGDM_BN256=1 \
+    python tools/ab_conv.py --variants base=lib/libsgdm_hip_base.so new=lib/libsgdm_hip.so new256=lib/libsgdm_hip.so:tune=2 \
         --shapes 80,256,256,64 80,512,512,32 ... [--rounds 7] [--reps 20] [--prec f16x3] [--plain]
 shape = n,cin,cout,hw[,ks]"""
 import argparse, ctypes as C, os, statistics, sys
@@ -62,7 +63,8 @@ for shp in a.shapes:
             q.res = res.data_ptr()
         q.w, q.cin_p, q.cout_p, q.bias = buf.data_ptr(), cp.value, op.value, bias.data_ptr()
         q.y, q.cout, q.y_ld, q.prec = y.data_ptr(), cout, cout, prec
-        if hasattr(lib, "sgd_igemm_work_bytes"):            # balanced tail (SGDM_BALANCE=0 in a variant's env turns it off)
+        q.tune, q.grid_cap = int(env.pop("tune", 0)), int(env.pop("grid_cap", 0))
+        if hasattr(lib, "sgd_igemm_work_bytes"):            # balanced tail (tune=16 turns it off)
             wb = int(lib.sgd_igemm_work_bytes())
             if name not in WORK:
                 WORK[name] = torch.zeros(wb // 4, device="cuda")

@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
-"""Which launch of a UNet evaluation differs between two settings of an environment switch the library reads per call
-(SGDM_FLAT2, SGDM_BN256, SGDM_BALANCE ...)?  Runs the forward program launch by launch under both settings, on the same
-inputs, and compares the output tensor of every sgd_igemm launch.
+"""Which launch of a UNet evaluation differs between two settings of sgd_igemm_args.tune (SGD_TUNE_* bits: tile width,
+two-plane flat instance, loader-side epilogue, plain schedule)?  Runs the forward program launch by launch under both
+settings, on the same inputs, and compares the output tensor of every sgd_igemm launch.
 
-    python tools/diff_variants.py --env SGDM_FLAT2 --a 0 --b 1 [--workload c5] [--batch 8] [--prec f16x3]"""
+    python tools/diff_variants.py --a 0 --b 4 [--workload c5] [--batch 8] [--prec f16x3]"""
 import argparse, ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "self-guided-diffusion-models_amd"))
@@ -12,12 +12,11 @@ import bench
 from sgdm_amd import _lib as L
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--env", default="SGDM_FLAT2"); ap.add_argument("--a", default="0"); ap.add_argument("--b", default="1")
+ap.add_argument("--a", type=int, default=0); ap.add_argument("--b", type=int, default=4)
 ap.add_argument("--workload", default="c5"); ap.add_argument("--batch", type=int, default=8); ap.add_argument("--prec", default="f16x3")
 a = ap.parse_args()
 wl = bench.WORKLOADS[a.workload]
 dev = torch.device("cuda", 0)
-os.environ[a.env] = a.a
 m, sd, data = bench.build_model(wl, dev, a.prec, a.batch)
 cond = data.get("cond"); cond = None if cond is None else (cond.to(dev) if wl["kind"] == "unet_fast" else cond.float().to(dev))
 layout = data["layout"].to(dev) if "layout" in data else None
@@ -40,10 +39,12 @@ def owner(ptr):
 # run op by op; after each igemm, snapshot its output buffer under setting a, then rerun the SAME op under b
 bad = 0
 for name, fn, args in eng.prog.ops:
-    os.environ[a.env] = a.a
+    is_ig = getattr(fn, "__name__", "") == "sgd_igemm"
+    if is_ig:
+        args[0]._obj.tune = a.a
     rc = fn(*args, st)
     assert rc == 0, name
-    if getattr(fn, "__name__", "") != "sgd_igemm":
+    if not is_ig:
         continue
     ia = args[0]._obj
     out = owner(ia.y)
@@ -51,7 +52,7 @@ for name, fn, args in eng.prog.ops:
         continue
     torch.cuda.synchronize()
     ref = out.clone()
-    os.environ[a.env] = a.b
+    ia.tune = a.b
     out.fill_(float("nan")) if ia.orows_in == 0 and ia.y_ld == ia.cout and not ia.res else None
     assert fn(*args, st) == 0
     torch.cuda.synchronize()
@@ -61,6 +62,7 @@ for name, fn, args in eng.prog.ops:
         print(f"DIFF {name:44s} m={ia.m} c0={ia.c0} c1={ia.c1} cout={ia.cout} y_ld={ia.y_ld} pro={ia.pro} silu={ia.pro_silu} "
               f"orows=({ia.orows_in},{ia.orows_out},{ia.orow_off}) res={bool(ia.res)} stats={bool(ia.stats)} max|d|={d:.3e} ref max {ref.abs().max().item():.3e}")
         bad += 1
-        os.environ[a.env] = a.a                       # restore the reference output for the layers behind it
+        ia.tune = a.a                                 # restore the reference output for the layers behind it
         fn(*args, st)
+    ia.tune = 0
 print("differing igemm launches:", bad)

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""LayerNorm-row prologue on the two-plane flat instance: how often it goes wrong, where, and what
+"""(needs the diagnostic code of profiles/r5_igemm_experiments.patch applied to csrc/igemm.hip: `git apply profiles/r5_igemm_experiments.patch`)
+LayerNorm-row prologue on the two-plane flat instance: how often it goes wrong, where, and what
 makes it stop.  Needs a library built with -DSGDM_FLAT2_LN -DSGDM_EXP:
     SGDM_BUILD_TAG=_exp SGDM_EXTRA_FLAGS="-DSGDM_FLAT2_LN -DSGDM_EXP" python self-guided-diffusion-models_amd/build.py
     SGDM_LIB_PATH=.../libsgdm_hip_exp.so python tools/ln_hazard.py [--prec f16x3] [--reps 20]
