@@ -682,3 +682,54 @@ def test_linear_splitk(m, n, k, ksplit):
     assert max_rel(y[:, :n].cpu(), ref) < 2e-6
     assert torch.isnan(y[:, n:]).all()
     assert lib.sgd_linear_splitk(_p(xd), k + 3, _p(wd), _p(bd), 257, n, k, _p(work), ksplit, _p(y), n + 2, _stream()) == 1
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# canary for the quarter-wave zero product of the LayerNorm-row prologue (profiles/r4_ln_hazard.txt)
+# --------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("prec", ["f16x3", "bf16x3", "f32"])
+@pytest.mark.parametrize("shape", [(160 * 256, 512, 512), (160 * 256, 512, 128), (16 * 256, 512, 128), (128, 512, 128)],
+                         ids=["c5_to_q", "c5_to_kv", "b8_to_kv", "one_workgroup"])
+def test_layernorm_prologue_canary_on_the_shipped_instance(shape, prec):
+    """The LayerNorm-row prologue (Attention_LR's to_q / to_kv, crossattetion_lr.py:81-88) on the SHIPPED one-plane 1x1
+    instance, at the shapes C5 launches (UNet batch 160, 16x16 maps, 512 channels; to_kv has 128 outputs) and at the
+    one-workgroup size where the two-plane experiment failed on every launch.  The fault found in round 4 on the opt-in
+    two-plane instance returned, in the last quarter-wave of a loader wave, the LayerNorm value with a zero product --
+    EXACTLY beta -- and came and went with unrelated code motion.  With W = I the output IS the staged operand, so the
+    signature is directly visible: over 200 launches no cell may equal beta exactly where the true value is not beta, and
+    every cell is within the split's rounding of ((x - mean) * rstd) * gamma + beta.  Seconds on the GPU; it fails first
+    if a future edit of csrc/igemm.hip arms the fault in the instance the product runs."""
+    L, lib = _lib()
+    m, cin, cout = shape
+    p = L.PREC_BY_NAME[prec]
+    g = torch.Generator().manual_seed(404)
+    x = (torch.randn(m, cin, generator=g) * 1.3 + 0.2).cuda()
+    gamma = (1.0 + 0.25 * torch.randn(cin, generator=g)).cuda()
+    beta = (0.5 + 0.25 * torch.randn(cin, generator=g)).cuda()               # no zeros: exact-beta cells are unambiguous
+    w = torch.zeros(cout, cin)
+    w[torch.arange(cout), torch.arange(cout)] = 1.0                           # first `cout` rows of the identity
+    wbuf, cin_p, cout_p = _pack(w.cuda(), 1, p)
+    st = torch.empty(m, 2, device="cuda")
+    L.check(lib.sgd_ln_stats(_p(x), m, cin, 1e-5, _p(st), _stream()), "ln_stats")
+    y = torch.empty(m, cout, device="cuda")
+    a = L.IgemmArgs()
+    a.x0, a.c0 = x.data_ptr(), cin
+    a.mode, a.m, a.stride = L.MODE_FLAT, m, 1
+    a.pro, a.pa, a.pb, a.pc = L.PRO_LN_ROW, st.data_ptr(), gamma.data_ptr(), beta.data_ptr()
+    a.w, a.cin_p, a.cout_p = wbuf.data_ptr(), cin_p, cout_p
+    a.y, a.cout, a.y_ld, a.prec = y.data_ptr(), cout, cout, p
+    work = torch.zeros(int(lib.sgd_igemm_work_bytes()) // 4, device="cuda")
+    a.work, a.work_bytes = work.data_ptr(), work.numel() * 4
+    torch.cuda.synchronize()
+    want = ((x[:, :cout] - st[:, :1]) * st[:, 1:2]) * gamma[:cout] + beta[:cout]
+    far = (want - beta[:cout]).abs() > 1e-3                                    # cells whose true value is visibly not beta
+    tol = {"f32": 2e-6, "f16x3": 4e-6, "bf16x3": 6e-5}[prec] * float(want.abs().max())
+    bad_beta = bad_val = 0
+    for rep in range(200):
+        y.fill_(float("nan"))
+        L.check(lib.sgd_igemm(C.byref(a), _stream()), "igemm")
+        bad_beta += int(((y == beta[:cout]) & far).sum())
+        bad_val += int(((y - want).abs() > tol).sum())
+    torch.cuda.synchronize()
+    assert bad_beta == 0, f"{bad_beta} cells returned exactly beta (zero LayerNorm product) in 200 launches"
+    assert bad_val == 0, f"{bad_val} cells off by more than {tol:.1e} in 200 launches"

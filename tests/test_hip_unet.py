@@ -52,8 +52,10 @@ def inputs(name):
 @pytest.mark.parametrize("prec", ["f32", "f16x3", "bf16x3"])
 @pytest.mark.parametrize("name", sorted(INDEX))
 def test_unet_forward_vs_reference_golden(name, prec):
-    if "_s64" in name and prec == "bf16x3":
-        pytest.skip("full-width instance covered in f32 and f16x3")
+    if "_s64" in name and prec == "bf16x3" and name != "uf_cluster5000_c128_s64":
+        # bf16x3 at full width: the C2 fixture; the other five full-width instances differ from it
+        # in plan, not in arithmetic, and run in f32 and f16x3
+        pytest.skip("bf16x3 at full width is checked on the C2 fixture")
     m, entry = build_model(name, prec)
     v, x, t, cond, layout = inputs(name)
     B = x.shape[0]
