@@ -294,33 +294,94 @@ def train_step_bench(model, diff, data, cond, layout, B, world, barrier, wl, ste
                 exchange_buckets=ov.get("per_bucket"), exchange_backward_ms=ov.get("backward_ms"))
 
 
-def exchange_probe(model, diff, data, cond, layout, B, barrier, wl):
-    """the data-parallel training step on ONE rank: a world-size-1 "nccl" (= RCCL) group, `hip_force_exchange` on the model.
-    Never fatal: what fails is reported as a string."""
-    import tempfile
-    import torch.distributed as dist
-    rec = None
+def exchange_probe(args, TB):
+    """the data-parallel training step on ONE rank: a world-size-1 "nccl" (= RCCL) group with `hip_force_exchange` on the
+    model -- arena, bucket hooks, all-reduce through librccl on the side stream, CU reserve, overlap record.  Runs as a
+    CHILD process (RCCL reads its environment once per process and writes a banner to stdout; a hang must not take the
+    bench line with it).  Never fatal: what fails is reported as a string."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--exchange-probe-child", "--workload", args.workload, "--prec", args.prec,
+           "--train-batch", str(TB)]
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
     try:
-        from sgdm_amd.ddp import cap_exchange_channels
-        cap_exchange_channels()
-        with tempfile.TemporaryDirectory() as td:
-            dist.init_process_group("nccl", init_method=f"file://{os.path.join(td, 'store')}", rank=0, world_size=1)
-            try:
-                for e in model._engines.values():
-                    e.backward = None                        # next backward: arena + bucket hooks
-                model.hip_force_exchange = True
-                model._hip_ddp_synced = False
-                rec = train_step_bench(model, diff, data, cond, layout, B, 1, barrier, wl, steps=3, warmup=2)
-            finally:
-                model.hip_force_exchange = False
-                for e in model._engines.values():
-                    e.backward = None
-                dist.destroy_process_group()
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("EXCHANGE ")]
+        if r.returncode != 0 or not lines:
+            return dict(error=f"child rc {r.returncode}: {r.stderr[-300:]}")
+        return json.loads(lines[-1][len("EXCHANGE "):])
     except Exception as exc:                                 # pragma: no cover - depends on the box
         return dict(error=f"{type(exc).__name__}: {exc}"[:400])
+
+
+def exchange_probe_child(args):
+    import tempfile
+    import torch.distributed as dist
+    from sgdm_amd.ddp import cap_exchange_channels
+    from sgdm_amd.diffusion import LatentDiffusion
+    from sgdm_amd.synth import synth_batch
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    cap_exchange_channels()
+    wl = WORKLOADS[args.workload]
+    TB, S = args.train_batch, wl["image"]
+    with tempfile.TemporaryDirectory() as td:
+        dist.init_process_group("nccl", init_method=f"file://{os.path.join(td, 'store')}", rank=0, world_size=1)
+        model, _, _ = build_model(wl, dev, args.prec, TB)
+        model.hip_force_exchange = True
+        diff = LatentDiffusion(device=str(dev), **MODEL_PARAMS)
+        diff.set_denoise_fn(model.forward, model.forward_with_cond_scale)
+        tdata = synth_batch(wl["method"], TB, S, wl["cond_dim"], wl["layout_dim"], seed=29)
+        tcond = tdata.get("cond")
+        if tcond is not None:
+            tcond = tcond.to(dev) if wl["kind"] == "unet_fast" else tcond.float().to(dev)
+        tlayout = tdata["layout"].to(dev) if "layout" in tdata else None
+
+        def barrier():
+            torch.cuda.synchronize()
+        rec = train_step_bench(model, diff, tdata, tcond, tlayout, TB, 1, barrier, wl, steps=4, warmup=3)
+        dist.destroy_process_group()
     keep = ("ms", "batch_per_gpu", "steps", "world_size", "backend", "exchange", "reserved_cus", "exchange_ms",
             "exposed_exchange_ms", "first_bucket_at_frac_of_backward", "exchange_backward_ms", "exchange_buckets")
-    return {k: rec[k] for k in keep}
+    print("EXCHANGE " + json.dumps({k: rec[k] for k in keep}), flush=True)
+
+
+def device_probe(dev, seconds=0.15):
+    """what THIS device delivers right now: the boxes of the pool differ by 5-7 % for one binary
+    and the chip trades clock for matrix-pipe duty, so the roofline fraction is reported a second time against a ceiling
+    measured in this process, seconds after the timed steps: a bare v_mfma_f32_16x16x32_f16 loop on random register operands
+    (one wave per SIMD on every CU, csrc/probe.hip) and a 16-byte grid-stride copy of 256 MiB."""
+    from sgdm_amd import _lib as L
+    lib = L.load()
+    st = torch.cuda.current_stream().cuda_stream
+    cus = int(torch.cuda.get_device_properties(dev).multi_processor_count)
+    sink = torch.empty(cus * 256, device=dev)
+
+    def timed(fn):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); fn(); e1.record(); e1.synchronize()
+        return e0.elapsed_time(e1) * 1e-3
+    iters = 20000
+    run = lambda: L.check(lib.sgd_debug_mfma_probe(cus, iters, 12345, C_void(sink), st), "mfma_probe")
+    run()
+    t = timed(run)
+    iters = max(1000, int(iters * seconds / max(t, 1e-6)))          # one launch of ~`seconds`: the clock settles under the load
+    t = timed(run)
+    mfma_tf = float(lib.sgd_debug_mfma_probe_flops(cus, iters)) / t / 1e12
+    n = 64 << 20                                                      # floats: 256 MiB read + 256 MiB written per pass
+    src, dst = torch.randn(n, device=dev), torch.empty(n, device=dev)
+    cp = lambda: [L.check(lib.sgd_debug_copy_probe(C_void(src), C_void(dst), n, st), "copy_probe") for _ in range(10)]
+    cp()
+    tc = timed(cp)
+    assert torch.equal(src[-4096:], dst[-4096:])
+    return dict(device_mfma_tflops=round(mfma_tf, 1), device_mfma_probe_ms=round(t * 1e3, 1),
+                device_copy_tbps=round(10 * 2 * 4.0 * n / tc / 1e12, 3), device_cus=cus)
+
+
+def C_void(t):
+    import ctypes
+    return ctypes.c_void_p(t.data_ptr())
 
 
 def train_step_roofline(model, prec, B, S):
@@ -379,8 +440,11 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="skip the f32_exact / c5 / c1 sub-records")
     ap.add_argument("--no-full", action="store_true", help="skip the complete 1000-step trajectory (full_trajectory)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of the hipGraph-captured step")
+    ap.add_argument("--exchange-probe-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
+    if args.exchange_probe_child:
+        return exchange_probe_child(args)
     if args.gpus > 1 and "RANK" not in os.environ:
         sys.exit(self_launch(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -512,6 +576,19 @@ def main():
                                                    tflops_per_s=round(v[1] / (v[0] * 1e-3) / 1e12, 1),
                                                    frac=round(v[1] / (v[0] * 1e-3) / 1e12 / peak, 4))
                                            for k, v in sorted(inst.items())})
+            # the same figure against what this device delivers NOW (bare 16-bit MFMA loop / 3 products; exact mode: the
+            # fp32 MFMA peak has no such probe, the field stays null)
+            try:
+                pr = device_probe(dev)
+                roof.update(pr)
+                if args.prec != "f32":
+                    ceil = pr["device_mfma_tflops"] / 3.0
+                    roof["device_ceiling_tflops"] = round(ceil, 1)
+                    roof["frac_of_device_ceiling"] = round(ach / ceil, 4)
+                    for v in roof["igemm_by_instance"].values():
+                        v["frac_of_device_ceiling"] = round(v["tflops_per_s"] / ceil, 4)
+            except Exception as exc:                          # a diagnostic must not cost the bench line
+                roof["device_probe_error"] = f"{type(exc).__name__}: {exc}"[:200]
 
     # ---- second half of BASELINE.json's metric: DDPM train-step time (q_sample + UNet fwd/bwd + RCCL gradient
     # all-reduce overlapped with backward + AdamW + EMA), per-GPU batch of the config, dropout as configured
@@ -536,7 +613,7 @@ def main():
         # exchange forced (arena, bucketed all-reduce through librccl on the side stream, CU reserve): what the N > 1 legs
         # run, with its overlap record.  A record of the path, not a scaling number.
         if world == 1 and not args.no_exchange_probe:
-            train["exchange_world1"] = exchange_probe(model, diff, tdata, tcond, tlayout, TB, barrier, wl)
+            train["exchange_world1"] = exchange_probe(args, TB)
 
     def time_sampling(mdl, dif, bsz, size, kw, steps, warm, skw_):
         """ms per CFG sampling step of `mdl` (setup outside, W untimed + K timed steps, barrier + sync around)"""
@@ -640,10 +717,18 @@ def main():
             "full_trajectory": full,
         }
         out.update(extra)
-        print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if out is not None:
+        # ONE line, and the last thing on stdout: whatever native libraries hold in C stdio buffers (RCCL writes a version
+        # banner to stdout, flushed at exit -- i.e. AFTER a line printed here) goes out first
+        import ctypes
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -142,6 +142,15 @@ int64_t sgd_igemm_work_status_offset(void);
  * LDS each, so nothing else fits beside it -- for `milliseconds` of wall-clock time.  Stands in for RCCL's kernels on a
  * side stream in the single-GPU contention tests. */
 int sgd_debug_occupy(int32_t blocks, float milliseconds, void* stream);
+/* Diagnostics (bench.py: the in-run device calibration beside every roofline figure; csrc/probe.hip).
+ * sgd_debug_mfma_probe: `blocks` blocks of 4 waves (150 KB of LDS each: one block per compute unit, one wave per SIMD) run
+ * `iters` x 8 independent v_mfma_f32_16x16x32_f16 on random register operands and nothing else;
+ * sgd_debug_mfma_probe_flops gives the flop count of such a launch.  out: NULL or blocks * 256 floats (keeps the work live).
+ * sgd_debug_copy_probe: dst[0..count) = src[0..count), 16 bytes per lane, four loads in flight (count % 4 == 0, both
+ * pointers 16-byte aligned): the practical HBM rate of one read and one write stream. */
+int sgd_debug_mfma_probe(int32_t blocks, int64_t iters, uint32_t seed, float* out, void* stream);
+int64_t sgd_debug_mfma_probe_flops(int32_t blocks, int64_t iters);
+int sgd_debug_copy_probe(const float* src, float* dst, int64_t count, void* stream);
 /* Host-only test hook (no launch): the balanced-tail workspace layout of a launch of `total_tiles` tiles with `nchunks`
  * 32-channel chunks per tile and `taps` (9 / 1) K steps per chunk on `grid` persistent blocks.  out[4*b .. 4*b+3] =
  * {K split of block b's last tile (0: none), index of its arrival counter, first producer slab, producer slabs}.

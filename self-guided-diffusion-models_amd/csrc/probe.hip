@@ -1,0 +1,90 @@
+// In-run calibration of the device (bench.py: roofline.device_mfma_tflops / device_copy_tbps).  gfx950 only.
+//
+// The boxes of the pool differ by ~5-7 % for one binary and the chip trades clock for matrix-pipe duty on random data
+// (DESIGN.md section 4), so a bench line alone cannot tell a slower box from slower code.  These two kernels measure, in
+// the same process and thermal state as the timed steps, what THIS device delivers at that moment:
+//   * sgd_debug_mfma_probe: nothing but v_mfma_f32_16x16x32_f16 on random register operands, one wave per SIMD on every
+//     compute unit, eight independent accumulator tiles per wave (the pipe never waits on a dependency), no memory
+//     traffic inside the loop -- the matrix pipe's sustained rate under its own power draw;
+//   * sgd_debug_copy_probe: a 16-byte-per-lane grid-stride copy (four loads in flight per lane) -- the practical HBM rate
+//     for one read + one write stream.
+// Diagnostics like sgd_debug_occupy: never on the product path.
+#include "sgdm_common.h"
+#include "../../include/sgdm_hip.h"
+
+namespace {
+
+__device__ __forceinline__ uint32_t mix32(uint32_t h) {
+    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+    return h;
+}
+
+// a random f16 in [-1, 1) with a full random mantissa (the data the conv kernels see is dense in toggling bits)
+__device__ __forceinline__ _Float16 rnd_f16(uint32_t h) {
+    const float f = (float)(int)(h >> 8) * (1.0f / 8388608.0f) - 1.0f;
+    return (_Float16)f;
+}
+
+__global__ __launch_bounds__(256) void mfma_probe_kernel(uint32_t seed, long iters, float* __restrict__ out) {
+    extern __shared__ float hold[];                  // 150 KB of dynamic LDS: one block per compute unit, nothing beside it
+    (void)hold;
+    const uint32_t id = (blockIdx.x * 256u + threadIdx.x) * 64u + seed;
+    f16x8 a[4], b[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            a[i][j] = rnd_f16(mix32(id + (uint32_t)(i * 8 + j)));
+            b[i][j] = rnd_f16(mix32(id + 32u + (uint32_t)(i * 8 + j)));
+        }
+    f32x4 acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (long it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i & 3], b[(i + (i >> 2)) & 3], acc[i], 0, 0, 0);
+    }
+    f32x4 s = acc[0];
+#pragma unroll
+    for (int i = 1; i < 8; ++i) s += acc[i];
+    if (out) out[(size_t)blockIdx.x * 256 + threadIdx.x] = s[0] + s[1] + s[2] + s[3];
+}
+
+__global__ __launch_bounds__(256) void copy_probe_kernel(const f32x4* __restrict__ src, f32x4* __restrict__ dst, long n) {
+    const long stride = (long)gridDim.x * 256;
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    for (; i + 3 * stride < n; i += 4 * stride) {
+        const f32x4 v0 = src[i], v1 = src[i + stride], v2 = src[i + 2 * stride], v3 = src[i + 3 * stride];
+        dst[i] = v0; dst[i + stride] = v1; dst[i + 2 * stride] = v2; dst[i + 3 * stride] = v3;
+    }
+    for (; i < n; i += stride) dst[i] = src[i];
+}
+
+}  // namespace
+
+extern "C" int sgd_debug_mfma_probe(int32_t blocks, int64_t iters, uint32_t seed, float* out, void* stream) {
+    SGD_CLEAR_ERR();
+    if (blocks <= 0 || blocks > 4096 || iters <= 0) return SGD_ERR_ARG;
+    const size_t LDS = 150 * 1024;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)mfma_probe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
+        attr = true;
+    }
+    hipLaunchKernelGGL(mfma_probe_kernel, dim3(blocks), dim3(256), LDS, (hipStream_t)stream, seed, (long)iters, out);
+    return sgd_check_launch();
+}
+
+extern "C" int64_t sgd_debug_mfma_probe_flops(int32_t blocks, int64_t iters) {
+    // blocks x 4 waves x iters x 8 MFMAs x (16 x 16 x 32 multiply-adds = 16,384 flop)
+    return (int64_t)blocks * 4 * iters * 8 * 16384;
+}
+
+extern "C" int sgd_debug_copy_probe(const float* src, float* dst, int64_t count, void* stream) {
+    SGD_CLEAR_ERR();
+    if (!src || !dst || count <= 0 || (count & 3) || (((uintptr_t)src | (uintptr_t)dst) & 15)) return SGD_ERR_ARG;
+    hipLaunchKernelGGL(copy_probe_kernel, dim3(256 * 8), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const f32x4*>(src), reinterpret_cast<f32x4*>(dst), (long)(count >> 2));
+    return sgd_check_launch();
+}

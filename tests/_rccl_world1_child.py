@@ -99,9 +99,10 @@ def main():
         out["aliased_into_arena"] = sum(1 for k, p in model.named_parameters()
                                         if p.grad is not None and eng.backward.arena.flat.data_ptr() <= p.grad.data_ptr()
                                         < eng.backward.arena.flat.data_ptr() + eng.backward.arena.flat.numel() * 4)
-        # a second step re-uses communicator, arena and marks
+        # a second step re-uses communicator, arena and marks; its record is the steady state (the first step's holds the
+        # creation of the exchange's communicator: tens of ms of host time inside the backward)
         step()
-        out["overlap_second_step"] = red.overlap_stats() is not None
+        out["overlap_second_step"] = red.overlap_stats()
         bad2 = [k for k in ref if not torch.equal(model.get_parameter(k).grad, ref[k])]
         out["second_step_mismatched"] = bad2[:8]
         dist.barrier()

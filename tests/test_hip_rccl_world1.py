@@ -38,7 +38,7 @@ def test_training_step_through_world1_rccl_group(workload):
     assert out["plain_backward_has_arena"] is False
     # the exchange ran: arena + active reducer on RCCL's stream-ordered path, several buckets (64 MB each of ~300 MB)
     assert out["reducer_active"] and out["stream_ordered"] and out["arena_buckets"] >= 3
-    assert out["n_grads"] > 300 and out["aliased_into_arena"] >= 0.9 * out["n_grads"]
+    assert out["n_grads"] > 250 and out["aliased_into_arena"] >= 0.9 * out["n_grads"]
     # RCCL's communicator exists after the step (the collectives really went through librccl) ...
     assert out["comm_after"] is True
     # ... the reserve was decided by the policy (backend on the GPU), applied to the backward program only, and RCCL's
@@ -46,16 +46,22 @@ def test_training_step_through_world1_rccl_group(workload):
     assert out["reserved_cus"] == 16 and out["grid_cap"] == out["cus"] - 16
     assert out["backward_grid_caps"] == [out["cus"] - 16] and out["forward_grid_caps"] == [0]
     assert out["nchannels_env"] == "16"
-    assert out["sent"] > 300
+    assert out["sent"] > 250
     # gradients bit-equal to the non-DDP step, both steps
     assert out["same_keys"] and out["mismatched"] == [] and out["losses_equal"]
     assert out["second_step_mismatched"] == []
     # the overlap record: every bucket enqueued inside the backward, completed after it was enqueued
-    ov = out["overlap"]
-    assert ov is not None and ov["buckets"] == out["arena_buckets"] and out["overlap_second_step"]
-    assert 0.0 < ov["first_bucket_at_frac_of_backward"] < 0.9, ov
-    assert ov["backward_ms"] > 0 and ov["exchange_ms"] >= 0 and ov["exposed_exchange_ms"] >= 0
-    for b in ov["per_bucket"]:
-        assert b["complete_at_ms"] >= b["enqueued_at_ms"] - 1e-3, ov
-    enq = [b["enqueued_at_ms"] for b in ov["per_bucket"]]
-    assert enq == sorted(enq)
+    assert out["overlap"] is not None
+    for ov in (out["overlap"], out["overlap_second_step"]):
+        assert ov is not None and ov["buckets"] == out["arena_buckets"]
+        assert 0.0 < ov["first_bucket_at_frac_of_backward"] < 0.9, ov
+        assert ov["backward_ms"] > 0 and ov["exchange_ms"] >= 0 and ov["exposed_exchange_ms"] >= 0
+        for b in ov["per_bucket"]:
+            assert b["complete_at_ms"] >= b["enqueued_at_ms"] - 1e-3, ov
+        enq = [b["enqueued_at_ms"] for b in ov["per_bucket"]]
+        assert enq == sorted(enq)
+    # steady state on one rank: a collective with nobody to talk to completes right behind its enqueue, and nothing of the
+    # exchange is left exposed behind the backward
+    ov = out["overlap_second_step"]
+    assert all(b["complete_at_ms"] - b["enqueued_at_ms"] < 5.0 for b in ov["per_bucket"]), ov
+    assert ov["exposed_exchange_ms"] < 2.0, ov
