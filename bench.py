@@ -363,12 +363,12 @@ def device_probe(dev, seconds=0.15):
         e0.record(); fn(); e1.record(); e1.synchronize()
         return e0.elapsed_time(e1) * 1e-3
     iters = 20000
-    run = lambda: L.check(lib.sgd_debug_mfma_probe(cus, iters, 12345, C_void(sink), st), "mfma_probe")
+    run = lambda: L.check(lib.sgd_debug_mfma_probe(cus, iters, 12345, 0, C_void(sink), st), "mfma_probe")
     run()
     t = timed(run)
     iters = max(1000, int(iters * seconds / max(t, 1e-6)))          # one launch of ~`seconds`: the clock settles under the load
     t = timed(run)
-    mfma_tf = float(lib.sgd_debug_mfma_probe_flops(cus, iters)) / t / 1e12
+    mfma_tf = float(lib.sgd_debug_mfma_probe_flops(cus, iters, 0)) / t / 1e12
     n = 64 << 20                                                      # floats: 256 MiB read + 256 MiB written per pass
     src, dst = torch.randn(n, device=dev), torch.empty(n, device=dev)
     cp = lambda: [L.check(lib.sgd_debug_copy_probe(C_void(src), C_void(dst), n, st), "copy_probe") for _ in range(10)]

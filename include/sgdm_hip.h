@@ -148,8 +148,9 @@ int sgd_debug_occupy(int32_t blocks, float milliseconds, void* stream);
  * sgd_debug_mfma_probe_flops gives the flop count of such a launch.  out: NULL or blocks * 256 floats (keeps the work live).
  * sgd_debug_copy_probe: dst[0..count) = src[0..count), 16 bytes per lane, four loads in flight (count % 4 == 0, both
  * pointers 16-byte aligned): the practical HBM rate of one read and one write stream. */
-int sgd_debug_mfma_probe(int32_t blocks, int64_t iters, uint32_t seed, float* out, void* stream);
-int64_t sgd_debug_mfma_probe_flops(int32_t blocks, int64_t iters);
+int sgd_debug_mfma_probe(int32_t blocks, int64_t iters, uint32_t seed, int32_t variant /* 0: 16x16x32 on random operands,
+                         1: on zeros, 2: 32x32x16 on random operands */, float* out, void* stream);
+int64_t sgd_debug_mfma_probe_flops(int32_t blocks, int64_t iters, int32_t variant);
 int sgd_debug_copy_probe(const float* src, float* dst, int64_t count, void* stream);
 /* Host-only test hook (no launch): the balanced-tail workspace layout of a launch of `total_tiles` tiles with `nchunks`
  * 32-channel chunks per tile and `taps` (9 / 1) K steps per chunk on `grid` persistent blocks.  out[4*b .. 4*b+3] =

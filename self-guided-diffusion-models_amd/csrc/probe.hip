@@ -25,6 +25,9 @@ __device__ __forceinline__ _Float16 rnd_f16(uint32_t h) {
     return (_Float16)f;
 }
 
+// VARIANT 0: 16x16x32 on random operands (the figure bench.py reports); 1: the same on all-zero operands (the issue rate at
+// the clock an idle-data loop holds: separates "issue-limited" from "power-limited"); 2: 32x32x16 on random operands
+template <int VARIANT>
 __global__ __launch_bounds__(256) void mfma_probe_kernel(uint32_t seed, long iters, float* __restrict__ out) {
     extern __shared__ float hold[];                  // 150 KB of dynamic LDS: one block per compute unit, nothing beside it
     (void)hold;
@@ -34,21 +37,41 @@ __global__ __launch_bounds__(256) void mfma_probe_kernel(uint32_t seed, long ite
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            a[i][j] = rnd_f16(mix32(id + (uint32_t)(i * 8 + j)));
-            b[i][j] = rnd_f16(mix32(id + 32u + (uint32_t)(i * 8 + j)));
+            a[i][j] = VARIANT == 1 ? (_Float16)0.f : rnd_f16(mix32(id + (uint32_t)(i * 8 + j)));
+            b[i][j] = VARIANT == 1 ? (_Float16)0.f : rnd_f16(mix32(id + 32u + (uint32_t)(i * 8 + j)));
         }
-    f32x4 acc[8];
+    float total = 0.f;
+    if constexpr (VARIANT == 2) {
+        f32x16 acc[4];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (long it = 0; it < iters; ++it) {
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
-            acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i & 3], b[(i + (i >> 2)) & 3], acc[i], 0, 0, 0);
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        for (long it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)       // (inline asm: in-place accumulation, see below)
+                asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc[i]) : "v"(a[i]), "v"(b[(i + 1) & 3]));
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) total += acc[i][r];
+    } else {
+        f32x4 acc[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (long it = 0; it < iters; ++it) {
+#pragma unroll
+            // inline asm with the accumulator as an in-place AGPR operand: through the builtin the register allocator rotated
+            // the eight tiles through one another every iteration (~40 v_accvgpr moves per 8 MFMAs: the loop measured the
+            // moves, 883 TF on a device whose conv kernel sustains 1,170)
+            for (int i = 0; i < 8; ++i)
+                asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc[i]) : "v"(a[i & 3]), "v"(b[(i + (i >> 2)) & 3]));
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) total += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
     }
-    f32x4 s = acc[0];
-#pragma unroll
-    for (int i = 1; i < 8; ++i) s += acc[i];
-    if (out) out[(size_t)blockIdx.x * 256 + threadIdx.x] = s[0] + s[1] + s[2] + s[3];
+    if (out) out[(size_t)blockIdx.x * 256 + threadIdx.x] = total;
 }
 
 __global__ __launch_bounds__(256) void copy_probe_kernel(const f32x4* __restrict__ src, f32x4* __restrict__ dst, long n) {
@@ -63,22 +86,29 @@ __global__ __launch_bounds__(256) void copy_probe_kernel(const f32x4* __restrict
 
 }  // namespace
 
-extern "C" int sgd_debug_mfma_probe(int32_t blocks, int64_t iters, uint32_t seed, float* out, void* stream) {
-    SGD_CLEAR_ERR();
-    if (blocks <= 0 || blocks > 4096 || iters <= 0) return SGD_ERR_ARG;
+template <int VARIANT>
+static int launch_mfma_probe(int32_t blocks, int64_t iters, uint32_t seed, float* out, void* stream) {
     const size_t LDS = 150 * 1024;
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute((const void*)mfma_probe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
+        (void)hipFuncSetAttribute((const void*)mfma_probe_kernel<VARIANT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
         attr = true;
     }
-    hipLaunchKernelGGL(mfma_probe_kernel, dim3(blocks), dim3(256), LDS, (hipStream_t)stream, seed, (long)iters, out);
+    hipLaunchKernelGGL((mfma_probe_kernel<VARIANT>), dim3(blocks), dim3(256), LDS, (hipStream_t)stream, seed, (long)iters, out);
     return sgd_check_launch();
 }
 
-extern "C" int64_t sgd_debug_mfma_probe_flops(int32_t blocks, int64_t iters) {
-    // blocks x 4 waves x iters x 8 MFMAs x (16 x 16 x 32 multiply-adds = 16,384 flop)
-    return (int64_t)blocks * 4 * iters * 8 * 16384;
+extern "C" int sgd_debug_mfma_probe(int32_t blocks, int64_t iters, uint32_t seed, int32_t variant, float* out, void* stream) {
+    SGD_CLEAR_ERR();
+    if (blocks <= 0 || blocks > 4096 || iters <= 0 || variant < 0 || variant > 2) return SGD_ERR_ARG;
+    if (variant == 1) return launch_mfma_probe<1>(blocks, iters, seed, out, stream);
+    if (variant == 2) return launch_mfma_probe<2>(blocks, iters, seed, out, stream);
+    return launch_mfma_probe<0>(blocks, iters, seed, out, stream);
+}
+
+extern "C" int64_t sgd_debug_mfma_probe_flops(int32_t blocks, int64_t iters, int32_t variant) {
+    // blocks x 4 waves x iters x (8 MFMAs of 16 x 16 x 32, or 4 of 32 x 32 x 16) x 2 flop per multiply-add
+    return (int64_t)blocks * 4 * iters * (variant == 2 ? 4 * 32768 : 8 * 16384);
 }
 
 extern "C" int sgd_debug_copy_probe(const float* src, float* dst, int64_t count, void* stream) {

@@ -59,8 +59,8 @@ SIGNATURES = {
     "sgd_igemm_work_bytes": (i64, []),
     "sgd_igemm_work_status_offset": (i64, []),
     "sgd_debug_occupy": (i32, [i32, f32, vp]),
-    "sgd_debug_mfma_probe": (i32, [i32, i64, C.c_uint32, vp, vp]),
-    "sgd_debug_mfma_probe_flops": (i64, [i32, i64]),
+    "sgd_debug_mfma_probe": (i32, [i32, i64, C.c_uint32, i32, vp, vp]),
+    "sgd_debug_mfma_probe_flops": (i64, [i32, i64, i32]),
     "sgd_debug_copy_probe": (i32, [vp, vp, i64, vp]),
     "sgd_igemm_tail_layout": (i32, [i32, i32, i32, i32, C.POINTER(i32)]),
     "sgd_stats_reduce": (i32, [vp, i32, i32, i32, vp, i32, i32, vp]),

@@ -570,6 +570,7 @@ class _Engine:
         self.lse = {}             # attention log-sum-exp buffers (written only when present)
         self.stats_of = {}        # tensor data_ptr -> (partial statistics buffer, parts, channels) written by its producer
         self._p_drop = 0.0
+        self._grid_cap = 0        # persistent-grid cap of the backward program's launches (set_grid_cap)
         self.refresh_hooks = []   # derived device state that follows the parameters (run by refresh(), never captured)
         # scratch of sgd_igemm's balanced tail (partial accumulators of K-split tiles + self-resetting arrival counters):
         # zeroed once, shared by every launch of this engine's programs -- they are ordered on one stream

@@ -146,9 +146,13 @@ def _grads_for_seed(seed, ddp, name="uf_clusterlayout_c32_s16", torch_ddp=False)
         # backward programs carries the cap -- and the replicas were synchronised once
         eng = next(iter(m._engines.values()))
         cus = torch.cuda.get_device_properties(0).multi_processor_count
-        assert eng._grid_cap == cus - 16, eng._grid_cap
+        # (round 5: a backend that launches no kernels on the device -- gloo -- needs no compute units; RCCL gets 16.  The
+        # one-rank RCCL run of this path is tests/test_hip_rccl_world1.py)
+        want = cus - 16 if "nccl" in str(dist.get_backend()) else 0
+        assert eng._grid_cap == want, eng._grid_cap
         assert all(a.grid_cap == 0 for a, _ in eng._late) and all(a.grid_cap == eng._grid_cap for a, _ in eng.backward.late)
         assert getattr(m, "_hip_ddp_synced", False)
+        assert eng.backward.reducer is not None and eng.backward.reducer.overlap_stats() is not None
     return {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}
 
 

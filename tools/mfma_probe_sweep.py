@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""What does the bare-MFMA probe (csrc/probe.hip) measure?  Sweeps variant (16x16x32 random / zeros, 32x32x16 random),
+launch duration and the number of active compute units, interleaved in one process.
+    python tools/mfma_probe_sweep.py"""
+import ctypes as C, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "self-guided-diffusion-models_amd"))
+import torch
+from sgdm_amd import _lib as L
+lib = L.load()
+st = torch.cuda.current_stream().cuda_stream
+cus = torch.cuda.get_device_properties(0).multi_processor_count
+sink = torch.empty(4096 * 256, device="cuda")
+
+
+def run(blocks, iters, variant):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    L.check(lib.sgd_debug_mfma_probe(blocks, iters, 777, variant, C.c_void_p(sink.data_ptr()), st), "probe")
+    e1.record(); e1.synchronize()
+    t = e0.elapsed_time(e1) * 1e-3
+    return float(lib.sgd_debug_mfma_probe_flops(blocks, iters, variant)) / t / 1e12, t
+
+
+names = {0: "16x16x32 random", 1: "16x16x32 zeros", 2: "32x32x16 random"}
+for v in (0, 1, 2):
+    run(cus, 2000, v)
+for rnd in range(2):
+    for blocks in (cus, cus // 2, cus // 4, 2 * cus):
+        for v in (0, 1, 2):
+            for iters in (2000, 20000, 200000, 2000000):
+                it = iters if v != 2 else iters // 2
+                tf, t = run(blocks, it, v)
+                print(f"round {rnd} blocks {blocks:4d} {names[v]:16s} iters {it:8d}: {t * 1e3:9.2f} ms  {tf:7.1f} TF  "
+                      f"(implied clock at 16 cyc / 16x16x32: {tf * 1e12 / (blocks * 4 * 1024.0) / 1e9:.2f} GHz)", flush=True)
