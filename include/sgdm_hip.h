@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define SGD_ABI_VERSION 15
+#define SGD_ABI_VERSION 16
 int sgd_abi_version(void);
 /* 16 hex digits identifying the sources and flags the library was compiled from (build.py: source_id()); static storage.
  * __graft_entry__.build() and tests/test_boundary_cpu.py compare it with the tree on disk. */
@@ -381,8 +381,9 @@ int sgd_pack_weight_dgrad(const float* w_src, void* w_dst, int32_t cout_fwd, int
  * activated input; its w/bias/res/y fields are ignored).  Arithmetic follows fwd->prec: exact-fp32 MFMA, or the
  * three-product 16-bit split (3x3 stride-1 and 1x1 / linear; other geometries fall back to exact fp32).  Partial sums
  * of `ksplit` row slices are written to `slabs` [ksplit][taps][cout][cin] and folded by sgd_wgrad_reduce into the
- * reference layout.  bias_slabs (optional, [ksplit][cout]): partial column sums of gy = the bias gradient, taken from
- * the gy rows the kernel stages anyway; fold with sgd_colsum_fold. */
+ * reference layout.  bias_slabs (optional, [sgd_wgrad_bias_rows(..)][cout]): partial column sums of gy = the bias
+ * gradient, taken from the gy rows the kernel (or its pre-pass) stages anyway; fold with sgd_wgrad_reduce_bias /
+ * sgd_colsum_fold over that many rows. */
 int sgd_wgrad(const sgd_igemm_args* fwd /* HOST */, const float* gy, int32_t gy_ld, int32_t cout,
               float* slabs, int32_t ksplit, float* bias_slabs, void* stream);
 /* sgd_wgrad with a scratch buffer (DEVICE, sgd_wgrad_scratch_bytes(fwd, cout) bytes; any launch may reuse it): 3x3 stride-1
@@ -391,6 +392,11 @@ int sgd_wgrad(const sgd_igemm_args* fwd /* HOST */, const float* gy, int32_t gy_
  * repeats the GroupNorm-affine + SiLU + split of its operands (cin / 32 resp. cout / 128 times per element).  Same
  * results bit for bit; cases the planes form does not cover run exactly as sgd_wgrad. */
 int64_t sgd_wgrad_scratch_bytes(const sgd_igemm_args* fwd /* HOST pointer */, int32_t cout);
+/* rows of bias_slabs the launch writes (no launch, host arithmetic): ksplit, or -- planes form, whose pre-pass sums the
+ * gradient rows in ~1024 / (cout / 128) row chunks -- the number of chunks.  scratch_bytes: what sgd_wgrad_scratch will be
+ * given (0: sgd_wgrad). */
+int sgd_wgrad_bias_rows(const sgd_igemm_args* fwd /* HOST pointer */, int32_t cout, int32_t gy_ld, int32_t ksplit,
+                            int64_t scratch_bytes);
 int sgd_wgrad_scratch(const sgd_igemm_args* fwd /* HOST pointer */, const float* gy, int32_t gy_ld, int32_t cout,
                       float* slabs, int32_t ksplit, float* bias_slabs, void* scratch, int64_t scratch_bytes, void* stream);
 /* out[c] (+)= scale * sum_k partial[k, c]   (fixed order, double accumulation) */
@@ -400,10 +406,12 @@ int sgd_colsum_fold(const float* partial, int32_t chunks, int32_t c, float* out,
  * (`scale` undoes the power-of-two gradient scaling that keeps the split-f16 dgrad operands in range) */
 int sgd_wgrad_reduce(const float* slabs, int32_t ksplit, int32_t taps, int32_t cout, int32_t cin,
                      float* dw, int32_t accumulate, float scale, void* stream);
-/* sgd_wgrad_reduce + the bias gradient of the same layer in one launch: bias_slabs [ksplit, cout] are the partial column
- * sums the weight-gradient kernel wrote; dbias[cout] = scale * their sum (fixed order, double accumulation). */
+/* sgd_wgrad_reduce + the bias gradient of the same layer in one launch: bias_slabs [bias_rows, cout] are the partial column
+ * sums the weight-gradient launch wrote (bias_rows = sgd_wgrad_bias_rows); dbias[cout] = scale * their sum (fixed order,
+ * double accumulation). */
 int sgd_wgrad_reduce_bias(const float* slabs, int32_t ksplit, int32_t taps, int32_t cout, int32_t cin, float* dw,
-                          int32_t accumulate, float scale, const float* bias_slabs, float* dbias, void* stream);
+                          int32_t accumulate, float scale, const float* bias_slabs, int32_t bias_rows, float* dbias,
+                          void* stream);
 /* column sums of two [rows, c] matrices (row stride ld) in one launch, rows <= 256: GroupNorm's dgamma and dbeta from the
  * per-sample tables of sgd_gn_bwd_coef. */
 int sgd_colsum_pair(const float* g1, const float* g2, int32_t rows, int32_t c, int32_t ld, float* out1, float* out2,
@@ -432,6 +440,12 @@ int sgd_gn_bwd_coef(const float* S, const float* sums, const float* gamma, const
                     float* dfilm, void* stream);
 /* dx[row, c_off + c] (+)= A*gu*SiLU'(a x + b) + B*x + C  (+ extra residual-path gradient gres, same gu_mode rules)
  * written into dst (row stride dst_ld, channel offset dst_off); accumulate: add to what is there. */
+/* sgd_gn_bwd_coef + sgd_colsum_pair(dgamma_nc, dbeta_nc) in one launch (n <= 256, 8 * n * c / groups <= 60 KiB of LDS, else
+ * SGD_ERR_ARG: use the two calls): A, B, Cc, dfilm as sgd_gn_bwd_coef; dgamma[c] / dbeta[c] (+)= scale * column sums over the
+ * images, bit-identical to the two-call route. */
+int sgd_gn_bwd_coef_fold(const float* S, const float* sums, const float* gamma, const float* beta, const float* film,
+                         int32_t film_ld, int32_t n, int32_t c, int32_t groups, int32_t hw, float eps, float* A, float* B,
+                         float* Cc, float* dfilm, float* dgamma, float* dbeta, int32_t accumulate, float scale, void* stream);
 int sgd_gn_bwd_apply(const float* x, int32_t n, int32_t h, int32_t w, int32_t c, int32_t c_total, int32_t c_off,
                      const float* a, const float* b, int32_t silu,
                      const float* gu, int32_t gu_ld, int32_t gu_mode, float drop_p, uint32_t drop_seed,

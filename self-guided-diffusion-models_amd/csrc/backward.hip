@@ -542,18 +542,18 @@ __global__ __launch_bounds__(256, 2) void wgrad_conv_kernel(const WArgs w) {
 // Measured on the C2 training step (bs 80): the transforms cost 11.5 of the 22.5 ms of weight-gradient time.
 // ---------------------------------------------------------------------------------------------
 template <int PREC>
-__global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict__ g, long rows, int c, int ld,
-                                                         typename Split<PREC>::T* __restrict__ hi,
-                                                         typename Split<PREC>::T* __restrict__ lo, int chunks,
-                                                         float* __restrict__ colsum) {
-    // block = 128 channels (32 quads) x 8 row lanes over the rows of chunk blockIdx.y; colsum[chunk][c] = column sums of
+__device__ __forceinline__ void split_rows_body(const float* __restrict__ g, long rows, int c, int ld,
+                                                typename Split<PREC>::T* __restrict__ hi,
+                                                typename Split<PREC>::T* __restrict__ lo, int chunks,
+                                                float* __restrict__ colsum, int bx, int by) {
+    // block = 128 channels (32 quads) x 8 row lanes over the rows of chunk `by`; colsum[chunk][c] = column sums of
     // the chunk (the bias gradient's partial sums, same layout as sgd_wgrad's bias_slabs), or NULL
     typedef typename Split<PREC>::T T;
     typedef T T4 __attribute__((ext_vector_type(4)));
     const int q = threadIdx.x & 31, rl = threadIdx.x >> 5;
-    const int col = blockIdx.x * 128 + q * 4;
+    const int col = bx * 128 + q * 4;
     const long per = (rows + chunks - 1) / chunks;
-    const long r0 = blockIdx.y * per, r1 = (r0 + per < rows) ? r0 + per : rows;
+    const long r0 = by * per, r1 = (r0 + per < rows) ? r0 + per : rows;
     f32x4 sum = {0.f, 0.f, 0.f, 0.f};
     if (col < c) {
         for (long r = r0 + rl; r < r1; r += 32) {
@@ -588,41 +588,12 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict
         __shared__ float red[8][128];
         *reinterpret_cast<f32x4*>(&red[rl][q * 4]) = sum;
         __syncthreads();
-        if (threadIdx.x < 128 && blockIdx.x * 128 + threadIdx.x < c) {
+        if (threadIdx.x < 128 && bx * 128 + threadIdx.x < c) {
             float t = 0.f;
 #pragma unroll
             for (int k = 0; k < 8; ++k) t += red[k][threadIdx.x];
-            colsum[(long)blockIdx.y * c + blockIdx.x * 128 + threadIdx.x] = t;
+            colsum[(long)by * c + bx * 128 + threadIdx.x] = t;
         }
-    }
-}
-
-// bslab[0][c] = sum over chunks of part[chunk][c] (fixed order), bslab[1 .. ksplit-1][c] = 0
-// block = 32 columns x 8 chunk lanes (eight independent loads in flight per lane, fixed order of additions)
-__global__ __launch_bounds__(256) void colsum_fold_rows_kernel(const float* __restrict__ part, int chunks, int c,
-                                                              float* __restrict__ bslab, int ksplit) {
-    const int col = blockIdx.x * 32 + (threadIdx.x & 31), kl = threadIdx.x >> 5;
-    float t = 0.f;
-    if (col < c) {
-        int k = kl;
-        for (; k + 56 < chunks; k += 64) {
-            float v[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = part[(long)(k + 8 * j) * c + col];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) t += v[j];
-        }
-        for (; k < chunks; k += 8) t += part[(long)k * c + col];
-    }
-    __shared__ float red[8][32];
-    red[kl][threadIdx.x & 31] = t;
-    __syncthreads();
-    if (threadIdx.x < 32 && col < c) {
-        float u = 0.f;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) u += red[j][threadIdx.x];
-        bslab[col] = u;
-        for (int k = 1; k < ksplit; ++k) bslab[(long)k * c + col] = 0.f;
     }
 }
 
@@ -632,14 +603,14 @@ __global__ __launch_bounds__(256) void colsum_fold_rows_kernel(const float* __re
 // resolution -- rows = n * (hi / 2) * (wi / 2) -- and the consumer sees an unresampled input of those dims (round 4: these
 // launches ran on the generic per-tap kernel at ~400 us each, seven times their share)
 template <int PREC>
-__global__ __launch_bounds__(256) void act_split_kernel(const sgd_igemm_args a, long rows, int rows_per_n,
-                                                        typename Split<PREC>::T* __restrict__ hi,
-                                                        typename Split<PREC>::T* __restrict__ lo, int pool) {
+__device__ __forceinline__ void act_split_body(const sgd_igemm_args& a, long rows, int rows_per_n,
+                                               typename Split<PREC>::T* __restrict__ hi,
+                                               typename Split<PREC>::T* __restrict__ lo, int pool, long blk, long nblk) {
     typedef typename Split<PREC>::T T;
     typedef T T4 __attribute__((ext_vector_type(4)));
     const int cin = a.c0 + a.c1, cq = cin >> 2;
     const long total = rows * cq;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    for (long i = blk * (long)blockDim.x + threadIdx.x; i < total; i += nblk * blockDim.x) {
         const long row = i / cq;
         const int c = (int)(i - row * cq) * 4;
         const int n = (int)(row / rows_per_n);
@@ -675,6 +646,24 @@ __global__ __launch_bounds__(256) void act_split_kernel(const sgd_igemm_args a, 
             *reinterpret_cast<T4*>(lp) = l;
         }
     }
+}
+
+// Both pre-passes of a weight-gradient launch in ONE launch (round 5: 88 launches fewer per training step -- each boundary
+// between two short kernels costs the stream ~4 us): blocks [0, sr_blocks) split the gradient rows (block = (column tile,
+// row chunk), column sums of its chunk to colsum[chunk][c]), the others the activated input.
+struct PrepassArgs {
+    const float* g; long grows; int gc, gld; void* gh; void* gl; int chunks; float* colsum; int coltiles, sr_blocks;
+    sgd_igemm_args a; long urows; int rows_per_n; void* uh; void* ul; int pool;
+};
+template <int PREC>
+__global__ __launch_bounds__(256) void wgrad_prepass_kernel(const PrepassArgs p) {
+    typedef typename Split<PREC>::T T;
+    if ((int)blockIdx.x < p.sr_blocks)
+        split_rows_body<PREC>(p.g, p.grows, p.gc, p.gld, reinterpret_cast<T*>(p.gh), reinterpret_cast<T*>(p.gl), p.chunks, p.colsum,
+                              (int)blockIdx.x % p.coltiles, (int)blockIdx.x / p.coltiles);
+    else
+        act_split_body<PREC>(p.a, p.urows, p.rows_per_n, reinterpret_cast<T*>(p.uh), reinterpret_cast<T*>(p.ul), p.pool,
+                             (long)blockIdx.x - p.sr_blocks, (long)gridDim.x - p.sr_blocks);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -966,6 +955,14 @@ static void launch_wgrad_ws(const WArgs& w, long grid, hipStream_t st) {
     hipLaunchKernelGGL((wgrad_conv_ws_kernel<PREC, PLANES>), dim3((unsigned)grid), dim3(512), smem, st, w);
 }
 
+// row chunks of the gradient split (one block per (128-column tile, chunk)): ~1024 blocks
+static long planes_chunks(long grows, int cout) {
+    const int coltiles = (cout + 127) / 128;
+    long chunks = (1024 + coltiles - 1) / coltiles;
+    if (chunks > (grows + 31) / 32) chunks = (grows + 31) / 32;
+    return chunks < 1 ? 1 : chunks;
+}
+
 // pre-passes + the planes form of the wave-specialised kernel.  scratch: [gh | gl | uh | ul], 2 bytes per element each
 template <int PREC>
 static void launch_wgrad_planes(WArgs& w, long grid, void* scratch, hipStream_t st) {
@@ -979,23 +976,19 @@ static void launch_wgrad_planes(WArgs& w, long grid, void* scratch, hipStream_t 
     T* uh = gl + grows * w.cout;
     T* ul = uh + urows * cin;
     // enough row chunks to fill the chip (the K split of the main kernel can be as small as 2); the bias gradient's column
-    // sums go through per-chunk partials behind the planes and one fold into row 0 of bslab (rows 1.. zeroed: the caller
-    // folds all ksplit rows)
+    // sums of the chunks go straight into the caller's bias rows -- sgd_wgrad_bias_rows() of them, folded by
+    // sgd_wgrad_reduce_bias (round 5: the fold into row 0 was a launch of its own)
     const int coltiles = (w.cout + 127) / 128;
-    long chunks = (1024 + coltiles - 1) / coltiles;
-    if (chunks > (grows + 31) / 32) chunks = (grows + 31) / 32;
-    if (chunks < 1) chunks = 1;
-    float* part = w.bslab ? reinterpret_cast<float*>(ul + urows * cin) : nullptr;      // [chunks][cout]
-    hipLaunchKernelGGL((split_rows_kernel<PREC>), dim3(coltiles, (unsigned)chunks), dim3(256), 0, st, w.gy, grows, w.cout,
-                       w.gy_ld, gh, gl, (int)chunks, part);
-    if (w.bslab)
-        hipLaunchKernelGGL(colsum_fold_rows_kernel, dim3((w.cout + 31) / 32), dim3(256), 0, st, part, (int)chunks, w.cout,
-                           w.bslab, w.ksplit);
+    const long chunks = planes_chunks(grows, w.cout);
     const long quads = urows * (cin / 4);
     long ablk = (quads + 255) / 256;
     if (ablk > 16384) ablk = 16384;
-    hipLaunchKernelGGL((act_split_kernel<PREC>), dim3((unsigned)ablk), dim3(256), 0, st, a, urows,
-                       pool ? (a.hi / 2) * (a.wi / 2) : a.hi * a.wi, uh, ul, pool ? 1 : 0);
+    PrepassArgs pp;
+    pp.g = w.gy; pp.grows = grows; pp.gc = w.cout; pp.gld = w.gy_ld; pp.gh = gh; pp.gl = gl; pp.chunks = (int)chunks;
+    pp.colsum = w.bslab; pp.coltiles = coltiles; pp.sr_blocks = (int)(coltiles * chunks);
+    pp.a = a; pp.urows = urows; pp.rows_per_n = pool ? (a.hi / 2) * (a.wi / 2) : a.hi * a.wi; pp.uh = uh; pp.ul = ul;
+    pp.pool = pool ? 1 : 0;
+    hipLaunchKernelGGL((wgrad_prepass_kernel<PREC>), dim3((unsigned)(pp.sr_blocks + ablk)), dim3(256), 0, st, pp);
     w.gh = gh; w.gl = gl; w.uh = uh; w.ul = ul;
     if (pool) {                   // the main kernel sees the pooled planes as an unresampled input
         w.a.hi /= 2;
@@ -1154,7 +1147,7 @@ __global__ __launch_bounds__(256) void wgrad_narrow_kernel(const float* __restri
 // colsum_stage2_kernel (round 4: 71 sgd_colsum_fold launches of ~6.5 us per training step)
 __global__ void wgrad_reduce_kernel(const float* __restrict__ slabs, int ksplit, int taps, int cout, int cin,
                                     float* __restrict__ dw, int accumulate, float scale,
-                                    const float* __restrict__ bslab, float* __restrict__ dbias) {
+                                    const float* __restrict__ bslab, float* __restrict__ dbias, int brows) {
     const long per = (long)taps * cout * cin;
     if (bslab && blockIdx.x * 32 < cout) {
         // block b folds columns 32 b .. 32 b + 31: 8 slab lanes x 32 columns, independent loads in flight, fixed order
@@ -1163,7 +1156,7 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slabs, int ksplit,
         double t = 0;
         if (col < cout) {
 #pragma unroll 4
-            for (int k = rl; k < ksplit; k += 8) t += bslab[(long)k * cout + col];
+            for (int k = rl; k < brows; k += 8) t += bslab[(long)k * cout + col];
         }
         __shared__ double red[8][32];
         red[rl][threadIdx.x & 31] = t;
@@ -1393,6 +1386,92 @@ __global__ void gn_bwd_coef_kernel(const float* __restrict__ S, const float* __r
     }
 }
 
+// gn_bwd_coef_kernel + the dgamma / dbeta column sums (sgd_colsum_pair) in ONE launch (round 5: 49 launches fewer per
+// training step).  One block per GROUP: thread (nn, k) forms the coefficients of channel g0 + k of image nn exactly as
+// gn_bwd_coef_kernel does, leaves its dgamma / dbeta contributions in LDS tables [n][cpg], and the block then sums the
+// tables' columns over the images in colsum_stage1_kernel's order (8 row lanes, rows rl, rl + 8, .. in float; the lanes
+// folded in float; double * scale): bit-identical to the two-launch route.
+__global__ __launch_bounds__(256) void gn_bwd_coef_fold_kernel(const float* __restrict__ S, const float* __restrict__ sums,
+                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                               const float* __restrict__ film, int film_ld, int n, int c,
+                                                               int groups, int hw, float eps, float* __restrict__ A,
+                                                               float* __restrict__ B, float* __restrict__ Cc,
+                                                               float* __restrict__ dfilm, float* __restrict__ dgamma,
+                                                               float* __restrict__ dbeta, int accumulate, float scale) {
+    extern __shared__ float tab[];                    // dg[n][cpg] | db[n][cpg]
+    const int cpg = c / groups, g0 = blockIdx.x * cpg;
+    float* const tdg = tab;
+    float* const tdb = tab + (size_t)n * cpg;
+    for (int it = threadIdx.x; it < n * cpg; it += blockDim.x) {
+        const int nn = it / cpg, kk = it - nn * cpg, cc = g0 + kk;
+        const long i = (long)nn * c + cc;
+        double s = 0, ss = 0;
+        for (int k = 0; k < cpg; ++k) {
+            s += sums[((long)nn * c + g0 + k) * 2];
+            ss += sums[((long)nn * c + g0 + k) * 2 + 1];
+        }
+        const double m = (double)cpg * hw;
+        const double mean = s / m;
+        double var = ss / m - mean * mean;
+        if (var < 0) var = 0;
+        const double r = 1.0 / sqrt(var + (double)eps);
+        double m1 = 0, m2 = 0;
+        for (int k = 0; k < cpg; ++k) {
+            const long j = (long)nn * c + g0 + k;
+            const double sc = film ? 1.0 + film[(long)nn * film_ld + g0 + k] : 1.0;
+            const double gp = gamma[g0 + k] * sc;
+            const double S1 = S[j * 2], X = r * (S[j * 2 + 1] - mean * S1);
+            m1 += gp * S1;
+            m2 += gp * X;
+        }
+        m1 /= m;
+        m2 /= m;
+        const double sc = film ? 1.0 + film[(long)nn * film_ld + cc] : 1.0;
+        const double S1 = S[i * 2], X = r * (S[i * 2 + 1] - mean * S1);
+        A[i] = (float)(r * gamma[cc] * sc);
+        B[i] = (float)(-r * r * m2);
+        Cc[i] = (float)(r * r * m2 * mean - r * m1);
+        tdg[it] = (float)(X * sc);
+        tdb[it] = (float)(S1 * sc);
+        if (dfilm) {
+            dfilm[(long)nn * film_ld + cc] = (float)(X * gamma[cc] + S1 * beta[cc]);      // d/d scale
+            dfilm[(long)nn * film_ld + c + cc] = (float)S1;                               // d/d shift
+        }
+    }
+    __syncthreads();
+    // column sums over the images: thread = (table, column kk, row lane rl)
+    __shared__ float red[2][8][32];
+    const int t2 = threadIdx.x >> 7, rem = threadIdx.x & 127;          // 2 tables x (up to 16 columns x 8 lanes) per pass
+    for (int k0 = 0; k0 < cpg; k0 += 16) {
+        const int kk = k0 + (rem & 15), rl = rem >> 4;
+        float sacc = 0.f;
+        if (kk < cpg) {
+            const float* tp = t2 ? tdb : tdg;
+            int r = rl;
+            for (; r + 56 < n; r += 64) {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = tp[(r + 8 * j) * cpg + kk];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) sacc += v[j];
+            }
+            for (; r < n; r += 8) sacc += tp[r * cpg + kk];
+        }
+        red[t2][rl][rem & 15] = sacc;
+        __syncthreads();
+        if (rl == 0 && kk < cpg) {
+            float t = 0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t += red[t2][k][rem & 15];
+            double u = t;
+            u *= scale;
+            float* out = t2 ? dbeta : dgamma;
+            out[g0 + kk] = accumulate ? out[g0 + kk] + (float)u : (float)u;
+        }
+        __syncthreads();
+    }
+}
+
 __global__ void gn_bwd_apply_kernel(const float* __restrict__ x, int n, int h, int w, int c, int c_total, int c_off,
                                     const float* __restrict__ a, const float* __restrict__ b, int silu,
                                     const float* __restrict__ gu, int gu_ld, int gu_mode, float drop_p,
@@ -1487,6 +1566,37 @@ inline unsigned nblk(long total, int cap = 1 << 20) {
 
 }  // namespace
 
+// which kernel serves a weight-gradient launch: shared by wgrad_impl and sgd_wgrad_bias_rows (the caller sizes the bias rows)
+static bool wgrad_is_narrow(const sgd_igemm_args& a, int cout, long rows, int ksplit) {
+    // stem / head: a handful of channels on one side, a whole number of waves of lanes on the other (see the kernels)
+    const int cin = a.c0 + a.c1;
+    if (!(a.mode == SGD_MODE_CONV3 && a.stride == 1 && a.resample == SGD_RS_NONE && a.c1 == 0 && a.drop_p == 0.f
+          && ksplit <= (rows + 63) / 64 && !(a.tune & SGD_TUNE_WGRAD_GENERIC_NARROW)))
+        return false;
+    const bool lanes_co = cout % 64 == 0 && (cout == 256 || (cout < 256 && 256 % cout == 0));
+    const bool lanes_ci = cin % 64 == 0 && (cin == 256 || (cin < 256 && 256 % cin == 0));
+    if (cin <= 4 && cin >= 3 && a.pro == SGD_PRO_NONE && !a.pro_silu && lanes_co) return true;
+    return cout == 3 && (a.pro == SGD_PRO_NONE || a.pro == SGD_PRO_AFFINE_NC) && lanes_ci;
+}
+static bool wgrad_fast_conv(const sgd_igemm_args& a) {
+    return a.mode == SGD_MODE_CONV3 && a.stride == 1 && a.resample != SGD_RS_ZEROUP2 && a.ho > 0 && a.wo > 0 && a.ho % 8 == 0
+           && a.wo % 8 == 0;
+}
+static bool wgrad_ws_ok(const sgd_igemm_args& a, int cout, int gy_ld) {          // wave-specialised kernel (without planes: no pool)
+    const bool vec = (a.c0 % 4 == 0) && (a.c1 % 4 == 0);
+    const bool pooled = a.resample == SGD_RS_AVGPOOL2 && !(a.tune & SGD_TUNE_WGRAD_NO_POOLED_PLANES);
+    return wgrad_fast_conv(a) && a.prec != SGD_PREC_F32 && !(a.tune & SGD_TUNE_WGRAD_F32) && vec && gy_ld % 4 == 0 && cout % WT == 0
+           && (a.resample == SGD_RS_NONE || a.resample == SGD_RS_UP2 || pooled)
+           && (a.pro == SGD_PRO_NONE || a.pro == SGD_PRO_AFFINE_NC) && !(a.tune & SGD_TUNE_WGRAD_NO_WS);
+}
+static int64_t wgrad_planes_need(const sgd_igemm_args& a, int cout) {
+    const int64_t rows = (int64_t)a.n * a.ho * a.wo;
+    return 4 * (rows * cout + (int64_t)a.n * a.hi * a.wi * (a.c0 + a.c1));
+}
+static bool wgrad_planes_ok(const sgd_igemm_args& a, int cout, int gy_ld, bool have_scratch, int64_t scratch_bytes) {
+    return wgrad_ws_ok(a, cout, gy_ld) && have_scratch && scratch_bytes >= wgrad_planes_need(a, cout) && !(a.tune & SGD_TUNE_WGRAD_NO_PLANES);
+}
+
 static int wgrad_impl(const sgd_igemm_args* fwd, const float* gy, int32_t gy_ld, int32_t cout, float* slabs,
                       int32_t ksplit, float* bias_slabs, void* scratch, int64_t scratch_bytes, void* stream) {
     SGD_CLEAR_ERR();
@@ -1516,23 +1626,17 @@ static int wgrad_impl(const sgd_igemm_args* fwd, const float* gy, int32_t gy_ld,
         return SGD_ERR_ARG;
     }
     if (w.rows <= 0) return SGD_ERR_ARG;
-    // stem / head: a handful of channels on one side, a whole number of waves of lanes on the other (see the kernels)
-    if (a.mode == SGD_MODE_CONV3 && a.stride == 1 && a.resample == SGD_RS_NONE && a.c1 == 0 && a.drop_p == 0.f
-        && ksplit <= (w.rows + 63) / 64 && !(a.tune & SGD_TUNE_WGRAD_GENERIC_NARROW)) {
+    if (wgrad_is_narrow(a, cout, w.rows, ksplit)) {
         hipStream_t st0 = (hipStream_t)stream;
-        const bool lanes_co = cout % 64 == 0 && (cout == 256 || (cout < 256 && 256 % cout == 0));
-        const bool lanes_ci = cin % 64 == 0 && (cin == 256 || (cin < 256 && 256 % cin == 0));
-        if (cin <= 4 && cin >= 3 && a.pro == SGD_PRO_NONE && !a.pro_silu && lanes_co) {
+        if (cin <= 4) {
             if (cin == 3) hipLaunchKernelGGL((wgrad_narrow_kernel<3, false>), dim3(ksplit), dim3(256), 0, st0, a.x0, (const float*)nullptr, (const float*)nullptr, 0, gy, gy_ld, a.n, a.ho, a.wo, cout, ksplit, slabs, bias_slabs);
             else hipLaunchKernelGGL((wgrad_narrow_kernel<4, false>), dim3(ksplit), dim3(256), 0, st0, a.x0, (const float*)nullptr, (const float*)nullptr, 0, gy, gy_ld, a.n, a.ho, a.wo, cout, ksplit, slabs, bias_slabs);
             return sgd_check_launch();
         }
-        if (cout == 3 && (a.pro == SGD_PRO_NONE || a.pro == SGD_PRO_AFFINE_NC) && lanes_ci) {
-            hipLaunchKernelGGL((wgrad_narrow_kernel<3, true>), dim3(ksplit), dim3(256), 0, st0, a.x0, a.pro == SGD_PRO_AFFINE_NC ? a.pa : nullptr,
-                               a.pro == SGD_PRO_AFFINE_NC ? a.pb : nullptr, a.pro_silu, gy, gy_ld, a.n, a.ho, a.wo, cin, ksplit, slabs,
-                               bias_slabs);
-            return sgd_check_launch();
-        }
+        hipLaunchKernelGGL((wgrad_narrow_kernel<3, true>), dim3(ksplit), dim3(256), 0, st0, a.x0, a.pro == SGD_PRO_AFFINE_NC ? a.pa : nullptr,
+                           a.pro == SGD_PRO_AFFINE_NC ? a.pb : nullptr, a.pro_silu, gy, gy_ld, a.n, a.ho, a.wo, cin, ksplit, slabs,
+                           bias_slabs);
+        return sgd_check_launch();
     }
     w.gy = gy; w.gy_ld = gy_ld; w.cout = cout; w.slabs = slabs; w.bslab = bias_slabs;
     w.co_tiles = (cout + WT - 1) / WT;
@@ -1543,8 +1647,7 @@ static int wgrad_impl(const sgd_igemm_args* fwd, const float* gy, int32_t gy_ld,
     const bool vec = (a.c0 % 4 == 0) && (a.c1 % 4 == 0);
     hipStream_t st = (hipStream_t)stream;
     // split-precision kernels: 3x3 stride 1 on whole 8x8 output patches (all taps per block), and 1x1 / linear
-    const bool fast_conv = a.mode == SGD_MODE_CONV3 && a.stride == 1 && a.resample != SGD_RS_ZEROUP2 && a.ho % 8 == 0
-                           && a.wo % 8 == 0;
+    const bool fast_conv = wgrad_fast_conv(a);
     const bool fast_flat = a.mode == SGD_MODE_FLAT && a.pro != SGD_PRO_LN_ROW && cout >= 32 && cin >= 32;
     if ((fast_conv || fast_flat) && a.prec != SGD_PREC_F32 && !(a.tune & SGD_TUNE_WGRAD_F32)) {
         w.gvec = gy_ld % 4 == 0;
@@ -1553,15 +1656,12 @@ static int wgrad_impl(const sgd_igemm_args* fwd, const float* gy, int32_t gy_ld,
         if (fgrid > 0x7fffffffL) return SGD_ERR_ARG;
         // wave-specialised kernel: 16-byte gradient rows of whole 128-channel blocks, whole rows (cout % 128 == 0), vector
         // input rows, GroupNorm-affine / no prologue, no avg-pool.  (Dropout does not exclude it: with pre-split planes
-        // act_split_kernel applies the keep mask through apply_pro, and the in-kernel loader does the same.)
-        // the fused average pool (ResBlock(down)) only through the planes: act_split_kernel writes them pooled
+        // the pre-pass applies the keep mask through apply_pro, and the in-kernel loader does the same.)
+        // the fused average pool (ResBlock(down)) only through the planes: the pre-pass writes them pooled
         const bool pooled = a.resample == SGD_RS_AVGPOOL2 && !(a.tune & SGD_TUNE_WGRAD_NO_POOLED_PLANES);
-        const bool ws0 = fast_conv && vec && w.gvec && cout % WT == 0
-                         && (a.resample == SGD_RS_NONE || a.resample == SGD_RS_UP2 || pooled)
-                         && (a.pro == SGD_PRO_NONE || a.pro == SGD_PRO_AFFINE_NC) && !(a.tune & SGD_TUNE_WGRAD_NO_WS);
+        const bool ws0 = wgrad_ws_ok(a, cout, gy_ld);
         // ... and with a scratch buffer for the pre-split operand planes: the loaders only copy
-        const int64_t need = 4 * ((int64_t)w.rows * cout + (int64_t)a.n * a.hi * a.wi * cin) + 4 * 2048 * (int64_t)cout;
-        const bool planes = ws0 && scratch && scratch_bytes >= need && !(a.tune & SGD_TUNE_WGRAD_NO_PLANES);
+        const bool planes = wgrad_planes_ok(a, cout, gy_ld, scratch != nullptr, scratch_bytes);
         const bool ws = ws0 && (planes || !pooled);
 #define SGD_WG(P, V)                                                             \
         do { if (planes) launch_wgrad_planes<P>(w, fgrid, scratch, st);           \
@@ -1590,7 +1690,16 @@ extern "C" int sgd_wgrad(const sgd_igemm_args* fwd, const float* gy, int32_t gy_
 extern "C" int64_t sgd_wgrad_scratch_bytes(const sgd_igemm_args* fwd, int32_t cout) {
     if (!fwd || fwd->mode != SGD_MODE_CONV3) return 0;
     const int64_t rows = (int64_t)fwd->n * fwd->ho * fwd->wo, urows = (int64_t)fwd->n * fwd->hi * fwd->wi;
-    return 4 * (rows * cout + urows * (fwd->c0 + fwd->c1)) + 4 * 2048 * (int64_t)cout;   // planes + column-sum partials
+    return 4 * (rows * cout + urows * (fwd->c0 + fwd->c1));        // the four operand planes
+}
+
+extern "C" int sgd_wgrad_bias_rows(const sgd_igemm_args* fwd, int32_t cout, int32_t gy_ld, int32_t ksplit, int64_t scratch_bytes) {
+    if (!fwd || cout <= 0 || ksplit <= 0) return 0;
+    const sgd_igemm_args& a = *fwd;
+    const long rows = a.mode == SGD_MODE_CONV3 ? (long)a.n * a.ho * a.wo : (long)a.m;
+    if (wgrad_is_narrow(a, cout, rows, ksplit)) return ksplit;
+    if (wgrad_planes_ok(a, cout, gy_ld, scratch_bytes > 0, scratch_bytes)) return (int)planes_chunks(rows, cout);
+    return ksplit;
 }
 
 extern "C" int sgd_wgrad_scratch(const sgd_igemm_args* fwd, const float* gy, int32_t gy_ld, int32_t cout, float* slabs,
@@ -1604,18 +1713,19 @@ extern "C" int sgd_wgrad_reduce(const float* slabs, int32_t ksplit, int32_t taps
     if (!slabs || !dw || ksplit <= 0 || taps <= 0 || cout <= 0 || cin <= 0) return SGD_ERR_ARG;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nblk((long)taps * cout * cin, 8192)), dim3(256), 0,
                        (hipStream_t)stream, slabs, ksplit, taps, cout, cin, dw, accumulate, scale, (const float*)nullptr,
-                       (float*)nullptr);
+                       (float*)nullptr, 0);
     return sgd_check_launch();
 }
 
 extern "C" int sgd_wgrad_reduce_bias(const float* slabs, int32_t ksplit, int32_t taps, int32_t cout, int32_t cin, float* dw,
-                                     int32_t accumulate, float scale, const float* bias_slabs, float* dbias, void* stream) {
+                                     int32_t accumulate, float scale, const float* bias_slabs, int32_t bias_rows, float* dbias,
+                                     void* stream) {
     SGD_CLEAR_ERR();
-    if (!slabs || !dw || !bias_slabs || !dbias || ksplit <= 0 || taps <= 0 || cout <= 0 || cin <= 0) return SGD_ERR_ARG;
+    if (!slabs || !dw || !bias_slabs || !dbias || ksplit <= 0 || taps <= 0 || cout <= 0 || cin <= 0 || bias_rows <= 0) return SGD_ERR_ARG;
     unsigned grid = nblk((long)taps * cout * cin, 8192);
     if (grid < (unsigned)((cout + 31) / 32)) grid = (cout + 31) / 32;        // one block per 32 bias columns
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, slabs, ksplit, taps, cout, cin, dw,
-                       accumulate, scale, bias_slabs, dbias);
+                       accumulate, scale, bias_slabs, dbias, bias_rows);
     return sgd_check_launch();
 }
 
@@ -1682,6 +1792,23 @@ extern "C" int sgd_gn_bwd_coef(const float* S, const float* sums, const float* g
     if ((film || dfilm) && film_ld < 2 * c) return SGD_ERR_ARG;
     hipLaunchKernelGGL(gn_bwd_coef_kernel, dim3(nblk((long)n * c)), dim3(256), 0, (hipStream_t)stream, S, sums, gamma,
                        beta, film, film_ld, n, c, groups, hw, eps, A, B, Cc, dgamma_nc, dbeta_nc, dfilm);
+    return sgd_check_launch();
+}
+
+extern "C" int sgd_gn_bwd_coef_fold(const float* S, const float* sums, const float* gamma, const float* beta, const float* film,
+                                    int32_t film_ld, int32_t n, int32_t c, int32_t groups, int32_t hw, float eps, float* A, float* B,
+                                    float* Cc, float* dfilm, float* dgamma, float* dbeta, int32_t accumulate, float scale,
+                                    void* stream) {
+    SGD_CLEAR_ERR();
+    if (!S || !sums || !gamma || !beta || !A || !B || !Cc || !dgamma || !dbeta || n <= 0 || n > 256 || c <= 0 || groups <= 0 ||
+        c % groups || hw <= 0)
+        return SGD_ERR_ARG;
+    if ((film || dfilm) && film_ld < 2 * c) return SGD_ERR_ARG;
+    const int cpg = c / groups;
+    const size_t lds = (size_t)2 * n * cpg * sizeof(float);
+    if (lds > 60 * 1024) return SGD_ERR_ARG;          // (callers fall back to sgd_gn_bwd_coef + sgd_colsum_pair)
+    hipLaunchKernelGGL(gn_bwd_coef_fold_kernel, dim3(groups), dim3(256), lds, (hipStream_t)stream, S, sums, gamma, beta, film,
+                       film_ld, n, c, groups, hw, eps, A, B, Cc, dfilm, dgamma, dbeta, accumulate, scale);
     return sgd_check_launch();
 }
 

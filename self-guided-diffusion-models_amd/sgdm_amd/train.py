@@ -233,12 +233,14 @@ class Backward:
         ktiles = (rows + 63) // 64
         ksplit = wgrad_ksplit(taps, cout, cin, rows)
         slabs = self.buf(ksplit, taps, cout, cin)
-        # the bias gradient (column sums of gy) comes out of the same launch: the kernel stages the gy rows anyway
-        bslab = self.buf(ksplit, cout) if bias_name is not None else None
         # 3x3 convs: operands pre-split once into 16-bit planes (scratch shared by every launch of the program, grown to
         # the largest request before the first run: sgd_wgrad_scratch)
         need = int(self.lib.sgd_wgrad_scratch_bytes(C.byref(fwd_args), cout)) if taps == 9 else 0
         self.wscratch_bytes = max(getattr(self, "wscratch_bytes", 0), need)
+        # the bias gradient (column sums of gy) comes out of the same launch: the kernel (or its pre-pass) stages the gy
+        # rows anyway; as many partial rows as that launch writes
+        brows = int(self.lib.sgd_wgrad_bias_rows(C.byref(fwd_args), cout, gy_ld, ksplit, need)) if bias_name is not None else 0
+        bslab = self.buf(brows, cout) if bias_name is not None else None
         box = self
 
         def wgrad_launch(stream, fwd_args=fwd_args, gy=gy, slabs=slabs, bslab=bslab):
@@ -251,7 +253,7 @@ class Backward:
         if bias_name is not None:
             # weight and bias gradient of the layer folded by one launch
             self.prog.add(tag + ".wred", self.lib.sgd_wgrad_reduce_bias, _ptr(slabs), ksplit, taps, cout, cin, _ptr(dw), 0,
-                          self.unscale, _ptr(bslab), _ptr(self.pg(bias_name)))
+                          self.unscale, _ptr(bslab), brows, _ptr(self.pg(bias_name)))
         else:
             self.prog.add(tag + ".wred", self.lib.sgd_wgrad_reduce, _ptr(slabs), ksplit, taps, cout, cin, _ptr(dw), 0,
                           self.unscale)
@@ -308,12 +310,22 @@ class Backward:
             self.prog.add(tag + ".reduce", lib.sgd_gn_bwd_reduce, _ptr(t), n, h, w, c, ct, off, _ptr(a), _ptr(b), silu,
                           _ptr(gu), gu_ld, gu_mode, drop[0], drop[1], _ptr(S))
             off += c
-        A, B, Cc, dg, db = (self.buf(n, ct) for _ in range(5))
+        A, B, Cc = (self.buf(n, ct) for _ in range(3))
         gamma, beta = self.m.P(gname + ".weight"), self.m.P(gname + ".bias")
-        self.prog.add(tag + ".coef", lib.sgd_gn_bwd_coef, _ptr(S), _ptr(sums), _ptr(gamma), _ptr(beta),
-                      C.c_void_p(film_ptr), film_ld, n, ct, GN_GROUPS, h * w, GN_EPS, _ptr(A), _ptr(B), _ptr(Cc),
-                      _ptr(dg), _ptr(db), C.c_void_p(dfilm_ptr))
-        if n <= 256:             # dgamma and dbeta from the per-sample tables in one launch
+        fused = n <= 256 and 8 * n * (ct // GN_GROUPS) <= 60 * 1024 and os.environ.get("SGDM_GN_BWD_FOLD", "1") != "0"
+        if fused:                # coefficients + dgamma / dbeta column sums in ONE launch (bit-identical to the two below)
+            self.prog.add(tag + ".coef", lib.sgd_gn_bwd_coef_fold, _ptr(S), _ptr(sums), _ptr(gamma), _ptr(beta),
+                          C.c_void_p(film_ptr), film_ld, n, ct, GN_GROUPS, h * w, GN_EPS, _ptr(A), _ptr(B), _ptr(Cc),
+                          C.c_void_p(dfilm_ptr), _ptr(self.pg(gname + ".weight")), _ptr(self.pg(gname + ".bias")), 0,
+                          self.unscale)
+        else:
+            dg, db = self.buf(n, ct), self.buf(n, ct)
+            self.prog.add(tag + ".coef", lib.sgd_gn_bwd_coef, _ptr(S), _ptr(sums), _ptr(gamma), _ptr(beta),
+                          C.c_void_p(film_ptr), film_ld, n, ct, GN_GROUPS, h * w, GN_EPS, _ptr(A), _ptr(B), _ptr(Cc),
+                          _ptr(dg), _ptr(db), C.c_void_p(dfilm_ptr))
+        if fused:
+            pass
+        elif n <= 256:           # dgamma and dbeta from the per-sample tables in one launch
             self.prog.add(tag + ".dgamma_dbeta", lib.sgd_colsum_pair, _ptr(dg), _ptr(db), n, ct, ct,
                           _ptr(self.pg(gname + ".weight")), _ptr(self.pg(gname + ".bias")), 0, self.unscale)
         else:

@@ -53,23 +53,32 @@ def test_conv_dgrad_is_forward_kernel_on_adjoint_weights(shape, prec, tol):
 
 def _wgrad(L, lib, fwd, gy, cout, cin, taps, ksplit, scratch=False):
     slabs = torch.full((ksplit, taps, cout, cin), float("nan"), device="cuda")
-    bsl = torch.full((ksplit, cout), float("nan"), device="cuda")
-    if scratch:          # operands pre-split into 16-bit planes by two element-wise passes (sgd_wgrad_scratch)
-        nbytes = int(lib.sgd_wgrad_scratch_bytes(C.byref(fwd), cout))
+    nbytes = int(lib.sgd_wgrad_scratch_bytes(C.byref(fwd), cout)) if scratch else 0
+    # partial rows of the bias gradient the launch writes: ksplit, or the row chunks of the planes form's pre-pass
+    brows = int(lib.sgd_wgrad_bias_rows(C.byref(fwd), cout, gy.shape[-1], ksplit, nbytes))
+    assert brows >= 1
+    bsl = torch.full((brows + 1, cout), float("nan"), device="cuda")        # (+ a guard row that must stay untouched)
+    if scratch:          # operands pre-split into 16-bit planes by one element-wise pre-pass (sgd_wgrad_scratch)
         assert nbytes > 0
         buf = torch.full((nbytes // 4 + 4,), float("nan"), device="cuda")
         L.check(lib.sgd_wgrad_scratch(C.byref(fwd), _p(gy), gy.shape[-1], cout, _p(slabs), ksplit, _p(bsl), _p(buf), nbytes,
                                       _stream()), "wgrad_scratch")
     else:
         L.check(lib.sgd_wgrad(C.byref(fwd), _p(gy), gy.shape[-1], cout, _p(slabs), ksplit, _p(bsl), _stream()), "wgrad")
+    assert torch.isnan(bsl[brows]).all() and torch.isfinite(bsl[:brows]).all()
     # the bias gradient rides along: partial column sums of gy, folded like sgd_colsum's second stage
     db = torch.full((cout,), float("nan"), device="cuda")
-    L.check(lib.sgd_colsum_fold(_p(bsl), ksplit, cout, _p(db), 0, 1.0, _stream()), "fold")
+    L.check(lib.sgd_colsum_fold(_p(bsl), brows, cout, _p(db), 0, 1.0, _stream()), "fold")
     ref_db = gy.reshape(-1, gy.shape[-1])[:, :cout].double().sum(0).float()
     assert max_rel(db.cpu(), ref_db.cpu()) < 2e-6
     dw = torch.full((cout, cin, taps), float("nan"), device="cuda")
     L.check(lib.sgd_wgrad_reduce(_p(slabs), ksplit, taps, cout, cin, _p(dw), 0, 1.0, _stream()), "reduce")
     L.check(lib.sgd_wgrad_reduce(_p(slabs), ksplit, taps, cout, cin, _p(dw), 1, 1.0, _stream()), "reduce+")     # accumulate
+    # ... and the one-launch form of both folds (what the training program uses)
+    dw2, db2 = torch.full((cout, cin, taps), float("nan"), device="cuda"), torch.full((cout,), float("nan"), device="cuda")
+    L.check(lib.sgd_wgrad_reduce_bias(_p(slabs), ksplit, taps, cout, cin, _p(dw2), 0, 1.0, _p(bsl), brows, _p(db2), _stream()),
+            "reduce_bias")
+    assert torch.equal(db2, db) and torch.equal(dw2 * 2, dw)
     return dw.cpu() / 2
 
 
@@ -368,6 +377,43 @@ def test_groupnorm_silu_backward(gu_mode, silu, film):
     assert max_rel(db.cpu().sum(0), beta.grad) < 2e-5
     if film:
         assert max_rel(dfilm.cpu(), fl.grad) < 2e-5
+
+
+@pytest.mark.parametrize("n,c,film", [(80, 128, True), (80, 1024, True), (3, 96, False), (160, 384, False), (256, 512, True),
+                                      (7, 32, True)])
+def test_groupnorm_backward_coefficients_and_column_sums_in_one_launch(n, c, film):
+    """sgd_gn_bwd_coef_fold (round 5) against sgd_gn_bwd_coef + sgd_colsum_pair on the same statistics: A, B, C, dfilm and
+    the scaled dgamma / dbeta -- every bit (the fold keeps the two-stage column sum's order of additions), plain and
+    accumulating"""
+    L, lib = _lib()
+    g = torch.Generator().manual_seed(n * 1000 + c)
+    hw, groups = 4096, 32
+    S = torch.randn(n, c, 2, generator=g).cuda()
+    x1 = torch.randn(n, c, generator=g) * 40
+    sums = torch.stack([x1, x1 * x1 / hw + hw * (0.5 + torch.rand(n, c, generator=g))], -1).cuda()     # var > 0
+    gamma, beta = torch.randn(c, generator=g).cuda(), torch.randn(c, generator=g).cuda()
+    fl = torch.randn(n, 2 * c, generator=g).cuda() if film else None
+    scale = 1.0 / 4096.0
+    A, B, Cc, dg, db = (torch.empty(n, c, device="cuda") for _ in range(5))
+    dfilm = torch.zeros(n, 2 * c, device="cuda")
+    L.check(lib.sgd_gn_bwd_coef(_p(S), _p(sums), _p(gamma), _p(beta), _p(fl), 2 * c, n, c, groups, hw, 1e-5, _p(A), _p(B), _p(Cc),
+                                _p(dg), _p(db), _p(dfilm) if film else None, _stream()), "coef")
+    base = torch.randn(2, c, generator=g).cuda()
+    for acc in (0, 1):
+        o1, o2 = base[0].clone(), base[1].clone()
+        L.check(lib.sgd_colsum_pair(_p(dg), _p(db), n, c, c, _p(o1), _p(o2), acc, scale, _stream()), "pair")
+        A2, B2, C2 = (torch.full((n, c), float("nan"), device="cuda") for _ in range(3))
+        dfilm2 = torch.zeros(n, 2 * c, device="cuda")
+        p1, p2 = base[0].clone(), base[1].clone()
+        L.check(lib.sgd_gn_bwd_coef_fold(_p(S), _p(sums), _p(gamma), _p(beta), _p(fl), 2 * c, n, c, groups, hw, 1e-5, _p(A2),
+                                         _p(B2), _p(C2), _p(dfilm2) if film else None, _p(p1), _p(p2), acc, scale, _stream()),
+                "fold")
+        torch.cuda.synchronize()
+        assert torch.equal(A2, A) and torch.equal(B2, B) and torch.equal(C2, Cc) and torch.equal(dfilm2, dfilm)
+        assert torch.equal(p1, o1) and torch.equal(p2, o2)
+    # what does not fit the fold's LDS tables is refused, not truncated
+    assert lib.sgd_gn_bwd_coef_fold(_p(S), _p(sums), _p(gamma), _p(beta), None, 0, 257, c, groups, hw, 1e-5, _p(A), _p(B), _p(Cc),
+                                    None, _p(o1), _p(o2), 0, scale, _stream()) == 1
 
 
 @pytest.mark.parametrize("core,gscale", [("exact", 1.0), ("split", 1.0), ("split", 1e-2), ("split", 1e3)])
