@@ -440,7 +440,7 @@ int sgd_gn_bwd_coef(const float* S, const float* sums, const float* gamma, const
                     float* dfilm, void* stream);
 /* dx[row, c_off + c] (+)= A*gu*SiLU'(a x + b) + B*x + C  (+ extra residual-path gradient gres, same gu_mode rules)
  * written into dst (row stride dst_ld, channel offset dst_off); accumulate: add to what is there. */
-/* sgd_gn_bwd_coef + sgd_colsum_pair(dgamma_nc, dbeta_nc) in one launch (n <= 256, 8 * n * c / groups <= 60 KiB of LDS, else
+/* sgd_gn_bwd_coef + sgd_colsum_pair(dgamma_nc, dbeta_nc) in one launch (n <= 256, 8 * n * c / groups + 32 * n + 4 <= 64 KiB of LDS, else
  * SGD_ERR_ARG: use the two calls): A, B, Cc, dfilm as sgd_gn_bwd_coef; dgamma[c] / dbeta[c] (+)= scale * column sums over the
  * images, bit-identical to the two-call route. */
 int sgd_gn_bwd_coef_fold(const float* S, const float* sums, const float* gamma, const float* beta, const float* film,

@@ -955,10 +955,11 @@ static void launch_wgrad_ws(const WArgs& w, long grid, hipStream_t st) {
     hipLaunchKernelGGL((wgrad_conv_ws_kernel<PREC, PLANES>), dim3((unsigned)grid), dim3(512), smem, st, w);
 }
 
-// row chunks of the gradient split (one block per (128-column tile, chunk)): ~1024 blocks
+// row chunks of the gradient split (one block per (128-column tile, chunk)): ~512 blocks -- they run next to the thousands
+// of blocks of the activation split in the same launch, and every chunk is a partial row the bias fold has to read
 static long planes_chunks(long grows, int cout) {
     const int coltiles = (cout + 127) / 128;
-    long chunks = (1024 + coltiles - 1) / coltiles;
+    long chunks = (512 + coltiles - 1) / coltiles;
     if (chunks > (grows + 31) / 32) chunks = (grows + 31) / 32;
     return chunks < 1 ? 1 : chunks;
 }
@@ -1155,8 +1156,16 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slabs, int ksplit,
         const int col = blockIdx.x * 32 + (threadIdx.x & 31), rl = threadIdx.x >> 5;
         double t = 0;
         if (col < cout) {
-#pragma unroll 4
-            for (int k = rl; k < brows; k += 8) t += bslab[(long)k * cout + col];
+            // eight partial rows of this lane in flight (the planes form writes a few hundred of them), added in index order
+            int k = rl;
+            for (; k + 56 < brows; k += 64) {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = bslab[(long)(k + 8 * j) * cout + col];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) t += v[j];
+            }
+            for (; k < brows; k += 8) t += bslab[(long)k * cout + col];
         }
         __shared__ double red[8][32];
         red[rl][threadIdx.x & 31] = t;
@@ -1398,13 +1407,14 @@ __global__ __launch_bounds__(256) void gn_bwd_coef_fold_kernel(const float* __re
                                                                float* __restrict__ B, float* __restrict__ Cc,
                                                                float* __restrict__ dfilm, float* __restrict__ dgamma,
                                                                float* __restrict__ dbeta, int accumulate, float scale) {
-    extern __shared__ float tab[];                    // dg[n][cpg] | db[n][cpg]
+    extern __shared__ float tab[];                    // dg[n][cpg] | db[n][cpg] | per image: mean, r, m1, m2 (doubles)
     const int cpg = c / groups, g0 = blockIdx.x * cpg;
     float* const tdg = tab;
     float* const tdb = tab + (size_t)n * cpg;
-    for (int it = threadIdx.x; it < n * cpg; it += blockDim.x) {
-        const int nn = it / cpg, kk = it - nn * cpg, cc = g0 + kk;
-        const long i = (long)nn * c + cc;
+    double* const gst = reinterpret_cast<double*>(tab + (size_t)2 * n * cpg + ((2 * n * cpg) & 1));   // [n][4], 8-byte aligned
+    // the group quantities ONCE per image (gn_bwd_coef_kernel recomputes them in every one of the group's cpg threads -- fine
+    // over n * c / 256 blocks, not inside the 32 blocks of this launch): same additions in the same order, so the same bits
+    for (int nn = threadIdx.x; nn < n; nn += blockDim.x) {
         double s = 0, ss = 0;
         for (int k = 0; k < cpg; ++k) {
             s += sums[((long)nn * c + g0 + k) * 2];
@@ -1426,6 +1436,13 @@ __global__ __launch_bounds__(256) void gn_bwd_coef_fold_kernel(const float* __re
         }
         m1 /= m;
         m2 /= m;
+        gst[nn * 4] = mean; gst[nn * 4 + 1] = r; gst[nn * 4 + 2] = m1; gst[nn * 4 + 3] = m2;
+    }
+    __syncthreads();
+    for (int it = threadIdx.x; it < n * cpg; it += blockDim.x) {
+        const int nn = it / cpg, kk = it - nn * cpg, cc = g0 + kk;
+        const long i = (long)nn * c + cc;
+        const double mean = gst[nn * 4], r = gst[nn * 4 + 1], m1 = gst[nn * 4 + 2], m2 = gst[nn * 4 + 3];
         const double sc = film ? 1.0 + film[(long)nn * film_ld + cc] : 1.0;
         const double S1 = S[i * 2], X = r * (S[i * 2 + 1] - mean * S1);
         A[i] = (float)(r * gamma[cc] * sc);
@@ -1805,8 +1822,8 @@ extern "C" int sgd_gn_bwd_coef_fold(const float* S, const float* sums, const flo
         return SGD_ERR_ARG;
     if ((film || dfilm) && film_ld < 2 * c) return SGD_ERR_ARG;
     const int cpg = c / groups;
-    const size_t lds = (size_t)2 * n * cpg * sizeof(float);
-    if (lds > 60 * 1024) return SGD_ERR_ARG;          // (callers fall back to sgd_gn_bwd_coef + sgd_colsum_pair)
+    const size_t lds = (size_t)(2 * n * cpg + 1) * sizeof(float) + (size_t)n * 4 * sizeof(double);
+    if (lds > 64 * 1024) return SGD_ERR_ARG;          // (callers fall back to sgd_gn_bwd_coef + sgd_colsum_pair)
     hipLaunchKernelGGL(gn_bwd_coef_fold_kernel, dim3(groups), dim3(256), lds, (hipStream_t)stream, S, sums, gamma, beta, film,
                        film_ld, n, c, groups, hw, eps, A, B, Cc, dfilm, dgamma, dbeta, accumulate, scale);
     return sgd_check_launch();

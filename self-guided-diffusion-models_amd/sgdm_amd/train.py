@@ -312,7 +312,7 @@ class Backward:
             off += c
         A, B, Cc = (self.buf(n, ct) for _ in range(3))
         gamma, beta = self.m.P(gname + ".weight"), self.m.P(gname + ".bias")
-        fused = n <= 256 and 8 * n * (ct // GN_GROUPS) <= 60 * 1024 and os.environ.get("SGDM_GN_BWD_FOLD", "1") != "0"
+        fused = n <= 256 and 8 * n * (ct // GN_GROUPS) + 32 * n + 4 <= 64 * 1024 and os.environ.get("SGDM_GN_BWD_FOLD", "1") != "0"
         if fused:                # coefficients + dgamma / dbeta column sums in ONE launch (bit-identical to the two below)
             self.prog.add(tag + ".coef", lib.sgd_gn_bwd_coef_fold, _ptr(S), _ptr(sums), _ptr(gamma), _ptr(beta),
                           C.c_void_p(film_ptr), film_ld, n, ct, GN_GROUPS, h * w, GN_EPS, _ptr(A), _ptr(B), _ptr(Cc),

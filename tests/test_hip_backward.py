@@ -380,7 +380,7 @@ def test_groupnorm_silu_backward(gu_mode, silu, film):
 
 
 @pytest.mark.parametrize("n,c,film", [(80, 128, True), (80, 1024, True), (3, 96, False), (160, 384, False), (256, 512, True),
-                                      (7, 32, True)])
+                                      (7, 32, True), (160, 1024, False)])
 def test_groupnorm_backward_coefficients_and_column_sums_in_one_launch(n, c, film):
     """sgd_gn_bwd_coef_fold (round 5) against sgd_gn_bwd_coef + sgd_colsum_pair on the same statistics: A, B, C, dfilm and
     the scaled dgamma / dbeta -- every bit (the fold keeps the two-stage column sum's order of additions), plain and
