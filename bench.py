@@ -196,7 +196,7 @@ def pmc_traffic(args, B):
     WRITE_SIZE in separate rocprofv3 --pmc runs of this same bench command, gfx950 FETCH_SIZE x2 correction).
     PMC collection needs the profiler around the process, so it cannot be taken live inside this run; null when no
     committed pass matches the workload/precision/batch being benchmarked."""
-    for rnd in ("r4", "r3", "r2", "r1"):
+    for rnd in ("r5", "r4", "r3", "r2", "r1"):
         path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_hbm_{args.workload}.json")
         if os.path.exists(path):
             break
