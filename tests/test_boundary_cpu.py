@@ -197,12 +197,25 @@ def test_optimizer_chunk_table():
 
 
 @pytest.mark.parametrize("fname", ["r1_bench_c2_f16x3.json", "r2_bench_c2_f16x3_final.json", "r2_bench_c2_f16x3_final_b.json",
-                                   "r3_bench_c2_f16x3.json", "r3_bench_c2_f16x3_final.json", "r4_bench_c2_f16x3.json"])
+                                   "r3_bench_c2_f16x3.json", "r3_bench_c2_f16x3_final.json", "r4_bench_c2_f16x3.json",
+                                   "r5_bench_c2_f16x3.json"])
 def test_committed_bench_line_has_the_contract_fields(fname):
     """the bench lines committed under profiles/ (produced by bench.py on the MI355X) carry every field of the contract"""
     import json
     line = json.loads(open(os.path.join(ROOT, "profiles", fname)).read().strip().splitlines()[-1])
-    if fname.startswith("r4_"):
+    if fname.startswith("r5_"):
+        # round 5: in-run device calibration, the C3 per-GPU batch, the one-rank RCCL run of the exchange with its overlap record
+        r = line["roofline"]
+        assert r["device_mfma_tflops"] > 1000 and 0.3 < r["frac_of_device_ceiling"] < 1.0 and r["device_copy_tbps"] > 3
+        assert abs(r["device_ceiling_tflops"] * 3 - r["device_mfma_tflops"]) < 1.0
+        assert all("frac_of_device_ceiling" in v for v in r["igemm_by_instance"].values())
+        assert line["train_step_bs40"]["batch_per_gpu"] == 40 and line["train_step_bs40"]["ms"] > 0
+        tr = line["train_step"]
+        assert tr["exchange"] is False and tr["exchange_ms"] is None and "RCCL" not in tr["includes"]
+        ex = tr["exchange_world1"]
+        assert ex["backend"] == "nccl" and ex["world_size"] == 1 and ex["reserved_cus"] == 16 and ex["exchange"] == "forced on one rank"
+        assert 0.0 < ex["first_bucket_at_frac_of_backward"] < 1.0 and ex["exposed_exchange_ms"] >= 0 and len(ex["exchange_buckets"]) >= 3
+    if fname.startswith("r4_") or fname.startswith("r5_"):
         # round 4: the metric in full beside the K-step figure, the train step's per-kernel record, an honest checksum flag
         ft = line["full_trajectory"]
         assert ft["steps"] == 1000 and ft["images"] == line["n_gpus"] * line["config"]["batch_per_gpu"]
@@ -211,7 +224,7 @@ def test_committed_bench_line_has_the_contract_fields(fname):
         assert tr["grad_checksums_equal"] is None and tr["world_size"] == 1 and tr["reserved_cus"] == 0
         assert {"sgd_wgrad", "sgd_igemm(forward)", "sgd_igemm(dgrad)"} <= set(tr["roofline"]["per_kernel"])
         assert "_pmc_hbm_c2.json" in line["roofline"]["traffic_source"]
-    if fname.startswith("r3_") or fname.startswith("r4_"):
+    if fname[:3] in ("r3_", "r4_", "r5_"):
         assert "c2_bs80" in line      # (its grad_checksums_equal is trivially true: one rank; null from round 4 on)
     if fname.startswith("r3_"):
         assert "r3_pmc_hbm" in line["roofline"]["traffic_source"]
