@@ -510,6 +510,12 @@ int sgd_q_sample(const float* x0, const float* noise, const int64_t* t, const fl
 int sgd_conv3_narrow_in_parts(int32_t h, int32_t w);
 int sgd_conv3_narrow_in(const float* x, const float* w, const float* bias, float* y, float* stats, int32_t n, int32_t h,
                         int32_t wd, int32_t cin, int32_t cout, int32_t y_ld, int32_t adjoint, void* stream);
+/* The output head (openaimodel.py:830-835): y[n, h, w, :cout] = conv3x3(act(x)) + bias with cout = 3 or 4 and
+ * act(x) = SiLU?(x * pa[n, c] + pb[n, c]) (the GroupNorm coefficients of sgd_gn_coef*; pa = pb = NULL: no prologue).
+ * Plain fp32 FMAs (every arithmetic mode), cin % 32 == 0.  w9 is the conv's weight as [tap 0..8][cout][cin] -- a
+ * transposed copy of the OIHW parameter the caller keeps in step with it (the weights reach the FMAs as scalar operands). */
+int sgd_conv3_narrow_out(const float* x, const float* pa, const float* pb, int32_t silu, const float* w9, const float* bias,
+                         float* y, int32_t n, int32_t h, int32_t w, int32_t cin, int32_t cout, int32_t y_ld, void* stream);
 
 /* per_sample[b] = mean_chw (noise - eps)^2 ; geps_nhwc = d(mean_b per_sample)/d eps laid out NHWC for the backward
  * program (eps_nhwc is the UNet output in NHWC, noise NCHW) */

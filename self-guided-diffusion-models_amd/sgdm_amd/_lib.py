@@ -74,6 +74,7 @@ SIGNATURES = {
     "sgd_linear_splitk_t": (i32, [vp, i32, vp, i32, i32, i32, i32, vp, i32, vp, i32, vp]),
     "sgd_conv3_narrow_in_parts": (i32, [i32, i32]),
     "sgd_conv3_narrow_in": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "sgd_conv3_narrow_out": (i32, [vp, vp, vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "sgd_chan_stats": (i32, [vp, i32, i32, i32, vp, i32, i32, vp]),
     "sgd_gn_coef_parts": (i32, [vp, i32, i32, vp, i32, i32, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp, vp, vp]),
     "sgd_gn_coef": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, vp, vp, vp]),

@@ -646,6 +646,13 @@ class _Engine:
                   and conv[5] == 1 and conv[6] == 0 and cout % 4 == 0 and cout <= 1024 and y_off == 0 and orows == (0, 0, 0)
                   and len(pk.srcs) == 1 and pk.pad is None and pk.srcs[0].dtype == torch.float32 and pk.srcs[0].is_contiguous()
                   and os.environ.get("SGDM_NARROW_CONV", "1") != "0")
+        # the head (3 / 4 OUTPUT channels behind a GroupNorm + SiLU): a plain fp32 kernel of its own too (csrc/narrow.hip,
+        # round 5) -- on the implicit-GEMM kernel its 3 columns ride a 32-column tile.  Its weight operand is a [tap][co][ci]
+        # copy of the parameter, kept in step by refresh()
+        narrow_out = (conv is not None and launch and not narrow and c1 == 0 and cout in (3, 4) and c0 % 32 == 0 and res is None
+                      and pro in (L.PRO_NONE, L.PRO_AFFINE_NC) and conv[5] == 1 and conv[6] == 0 and y_off == 0
+                      and orows == (0, 0, 0) and not stats and len(pk.srcs) == 1 and pk.pad is None
+                      and pk.srcs[0].dtype == torch.float32 and os.environ.get("SGDM_NARROW_CONV", "1") != "0")
         if stats and os.environ.get("SGDM_FUSED_STATS", "1") != "0":
             parts = self.lib.sgd_conv3_narrow_in_parts(conv[3], conv[4]) if narrow else self.lib.sgd_igemm_stats_parts(C.byref(a))
             if parts > 0:
@@ -669,6 +676,24 @@ class _Engine:
             def sgd_conv3_narrow_in(stream):          # the parameter's address is read at launch time, like a repack would
                 return fn(x_p, C.c_void_p(wsrc.data_ptr()), b_p, y_p, s_p, nimg, ho, wo, c0, cout, y_ld, 0, stream)
             self.prog.add(tag, sgd_conv3_narrow_in, flops=flops, nbytes=nbytes)
+        elif narrow_out:
+            wsrc, fn = pk.srcs[0], self.lib.sgd_conv3_narrow_out
+            w9 = self.buf(9, cout, c0)
+            box = dict(sig=None)
+
+            def refresh_w9(stream, w9=w9, wsrc=wsrc, box=box):
+                sig = (wsrc.data_ptr(), wsrc._version)
+                if sig != box["sig"]:
+                    w9.copy_(wsrc.detach().float().permute(2, 3, 0, 1).reshape(9, cout, c0))
+                    box["sig"] = sig
+            self.refresh_hooks.append(refresh_w9)
+            x_p, y_p, b_p, w_p = _ptr(x0), C.c_void_p(a.y), C.c_void_p(a.bias or 0), _ptr(w9)
+            pa_p, pb_p = C.c_void_p(a.pa or 0), C.c_void_p(a.pb or 0)
+            nimg, ho, wo, y_ld = conv[0], conv[3], conv[4], a.y_ld
+
+            def sgd_conv3_narrow_out(stream):
+                return fn(x_p, pa_p, pb_p, int(silu), w_p, b_p, y_p, nimg, ho, wo, c0, cout, y_ld, stream)
+            self.prog.add(tag, sgd_conv3_narrow_out, flops=flops, nbytes=nbytes)
         elif launch:        # launch=False: descriptor only (the backward's weight gradient reads it)
             self.prog.add(tag, self.lib.sgd_igemm, C.byref(a), flops=flops, nbytes=nbytes)
         return a

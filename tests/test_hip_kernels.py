@@ -733,3 +733,35 @@ def test_layernorm_prologue_canary_on_the_shipped_instance(shape, prec):
     torch.cuda.synchronize()
     assert bad_beta == 0, f"{bad_beta} cells returned exactly beta (zero LayerNorm product) in 200 launches"
     assert bad_val == 0, f"{bad_val} cells off by more than {tol:.1e} in 200 launches"
+
+
+@pytest.mark.parametrize("n,h,w_,cin,cout,pro,silu", [(3, 64, 64, 128, 3, True, 1), (2, 20, 40, 64, 3, True, 1), (1, 8, 8, 32, 4, False, 0),
+                                                       (5, 16, 48, 256, 3, True, 0), (2, 33, 31, 96, 4, False, 1)])
+def test_head_conv_narrow_out(n, h, w_, cin, cout, pro, silu):
+    """sgd_conv3_narrow_out (the output head, openaimodel.py:830-835: GroupNorm + SiLU -> 3x3 conv with 3 / 4 output channels)
+    against float64: tiles that end inside the map, no-prologue and SiLU-only forms, strided output rows"""
+    L, lib = _lib()
+    g = torch.Generator().manual_seed(n * 100 + h)
+    x = torch.randn(n, cin, h, w_, generator=g, dtype=torch.float64)
+    wt = torch.randn(cout, cin, 3, 3, generator=g, dtype=torch.float64) / math.sqrt(cin * 9)
+    b = torch.randn(cout, generator=g, dtype=torch.float64)
+    pa = 1 + 0.3 * torch.randn(n, cin, generator=g, dtype=torch.float64)
+    pb = 0.3 * torch.randn(n, cin, generator=g, dtype=torch.float64)
+    act = x * pa[:, :, None, None] + pb[:, :, None, None] if pro else x
+    if silu:
+        act = F.silu(act)
+    ref = F.conv2d(act, wt, b, padding=1)
+    xd = _nhwc(x.float()).cuda()
+    w9 = wt.float().permute(2, 3, 0, 1).reshape(9, cout, cin).contiguous().cuda()
+    pad, pbd, bd = pa.float().cuda(), pb.float().cuda(), b.float().cuda()
+    y_ld = cout + 2
+    y = torch.full((n, h, w_, y_ld), float("nan"), device="cuda")
+    L.check(lib.sgd_conv3_narrow_out(_p(xd), _p(pad) if pro else None, _p(pbd) if pro else None, silu, _p(w9), _p(bd), _p(y), n, h, w_,
+                                     cin, cout, y_ld, _stream()), "narrow_out")
+    torch.cuda.synchronize()
+    assert torch.isnan(y[..., cout:]).all()
+    got = y[..., :cout].cpu().permute(0, 3, 1, 2).double()
+    assert float((got - ref).abs().max() / ref.abs().max()) < 6e-6     # (an fp32 FMA chain over 9 * cin terms)
+    # argument validation: widths the kernel has no form for are refused
+    assert lib.sgd_conv3_narrow_out(_p(xd), None, None, 0, _p(w9), None, _p(y), n, h, w_, cin, 5, y_ld, _stream()) == 1
+    assert lib.sgd_conv3_narrow_out(_p(xd), None, None, 0, _p(w9), None, _p(y), n, h, w_, cin + 4, cout, y_ld, _stream()) == 1
