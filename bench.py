@@ -14,9 +14,11 @@ metric value = images/s of a full 1000-step trajectory = (N * B) / (1000 * t_ste
 One JSON line on rank 0 with `roofline` (dominant kernel: the fused implicit-GEMM conv, timed with HIP
 events around every launch in an instrumented pass) and `cpu_baseline` (the CPU oracle -- the
 restatement of the reference's UNet -- timed on this box's host cores on a bounded sample), plus sub-records of
-the same run: `train_step` (metric's second half), `f32_exact` (the headline workload in exact-fp32 MFMA
-arithmetic), `c5` (BASELINE.json configs[4], unetca_fast bs=80) and `c1` (configs[0] at its true shape on the GPU,
-eager launches vs the hipGraph-captured step).
+the same run: `train_step` (metric's second half; `train_step_bs40`: configs[2]'s per-GPU batch; `exchange_world1`: the
+data-parallel step through a one-rank RCCL group), `f32_exact` (the headline workload in exact-fp32 MFMA arithmetic), `c5` /
+`c4` (BASELINE.json configs[4] / [3], unetca_fast bs=80: sampling step + train step) and `c1` (configs[0] at its true shape
+on the GPU, eager launches vs the hipGraph-captured step).  `roofline` also carries the device's own ceiling measured in the
+run (`device_mfma_tflops`, `frac_of_device_ceiling`, `device_copy_tbps`).
 
 Multi-GPU: the driver launches one rank per GPU through torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE in the
 environment).  Run by hand as `python bench.py --gpus N` it launches the N ranks ITSELF -- as child processes, before
@@ -684,6 +686,19 @@ def main():
         if not args.no_train:
             extra["c5"]["train_step"] = train_step_bench(m5, diff5, d5, k5["cond"], k5["layout"], w5["batch"], world, barrier, w5)
         del m5, diff5
+        gc.collect(); torch.cuda.empty_cache()
+        # ---- BASELINE.json configs[3] (C4): VOC-64 unetca_fast self-boxed clusterlayout (LOST), cond_dim 100, bs=80
+        w4 = WORKLOADS["c4"]
+        m4, _, d4 = build_model(w4, dev, args.prec, w4["batch"])
+        diff4 = LatentDiffusion(device=str(dev), **MODEL_PARAMS)
+        diff4.set_denoise_fn(m4.forward, m4.forward_with_cond_scale)
+        k4 = dict(cond=d4["cond"].float().to(dev), layout=d4["layout"].to(dev), cond_scale=2.0)
+        ms4 = time_sampling(m4, diff4, w4["batch"], S, k4, 5, 2, skw)
+        extra["c4"] = dict(workload=w4["desc"], ms_per_step=round(ms4, 3), value=round(w4["batch"] / ms4, 4), unit="images/s",
+                           tflops_per_s=round(2 * w4["batch"] * w4["gflop_per_eval_img"] / ms4, 1), steps=5, warmup=2)
+        if not args.no_train:
+            extra["c4"]["train_step"] = train_step_bench(m4, diff4, d4, k4["cond"], k4["layout"], w4["batch"], world, barrier, w4)
+        del m4, diff4
         gc.collect(); torch.cuda.empty_cache()
         # ---- the headline workload at C5's batch (bs=80, UNet batch 160): C2 and C5 side by side at one batch size
         if B != w5["batch"]:

@@ -239,6 +239,75 @@ def test_balanced_tail_poll_is_bounded():
     assert torch.equal(y, ref) and int(wi[status]) == 0
 
 
+def test_health_word_is_sticky_and_the_host_paths_raise():
+    """a balanced-tail time-out used to leave counters that later launches could trip over
+    silently.  Now (1) while the health word is up EVERY split tile on that workspace is poisoned (a launch with healthy
+    counters next to a raised word returns NaN in its split tiles, nothing else), (2) the host paths that own a workspace look
+    at the word: the sampler at the end of a trajectory (`_Engine.check_health`, synchronising) and the training step
+    through its asynchronous copy (`note_health` / `poll_health`) -- both raise and re-zero the workspace."""
+    import bench
+    from sgdm_amd.diffusion import LatentDiffusion
+    L, lib = _lib()
+    # ---- (1) kernel: the geometry of test_balanced_tail_poll_is_bounded, counters clean, word raised by hand
+    n, cin, cout, h = 161, 256, 128, 32
+    work = torch.zeros(int(lib.sgd_igemm_work_bytes()) // 4, device="cuda")
+    a, y, keep = _conv_args(L, lib, L.PREC_F16X3, n, cin, cout, h, work, 0)
+    L.check(lib.sgd_igemm(C.byref(a), _stream()), "igemm")
+    torch.cuda.synchronize()
+    ref = y.clone()
+    status = int(lib.sgd_igemm_work_status_offset()) // 4
+    wi = work.view(torch.int32)
+    wi[status] = 1
+    y.fill_(0.0)
+    t0 = time.time()
+    L.check(lib.sgd_igemm(C.byref(a), _stream()), "igemm")
+    torch.cuda.synchronize()
+    assert time.time() - t0 < 5.0                                  # no polling for a time-out: the word alone decides
+    bad = ~torch.isfinite(y)
+    assert bad.any() and torch.equal(y[~bad], ref[~bad]) and int(wi[status]) == 1
+    assert int(wi[:status].abs().sum()) == 0                        # the counters still reset themselves
+    work.zero_()
+    L.check(lib.sgd_igemm(C.byref(a), _stream()), "igemm")
+    torch.cuda.synchronize()
+    assert torch.equal(y, ref)
+    # ---- (2) host: sampler and training step
+    wl = bench.WORKLOADS["c2"]
+    B = 4
+    model, _, data = bench.build_model(wl, torch.device("cuda"), "f16x3", B)
+    diff = LatentDiffusion(device="cuda", **bench.MODEL_PARAMS)
+    diff.set_denoise_fn(model.forward, model.forward_with_cond_scale)
+    skw = dict(sampling_method="ddim", num_timesteps=2, ddim_eta=0.0, log_num_per_prog=2, clip_denoised=True, dtp=1,
+               temperature=1.0, noise_dropout=0, random_sample_condition=False, return_inter_dict=True)
+    kw = dict(cond=data["cond"].cuda(), layout=None, cond_scale=2.0)
+    with torch.no_grad():
+        diff.p_sample_loop("ddim", (B, 3, 64, 64), skw, denoise_sample_fn_kwargs=dict(kw), condition_kwargs={})     # healthy: no raise
+        eng = next(iter(model._engines.values()))
+        assert eng.work_bytes > 0
+        eng.work.view(torch.int32)[status] = 1
+        with pytest.raises(RuntimeError, match="balanced tail timed out"):
+            diff.p_sample_loop("ddim", (B, 3, 64, 64), skw, denoise_sample_fn_kwargs=dict(kw), condition_kwargs={})
+        assert int(eng.work.view(torch.int32).abs().sum()) == 0      # re-zeroed
+        diff.p_sample_loop("ddim", (B, 3, 64, 64), skw, denoise_sample_fn_kwargs=dict(kw), condition_kwargs={})     # and usable again
+    model.train()
+    model.dropout = 0.0
+    diff.train()
+    x0 = data["image"].cuda()
+    loss, _ = diff.forward_tao(x0, cond=kw["cond"], cond_drop_prob=0.1)
+    loss.backward()
+    teng = model._engines[(B, 64, 64, L.PREC_F16X3)]
+    torch.cuda.synchronize()
+    teng.poll_health()                                              # clean step: nothing
+    teng.work.view(torch.int32)[status] = 1
+    teng.note_health()                                              # (what Backward.run does after its program)
+    torch.cuda.synchronize()
+    with pytest.raises(RuntimeError, match="balanced tail timed out"):
+        diff.forward_tao(x0, cond=kw["cond"], cond_drop_prob=0.1)    # the next step's prepare() looks at the copy
+    assert int(teng.work.view(torch.int32).abs().sum()) == 0
+    loss, _ = diff.forward_tao(x0, cond=kw["cond"], cond_drop_prob=0.1)
+    loss.backward()
+    assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
+
+
 def test_bench_two_ranks_gloo_on_one_gpu():
     """`python bench.py --gpus 2 ...` as a fresh child process: it launches its two ranks itself (children spawned before
     the GPU is touched), the ranks share the one GPU over gloo (SGDM_DIST_BACKEND), and rank 0's line must show a
