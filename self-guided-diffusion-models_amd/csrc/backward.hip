@@ -32,6 +32,7 @@ struct WArgs {
     // gradient [rows][cout] and of the activated input [source rows][cin]
     const void* gh; const void* gl; const void* uh; const void* ul;
     int no_flat_pipe;           // SGD_TUNE_WGRAD_NO_PIPE (A/B runs): the synchronous staging of the 1x1 / linear kernel
+    int tap9;                   // 1: a strided 3x3 conv on the 1x1 / linear split kernel, one tap per block (round 5, see wgrad_impl)
 };
 __device__ __forceinline__ bool flat_pipe_off(const WArgs& w) { return w.no_flat_pipe != 0; }
 
@@ -178,10 +179,22 @@ __global__ __launch_bounds__(256, 2) void wgrad_conv_kernel(const WArgs w) {
     int bid = blockIdx.x;
     const int ks = bid % w.ksplit; bid /= w.ksplit;
     const int cit = bid % w.ci_tiles; bid /= w.ci_tiles;
-    const int cot = bid;
+    const int cot = bid % w.co_tiles;
+    const int tap = bid / w.co_tiles;                          // > 0 only in the per-tap form (w.tap9)
     const int co0 = cot * WT, ci0 = cit * CIT;
     const int cin = a.c0 + a.c1;
     const int pw = CONV ? a.wo >> 3 : 1, ppi = CONV ? pw * (a.ho >> 3) : 1;   // patches per row / per image
+    // per-tap form: the gradient rows are the conv's output pixels, the input row of output pixel (n, oy, ox) under this
+    // block's tap is conv-input pixel (oy * stride + tap / 3 - 1, ox * stride + tap % 3 - 1), or nothing (zero padding)
+    const int tdy = tap / 3 - 1, tdx = tap - (tap / 3) * 3 - 1;
+    auto tap_row = [&](long row, int& n) -> long {
+        const int ox = (int)row & (a.wo - 1);
+        const int t = (int)(row >> w.wo_l2);
+        const int oy = t & (a.ho - 1);
+        n = t >> w.ho_l2;
+        const int y = oy * a.stride + tdy, x = ox * a.stride + tdx;
+        return (y >= 0 && y < w.hc && x >= 0 && x < w.wc) ? ((long)n * a.hi + y) * a.wi + x : -1;
+    };
 
     f32x16 acc[NACC];
 #pragma unroll
@@ -266,7 +279,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_conv_kernel(const WArgs w) {
     bool flat_pipe = false;
     if constexpr (!CONV)
         flat_pipe = VEC && gy_fast && a.drop_p == 0.f && !flat_pipe_off(w)
-                    && (a.pro == SGD_PRO_NONE || (a.pro == SGD_PRO_AFFINE_NC && a.rows_per_n % 64 == 0));
+                    && (a.pro == SGD_PRO_NONE
+                        || (a.pro == SGD_PRO_AFFINE_NC && (w.tap9 ? (a.ho * a.wo) % 64 == 0 : a.rows_per_n % 64 == 0)));
     if (flat_pipe) {
         const int qd = tid & 31, r0 = tid >> 5;
         const int c = ci0 + qd * 4;
@@ -278,17 +292,29 @@ __global__ __launch_bounds__(256, 2) void wgrad_conv_kernel(const WArgs w) {
         // other is being read; two barriers per tile, as before.
         f32x4 gv[4], uv[4];
         Coef kq;
+        unsigned okx = 0xFu;                                     // per-tap form: which of the four requested input rows exist
         auto request = [&](int kt, int half) __attribute__((always_inline)) {
             const long base = (long)kt * 64;
             const long rlast = w.rows - 1;
             const long rfirst = base < w.rows ? base : rlast;
-            kq = load_coef<true>(a, a.pro == SGD_PRO_AFFINE_NC ? (int)(rfirst / a.rows_per_n) : 0, rfirst, cc);
+            // image of the K tile (64 rows of ONE image in both forms)
+            const int nimg = a.pro != SGD_PRO_AFFINE_NC ? 0
+                             : (w.tap9 ? (int)(rfirst >> (w.wo_l2 + w.ho_l2)) : (int)(rfirst / a.rows_per_n));
+            kq = load_coef<true>(a, nimg, rfirst, cc);
+            okx = 0xFu;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 long row = base + r0 + (half * 4 + i) * 8;
                 row = row < w.rows ? row : rlast;
                 gv[i] = ld4(gcol + row * w.gy_ld);
-                uv[i] = load_raw<true>(a, row, cc);
+                long urow = row;
+                if (w.tap9) {                                     // (wave-uniform flag; the load stays unconditional)
+                    int nn;
+                    const long sr = tap_row(row, nn);
+                    if (sr < 0) okx &= ~(1u << i);
+                    urow = sr >= 0 ? sr : 0;
+                }
+                uv[i] = load_raw<true>(a, urow, cc);
             }
         };
         auto store_half = [&](int kt, int half) __attribute__((always_inline)) {
@@ -299,7 +325,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_conv_kernel(const WArgs w) {
                 f32x4 g4 = gv[i];
                 f32x4 u4 = apply_pro(a, uv[i], kq, cc, row < w.rows ? row : w.rows - 1);
                 if (row >= w.rows) { g4 = f32x4{0.f, 0.f, 0.f, 0.f}; u4 = g4; }
-                if (c >= cin) u4 = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (c >= cin || !((okx >> i) & 1u)) u4 = f32x4{0.f, 0.f, 0.f, 0.f};
                 split_store(Gh + r * FGP + qd * 4, Gl + r * FGP + qd * 4, g4);
                 split_store(Uh + r * UPITCH + qd * 4, Ul + r * UPITCH + qd * 4, u4);
                 bsum += g4;
@@ -439,11 +465,18 @@ __global__ __launch_bounds__(256, 2) void wgrad_conv_kernel(const WArgs w) {
                 f32x4 uraw[4];
                 Coef kq[4];
                 long rows4[4];
+                bool okr[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const long row = (long)kt * 64 + r0 + (half * 4 + i) * 8;
                     rows4[i] = row < w.rows ? row : w.rows - 1;
-                    const int ni = a.pro == SGD_PRO_AFFINE_NC ? (int)(rows4[i] / a.rows_per_n) : 0;
+                    int ni = a.pro == SGD_PRO_AFFINE_NC && !w.tap9 ? (int)(rows4[i] / a.rows_per_n) : 0;
+                    okr[i] = true;
+                    if (w.tap9) {                                     // (wave-uniform flag; the loads below stay unconditional)
+                        const long sr = tap_row(rows4[i], ni);
+                        okr[i] = sr >= 0;
+                        rows4[i] = sr >= 0 ? sr : 0;
+                    }
                     kq[i] = load_coef<VEC>(a, ni, rows4[i], cc);
                     uraw[i] = load_raw<VEC>(a, rows4[i], cc);
                 }
@@ -451,7 +484,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_conv_kernel(const WArgs w) {
                 for (int i = 0; i < 4; ++i) {
                     const int r = r0 + (half * 4 + i) * 8;
                     f32x4 uv = apply_pro(a, uraw[i], kq[i], cc, rows4[i]);
-                    if (!((long)kt * 64 + r < w.rows && c < cin)) uv = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (!((long)kt * 64 + r < w.rows && c < cin && okr[i])) uv = f32x4{0.f, 0.f, 0.f, 0.f};
                     split_store(Uh + r * UPITCH + qd * 4, Ul + r * UPITCH + qd * 4, uv);
                 }
             }
@@ -505,7 +538,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_conv_kernel(const WArgs w) {
             }
         }
     }
-    if (w.bslab && cit == 0) {
+    if (w.bslab && cit == 0 && tap == 0) {
         // fold the 8 row lanes of every co quad through LDS (the planes are free after the last MFMA phase)
         __syncthreads();
         float* red = reinterpret_cast<float*>(wsm);       // [8][128]
@@ -523,7 +556,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_conv_kernel(const WArgs w) {
     for (int t = 0; t < NACC; ++t) {
         const int ci = ci0 + (CONV ? 0 : t * 32) + li;
         if (ci >= cin) continue;
-        float* slab = w.slabs + ((long)ks * TAPS + (CONV ? t : 0)) * w.cout * cin;
+        float* slab = w.slabs + ((long)ks * (w.tap9 ? 9 : TAPS) + (CONV ? t : tap)) * w.cout * cin;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int co = co0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
@@ -1621,6 +1654,7 @@ static int wgrad_impl(const sgd_igemm_args* fwd, const float* gy, int32_t gy_ld,
     WArgs w;
     w.a = *fwd;
     w.no_flat_pipe = (fwd->tune & SGD_TUNE_WGRAD_NO_PIPE) ? 1 : 0;
+    w.tap9 = 0;
     const sgd_igemm_args& a = w.a;
     if (!a.x0 || a.c0 <= 0 || a.c1 < 0 || (a.c1 > 0 && !a.x1)) return SGD_ERR_ARG;
     if (a.pro != SGD_PRO_NONE && (!a.pa || !a.pb)) return SGD_ERR_ARG;
@@ -1666,6 +1700,20 @@ static int wgrad_impl(const sgd_igemm_args* fwd, const float* gy, int32_t gy_ld,
     // split-precision kernels: 3x3 stride 1 on whole 8x8 output patches (all taps per block), and 1x1 / linear
     const bool fast_conv = wgrad_fast_conv(a);
     const bool fast_flat = a.mode == SGD_MODE_FLAT && a.pro != SGD_PRO_LN_ROW && cout >= 32 && cin >= 32;
+    // Strided 3x3 convs (Downsample, openaimodel_ca.py:167-174) in a split mode: nine 1x1-style weight gradients, one tap per
+    // block of the 1x1 / linear split kernel, whose input rows are the tap's (strided, shifted) pixels -- round 5: these two
+    // launches of C5 / C4 ran on the exact-f32 per-tap kernel below at 43-45 TF (0.55 ms each)
+    if (a.mode == SGD_MODE_CONV3 && a.stride == 2 && a.resample == SGD_RS_NONE && a.prec != SGD_PREC_F32 && vec && gy_ld % 4 == 0
+        && (a.pro == SGD_PRO_NONE || a.pro == SGD_PRO_AFFINE_NC) && a.drop_p == 0.f && cout >= 32 && cin >= 32
+        && !(a.tune & (SGD_TUNE_WGRAD_F32 | SGD_TUNE_WGRAD_GENERIC_NARROW))) {
+        w.tap9 = 1;
+        w.gvec = 1;
+        const long fgrid = 9L * w.co_tiles * w.ci_tiles * w.ksplit;
+        if (fgrid > 0x7fffffffL) return SGD_ERR_ARG;
+        if (a.prec == SGD_PREC_F16X3) launch_wgrad_fast<SGD_PREC_F16X3, true, 1>(w, fgrid, st);
+        else launch_wgrad_fast<SGD_PREC_BF16X3, true, 1>(w, fgrid, st);
+        return sgd_check_launch();
+    }
     if ((fast_conv || fast_flat) && a.prec != SGD_PREC_F32 && !(a.tune & SGD_TUNE_WGRAD_F32)) {
         w.gvec = gy_ld % 4 == 0;
         if (fast_conv) w.ci_tiles = (cin + 31) / 32;

@@ -155,6 +155,39 @@ def test_conv_wgrad_split_precision_at_production_shapes(shape, prec, tol):
         assert torch.equal(dw, dw2)
 
 
+@pytest.mark.parametrize("prec,tol", [("f16x3", 3e-5), ("bf16x3", 3e-4)])
+@pytest.mark.parametrize("shape,fused", [((80, 128, 128, 64), False), ((40, 256, 256, 32), False), ((6, 96, 160, 16), True)])
+def test_strided_conv_wgrad_per_tap_on_the_split_kernel(shape, fused, prec, tol):
+    """Downsample (conv 3x3 stride 2, openaimodel_ca.py:167-174) weight gradient: round 5 runs it as nine 1x1-style split-precision
+    weight gradients (one tap per block, the tap's strided / shifted input pixels as rows) instead of the exact-f32 per-tap kernel
+    (43-45 TF at C5's shapes).  Against float64 autograd at the training shapes, and against the kernel it replaces."""
+    L, lib = _lib()
+    n, cin, cout, h = shape
+    g = torch.Generator().manual_seed(41)
+    ho = h // 2
+    x = torch.randn(n, cin, h, h, generator=g)
+    pa, pb = 1 + 0.3 * torch.randn(n, cin, generator=g), 0.3 * torch.randn(n, cin, generator=g)
+    gy = torch.randn(n, cout, ho, ho, generator=g) / (n * ho * ho) ** 0.5
+    w = (torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(cin * 9)).double().requires_grad_(True)
+    u = x.double()
+    if fused:
+        u = F.silu(u * pa.double()[:, :, None, None] + pb.double()[:, :, None, None])
+    F.conv2d(u, w, stride=2, padding=1).backward(gy.double())
+    xd, pad, pbd = _nhwc(x).cuda(), pa.cuda(), pb.cuda()
+    fwd = _igemm_args(L, xd, None, conv=(n, h, h, ho, ho), pa=pad if fused else None, pb=pbd if fused else None,
+                      silu=1 if fused else 0, stride=2)
+    fwd.prec = L.PREC_BY_NAME[prec]
+    gyd = _nhwc(gy).cuda()
+    ks = _train_ksplit(9, cout, cin, n * ho * ho)
+    dw = _wgrad(L, lib, fwd, gyd, cout, cin, 9, ks)
+    err = max_rel(dw.reshape(cout, cin, 3, 3), w.grad.float())
+    assert err < tol, err
+    fwd.tune = L.TUNE_WGRAD_F32                                  # the exact-f32 per-tap kernel it replaces
+    dw_old = _wgrad(L, lib, fwd, gyd, cout, cin, 9, ks)
+    assert max_rel(dw_old.reshape(cout, cin, 3, 3), w.grad.float()) < 6e-6
+    assert max_rel(dw, dw_old) < tol
+
+
 @pytest.mark.parametrize("prec,tol", [("f32", 6e-6), ("f16x3", 4e-5)])
 def test_wgrad_random_configurations(prec, tol):
     """40 seeded random weight-gradient launches (3x3: plain / fused prologue / concat / avg-pool / nearest-up / stride 2;
