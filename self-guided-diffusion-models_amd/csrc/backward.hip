@@ -279,7 +279,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_conv_kernel(const WArgs w) {
     bool flat_pipe = false;
     if constexpr (!CONV)
         flat_pipe = VEC && gy_fast && a.drop_p == 0.f && !flat_pipe_off(w)
-                    && (a.pro == SGD_PRO_NONE
+                    && (a.pro == SGD_PRO_NONE || (a.pro == SGD_PRO_LN_ROW && !w.tap9)
                         || (a.pro == SGD_PRO_AFFINE_NC && (w.tap9 ? (a.ho * a.wo) % 64 == 0 : a.rows_per_n % 64 == 0)));
     if (flat_pipe) {
         const int qd = tid & 31, r0 = tid >> 5;
@@ -292,6 +292,15 @@ __global__ __launch_bounds__(256, 2) void wgrad_conv_kernel(const WArgs w) {
         // other is being read; two barriers per tile, as before.
         f32x4 gv[4], uv[4];
         Coef kq;
+        // LayerNorm-row prologue (to_q / to_kv): (mean, rstd) of each requested row next to it, gamma / beta of this thread's
+        // channel quad once per block
+        const bool lnp = a.pro == SGD_PRO_LN_ROW;
+        float2 rst[4];
+        f32x4 lng = {1.f, 1.f, 1.f, 1.f}, lnb = {0.f, 0.f, 0.f, 0.f};
+        if (lnp) {
+            lng = ld4(a.pb + cc);
+            if (a.pc) lnb = ld4(a.pc + cc);
+        }
         unsigned okx = 0xFu;                                     // per-tap form: which of the four requested input rows exist
         auto request = [&](int kt, int half) __attribute__((always_inline)) {
             const long base = (long)kt * 64;
@@ -300,7 +309,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_conv_kernel(const WArgs w) {
             // image of the K tile (64 rows of ONE image in both forms)
             const int nimg = a.pro != SGD_PRO_AFFINE_NC ? 0
                              : (w.tap9 ? (int)(rfirst >> (w.wo_l2 + w.ho_l2)) : (int)(rfirst / a.rows_per_n));
-            kq = load_coef<true>(a, nimg, rfirst, cc);
+            if (!lnp) kq = load_coef<true>(a, nimg, rfirst, cc);
             okx = 0xFu;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -315,6 +324,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_conv_kernel(const WArgs w) {
                     urow = sr >= 0 ? sr : 0;
                 }
                 uv[i] = load_raw<true>(a, urow, cc);
+                rst[i] = lnp ? *reinterpret_cast<const float2*>(a.pa + row * 2) : float2{0.f, 1.f};
             }
         };
         auto store_half = [&](int kt, int half) __attribute__((always_inline)) {
@@ -323,7 +333,16 @@ __global__ __launch_bounds__(256, 2) void wgrad_conv_kernel(const WArgs w) {
                 const int r = r0 + (half * 4 + i) * 8;
                 const long row = (long)kt * 64 + r;
                 f32x4 g4 = gv[i];
-                f32x4 u4 = apply_pro(a, uv[i], kq, cc, row < w.rows ? row : w.rows - 1);
+                f32x4 u4;
+                if (lnp) {
+                    u4 = (uv[i] - rst[i].x) * rst[i].y * lng + lnb;
+                    if (a.pro_silu) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) u4[e] = sgd_silu(u4[e]);
+                    }
+                } else {
+                    u4 = apply_pro(a, uv[i], kq, cc, row < w.rows ? row : w.rows - 1);
+                }
                 if (row >= w.rows) { g4 = f32x4{0.f, 0.f, 0.f, 0.f}; u4 = g4; }
                 if (c >= cin || !((okx >> i) & 1u)) u4 = f32x4{0.f, 0.f, 0.f, 0.f};
                 split_store(Gh + r * FGP + qd * 4, Gl + r * FGP + qd * 4, g4);
@@ -454,9 +473,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_conv_kernel(const WArgs w) {
                 }
                 split_store(Uh + hp * UPITCH + qd * 4, Ul + hp * UPITCH + qd * 4, uv);
             }
-        } else if (VEC && (a.pro == SGD_PRO_NONE || a.pro == SGD_PRO_AFFINE_NC) && w.rows > 0) {
+        } else if (VEC && w.rows > 0) {
             // 1x1 / linear: eight row quads per thread, requested four at a time from clamped addresses (raw row + the
-            // GroupNorm coefficients of its image), masked after the transform
+            // GroupNorm coefficients of its image, or the LayerNorm statistics of the row), masked after the transform
             const int qd = tid & 31, r0 = tid >> 5;
             const int c = ci0 + qd * 4;
             const int cc = c < cin ? c : 0;
@@ -1699,7 +1718,10 @@ static int wgrad_impl(const sgd_igemm_args* fwd, const float* gy, int32_t gy_ld,
     hipStream_t st = (hipStream_t)stream;
     // split-precision kernels: 3x3 stride 1 on whole 8x8 output patches (all taps per block), and 1x1 / linear
     const bool fast_conv = wgrad_fast_conv(a);
-    const bool fast_flat = a.mode == SGD_MODE_FLAT && a.pro != SGD_PRO_LN_ROW && cout >= 32 && cin >= 32;
+    // (round 5: the LayerNorm-row prologue -- Attention_LR's to_q / to_kv, crossattetion_lr.py:81-88 -- runs on the split kernel
+    // too: its staging takes the per-row statistics through load_coef like every other prologue; those six to_q launches of C5
+    // ran on the exact-f32 kernel at 56 TF, 0.19 ms each)
+    const bool fast_flat = a.mode == SGD_MODE_FLAT && cout >= 32 && cin >= 32;
     // Strided 3x3 convs (Downsample, openaimodel_ca.py:167-174) in a split mode: nine 1x1-style weight gradients, one tap per
     // block of the 1x1 / linear split kernel, whose input rows are the tap's (strided, shifted) pixels -- round 5: these two
     // launches of C5 / C4 ran on the exact-f32 per-tap kernel below at 43-45 TF (0.55 ms each)

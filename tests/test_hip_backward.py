@@ -188,6 +188,39 @@ def test_strided_conv_wgrad_per_tap_on_the_split_kernel(shape, fused, prec, tol)
     assert max_rel(dw, dw_old) < tol
 
 
+@pytest.mark.parametrize("prec,tol", [("f16x3", 3e-5), ("bf16x3", 3e-4)])
+@pytest.mark.parametrize("m,cin,cout,beta", [(80 * 256, 512, 512, True), (80 * 256, 512, 128, True), (1000, 96, 64, False)])
+def test_linear_wgrad_with_layernorm_prologue_on_the_split_kernel(m, cin, cout, beta, prec, tol):
+    """Attention_LR's to_q / to_kv (crossattetion_lr.py:81-88): y = LN(x) W^T.  Round 5: their weight gradients run on the
+    split-precision 1x1 kernel (the LayerNorm row statistics travel through load_coef like the GroupNorm coefficients) instead
+    of the exact-f32 per-tap kernel (56 TF at C5's shape).  Against float64 autograd, and against the kernel it replaces."""
+    L, lib = _lib()
+    g = torch.Generator().manual_seed(57)
+    x = torch.randn(m, cin, generator=g) * 1.5 + 0.3
+    gamma = 1 + 0.2 * torch.randn(cin, generator=g)
+    bt = 0.2 * torch.randn(cin, generator=g) if beta else None
+    w = (torch.randn(cout, cin, generator=g) / math.sqrt(cin)).double().requires_grad_(True)
+    gy = torch.randn(m, cout, generator=g) / m ** 0.5
+    xn = F.layer_norm(x.double(), (cin,), gamma.double(), bt.double() if beta else None, 1e-5)
+    F.linear(xn, w).backward(gy.double())
+    xd, gd = x.cuda(), gamma.cuda()
+    btd = bt.cuda() if beta else None
+    st = torch.empty(m, 2, device="cuda")
+    L.check(lib.sgd_ln_stats(_p(xd), m, cin, 1e-5, _p(st), _stream()), "ln_stats")
+    fwd = _igemm_args(L, xd, m=m)
+    fwd.pro, fwd.pa, fwd.pb, fwd.pc = L.PRO_LN_ROW, st.data_ptr(), gd.data_ptr(), (btd.data_ptr() if beta else 0)
+    fwd.prec = L.PREC_BY_NAME[prec]
+    gyd = gy.cuda()
+    ks = _train_ksplit(1, cout, cin, m)
+    dw = _wgrad(L, lib, fwd, gyd, cout, cin, 1, ks)
+    err = max_rel(dw.reshape(cout, cin), w.grad.float())
+    assert err < tol, err
+    fwd.tune = L.TUNE_WGRAD_F32
+    dw_old = _wgrad(L, lib, fwd, gyd, cout, cin, 1, ks)
+    assert max_rel(dw_old.reshape(cout, cin), w.grad.float()) < 6e-6
+    assert max_rel(dw, dw_old) < tol
+
+
 @pytest.mark.parametrize("prec,tol", [("f32", 6e-6), ("f16x3", 4e-5)])
 def test_wgrad_random_configurations(prec, tol):
     """40 seeded random weight-gradient launches (3x3: plain / fused prologue / concat / avg-pool / nearest-up / stride 2;
