@@ -301,6 +301,12 @@ int sgd_labelmap_nhot(const uint8_t* labels, int32_t b, int32_t hw, int32_t k, f
  * with sgd_linear_splitk when the weights change) */
 int sgd_linear_gather(const int64_t* ids, const uint8_t* mask, const float* w, const float* bias, const float* nullproj,
                       int32_t n_src, int32_t n, int32_t nout, int32_t k, float* out, int32_t ldo, void* stream);
+/* the same Linear on the reference's own input format for the cluster / label methods -- an int64 one-hot ROW per sample, cond
+ * [n_src, k] (unsupervised_cluster.py:33-46, supervised_label.py:31-40): y[r, :] = bias + sum over the non-zero entries of row
+ * r % n_src of value * w[:, entry]; any integer row (multi-hot, counts), entries summed in ascending k.  k <= 7,936 (the list of
+ * entries lives in LDS); SGD_ERR_ARG above that -- the caller keeps the dense sgd_linear_splitk for longer rows */
+int sgd_linear_sparse_rows(const int64_t* cond, const uint8_t* mask, const float* w, const float* bias, const float* nullproj,
+                           int32_t n_src, int32_t n, int32_t nout, int32_t k, float* out, int32_t ldo, void* stream);
 
 int sgd_nhwc_to_nchw(const float* x, int32_t n, int32_t h, int32_t w, int32_t c, float* out, void* stream);
 /* broadcast null_kv rows into the shared K/V buffer (crossattetion_lr.py:95-97):

@@ -915,19 +915,22 @@ __global__ __launch_bounds__(512) void wgrad_conv_ws_kernel(const WArgs w) {
     // this load (profiles/r3_pmc_mfma_form_clock.txt).  The wave's [32 co x 32 ci] tile of a tap is 2 x 2 blocks of 16 x 16,
     // a K step is 32 pixels of the 8x8 patch: lane group g = lane >> 4 addresses pixel rows 8 g + q (and + 4) of the step,
     // the transposing read hands lane j of a group channel j of the 16-channel block, 4 + 4 consecutive pixels.
-    f32x4 acc[9][2][2];
+    // (round 5: the four waves tile the block's [128 co x 32 ci] as 2 x 2 -- 64 co x 16 ci each -- instead of 4 x 1 (32 co x 32
+    // ci): per K step a wave still issues 108 MFMAs but reads 16 + 36 transposed 8-byte LDS fragments instead of 8 + 72: the
+    // input-side fragment is re-read for every tap, the gradient-side one only once per step, so the wave takes more of the
+    // latter.  Same products in the same order into every accumulator: bit-identical slabs.)
+    f32x4 acc[9][4];
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) acc[t][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < 4; ++i) acc[t][i] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int gidx = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+    const int wco = wave & 1, wci = wave >> 1;
     // one per-lane element offset per operand; everything else (K step, block, tap, plane) is a compile-time constant that
     // folds into the read's immediate offset: pixel 32 s + 8 g + q of the patch sits at halo index
     // (4 s + g + 1) * 10 + q + 1
-    const int goff = (8 * gidx + q) * FGP + wave * 32 + 4 * pp;
-    const int uoff = ((gidx + 1) * 10 + q + 1) * UPITCH + 4 * pp;
+    const int goff = (8 * gidx + q) * FGP + wco * 64 + 4 * pp;
+    const int uoff = ((gidx + 1) * 10 + q + 1) * UPITCH + wci * 16 + 4 * pp;
     auto trd = [&](const T* p) -> T4 {
         s4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)p);
         return __builtin_bit_cast(T4, v);
@@ -944,31 +947,28 @@ __global__ __launch_bounds__(512) void wgrad_conv_ws_kernel(const WArgs w) {
         const T* Ul = Uh + 100 * UPITCH;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            T8 ah[2], al[2];
+            T8 ah[4], al[4];
 #pragma unroll
-            for (int cb = 0; cb < 2; ++cb) {
+            for (int cb = 0; cb < 4; ++cb) {
                 ah[cb] = rd8(Gh + 32 * s * FGP + cb * 16, 4 * FGP);
                 al[cb] = rd8(Gl + 32 * s * FGP + cb * 16, 4 * FGP);
             }
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
                 const int off = (40 * s + (t / 3 - 1) * 10 + (t % 3 - 1)) * UPITCH;
+                const T8 bh = rd8(Uh + off, 4 * UPITCH);
+                const T8 bl = rd8(Ul + off, 4 * UPITCH);
 #pragma unroll
-                for (int cj = 0; cj < 2; ++cj) {
-                    const T8 bh = rd8(Uh + off + cj * 16, 4 * UPITCH);
-                    const T8 bl = rd8(Ul + off + cj * 16, 4 * UPITCH);
-#pragma unroll
-                    for (int cb = 0; cb < 2; ++cb) {
-                        f32x4& c = acc[t][cb][cj];
-                        if constexpr (PREC == SGD_PREC_F16X3) {
-                            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[cb], bl, c, 0, 0, 0);
-                            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[cb], bh, c, 0, 0, 0);
-                            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[cb], bh, c, 0, 0, 0);
-                        } else {
-                            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[cb], bl, c, 0, 0, 0);
-                            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[cb], bh, c, 0, 0, 0);
-                            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[cb], bh, c, 0, 0, 0);
-                        }
+                for (int cb = 0; cb < 4; ++cb) {
+                    f32x4& c = acc[t][cb];
+                    if constexpr (PREC == SGD_PREC_F16X3) {
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[cb], bl, c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[cb], bh, c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[cb], bh, c, 0, 0, 0);
+                    } else {
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[cb], bl, c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[cb], bh, c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[cb], bh, c, 0, 0, 0);
                     }
                 }
             }
@@ -977,21 +977,18 @@ __global__ __launch_bounds__(512) void wgrad_conv_ws_kernel(const WArgs w) {
     }
     __syncthreads();                                               // pairs with the loaders' bias-reduction barrier
     // ---- slab store: D block [16 co x 16 ci]: rows 4 (lane >> 4) + r in registers, column lane & 15
+    const int ci = ci0 + wci * 16 + (lane & 15);
+    if (ci >= cin) return;
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
         float* slab = w.slabs + ((long)ks * 9 + t) * w.cout * cin;
 #pragma unroll
-        for (int cj = 0; cj < 2; ++cj) {
-            const int ci = ci0 + cj * 16 + (lane & 15);
-            if (ci >= cin) continue;
+        for (int cb = 0; cb < 4; ++cb)
 #pragma unroll
-            for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int co = co0 + wave * 32 + cb * 16 + 4 * gidx + r;
-                    if (co < w.cout) slab[(long)co * cin + ci] = acc[t][cb][cj][r];
-                }
-        }
+            for (int r = 0; r < 4; ++r) {
+                const int co = co0 + wco * 64 + cb * 16 + 4 * gidx + r;
+                if (co < w.cout) slab[(long)co * cin + ci] = acc[t][cb][r];
+            }
     }
 }
 

@@ -120,6 +120,59 @@ __global__ void linear_gather_kernel(const int64_t* __restrict__ ids, const uint
     out[(long)r * ldo + c] = v;
 }
 
+// y[r, :] = bias + sum over the NON-ZERO entries of an int64 condition row of value * w[:, k]: the first Linear of mlp_cond on
+// the reference's own input format (unsupervised_cluster.py:33-46 hands the UNet a one-hot int64 [B, K] row, K = 5000 at C2).
+// A dense GEMM over that row multiplies 4,999 zeros per sample (sgd_linear_splitk: 0.095 ms per UNet evaluation, 5 MB of weight
+// read for 160 columns of it); this kernel finds the row's non-zero entries (one block per row: count per thread chunk, prefix,
+// write the (index, value) list in ascending k -- deterministic) and gathers just those weight columns.  Any integer row is
+// handled (multi-hot, counts, negative entries): skipped terms are exact zeros; a one-hot row gives fmaf(1, w, 0) + bias, the
+// dense kernel's bits.  Dropped rows (mask) take the projection of the null embedding, as in linear_gather_kernel.
+__global__ __launch_bounds__(256) void linear_sparse_rows_kernel(const int64_t* __restrict__ cond, const uint8_t* __restrict__ mask,
+                                                                 const float* __restrict__ w, const float* __restrict__ bias,
+                                                                 const float* __restrict__ nullproj, int n_src, int nout, int k,
+                                                                 float* __restrict__ out, int ldo) {
+    extern __shared__ int sparse_lds[];              // idx[k] | val[k]
+    __shared__ int cnt[257];
+    int* idx = sparse_lds;
+    float* val = reinterpret_cast<float*>(sparse_lds + k);
+    const int r = blockIdx.x, t = threadIdx.x;
+    if (mask && mask[r]) {
+        for (int c = t; c < nout; c += 256) out[(long)r * ldo + c] = nullproj[c];
+        return;
+    }
+    const int64_t* row = cond + (long)(r % n_src) * k;
+    const int per = (k + 255) / 256, k0 = t * per, k1 = (k0 + per < k) ? k0 + per : k;
+    int mine = 0;
+    for (int j = k0; j < k1; ++j) mine += row[j] != 0;
+    cnt[t + 1] = mine;
+    if (t == 0) cnt[0] = 0;
+    __syncthreads();
+    if (t < 64) {                                    // inclusive scan of the 256 counts by one wave: 4 per lane + wave scan
+        int a0 = cnt[4 * t + 1], a1 = a0 + cnt[4 * t + 2], a2 = a1 + cnt[4 * t + 3], a3 = a2 + cnt[4 * t + 4];
+        int run = a3;
+        for (int d = 1; d < 64; d <<= 1) {
+            const int up = __shfl_up(run, d);
+            if (t >= d) run += up;
+        }
+        const int base = run - a3;
+        cnt[4 * t + 1] = base + a0; cnt[4 * t + 2] = base + a1; cnt[4 * t + 3] = base + a2; cnt[4 * t + 4] = base + a3;
+    }
+    __syncthreads();
+    int at = cnt[t];
+    for (int j = k0; j < k1; ++j) {
+        const int64_t v = row[j];
+        if (v != 0) { idx[at] = j; val[at] = (float)v; ++at; }
+    }
+    __syncthreads();
+    const int total = cnt[256];
+    for (int c = t; c < nout; c += 256) {
+        const float* wr = w + (long)c * k;
+        float acc = 0.f;
+        for (int e = 0; e < total; ++e) acc = fmaf(val[e], wr[idx[e]], acc);
+        out[(long)r * ldo + c] = acc + (bias ? bias[c] : 0.f);
+    }
+}
+
 __global__ void nhwc_to_nchw_kernel(const float* __restrict__ x, int n, int hw, int c, float* __restrict__ out) {
     const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
     if (i >= (long)n * hw * c) return;
@@ -294,6 +347,18 @@ extern "C" int sgd_linear_gather(const int64_t* ids, const uint8_t* mask, const 
     if (!ids || !w || !out || n_src <= 0 || n <= 0 || nout <= 0 || k <= 0 || ldo < nout || (mask && !nullproj)) return SGD_ERR_ARG;
     hipLaunchKernelGGL(linear_gather_kernel, dim3(nblk((long)n * nout)), dim3(256), 0, (hipStream_t)stream, ids, mask, w,
                        bias, nullproj, n_src, n, nout, k, out, ldo);
+    return sgd_check_launch();
+}
+
+extern "C" int sgd_linear_sparse_rows(const int64_t* cond, const uint8_t* mask, const float* w, const float* bias,
+                                      const float* nullproj, int32_t n_src, int32_t n, int32_t nout, int32_t k, float* out,
+                                      int32_t ldo, void* stream) {
+    SGD_CLEAR_ERR();
+    if (!cond || !w || !out || n_src <= 0 || n <= 0 || nout <= 0 || k <= 0 || ldo < nout || (mask && !nullproj)) return SGD_ERR_ARG;
+    const size_t lds = 8 * (size_t)k;
+    if (lds > 64 * 1024 - 2048) return SGD_ERR_ARG;          // (the caller keeps longer rows on the dense kernel)
+    hipLaunchKernelGGL(linear_sparse_rows_kernel, dim3(n), dim3(256), lds, (hipStream_t)stream, cond, mask, w, bias, nullproj,
+                       n_src, nout, k, out, ldo);
     return sgd_check_launch();
 }
 

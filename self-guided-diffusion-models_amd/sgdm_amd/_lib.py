@@ -115,6 +115,7 @@ SIGNATURES = {
     "sgd_pack_input_compact": (i32, [vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp]),
     "sgd_labelmap_nhot": (i32, [vp, i32, i32, i32, vp, vp]),
     "sgd_linear_gather": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, i32, vp]),
+    "sgd_linear_sparse_rows": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, i32, vp]),
     "sgd_nhwc_to_nchw": (i32, [vp, i32, i32, i32, i32, vp, vp]),
     "sgd_fill_null_kv": (i32, [vp, i32, i32, i32, i32, vp, vp]),
     "sgd_ddpm_step": (i32, [vp, vp, vp, i32, f32, C.POINTER(f32), i32, i32, i32, i32, vp, vp, vp]),

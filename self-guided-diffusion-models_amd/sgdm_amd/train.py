@@ -615,7 +615,7 @@ class Backward:
         # stored -- the conv kernel walked it with 4 tiles (0.75 ms per step); the concatenation follows the parameters
         skinny = n <= 256 and fw >= 2048 and os.environ.get("SGDM_SKINNY_DGRAD", "1") != "0"
         if skinny:
-            wcat = self.buf(fw, ted + cc)
+            wcat = self.buf(fw, ech)
             box = dict(sig=None)
 
             def refresh_wcat(stream, wcat=wcat, box=box):
@@ -625,14 +625,28 @@ class Backward:
                     box["sig"] = sig
                 return 0
             self.prog.add("emb_layers.wcat", refresh_wcat)
-            ksplit = max(1, min(128, fw // 128))          # ~4 blocks per CU: the kernel is latency-bound per K tile
+            # y[n, ech] = sum_k gfilm[n, k] wcat[k, ech] IS a weight gradient seen from the other side: "rows" = the fw FiLM
+            # outputs, "gy" = gfilm transposed (fw x n), "a" = wcat.  The split 1x1 weight-gradient kernel (MFMA, split K over
+            # the rows) replaces the fp32-FMA sgd_linear_splitk_t (LDS-bound: 0.25 ms per step at C2 for 1.7 GFLOP)
+            gfT, gall = self.buf(fw, n), self.buf(n, ech)
+            self.copy_op("emb_layers.gfilm_t", gfT, self.gfilm.view(n, fw).t())
+            wa = L.IgemmArgs()
+            wa.x0, wa.c0, wa.mode, wa.m, wa.stride, wa.prec = wcat.data_ptr(), ech, L.MODE_FLAT, fw, 1, self.prec
+            self.keep.append(wa)
+            ksplit = max(1, min((fw + 63) // 64 // 4, 512 // ((ech + 127) // 128)))
+            slabs = self.buf(ksplit, 1, n, ech)
+            lib = self.lib
+
+            def sgd_wgrad(stream):
+                ws = self._wscratch()
+                return lib.sgd_wgrad_scratch(C.byref(wa), _ptr(gfT), n, n, _ptr(slabs), ksplit, None, _ptr(ws), ws.numel() * 4,
+                                             stream)
+            self.prog.add("emb_layers.dgrad", sgd_wgrad, flops=2.0 * n * ech * fw)
+            self.prog.add("emb_layers.dgrad.fold", lib.sgd_wgrad_reduce, _ptr(slabs), ksplit, 1, n, ech, _ptr(gall), 0, 1.0)
         for t, o, c in parts:
             gact = self.buf(n, c)
             if skinny:
-                work = self.buf(ksplit, n, c)
-                self.prog.add(f"emb_layers.dgrad{o}", self.lib.sgd_linear_splitk_t, _ptr(self.gfilm), fw,
-                              C.c_void_p(wcat.data_ptr() + 4 * o), ted + cc, n, c, fw, _ptr(work), ksplit, _ptr(gact), c,
-                              flops=2.0 * n * c * fw)
+                self.copy_op(f"emb_layers.dgrad.part{o}", gact, gall[:, o:o + c])
             else:
                 self.dgrad(f"emb_layers.dgrad{o}", self.gfilm, fw, gact, c, wparams, lambda o=o, c=c: cat()[:, o:o + c], fw, c,
                            1, m=n)

@@ -1010,10 +1010,12 @@ class _Engine:
             L.check(lib.sgd_pack_input(_ptr(x), _ptr(layout) if cl else C.c_void_p(0), _ptr(mask_u8),
                                        _ptr(m.null_layout_emb) if cl else C.c_void_p(0), B, n, m.in_channels, cl,
                                        self.h, self.w, _ptr(self.x_in), stream), "pack_input")
-        self.cond_ids = None
+        self.cond_ids = self.cond_rows = None
         if m._cond_width:
             if is_i64 == 2 and getattr(self, "gather_cond", False) and not self._train_mode:
                 self.cond_ids = (cond, mask_u8, B)           # mlp_cond.0 runs as a column gather (see _build_cond_path)
+            elif is_i64 == 1 and getattr(self, "sparse_cond", False) and not self._train_mode:
+                self.cond_rows = (cond, mask_u8, B)          # ... or over the non-zero entries of the int64 one-hot rows
             else:
                 L.check(lib.sgd_cond_select(_ptr(cond), int(is_i64), _ptr(mask_u8), _ptr(m.null_cond_emb), B, n,
                                             m._cond_width, _ptr(self.cond_m), stream), "cond_select")
@@ -1180,11 +1182,16 @@ class UNetModel(UNetModelBase):
             nullproj = eng.buf(nout)
             nwork = eng.buf(ksplit, 1, nout)
             eng.gather_cond = True
+            eng.sparse_cond = 8 * K <= 64 * 1024 - 2048 and os.environ.get("SGDM_SPARSE_COND", "1") != "0"
             box = dict(sig=None)
 
             def mlp_cond0(stream):
                 """dense skinny GEMM for one-hot / float cond rows; for class / cluster IDS the same result as a column
                 gather of the weight (sgd_linear_gather), dropped rows taking the projection of the null embedding"""
+                if eng.cond_rows is not None:        # int64 one-hot rows (the reference's dataset format): non-zero entries only
+                    rows_, mask_u8, B = eng.cond_rows
+                    return lib.sgd_linear_sparse_rows(_ptr(rows_), _ptr(mask_u8), _ptr(wt), _ptr(bs), _ptr(nullproj), B, n, nout,
+                                                      K, _ptr(c1), nout, stream)
                 if eng.cond_ids is None:
                     return lib.sgd_linear_splitk(_ptr(eng.cond_m), K, _ptr(wt), _ptr(bs), n, nout, K, _ptr(work), ksplit,
                                                  _ptr(c1), nout, stream)

@@ -362,11 +362,13 @@ def test_conv_wgrad_fused_avgpool_through_pooled_planes(shape, prec, tol, monkey
 
 
 @pytest.mark.parametrize("prec,tol", [("f16x3", 3e-5), ("bf16x3", 3e-4)])
-def test_linear_wgrad_split_precision_at_production_shapes(prec, tol):
-    """1x1 / linear weight gradient in split precision: attention qkv (512 -> 1536 over 80*256 rows)"""
+@pytest.mark.parametrize("m,k,nout", [(80 * 256, 512, 1536), (13824, 768, 80)])
+def test_linear_wgrad_split_precision_at_production_shapes(m, k, nout, prec, tol):
+    """1x1 / linear weight gradient in split precision: attention qkv (512 -> 1536 over 80*256 rows), and the input gradient of
+    all ResBlocks' emb_layers seen as a weight gradient (train.py, _film: "rows" = the 13,824 FiLM outputs of C2, "gy" = the
+    FiLM gradient transposed, 80 columns = the batch)"""
     L, lib = _lib()
     g = torch.Generator().manual_seed(22)
-    m, k, nout = 80 * 256, 512, 1536
     x = torch.randn(m, k, generator=g)
     w = (torch.randn(nout, k, generator=g) / math.sqrt(k)).double().requires_grad_(True)
     gy = torch.randn(m, nout, generator=g) / m ** 0.5

@@ -6,6 +6,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
+from conftest import max_rel
 from test_hip_unet import build_model
 
 pytestmark = pytest.mark.gpu
@@ -67,6 +68,46 @@ def test_unet_fast_cluster_ids_equal_onehot(prec):
         a = m.forward_with_cond_scale(x, t, cond_scale=2.0, cond=onehot.cuda())
         b = m.forward_with_cond_scale(x, t, cond_scale=2.0, cond=ids.cuda())
     assert torch.equal(a, b)
+    # int64 one-hot ROWS (the dataset's format) run over their non-zero entries (sgd_linear_sparse_rows); the same rows as
+    # float take the dense skinny GEMM: bit-identical for one-hot rows
+    with torch.no_grad():
+        c = m.forward_with_cond_scale(x, t, cond_scale=2.0, cond=onehot.float().cuda())
+    assert torch.equal(a, c)
+
+
+def test_mlp_cond_sparse_rows_kernel():
+    """sgd_linear_sparse_rows against the dense product: one-hot rows bit-exact, multi-hot / counted / negative rows to fp32
+    rounding, dropped rows take the null projection, an all-zero row gives the bias"""
+    from sgdm_amd import _lib as L
+    import ctypes as C
+    lib = L.load()
+    g = torch.Generator().manual_seed(9)
+    B, n, K, nout = 5, 10, 5000, 256
+    w = torch.randn(nout, K, generator=g)
+    b = torch.randn(nout, generator=g)
+    nullproj = torch.randn(nout, generator=g)
+    cond = torch.zeros(B, K, dtype=torch.int64)
+    cond[0, 4999] = 1                                   # one-hot (last column)
+    cond[1, 0] = 1                                      # one-hot (first column)
+    cond[2, torch.randint(0, K, (300,), generator=g)] = 1          # multi-hot
+    cond[3] = torch.randint(-2, 3, (K,), generator=g)   # dense integer row: every list slot in use
+    mask = torch.zeros(n, dtype=torch.uint8)            # row 4 all zero
+    mask[7] = 1
+    out = torch.full((n, nout), float("nan"), device="cuda")
+    p = lambda t_: C.c_void_p(t_.data_ptr())
+    wd, bd, nd, cd, md = w.cuda(), b.cuda(), nullproj.cuda(), cond.cuda(), mask.cuda()
+    L.check(lib.sgd_linear_sparse_rows(p(cd), p(md), p(wd), p(bd), p(nd), B, n, nout, K, p(out), nout,
+                                       C.c_void_p(torch.cuda.current_stream().cuda_stream)), "sparse_rows")
+    got = out.cpu()
+    ref = (cond.double() @ w.double().t() + b.double()).float().repeat(2, 1)
+    ref[7] = nullproj
+    assert torch.equal(got[0], w[:, 4999] + b) and torch.equal(got[1], w[:, 0] + b) and torch.equal(got[5], got[0])
+    assert torch.equal(got[4], b) and torch.equal(got[7], nullproj)
+    # (row 3 -- 5,000 non-zero entries -- is one sequential fp32 sum per output: ~sqrt(5000) roundings)
+    err_sparse, err_dense = max_rel(got[[0, 1, 2, 4]], ref[[0, 1, 2, 4]]), max_rel(got, ref)
+    assert err_sparse < 2e-6 and err_dense < 2e-5, (err_sparse, err_dense)
+    # rows too long for the LDS list are refused (the caller keeps the dense kernel)
+    assert lib.sgd_linear_sparse_rows(p(cd), p(md), p(wd), p(bd), p(nd), B, n, nout, 9000, p(out), nout, None) != 0
 
 
 def test_unetca_label_map_and_nhot_equal_expanded():

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-launch table of one training step's backward (or, --forward, forward) program (HIP events around every launch),
 slowest first.
-    python tools/profile_train_layers.py [--workload c2|c5|c4] [--batch 80] [--top 40] [--match wgrad] [--forward] [--dropout 0.0]"""
+    python tools/profile_train_layers.py [--workload c2|c5|c4] [--batch 80] [--top 40] [--match wgrad] [--forward] [--dropout 0.0] [--lib libsgdm_hip_base.so]"""
 import argparse, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "self-guided-diffusion-models_amd"))
@@ -15,7 +15,9 @@ ap.add_argument("--batch", type=int, default=80); ap.add_argument("--top", type=
 ap.add_argument("--prec", default="f16x3"); ap.add_argument("--forward", action="store_true")
 ap.add_argument("--dropout", type=float, default=-1.0, help="override the model dropout")
 ap.add_argument("--workload", default="c2")
+ap.add_argument("--lib", default="", help="another build of the library (path relative to sgdm_amd/lib/): A/B on one box")
 a = ap.parse_args()
+if a.lib: L.LIB_PATH = os.path.join(os.path.dirname(L.LIB_PATH), a.lib)
 dev = torch.device("cuda", 0)
 wl = bench.WORKLOADS[a.workload]
 m, sd, data = bench.build_model(wl, dev, a.prec, a.batch)
