@@ -130,7 +130,8 @@ enum {
     SGD_TUNE_WGRAD_F32 = 1024,            /* sgd_wgrad: the exact-f32 per-tap kernel in every mode */
     SGD_TUNE_WGRAD_NO_WS = 2048,          /* sgd_wgrad: the round-2 all-taps kernel instead of the wave-specialised one */
     SGD_TUNE_WGRAD_NO_PLANES = 4096,      /* sgd_wgrad: no pre-split operand planes even with scratch */
-    SGD_TUNE_WGRAD_NO_PIPE = 8192         /* sgd_wgrad, 1x1 / linear: synchronous staging (no register pipelining) */
+    SGD_TUNE_WGRAD_NO_PIPE = 8192,        /* sgd_wgrad, 1x1 / linear: synchronous staging (no register pipelining) */
+    SGD_TUNE_WGRAD_PLANES_ALWAYS = 16384  /* sgd_wgrad: pre-split planes also for a single 128-channel output tile */
 };
 int64_t sgd_igemm_work_bytes(void);
 /* Balanced-tail health word (DEVICE int32 inside the workspace, byte offset sgd_igemm_work_status_offset()): 0 after a

@@ -912,7 +912,7 @@ __global__ __launch_bounds__(512) void wgrad_conv_ws_kernel(const WArgs w) {
 
     // =================================== compute waves: LDS -> MFMA ===================================
     // v_mfma_f32_16x16x32 (round 3): the same matrix-pipe cycles per flop as 32x32x16, and a measured +14..16 % clock under
-    // this load (profiles/r3_pmc_mfma_form_clock.txt).  The wave's [32 co x 32 ci] tile of a tap is 2 x 2 blocks of 16 x 16,
+    // this load (profiles/r3_pmc_mfma_form_clock.txt).  The wave's [64 co x 16 ci] tile of a tap is 4 x 1 blocks of 16 x 16,
     // a K step is 32 pixels of the 8x8 patch: lane group g = lane >> 4 addresses pixel rows 8 g + q (and + 4) of the step,
     // the transposing read hands lane j of a group channel j of the 16-channel block, 4 + 4 consecutive pixels.
     // (round 5: the four waves tile the block's [128 co x 32 ci] as 2 x 2 -- 64 co x 16 ci each -- instead of 4 x 1 (32 co x 32
@@ -1660,7 +1660,18 @@ static int64_t wgrad_planes_need(const sgd_igemm_args& a, int cout) {
     return 4 * (rows * cout + (int64_t)a.n * a.hi * a.wi * (a.c0 + a.c1));
 }
 static bool wgrad_planes_ok(const sgd_igemm_args& a, int cout, int gy_ld, bool have_scratch, int64_t scratch_bytes) {
-    return wgrad_ws_ok(a, cout, gy_ld) && have_scratch && scratch_bytes >= wgrad_planes_need(a, cout) && !(a.tune & SGD_TUNE_WGRAD_NO_PLANES);
+    if (!(wgrad_ws_ok(a, cout, gy_ld) && have_scratch && scratch_bytes >= wgrad_planes_need(a, cout) && !(a.tune & SGD_TUNE_WGRAD_NO_PLANES)))
+        return false;
+    // The pre-pass moves 8 bytes per element of both operands through HBM -- rows x (cin + cout) -- against rows x cin x cout x 9
+    // products: its share of the launch goes as 1 / cin + 1 / cout.  On the narrow layers (the 64x64 levels of the UNet, 128
+    // output channels) it costs more than the loaders' in-kernel transform does.  Measured round 5 (C2 batch 80, per launch,
+    // planes -> in-kernel split; tools/profile_train_layers.py with SGDM_WGRAD_TUNE): 128 -> 128 @64^2 0.328 -> 0.267 ms (with
+    // dropout 0.329 -> 0.305), 256 -> 128 0.608 -> 0.524, 384 -> 128 0.886 -> 0.772, 128 -> 256 @32^2 0.158 -> 0.139; from
+    // 256 -> 256 on the planes win (0.275 vs 0.31; 512 -> 512 @16^2 0.243 vs 0.31).  A third form -- planes for the gradient rows
+    // only, which cin / 32 blocks stage each -- was built and lost to both (0.38 ms on 128 -> 128).  The pooled form
+    // (ResBlock(down)) exists only with planes.
+    const long cin = a.c0 + a.c1;
+    return cin * cout > 100 * (cin + cout) || a.resample == SGD_RS_AVGPOOL2 || (a.tune & SGD_TUNE_WGRAD_PLANES_ALWAYS);
 }
 
 static int wgrad_impl(const sgd_igemm_args* fwd, const float* gy, int32_t gy_ld, int32_t cout, float* slabs,

@@ -25,7 +25,7 @@ ABI_VERSION = 16
 # sgd_igemm_args.tune (include/sgdm_hip.h: SGD_TUNE_*): per-call schedule overrides for parity tests and A/B tools
 TUNE_BN128, TUNE_BN256, TUNE_FLAT2, TUNE_DEFER, TUNE_PLAIN_SCHEDULE = 1, 2, 4, 8, 16
 TUNE_WGRAD_GENERIC_NARROW, TUNE_WGRAD_NO_POOLED_PLANES, TUNE_WGRAD_F32 = 256, 512, 1024
-TUNE_WGRAD_NO_WS, TUNE_WGRAD_NO_PLANES, TUNE_WGRAD_NO_PIPE = 2048, 4096, 8192
+TUNE_WGRAD_NO_WS, TUNE_WGRAD_NO_PLANES, TUNE_WGRAD_NO_PIPE, TUNE_WGRAD_PLANES_ALWAYS = 2048, 4096, 8192, 16384
 
 vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 

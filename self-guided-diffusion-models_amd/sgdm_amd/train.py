@@ -233,6 +233,9 @@ class Backward:
         ktiles = (rows + 63) // 64
         ksplit = wgrad_ksplit(taps, cout, cin, rows)
         slabs = self.buf(ksplit, taps, cout, cin)
+        xt = os.environ.get("SGDM_WGRAD_TUNE")      # A/B switch of tools/profile_train_layers.py: "<SGD_TUNE_WGRAD_* bits>[:max cin*cout]"
+        if xt and taps == 9 and cin * cout <= int((xt.split(":") + ["1000000000"])[1]):
+            fwd_args.tune |= int(xt.split(":")[0])
         # 3x3 convs: operands pre-split once into 16-bit planes (scratch shared by every launch of the program, grown to
         # the largest request before the first run: sgd_wgrad_scratch)
         need = int(self.lib.sgd_wgrad_scratch_bytes(C.byref(fwd_args), cout)) if taps == 9 else 0

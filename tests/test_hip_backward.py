@@ -150,9 +150,13 @@ def test_conv_wgrad_split_precision_at_production_shapes(shape, prec, tol):
     dw = _wgrad(L, lib, fwd, gyd, cout, cin, 9, _train_ksplit(9, cout, cin, n * h * h))
     err = max_rel(dw.reshape(cout, cin, 3, 3), w.grad.float())
     assert err < tol, err
-    if prec != "f32":    # the planes form (what the training program launches): the same arithmetic, bit for bit
+    if prec != "f32":    # the planes forms (what the training program launches): the same arithmetic, bit for bit
+        # default rule: both operands pre-split for cout > 128, only the gradient rows for a single 128-channel output tile
         dw2 = _wgrad(L, lib, fwd, gyd, cout, cin, 9, _train_ksplit(9, cout, cin, n * h * h), scratch=True)
         assert torch.equal(dw, dw2)
+        fwd.tune = L.TUNE_WGRAD_PLANES_ALWAYS
+        dw3 = _wgrad(L, lib, fwd, gyd, cout, cin, 9, _train_ksplit(9, cout, cin, n * h * h), scratch=True)
+        assert torch.equal(dw, dw3)
 
 
 @pytest.mark.parametrize("prec,tol", [("f16x3", 3e-5), ("bf16x3", 3e-4)])

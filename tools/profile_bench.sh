@@ -1,6 +1,8 @@
 #!/bin/bash
 # rocprofv3 kernel statistics of a bench.py command (run on the GPU box, from the repo root):
-#   tools/profile_bench.sh gpurun_out/r3_sampling  bench.py --steps 20 --warmup 3 --no-train --no-extra
+#   tools/profile_bench.sh gpurun_out/r3_sampling  bench.py --steps 20 --warmup 3 --no-train --no-extra --no-full
+# (--no-full: with the 1000-step trajectory -- 1000 graph replays of ~130 kernel nodes -- inside the traced process a thread of the
+# profiler dies with SIGSEGV on this image, whatever kernels the step holds; the timed K steps are the same launches)
 # writes <prefix>_kernel_stats.csv (the --stats summary) and <prefix>_bench.json (the bench line of that same process).
 R=${GRAFT_REPO_ROOT:-/root/repo}
 PFX="$R/$1"; shift
