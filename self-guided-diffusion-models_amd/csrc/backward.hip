@@ -953,22 +953,41 @@ __global__ __launch_bounds__(512) void wgrad_conv_ws_kernel(const WArgs w) {
                 ah[cb] = rd8(Gh + 32 * s * FGP + cb * 16, 4 * FGP);
                 al[cb] = rd8(Gl + 32 * s * FGP + cb * 16, 4 * FGP);
             }
+            // The three taps of a kernel row read three windows -- columns [0, 8), [1, 9), [2, 10) -- of the same ten halo pixels:
+            // 12 consecutive pixels come in once (three transposed reads per plane; the last two values belong to the next halo
+            // row and are not used) and the windows are formed in registers (the odd one costs four 16-bit funnel shifts per
+            // plane).  18 input-side reads per K step instead of 36; the same operands into the same MFMAs.
 #pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const int off = (40 * s + (t / 3 - 1) * 10 + (t % 3 - 1)) * UPITCH;
-                const T8 bh = rd8(Uh + off, 4 * UPITCH);
-                const T8 bl = rd8(Ul + off, 4 * UPITCH);
+            for (int dy = 0; dy < 3; ++dy) {
+                const int off = (40 * s + (dy - 1) * 10 - 1) * UPITCH;
+                const T4 h0 = trd(Uh + off), h1 = trd(Uh + off + 4 * UPITCH), h2 = trd(Uh + off + 8 * UPITCH);
+                const T4 l0 = trd(Ul + off), l1 = trd(Ul + off + 4 * UPITCH), l2 = trd(Ul + off + 8 * UPITCH);
 #pragma unroll
-                for (int cb = 0; cb < 4; ++cb) {
-                    f32x4& c = acc[t][cb];
-                    if constexpr (PREC == SGD_PREC_F16X3) {
-                        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[cb], bl, c, 0, 0, 0);
-                        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[cb], bh, c, 0, 0, 0);
-                        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[cb], bh, c, 0, 0, 0);
+                for (int dx = 0; dx < 3; ++dx) {
+                    T8 bh, bl;
+                    if (dx == 0) {
+                        bh = T8{h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+                        bl = T8{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+                    } else if (dx == 1) {
+                        bh = T8{h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3], h2[0]};
+                        bl = T8{l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3], l2[0]};
                     } else {
-                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[cb], bl, c, 0, 0, 0);
-                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[cb], bh, c, 0, 0, 0);
-                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[cb], bh, c, 0, 0, 0);
+                        bh = T8{h0[2], h0[3], h1[0], h1[1], h1[2], h1[3], h2[0], h2[1]};
+                        bl = T8{l0[2], l0[3], l1[0], l1[1], l1[2], l1[3], l2[0], l2[1]};
+                    }
+                    const int t = dy * 3 + dx;
+#pragma unroll
+                    for (int cb = 0; cb < 4; ++cb) {
+                        f32x4& c = acc[t][cb];
+                        if constexpr (PREC == SGD_PREC_F16X3) {
+                            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[cb], bl, c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[cb], bh, c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[cb], bh, c, 0, 0, 0);
+                        } else {
+                            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[cb], bl, c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[cb], bh, c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[cb], bh, c, 0, 0, 0);
+                        }
                     }
                 }
             }
@@ -994,7 +1013,8 @@ __global__ __launch_bounds__(512) void wgrad_conv_ws_kernel(const WArgs w) {
 
 template <int PREC, bool PLANES>
 static void launch_wgrad_ws(const WArgs& w, long grid, hipStream_t st) {
-    constexpr size_t smem = (size_t)2 * (2 * 64 * FGP + 2 * 100 * 32) * 2;         // two K-tile slots
+    // two K-tile slots (+ 2 halo rows: the compute waves' 12-pixel reads of the last halo row run two rows past a plane)
+    constexpr size_t smem = (size_t)2 * (2 * 64 * FGP + 2 * 100 * 32) * 2 + 2 * 32 * 2;
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute((const void*)wgrad_conv_ws_kernel<PREC, PLANES>, hipFuncAttributeMaxDynamicSharedMemorySize,
