@@ -156,7 +156,13 @@ constexpr int FGP = 160;        // GY plane row pitch (16-bit elements)
 // TAPS == 9: 3x3 stride-1 conv as described above (U = 10x10 halo x 32 ci, pitch 64 B, accumulators = taps).
 // TAPS == 1: 1x1 conv / linear: K tile = 64 consecutive rows, U = [64 rows][128 ci] at the GY pitch, the four
 //            accumulators are the four 32-channel ci sub-blocks (same transposing reads, no halo).
-template <int PREC, bool VEC, int TAPS>
+// FK (1x1 / linear only): 0 = every staging form behind run-time flags (what a launch with a partial 128-channel gradient block,
+// dropout, scalar rows ... takes); 1 / 2 / 3 = the register-pipelined staging alone, for no / GroupNorm-affine prologue, the per-tap
+// form of a strided conv, the LayerNorm-row prologue: the launcher (wgrad_flat_kind) proves the pipelined form's conditions for
+// the WHOLE launch, and the instance holds nothing else.  Round 5: with all forms in one body the kernel needed 256 registers and
+// spilled 46 -- ~70 scratch reloads of loop-invariant 64-bit row pointers inside the pipelined loop, each of them a vector memory
+// operation the in-order vmcnt counts behind the row requests it was supposed to overlap.
+template <int PREC, bool VEC, int TAPS, int FK = 0>
 __global__ __launch_bounds__(256, 2) void wgrad_conv_kernel(const WArgs w) {
     typedef typename Split<PREC>::T T;
     typedef T T4 __attribute__((ext_vector_type(4)));
@@ -276,8 +282,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_conv_kernel(const WArgs w) {
     // ONE image per K tile or no prologue, no dropout): the rows of K tile kt + ksplit are requested into registers before
     // the MFMA phase of tile kt and transformed into LDS after it -- round 4: the staging below is synchronous (request ->
     // wait -> split -> barrier -> 48 MFMAs), two exposed memory latencies per 1.5k-cycle MFMA phase, 150 TF
-    bool flat_pipe = false;
-    if constexpr (!CONV)
+    static_assert(FK == 0 || (!CONV && VEC), "specialised pipelined instances: 1x1 / linear, 16-byte rows");
+    const bool tap9 = FK ? FK == 2 : w.tap9 != 0;
+    bool flat_pipe = FK != 0;
+    if constexpr (!CONV && FK == 0)
         flat_pipe = VEC && gy_fast && a.drop_p == 0.f && !flat_pipe_off(w)
                     && (a.pro == SGD_PRO_NONE || (a.pro == SGD_PRO_LN_ROW && !w.tap9)
                         || (a.pro == SGD_PRO_AFFINE_NC && (w.tap9 ? (a.ho * a.wo) % 64 == 0 : a.rows_per_n % 64 == 0)));
@@ -294,7 +302,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_conv_kernel(const WArgs w) {
         Coef kq;
         // LayerNorm-row prologue (to_q / to_kv): (mean, rstd) of each requested row next to it, gamma / beta of this thread's
         // channel quad once per block
-        const bool lnp = a.pro == SGD_PRO_LN_ROW;
+        const bool lnp = FK ? FK == 3 : a.pro == SGD_PRO_LN_ROW;
         float2 rst[4];
         f32x4 lng = {1.f, 1.f, 1.f, 1.f}, lnb = {0.f, 0.f, 0.f, 0.f};
         if (lnp) {
@@ -308,7 +316,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_conv_kernel(const WArgs w) {
             const long rfirst = base < w.rows ? base : rlast;
             // image of the K tile (64 rows of ONE image in both forms)
             const int nimg = a.pro != SGD_PRO_AFFINE_NC ? 0
-                             : (w.tap9 ? (int)(rfirst >> (w.wo_l2 + w.ho_l2)) : (int)(rfirst / a.rows_per_n));
+                             : (tap9 ? (int)(rfirst >> (w.wo_l2 + w.ho_l2)) : (int)(rfirst / a.rows_per_n));
             if (!lnp) kq = load_coef<true>(a, nimg, rfirst, cc);
             okx = 0xFu;
 #pragma unroll
@@ -317,7 +325,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_conv_kernel(const WArgs w) {
                 row = row < w.rows ? row : rlast;
                 gv[i] = ld4(gcol + row * w.gy_ld);
                 long urow = row;
-                if (w.tap9) {                                     // (wave-uniform flag; the load stays unconditional)
+                if (tap9) {                                     // (wave-uniform flag; the load stays unconditional)
                     int nn;
                     const long sr = tap_row(row, nn);
                     if (sr < 0) okx &= ~(1u << i);
@@ -350,33 +358,40 @@ __global__ __launch_bounds__(256, 2) void wgrad_conv_kernel(const WArgs w) {
                 bsum += g4;
             }
         };
+        // (round 5: the four waves tile the block's [128 co x 128 ci] as 2 x 2 -- 64 co x 64 ci each -- instead of 4 x 1 (32 co x
+        // 128 ci): 8 + 8 transposed fragment reads per k-step instead of 4 + 16 for the same 12 MFMAs; same products, same order)
         auto mma_half = [&](int half) __attribute__((always_inline)) {
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 const int k0 = 16 * (half * 2 + s2) + kbase;
-                T8 ah, al;
-                {
-                    const T* g0 = Gh + k0 * FGP + wave * 32 + chl;
-                    const T* g1 = Gl + k0 * FGP + wave * 32 + chl;
+                T8 ah[2], al[2];
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb) {
+                    const T* g0 = Gh + k0 * FGP + (wave & 1) * 64 + cb * 32 + chl;
+                    const T* g1 = Gl + k0 * FGP + (wave & 1) * 64 + cb * 32 + chl;
                     const T4 h0 = trd(g0), h1 = trd(g0 + 4 * FGP), l0 = trd(g1), l1 = trd(g1 + 4 * FGP);
-                    ah = T8{h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
-                    al = T8{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+                    ah[cb] = T8{h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+                    al[cb] = T8{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
                 }
 #pragma unroll
-                for (int t = 0; t < NACC; ++t) {
-                    const T* u0 = Uh + k0 * UPITCH + t * 32 + chl;
-                    const T* u1 = Ul + k0 * UPITCH + t * 32 + chl;
+                for (int cj = 0; cj < 2; ++cj) {
+                    const T* u0 = Uh + k0 * UPITCH + (wave >> 1) * 64 + cj * 32 + chl;
+                    const T* u1 = Ul + k0 * UPITCH + (wave >> 1) * 64 + cj * 32 + chl;
                     const T4 h0 = trd(u0), h1 = trd(u0 + 4 * UPITCH), l0 = trd(u1), l1 = trd(u1 + 4 * UPITCH);
                     const T8 bh = T8{h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
                     const T8 bl = T8{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
-                    if constexpr (PREC == SGD_PREC_F16X3) {
-                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[t], 0, 0, 0);
-                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[t], 0, 0, 0);
-                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[t], 0, 0, 0);
-                    } else {
-                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[t], 0, 0, 0);
-                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[t], 0, 0, 0);
-                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[t], 0, 0, 0);
+#pragma unroll
+                    for (int cb = 0; cb < 2; ++cb) {
+                        f32x16& c = acc[cb * 2 + cj];
+                        if constexpr (PREC == SGD_PREC_F16X3) {
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cb], bl, c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[cb], bh, c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cb], bh, c, 0, 0, 0);
+                        } else {
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[cb], bl, c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[cb], bh, c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[cb], bh, c, 0, 0, 0);
+                        }
                     }
                 }
             }
@@ -393,7 +408,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_conv_kernel(const WArgs w) {
             __syncthreads();                                     // barrier 2: second half staged
             mma_half(1);
         }
-    } else
+    } else if constexpr (FK == 0)
     for (int kt = ks; kt < w.ktiles; kt += w.ksplit) {
         const int n = CONV ? kt / ppi : 0, pr = kt - n * ppi;
         const int y0 = CONV ? (pr / pw) * 8 : 0, x0 = CONV ? (pr - (pr / pw) * pw) * 8 : 0;
@@ -527,32 +542,66 @@ __global__ __launch_bounds__(256, 2) void wgrad_conv_kernel(const WArgs w) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const int k0 = 16 * s + kbase;
-            T8 ah, al;
-            {
-                const T* g0 = Gh + k0 * FGP + wave * 32 + chl;
-                const T* g1 = Gl + k0 * FGP + wave * 32 + chl;
-                const T4 h0 = trd(g0), h1 = trd(g0 + 4 * FGP), l0 = trd(g1), l1 = trd(g1 + 4 * FGP);
-                ah = T8{h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
-                al = T8{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
-            }
-            // CONV: halo pixel of tap (0, 0) for this lane's k (patch row k0 >> 3, col k0 & 7); read 1 = 4 pixels on
-            const int hb = CONV ? ((k0 >> 3) + 1) * 10 + (k0 & 7) + 1 : k0;
+            if constexpr (CONV) {
+                T8 ah, al;
+                {
+                    const T* g0 = Gh + k0 * FGP + wave * 32 + chl;
+                    const T* g1 = Gl + k0 * FGP + wave * 32 + chl;
+                    const T4 h0 = trd(g0), h1 = trd(g0 + 4 * FGP), l0 = trd(g1), l1 = trd(g1 + 4 * FGP);
+                    ah = T8{h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+                    al = T8{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+                }
+                // halo pixel of tap (0, 0) for this lane's k (patch row k0 >> 3, col k0 & 7); read 1 = 4 pixels on
+                const int hb = ((k0 >> 3) + 1) * 10 + (k0 & 7) + 1;
 #pragma unroll
-            for (int t = 0; t < NACC; ++t) {
-                const int off = CONV ? ((t / 3 - 1) * 10 + (t % 3 - 1)) * UPITCH : t * 32;
-                const T* u0 = Uh + hb * UPITCH + off + chl;
-                const T* u1 = Ul + hb * UPITCH + off + chl;
-                const T4 h0 = trd(u0), h1 = trd(u0 + 4 * UPITCH), l0 = trd(u1), l1 = trd(u1 + 4 * UPITCH);
-                const T8 bh = T8{h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
-                const T8 bl = T8{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
-                if constexpr (PREC == SGD_PREC_F16X3) {
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[t], 0, 0, 0);
-                } else {
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[t], 0, 0, 0);
+                for (int t = 0; t < NACC; ++t) {
+                    const int off = ((t / 3 - 1) * 10 + (t % 3 - 1)) * UPITCH;
+                    const T* u0 = Uh + hb * UPITCH + off + chl;
+                    const T* u1 = Ul + hb * UPITCH + off + chl;
+                    const T4 h0 = trd(u0), h1 = trd(u0 + 4 * UPITCH), l0 = trd(u1), l1 = trd(u1 + 4 * UPITCH);
+                    const T8 bh = T8{h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+                    const T8 bl = T8{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+                    if constexpr (PREC == SGD_PREC_F16X3) {
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[t], 0, 0, 0);
+                    } else {
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[t], 0, 0, 0);
+                    }
+                }
+            } else {
+                // 1x1 / linear: 2 x 2 wave tiles (see mma_half above)
+                T8 ah[2], al[2];
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb) {
+                    const T* g0 = Gh + k0 * FGP + (wave & 1) * 64 + cb * 32 + chl;
+                    const T* g1 = Gl + k0 * FGP + (wave & 1) * 64 + cb * 32 + chl;
+                    const T4 h0 = trd(g0), h1 = trd(g0 + 4 * FGP), l0 = trd(g1), l1 = trd(g1 + 4 * FGP);
+                    ah[cb] = T8{h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+                    al[cb] = T8{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+                }
+#pragma unroll
+                for (int cj = 0; cj < 2; ++cj) {
+                    const T* u0 = Uh + k0 * UPITCH + (wave >> 1) * 64 + cj * 32 + chl;
+                    const T* u1 = Ul + k0 * UPITCH + (wave >> 1) * 64 + cj * 32 + chl;
+                    const T4 h0 = trd(u0), h1 = trd(u0 + 4 * UPITCH), l0 = trd(u1), l1 = trd(u1 + 4 * UPITCH);
+                    const T8 bh = T8{h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+                    const T8 bl = T8{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+#pragma unroll
+                    for (int cb = 0; cb < 2; ++cb) {
+                        f32x16& c = acc[cb * 2 + cj];
+                        if constexpr (PREC == SGD_PREC_F16X3) {
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cb], bl, c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[cb], bh, c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cb], bh, c, 0, 0, 0);
+                        } else {
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[cb], bl, c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[cb], bh, c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[cb], bh, c, 0, 0, 0);
+                        }
+                    }
                 }
             }
         }
@@ -573,12 +622,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_conv_kernel(const WArgs w) {
     // ---- slab store: D rows = co (registers), cols = ci (lanes)
 #pragma unroll
     for (int t = 0; t < NACC; ++t) {
-        const int ci = ci0 + (CONV ? 0 : t * 32) + li;
+        // CONV: accumulator = tap, wave = 32 co; 1x1 / linear: accumulator (cb, cj) = t >> 1, t & 1 of the wave's 64 co x 64 ci
+        const int ci = ci0 + (CONV ? 0 : (wave >> 1) * 64 + (t & 1) * 32) + li;
         if (ci >= cin) continue;
         float* slab = w.slabs + ((long)ks * (w.tap9 ? 9 : TAPS) + (CONV ? t : tap)) * w.cout * cin;
+        const int cow = co0 + (CONV ? wave * 32 : (wave & 1) * 64 + (t >> 1) * 32);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int co = co0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const int co = cow + (r & 3) + 8 * (r >> 2) + 4 * lh;
             if (co < w.cout) slab[(long)co * cin + ci] = acc[t][r];
         }
     }
@@ -1068,16 +1119,37 @@ static void launch_wgrad_planes(WArgs& w, long grid, void* scratch, hipStream_t 
     launch_wgrad_ws<PREC, true>(w, grid, st);
 }
 
-template <int PREC, bool VEC, int TAPS>
+template <int PREC, bool VEC, int TAPS, int FK = 0>
 static void launch_wgrad_fast(const WArgs& w, long grid, hipStream_t st) {
     constexpr size_t smem = (2 * 64 * FGP + 2 * (TAPS == 9 ? 100 * 32 : 64 * FGP)) * 2;
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute((const void*)wgrad_conv_kernel<PREC, VEC, TAPS>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute((const void*)wgrad_conv_kernel<PREC, VEC, TAPS, FK>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)smem);
         attr = true;
     }
-    hipLaunchKernelGGL((wgrad_conv_kernel<PREC, VEC, TAPS>), dim3((unsigned)grid), dim3(256), smem, st, w);
+    hipLaunchKernelGGL((wgrad_conv_kernel<PREC, VEC, TAPS, FK>), dim3((unsigned)grid), dim3(256), smem, st, w);
+}
+
+// which specialised instance of the 1x1 / linear kernel serves the WHOLE launch (0: the general one): the pipelined staging's
+// conditions (wgrad_conv_kernel, flat_pipe) with "this block's gradient columns are a whole 128-channel block" true for all blocks
+static int wgrad_flat_kind(const sgd_igemm_args& a, const WArgs& w, bool vec) {
+    if (!vec || !w.gvec || w.cout % WT != 0 || a.drop_p != 0.f || w.no_flat_pipe || w.rows <= 0) return 0;
+    if (w.tap9) return (a.pro == SGD_PRO_NONE || (a.pro == SGD_PRO_AFFINE_NC && (a.ho * a.wo) % 64 == 0)) ? 2 : 0;
+    if (a.pro == SGD_PRO_NONE) return 1;
+    if (a.pro == SGD_PRO_AFFINE_NC) return (a.rows_per_n > 0 && a.rows_per_n % 64 == 0) ? 1 : 0;
+    return a.pro == SGD_PRO_LN_ROW ? 3 : 0;
+}
+template <int PREC>
+static void launch_wgrad_flat(const WArgs& w, long grid, hipStream_t st, bool vec) {
+    switch (wgrad_flat_kind(w.a, w, vec)) {
+    case 1: launch_wgrad_fast<PREC, true, 1, 1>(w, grid, st); break;
+    case 2: launch_wgrad_fast<PREC, true, 1, 2>(w, grid, st); break;
+    case 3: launch_wgrad_fast<PREC, true, 1, 3>(w, grid, st); break;
+    default:
+        if (vec) launch_wgrad_fast<PREC, true, 1>(w, grid, st);
+        else launch_wgrad_fast<PREC, false, 1>(w, grid, st);
+    }
 }
 
 // =============================================================================================
@@ -1760,8 +1832,8 @@ static int wgrad_impl(const sgd_igemm_args* fwd, const float* gy, int32_t gy_ld,
         w.gvec = 1;
         const long fgrid = 9L * w.co_tiles * w.ci_tiles * w.ksplit;
         if (fgrid > 0x7fffffffL) return SGD_ERR_ARG;
-        if (a.prec == SGD_PREC_F16X3) launch_wgrad_fast<SGD_PREC_F16X3, true, 1>(w, fgrid, st);
-        else launch_wgrad_fast<SGD_PREC_BF16X3, true, 1>(w, fgrid, st);
+        if (a.prec == SGD_PREC_F16X3) launch_wgrad_flat<SGD_PREC_F16X3>(w, fgrid, st, true);
+        else launch_wgrad_flat<SGD_PREC_BF16X3>(w, fgrid, st, true);
         return sgd_check_launch();
     }
     if ((fast_conv || fast_flat) && a.prec != SGD_PREC_F32 && !(a.tune & SGD_TUNE_WGRAD_F32)) {
@@ -1781,7 +1853,7 @@ static int wgrad_impl(const sgd_igemm_args* fwd, const float* gy, int32_t gy_ld,
 #define SGD_WG(P, V)                                                             \
         do { if (planes) launch_wgrad_planes<P>(w, fgrid, scratch, st);           \
              else if (ws) launch_wgrad_ws<P, false>(w, fgrid, st);               \
-             else if (fast_conv) launch_wgrad_fast<P, V, 9>(w, fgrid, st); else launch_wgrad_fast<P, V, 1>(w, fgrid, st); } while (0)
+             else if (fast_conv) launch_wgrad_fast<P, V, 9>(w, fgrid, st); else launch_wgrad_flat<P>(w, fgrid, st, V); } while (0)
         if (a.prec == SGD_PREC_F16X3) { if (vec) SGD_WG(SGD_PREC_F16X3, true); else SGD_WG(SGD_PREC_F16X3, false); }
         else { if (vec) SGD_WG(SGD_PREC_BF16X3, true); else SGD_WG(SGD_PREC_BF16X3, false); }
 #undef SGD_WG
