@@ -55,6 +55,42 @@ def test_release_library_reads_no_environment():
     assert L.IgemmArgs.tune.offset == L.IgemmArgs.grid_cap.offset + 4
 
 
+def _kernel_resources(obj):
+    """(name, vgpr spills, scratch bytes) of every gfx950 kernel in one object of csrc/build (tools/kernel_resources.sh)"""
+    import subprocess
+    import tempfile
+    llvm = "/opt/rocm/lib/llvm/bin"
+    path = os.path.join(ROOT, "self-guided-diffusion-models_amd", "csrc", "build", obj)
+    if not (os.path.exists(path) and os.path.exists(os.path.join(llvm, "llvm-readelf"))):
+        pytest.skip("object file or llvm tools missing")
+    with tempfile.TemporaryDirectory() as t:
+        subprocess.check_call([f"{llvm}/llvm-objcopy", f"--dump-section=.hip_fatbin={t}/fat.bin", path])
+        subprocess.check_call([f"{llvm}/clang-offload-bundler", "--unbundle", "--type=o", f"--input={t}/fat.bin",
+                               "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={t}/dev.co"])
+        notes = subprocess.check_output([f"{llvm}/llvm-readelf", "--notes", f"{t}/dev.co"], text=True)
+    out = []
+    for blk in notes.split("- .agpr_count")[1:]:
+        g = lambda k: re.search(r"\." + k + r":\s+(\S+)", blk).group(1)
+        out.append((g("name"), int(g("vgpr_spill_count")), int(g("private_segment_fixed_size"))))
+    return out
+
+
+def test_hot_kernels_have_no_scratch():
+    """A kernel with any scratch pays ~3 us on every launch, and a spill reload inside a pipelined loop is a vector memory
+    operation the in-order vmcnt counts behind the loads it was meant to overlap (round 5: the 1x1 weight-gradient kernel lost
+    up to a third of its rate that way).  The instances the sampler and the training step launch per layer must stay clean:
+    every instance of the conv kernel, the wave-specialised 3x3 weight gradient, the pipelined 1x1 weight-gradient forms."""
+    for obj in ("igemm_f16x3.o", "igemm_bf16x3.o", "igemm_f32.o"):
+        ks = [k for k in _kernel_resources(obj) if "igemm_kernel" in k[0]]
+        assert ks, obj
+        assert all(sp == 0 and scr == 0 for _, sp, scr in ks), [k for k in ks if k[1] or k[2]]
+    ks = _kernel_resources("backward.o")
+    ws = [k for k in ks if "wgrad_conv_ws_kernel" in k[0]]
+    flat = [k for k in ks if re.search(r"wgrad_conv_kernelILi\dELb1ELi1ELi[123]E", k[0])]
+    assert len(ws) == 4 and len(flat) == 6, (len(ws), len(flat))
+    assert all(sp == 0 and scr == 0 for _, sp, scr in ws + flat), [k for k in ws + flat if k[1] or k[2]]
+
+
 def _build(name):
     entry = INDEX[name]
     kw = dict(entry["ctor"])
