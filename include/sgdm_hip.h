@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define SGD_ABI_VERSION 16
+#define SGD_ABI_VERSION 17
 int sgd_abi_version(void);
 /* 16 hex digits identifying the sources and flags the library was compiled from (build.py: source_id()); static storage.
  * __graft_entry__.build() and tests/test_boundary_cpu.py compare it with the tree on disk. */
@@ -159,9 +159,10 @@ int sgd_debug_copy_probe(const float* src, float* dst, int64_t count, void* stre
  * Two split tiles of one launch must never share a counter or a slab (tests/test_boundary_cpu.py). */
 int sgd_igemm_tail_layout(int32_t total_tiles, int32_t nchunks, int32_t taps, int32_t grid, int32_t* out);
 
-/* the keep/drop hash, shared by device code and host tests:
+/* the keep/drop hash, shared by device code and host tests (ABI 17: one hash per PAIR of elements):
+ *   pair = index >> 1  (index = row * channels + channel);  lo/hi = the 32-bit halves of pair
  *   h = seed ^ (lo * 0x9E3779B1) ^ (hi * 0x632BE5AB); h ^= h>>16; h *= 0x85EBCA6B; h ^= h>>13; h *= 0xC2B2AE35; h ^= h>>16;
- *   keep  <=>  (h >> 8) >= (uint32_t)(p * 16777216)                                       (lo/hi = halves of the index) */
+ *   keep  <=>  (index & 1 ? h >> 16 : h & 0xFFFF) >= (uint32_t)(p * 65536) */
 
 int sgd_igemm(const sgd_igemm_args* args /* HOST pointer */, void* stream);
 /* number of per-image partial-statistics slots the epilogue of this launch writes (see args->stats) */

@@ -1425,13 +1425,7 @@ __device__ __forceinline__ f32x4 fetch_g(const float* g, int ld, int mode, int n
 }
 
 // gradient through the train-time dropout that sits between the activation and the consumer conv
-__device__ __forceinline__ f32x4 drop_mask(f32x4 g, float p, uint32_t seed, long base) {
-    const uint32_t thr = (uint32_t)(p * 16777216.f);
-    const float inv = 1.0f / (1.0f - p);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) g[j] = sgd_drop_keep(seed, base + j, thr) ? g[j] * inv : 0.f;
-    return g;
-}
+__device__ __forceinline__ f32x4 drop_mask(f32x4 g, float p, uint32_t seed, long base) { return sgd_drop4(g, p, seed, base); }
 
 // block per (n, 32-channel slab): 8 channel quads x 32 row lanes
 __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const float* __restrict__ x, int h, int w, int c,

@@ -123,13 +123,7 @@ __device__ __forceinline__ f32x4 apply_pro(const sgd_igemm_args& a, f32x4 v, con
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = sgd_silu(v[j]);
     }
-    if (a.drop_p > 0.f) {
-        const uint32_t thr = (uint32_t)(a.drop_p * 16777216.f);
-        const float inv = 1.0f / (1.0f - a.drop_p);
-        const long base = row * (a.c0 + a.c1) + c;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = sgd_drop_keep(a.drop_seed, base + j, thr) ? v[j] * inv : 0.f;
-    }
+    if (a.drop_p > 0.f) v = sgd_drop4(v, a.drop_p, a.drop_seed, row * (a.c0 + a.c1) + c);
     return v;
 }
 

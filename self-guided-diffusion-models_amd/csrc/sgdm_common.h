@@ -29,11 +29,35 @@ __device__ __forceinline__ float sgd_silu(float v) {
     return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));
 }
 
-// counter-based dropout mask (include/sgdm_hip.h: sgd_igemm_args.drop_p)
-__device__ __forceinline__ bool sgd_drop_keep(uint32_t seed, long idx, uint32_t thr24) {
-    uint32_t h = seed ^ ((uint32_t)idx * 0x9E3779B1u) ^ ((uint32_t)((unsigned long)idx >> 32) * 0x632BE5ABu);
+// counter-based dropout mask (include/sgdm_hip.h: sgd_igemm_args.drop_p).  One 32-bit hash serves TWO elements: element idx
+// takes the (idx & 1)-th 16-bit half of the hash of pair idx >> 1, and is kept iff that half is >= p * 65536.  (Round 5: a hash
+// per element was nine quarter-rate multiplies per channel quad in every kernel that recomputes the mask -- conv loaders,
+// weight-gradient staging, both GroupNorm-backward passes; the HBM-bound reduce pass ran at 3.7 instead of 4.9 TB/s with it.)
+__device__ __forceinline__ uint32_t sgd_drop_hash(uint32_t seed, long pair) {
+    uint32_t h = seed ^ ((uint32_t)pair * 0x9E3779B1u) ^ ((uint32_t)((unsigned long)pair >> 32) * 0x632BE5ABu);
     h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
-    return (h >> 8) >= thr24;
+    return h;
+}
+__device__ __forceinline__ uint32_t sgd_drop_thr(float p) { return (uint32_t)(p * 65536.f); }
+__device__ __forceinline__ bool sgd_drop_keep(uint32_t seed, long idx, uint32_t thr16) {
+    const uint32_t h = sgd_drop_hash(seed, idx >> 1);
+    return ((idx & 1) ? (h >> 16) : (h & 0xFFFFu)) >= thr16;
+}
+// four consecutive elements from index `base`: kept values times 1 / (1 - p), dropped ones zero
+__device__ __forceinline__ f32x4 sgd_drop4(f32x4 v, float p, uint32_t seed, long base) {
+    const uint32_t thr = sgd_drop_thr(p);
+    const float inv = 1.0f / (1.0f - p);
+    if ((base & 1) == 0) {                  // every 16-byte path (channel counts that are multiples of four): two hashes
+        const uint32_t h0 = sgd_drop_hash(seed, base >> 1), h1 = sgd_drop_hash(seed, (base >> 1) + 1);
+        v[0] = (h0 & 0xFFFFu) >= thr ? v[0] * inv : 0.f;
+        v[1] = (h0 >> 16) >= thr ? v[1] * inv : 0.f;
+        v[2] = (h1 & 0xFFFFu) >= thr ? v[2] * inv : 0.f;
+        v[3] = (h1 >> 16) >= thr ? v[3] * inv : 0.f;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = sgd_drop_keep(seed, base + j, thr) ? v[j] * inv : 0.f;
+    }
+    return v;
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -20,7 +20,7 @@ RS_NONE, RS_AVGPOOL2, RS_UP2, RS_ZEROUP2 = 0, 1, 2, 3
 PRO_NONE, PRO_AFFINE_NC, PRO_LN_ROW = 0, 1, 2
 PREC_F32, PREC_F16X3, PREC_BF16X3 = 0, 1, 2
 PREC_BY_NAME = {"f32": PREC_F32, "f16x3": PREC_F16X3, "bf16x3": PREC_BF16X3}
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 # sgd_igemm_args.tune (include/sgdm_hip.h: SGD_TUNE_*): per-call schedule overrides for parity tests and A/B tools
 TUNE_BN128, TUNE_BN256, TUNE_FLAT2, TUNE_DEFER, TUNE_PLAIN_SCHEDULE = 1, 2, 4, 8, 16

@@ -201,14 +201,17 @@ def test_ddp_bucketed_allreduce_two_ranks(name, backend):
 
 
 def _host_keep_mask(seed, n_rows, c, p):
-    """numpy re-statement of sgd_drop_keep (include/sgdm_hip.h) for element index row*c + channel"""
+    """numpy re-statement of sgd_drop_keep (include/sgdm_hip.h) for element index row*c + channel: one hash per pair of elements,
+    the element's 16-bit half of it against p * 65536"""
     idx = np.arange(n_rows * c, dtype=np.uint64)
-    lo, hi = (idx & 0xFFFFFFFF).astype(np.uint64), (idx >> np.uint64(32)).astype(np.uint64)
+    pair = idx >> np.uint64(1)
+    lo, hi = (pair & 0xFFFFFFFF).astype(np.uint64), (pair >> np.uint64(32)).astype(np.uint64)
     h = (np.uint64(seed) ^ (lo * np.uint64(0x9E3779B1)) ^ (hi * np.uint64(0x632BE5AB))) & np.uint64(0xFFFFFFFF)
     h ^= h >> np.uint64(16); h = (h * np.uint64(0x85EBCA6B)) & np.uint64(0xFFFFFFFF)
     h ^= h >> np.uint64(13); h = (h * np.uint64(0xC2B2AE35)) & np.uint64(0xFFFFFFFF)
     h ^= h >> np.uint64(16)
-    return ((h >> np.uint64(8)) >= np.uint64(int(np.float32(p) * np.float32(16777216.0)))).reshape(n_rows, c)
+    half = np.where((idx & np.uint64(1)) == 1, h >> np.uint64(16), h & np.uint64(0xFFFF))
+    return (half >= np.uint64(int(np.float32(p) * np.float32(65536.0)))).reshape(n_rows, c)
 
 
 def test_train_step_with_dropout_matches_oracle_on_the_same_masks():
