@@ -629,16 +629,21 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
             // chain of small basic blocks (selects between the transformed and untransformed value, moves at the joins),
             // which the scheduler could neither interleave nor strip -- and loader issue slots are what paces the block.
             const bool uni_rt = VEC && g.nb == 1 && a.pro == SGD_PRO_AFFINE_NC;
+            // (round 5: train-time dropout -- the 22 out_layers.3 convs of a training forward -- rides on the GroupNorm + SiLU
+            // instantiation: two hashes per item, sgd_drop4; those launches took the general loader before, +13 % each)
+            const bool drop_rt = a.drop_p > 0.f;
             const bool lean2 = g.fast_a && VEC && ((uni_rt && a.pro_silu) || (a.pro == SGD_PRO_NONE && !a.pro_silu))
-                               && a.drop_p == 0.f && cin % KC == 0 && (a.c1 == 0 || a.c0 % KC == 0) && !DBG(3);
+                               && (!drop_rt || (uni_rt && a.pro_silu && a.resample != SGD_RS_AVGPOOL2))
+                               && cin % KC == 0 && (a.c1 == 0 || a.c0 % KC == 0) && !DBG(3);
             if (lean2) {
                 constexpr int LT = A_THREADS;                            // 256 loader threads
                 constexpr int AJ = (FAST_PIX * 8 + LT - 1) / LT;         // input items per thread per chunk (6)
                 const int lt = tid - NCOMP;
                 const int c4 = lt & 7;                                   // channel quad (inputs and weights alike)
                 const int items = g.pix * 8;
-                auto go = [&](auto unic, auto poolc) __attribute__((always_inline)) {
+                auto go = [&](auto unic, auto poolc, auto dropc) __attribute__((always_inline)) {
                     constexpr bool uni = decltype(unic)::value;          // true: GN affine + SiLU, false: raw input
+                    constexpr bool DROP = decltype(dropc)::value;        // train-time dropout behind the SiLU (uni, no pool)
                     constexpr bool LATE = false;
                     constexpr int NS = decltype(poolc)::value ? 4 : 1;   // source pixels per item (fused 2x2 average pool)
                     constexpr int T0 = LATE ? 5 : 1;
@@ -719,18 +724,22 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
                     // branch per item made six separate basic blocks: the six dependency chains (affine -> exp -> rcp -> split)
                     // ran one after the other, and next to an MFMA wave a single serial chain gets ~2 issue slots per MFMA
                     // (measured 7.9k cycles for ~400 instructions per chunk -- the loaders paced the whole block).
+                    S s2;                                               // chunk whose raw rows are in flight / in registers
                     auto finish = [&](int slot, int j) __attribute__((always_inline)) {
                         const bool ok = (valid1 >> j) & 1u;
                         f32x4 v = transform(araw[j][0], ok);
                         if constexpr (NS == 4)
                             v = 0.25f * (v + transform(araw[j][1], ok) + transform(araw[j][2], ok) + transform(araw[j][3], ok));
+                        // the mask of element (source row, concat channel), as apply_pro forms it (a padding pixel is 0 either way);
+                        // s2 / rows2 still describe the chunk being transformed: stage() advances them after finish_all()
+                        if constexpr (DROP)
+                            v = sgd_drop4(v, a.drop_p, a.drop_seed, (long)rows2[j] * cin + s2.chunk * KC + c4 * 4);
                         if (!ABL(1024)) lds_store_act<PREC>(As + (size_t)(slot % NA) * a_floats + (size_t)pixj[j] * LDA, c4, v);
                         else KEEP_LIVE(v);
                     };
                     // ---- ONE barrier per chunk; the loaders run two chunks ahead of the compute waves in LDS (ring of 3)
                     // and three ahead in global memory: in period q they transform chunk q+2 (requested in period q-1) into
                     // slot (q+2) % 3 and request chunk q+3.  Prologue: chunks 0 and 1 staged before barrier 0.
-                    S s2;                                               // chunk whose raw rows are in flight / in registers
                     auto stage = [&](int slot) __attribute__((always_inline)) {                        // transform the chunk under s2, request the next one
                         valid1 = valid2;
                         auto finish_all = [&]() {
@@ -768,11 +777,12 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
                     else with_nq(periods);
                 };
                 if (uni_rt) {
-                    if (a.resample == SGD_RS_AVGPOOL2) go(std::true_type(), std::true_type());
-                    else go(std::true_type(), std::false_type());
+                    if (a.resample == SGD_RS_AVGPOOL2) go(std::true_type(), std::true_type(), std::false_type());
+                    else if (drop_rt) go(std::true_type(), std::false_type(), std::true_type());
+                    else go(std::true_type(), std::false_type(), std::false_type());
                 } else {
-                    if (a.resample == SGD_RS_AVGPOOL2) go(std::false_type(), std::true_type());
-                    else go(std::false_type(), std::false_type());
+                    if (a.resample == SGD_RS_AVGPOOL2) go(std::false_type(), std::true_type(), std::false_type());
+                    else go(std::false_type(), std::false_type(), std::false_type());
                 }
                 PROBE_END(1);
                 return;
