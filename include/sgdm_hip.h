@@ -153,6 +153,12 @@ int sgd_debug_mfma_probe(int32_t blocks, int64_t iters, uint32_t seed, int32_t v
                          1: on zeros, 2: 32x32x16 on random operands */, float* out, void* stream);
 int64_t sgd_debug_mfma_probe_flops(int32_t blocks, int64_t iters, int32_t variant);
 int sgd_debug_copy_probe(const float* src, float* dst, int64_t count, void* stream);
+/* diagnostic: the conv kernel's compute-wave stream in isolation -- 48 split-precision 16x16x32 MFMAs per step into 64 accumulator
+ * registers, the row-block operands re-read from LDS every step (row_blocks = 8: 16 reads per step, the shipped 128 x 32 wave tile;
+ * 4: 8 reads, a 64 x 64 tile; 0: none), on one or two MFMA waves per SIMD.  out: blocks * 256 * waves_per_simd floats or NULL.
+ * flops = blocks * 4 * waves_per_simd * iters * 48 * 16384 (tools/mfma_probe_sweep.py --lds) */
+int sgd_debug_mfma_lds_probe(int32_t blocks, int64_t iters, uint32_t seed, int32_t row_blocks, int32_t waves_per_simd, float* out,
+                             void* stream);
 /* Host-only test hook (no launch): the balanced-tail workspace layout of a launch of `total_tiles` tiles with `nchunks`
  * 32-channel chunks per tile and `taps` (9 / 1) K steps per chunk on `grid` persistent blocks.  out[4*b .. 4*b+3] =
  * {K split of block b's last tile (0: none), index of its arrival counter, first producer slab, producer slabs}.

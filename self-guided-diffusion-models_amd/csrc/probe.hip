@@ -84,7 +84,87 @@ __global__ __launch_bounds__(256) void copy_probe_kernel(const f32x4* __restrict
     for (; i < n; i += stride) dst[i] = src[i];
 }
 
+// What does the conv kernel's compute-wave stream cost the matrix pipe, and would a second MFMA wave per SIMD give it back?
+// One "K step" of a wave = MT row blocks x NT column blocks of 16 x 16 x 32 products in three split-precision MFMAs each (MT * NT =
+// 16: 48 MFMAs, 64 accumulator registers), with the row-block operands (hi + lo: two 16-byte LDS reads per row block, 2 * MT per
+// step) re-read from LDS for every step right after their last use, as igemm_kernel does; the column-block operands stay in
+// registers (the conv kernel streams them from L2).  MT = 8, NT = 2 is the shipped 128 x 32 wave tile (16 reads per 48 MFMAs),
+// MT = 4, NT = 4 the 64 x 64 one (8 reads), MT = 0 no reads at all.  WPS = MFMA waves per SIMD (block = 256 * WPS threads).
+template <int MT, int NT, int WPS>
+__global__ __launch_bounds__(256 * WPS) void mfma_lds_probe_kernel(uint32_t seed, long iters, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) _Float16 plds[];          // 150 KB: one block per CU; the first 64 KB are read
+    constexpr int RMT = MT > 0 ? MT : 8;                 // row blocks (MT == 0: operands never reloaded)
+    constexpr int RNT = 16 / RMT;
+    static_assert(MT == 0 || MT * NT == 16, "48 MFMAs per step");
+    for (int i = threadIdx.x; i < 32768; i += 256 * WPS) plds[i] = rnd_f16(mix32(seed + 17u * (uint32_t)i + blockIdx.x));
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const uint32_t id = (blockIdx.x * 256u * WPS + threadIdx.x) * 64u + seed;
+    f16x8 bh[RNT], bl[RNT], ah[RMT], al[RMT];
+#pragma unroll
+    for (int i = 0; i < RNT; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { bh[i][j] = rnd_f16(mix32(id + (uint32_t)(i * 8 + j))); bl[i][j] = rnd_f16(mix32(id + 64u + (uint32_t)(i * 8 + j))); }
+    // lane l reads 16 consecutive bytes at 16 l: every ds_read_b128 is conflict-free; (step & 3, row block, plane) select the 1 KB slice
+    const _Float16* base = plds + lane * 8;
+    auto slice = [&](long step, int mt, int plane) { return base + ((int)(step & 3) * 16 + mt * 2 + plane) * 512; };
+#pragma unroll
+    for (int mt = 0; mt < RMT; ++mt) { ah[mt] = *reinterpret_cast<const f16x8*>(slice(0, mt, 0)); al[mt] = *reinterpret_cast<const f16x8*>(slice(0, mt, 1)); }
+    f32x4 acc[RMT][RNT];
+#pragma unroll
+    for (int i = 0; i < RMT; ++i)
+#pragma unroll
+        for (int j = 0; j < RNT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (long it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int nt = 0; nt < RNT; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < RMT; ++mt) {
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mt], bl[nt], acc[mt][nt], 0, 0, 0);
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+                if (MT > 0 && nt == RNT - 1) {           // last use of row block mt in this step: its operands of the next step
+                    ah[mt] = *reinterpret_cast<const f16x8*>(slice(it + 1, mt, 0));
+                    al[mt] = *reinterpret_cast<const f16x8*>(slice(it + 1, mt, 1));
+                }
+            }
+    }
+    float total = 0.f;
+#pragma unroll
+    for (int i = 0; i < RMT; ++i)
+#pragma unroll
+        for (int j = 0; j < RNT; ++j) total += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    if (out) out[(size_t)blockIdx.x * 256 * WPS + threadIdx.x] = total;
+}
+
 }  // namespace
+
+template <int MT, int NT, int WPS>
+static int launch_mfma_lds_probe(int32_t blocks, int64_t iters, uint32_t seed, float* out, void* stream) {
+    const size_t LDS = 150 * 1024;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)mfma_lds_probe_kernel<MT, NT, WPS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
+        attr = true;
+    }
+    hipLaunchKernelGGL((mfma_lds_probe_kernel<MT, NT, WPS>), dim3(blocks), dim3(256 * WPS), LDS, (hipStream_t)stream, seed, (long)iters, out);
+    return sgd_check_launch();
+}
+
+// row_blocks: 8 (the shipped 128 x 32 wave tile), 4 (64 x 64) or 0 (no LDS reads); waves_per_simd: 1 or 2.  Flops of a launch:
+// blocks * 4 * waves_per_simd * iters * 48 * 16384.
+extern "C" int sgd_debug_mfma_lds_probe(int32_t blocks, int64_t iters, uint32_t seed, int32_t row_blocks, int32_t waves_per_simd,
+                                        float* out, void* stream) {
+    SGD_CLEAR_ERR();
+    if (blocks <= 0 || blocks > 4096 || iters <= 0 || (waves_per_simd != 1 && waves_per_simd != 2)) return SGD_ERR_ARG;
+#define SGD_LP(MT, NT) return waves_per_simd == 1 ? launch_mfma_lds_probe<MT, NT, 1>(blocks, iters, seed, out, stream) \
+                                                  : launch_mfma_lds_probe<MT, NT, 2>(blocks, iters, seed, out, stream)
+    if (row_blocks == 8) { SGD_LP(8, 2); }
+    if (row_blocks == 4) { SGD_LP(4, 4); }
+    if (row_blocks == 0) { SGD_LP(0, 0); }
+#undef SGD_LP
+    return SGD_ERR_ARG;
+}
 
 template <int VARIANT>
 static int launch_mfma_probe(int32_t blocks, int64_t iters, uint32_t seed, float* out, void* stream) {

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """What does the bare-MFMA probe (csrc/probe.hip) measure?  Sweeps variant (16x16x32 random / zeros, 32x32x16 random),
 launch duration and the number of active compute units, interleaved in one process.
-    python tools/mfma_probe_sweep.py"""
+    python tools/mfma_probe_sweep.py [--lds]"""
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "self-guided-diffusion-models_amd"))
@@ -21,6 +21,27 @@ def run(blocks, iters, variant):
     t = e0.elapsed_time(e1) * 1e-3
     return float(lib.sgd_debug_mfma_probe_flops(blocks, iters, variant)) / t / 1e12, t
 
+
+def run_lds(blocks, iters, row_blocks, wps):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    L.check(lib.sgd_debug_mfma_lds_probe(blocks, iters, 777, row_blocks, wps, C.c_void_p(sink.data_ptr()), st), "lds probe")
+    e1.record(); e1.synchronize()
+    t = e0.elapsed_time(e1) * 1e-3
+    return blocks * 4.0 * wps * iters * 48 * 16384 / t / 1e12, t
+
+
+if "--lds" in sys.argv:
+    # the conv kernel's compute-wave stream alone: 48 MFMAs per step, 16 / 8 / 0 LDS fragment reads per step, 1 or 2 waves per SIMD
+    for rb, wps in ((0, 1), (8, 1), (4, 1), (0, 2), (8, 2), (4, 2)):
+        run_lds(cus, 2000, rb, wps)
+    for rnd in range(3):
+        for rb in (0, 8, 4):
+            for wps in (1, 2):
+                tf, t = run_lds(cus, 40000 // wps, rb, wps)
+                print(f"round {rnd} row blocks {rb} ({2 * rb:2d} LDS reads per 48 MFMAs) waves/SIMD {wps}: {t * 1e3:8.2f} ms  {tf:7.1f} TF raw "
+                      f"= {tf / 3:6.1f} TF per fp32 product", flush=True)
+    sys.exit(0)
 
 names = {0: "16x16x32 random", 1: "16x16x32 zeros", 2: "32x32x16 random"}
 for v in (0, 1, 2):
