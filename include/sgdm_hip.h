@@ -159,6 +159,13 @@ int sgd_debug_copy_probe(const float* src, float* dst, int64_t count, void* stre
  * flops = blocks * 4 * waves_per_simd * iters * 48 * 16384 (tools/mfma_probe_sweep.py --lds) */
 int sgd_debug_mfma_lds_probe(int32_t blocks, int64_t iters, uint32_t seed, int32_t row_blocks, int32_t waves_per_simd, float* out,
                              void* stream);
+/* diagnostic: that stream on the shipped wave tile with the rest of the conv kernel's per-step traffic added piece by piece --
+ * extras bit 0: the weight fragments re-loaded from global memory every step (wbuf: >= 1 MiB, stays in L2); bit 1: four loader
+ * waves per block moving six 16-byte rows per thread and chunk of 9 steps from abuf (arows rows, streamed) through affine + SiLU +
+ * hi / lo split into LDS; bit 2 (with bit 1): one barrier per chunk; bit 3 (with bit 1, instead of bit 2): producer / consumer
+ * counters in LDS.  flops = blocks * 4 * (iters / 9 * 9) * 48 * 16384 */
+int sgd_debug_mfma_stream_probe(int32_t blocks, int64_t iters, uint32_t seed, int32_t extras, const void* wbuf, const void* abuf,
+                                int64_t arows, float* out, void* stream);
 /* Host-only test hook (no launch): the balanced-tail workspace layout of a launch of `total_tiles` tiles with `nchunks`
  * 32-channel chunks per tile and `taps` (9 / 1) K steps per chunk on `grid` persistent blocks.  out[4*b .. 4*b+3] =
  * {K split of block b's last tile (0: none), index of its arrival counter, first producer slab, producer slabs}.

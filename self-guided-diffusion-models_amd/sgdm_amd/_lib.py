@@ -63,6 +63,7 @@ SIGNATURES = {
     "sgd_debug_mfma_probe_flops": (i64, [i32, i64, i32]),
     "sgd_debug_copy_probe": (i32, [vp, vp, i64, vp]),
     "sgd_debug_mfma_lds_probe": (i32, [i32, i64, C.c_uint32, i32, i32, vp, vp]),
+    "sgd_debug_mfma_stream_probe": (i32, [i32, i64, C.c_uint32, i32, vp, vp, i64, vp, vp]),
     "sgd_igemm_tail_layout": (i32, [i32, i32, i32, i32, C.POINTER(i32)]),
     "sgd_stats_reduce": (i32, [vp, i32, i32, i32, vp, i32, i32, vp]),
     "sgd_packed_weight_bytes": (i64, [i32, i32, i32, i32]),

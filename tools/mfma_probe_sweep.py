@@ -41,6 +41,28 @@ if "--lds" in sys.argv:
                 tf, t = run_lds(cus, 40000 // wps, rb, wps)
                 print(f"round {rnd} row blocks {rb} ({2 * rb:2d} LDS reads per 48 MFMAs) waves/SIMD {wps}: {t * 1e3:8.2f} ms  {tf:7.1f} TF raw "
                       f"= {tf / 3:6.1f} TF per fp32 product", flush=True)
+    # ... and the rest of the conv kernel's per-step traffic added to the shipped tile's stream piece by piece
+    wbuf = torch.randn(1 << 19, device="cuda").half()                       # 1 MiB of weight fragments (stays in L2)
+    arows = 1 << 24
+    abuf = torch.randn(arows * 4, device="cuda")                           # 256 MiB of 16-byte input rows (streamed)
+    label = {0: "stream only (16 LDS reads)", 1: "+ weight fragments from L2", 2: "+ loader waves", 3: "+ weights + loaders",
+             6: "+ loaders + barrier per chunk", 7: "+ weights + loaders + barrier", 10: "+ loaders + LDS counters",
+             11: "+ weights + loaders + LDS counters"}
+
+    def run_ex(ex, iters=36000):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        L.check(lib.sgd_debug_mfma_stream_probe(cus, iters, 777, ex, C.c_void_p(wbuf.data_ptr()), C.c_void_p(abuf.data_ptr()), arows,
+                                                C.c_void_p(sink.data_ptr()), st), "stream probe")
+        e1.record(); e1.synchronize()
+        t = e0.elapsed_time(e1) * 1e-3
+        return cus * 4.0 * (iters // 9 * 9) * 48 * 16384 / t / 1e12, t
+    for ex in label:
+        run_ex(ex, 1800)
+    for rnd in range(3):
+        for ex in label:
+            tf, t = run_ex(ex)
+            print(f"round {rnd} {label[ex]:34s}: {t * 1e3:8.2f} ms  {tf:7.1f} TF raw = {tf / 3:6.1f} TF per fp32 product", flush=True)
     sys.exit(0)
 
 names = {0: "16x16x32 random", 1: "16x16x32 zeros", 2: "32x32x16 random"}
