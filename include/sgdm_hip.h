@@ -163,7 +163,7 @@ int sgd_debug_mfma_lds_probe(int32_t blocks, int64_t iters, uint32_t seed, int32
  * extras bit 0: the weight fragments re-loaded from global memory every step (wbuf: >= 1 MiB, stays in L2); bit 1: four loader
  * waves per block moving six 16-byte rows per thread and chunk of 9 steps from abuf (arows rows, streamed) through affine + SiLU +
  * hi / lo split into LDS; bit 2 (with bit 1): one barrier per chunk; bit 3 (with bit 1, instead of bit 2): producer / consumer
- * counters in LDS.  flops = blocks * 4 * (iters / 9 * 9) * 48 * 16384 */
+ * counters in LDS; bit 4: eight MFMA waves of 64 x 64 (two per SIMD) instead of four of 128 x 32 (wbuf >= 2 MiB).  flops = blocks * (4 or 8) * (iters / 9 * 9) * 48 * 16384 */
 int sgd_debug_mfma_stream_probe(int32_t blocks, int64_t iters, uint32_t seed, int32_t extras, const void* wbuf, const void* abuf,
                                 int64_t arows, float* out, void* stream);
 /* Host-only test hook (no launch): the balanced-tail workspace layout of a launch of `total_tiles` tiles with `nchunks`

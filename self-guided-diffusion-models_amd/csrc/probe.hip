@@ -145,22 +145,26 @@ __global__ __launch_bounds__(256 * WPS) void mfma_lds_probe_kernel(uint32_t seed
 //      buffer through a GroupNorm-affine + SiLU + hi / lo split (the lean conv loader's arithmetic) into LDS (2 x 8 bytes);
 //   4  compute and loader waves meet at one s_barrier per chunk;
 //   8  (instead of 4) producer / consumer counters in LDS: a wave waits only when the other role is really behind.
-template <int EX>
-__global__ __launch_bounds__((EX & 2) ? 512 : 256) void mfma_stream_probe_kernel(uint32_t seed, long iters, const f16x8* __restrict__ wbuf,
+// WIDE: the 8-wave variant -- eight MFMA waves (two per SIMD) of 64 x 64 (4 row blocks x 4 column blocks: 8 LDS reads and 8 weight
+// loads per step and wave; pairs of waves load the same weight fragments) next to the same four loader waves, whose chunk now feeds
+// twice the MFMAs
+template <int EX, bool WIDE>
+__global__ __launch_bounds__((WIDE ? 512 : 256) + ((EX & 2) ? 256 : 0)) void mfma_stream_probe_kernel(uint32_t seed, long iters, const f16x8* __restrict__ wbuf,
                                                                               const f32x4* __restrict__ abuf, long arows,
                                                                               float* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) _Float16 plds[];
-    constexpr int NTHR = (EX & 2) ? 512 : 256;
+    constexpr int CTHR = WIDE ? 512 : 256, NTHR = CTHR + ((EX & 2) ? 256 : 0);
+    constexpr int CW = CTHR / 64, RMT = WIDE ? 4 : 8, RNT = WIDE ? 4 : 2;
     __shared__ int flags[2];                             // (EX & 8) ready: chunks staged x 4 loader waves; done: chunks consumed x 4
     if (threadIdx.x < 2) flags[threadIdx.x] = 0;
     for (int i = threadIdx.x; i < 32768; i += NTHR) plds[i] = rnd_f16(mix32(seed + 17u * (uint32_t)i + blockIdx.x));
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long chunks = iters / 9;
-    if (wave >= 4) {
+    if (wave >= CW) {
         // ---- loader role
         if constexpr ((EX & 2) != 0) {
-            const int lt = threadIdx.x - 256;
+            const int lt = threadIdx.x - CTHR;
             _Float16* dst = plds + 40960 + lt * 8;                       // beyond the slices the compute waves read
             const f32x4 ka = {1.01f, 0.99f, 1.02f, 0.98f}, kb = {0.01f, -0.02f, 0.03f, -0.01f};
             f32x4 raw[6];
@@ -188,7 +192,7 @@ __global__ __launch_bounds__((EX & 2) ? 512 : 256) void mfma_stream_probe_kernel
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     if (lane == 0) __hip_atomic_fetch_add(&flags[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     if (c >= 1) {
-                        const int need = 4 * (int)c;                             // four compute waves finished chunk c - 1
+                        const int need = CW * (int)c;                            // every compute wave finished chunk c - 1
                         while (__hip_atomic_load(&flags[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need) __builtin_amdgcn_s_sleep(1);
                     }
                 }
@@ -196,12 +200,13 @@ __global__ __launch_bounds__((EX & 2) ? 512 : 256) void mfma_stream_probe_kernel
         }
         return;
     }
-    const uint32_t id = (blockIdx.x * 256u + threadIdx.x) * 64u + seed;
-    f16x8 bh[2], bl[2], ah[8], al[8];
-    const f16x8* wl = wbuf + (size_t)wave * 4 * 64 + lane;              // [step & 63][wave][nt][plane][lane]
-    auto wslice = [&](long step, int nt, int plane) { return wl + ((size_t)(step & 63) * 16 + nt * 2 + plane) * 64; };
+    const uint32_t id = (blockIdx.x * (uint32_t)CTHR + threadIdx.x) * 64u + seed;
+    f16x8 bh[RNT], bl[RNT], ah[RMT], al[RMT];
+    // [step & 63][column group][nt][plane][lane]: 4 groups of 2 blocks (one per wave) or, WIDE, 4 groups of 4 (shared by two waves)
+    const f16x8* wl = wbuf + (size_t)(WIDE ? wave & 3 : wave) * (RNT * 2) * 64 + lane;
+    auto wslice = [&](long step, int nt, int plane) { return wl + ((size_t)(step & 63) * (4 * RNT * 2) + nt * 2 + plane) * 64; };
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < RNT; ++i) {
         if constexpr ((EX & 1) != 0) { bh[i] = *wslice(0, i, 0); bl[i] = *wslice(0, i, 1); }
         else {
 #pragma unroll
@@ -211,28 +216,28 @@ __global__ __launch_bounds__((EX & 2) ? 512 : 256) void mfma_stream_probe_kernel
     const _Float16* base = plds + lane * 8;
     auto slice = [&](long step, int mt, int plane) { return base + ((int)(step & 3) * 16 + mt * 2 + plane) * 512; };
 #pragma unroll
-    for (int mt = 0; mt < 8; ++mt) { ah[mt] = *reinterpret_cast<const f16x8*>(slice(0, mt, 0)); al[mt] = *reinterpret_cast<const f16x8*>(slice(0, mt, 1)); }
-    f32x4 acc[8][2];
+    for (int mt = 0; mt < RMT; ++mt) { ah[mt] = *reinterpret_cast<const f16x8*>(slice(0, mt, 0)); al[mt] = *reinterpret_cast<const f16x8*>(slice(0, mt, 1)); }
+    f32x4 acc[RMT][RNT];
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < RMT; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < RNT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     long it = 0;
     for (long c = 0; c < chunks; ++c) {
 #pragma unroll 1
         for (int tap = 0; tap < 9; ++tap, ++it) {
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
+            for (int nt = 0; nt < RNT; ++nt)
 #pragma unroll
-                for (int mt = 0; mt < 8; ++mt) {
+                for (int mt = 0; mt < RMT; ++mt) {
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mt], bl[nt], acc[mt][nt], 0, 0, 0);
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[mt], bh[nt], acc[mt][nt], 0, 0, 0);
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
-                    if (nt == 1) {
+                    if (nt == RNT - 1) {
                         ah[mt] = *reinterpret_cast<const f16x8*>(slice(it + 1, mt, 0));
                         al[mt] = *reinterpret_cast<const f16x8*>(slice(it + 1, mt, 1));
                     }
-                    if ((EX & 1) && mt == 7) { bh[nt] = *wslice(it + 1, nt, 0); bl[nt] = *wslice(it + 1, nt, 1); }
+                    if ((EX & 1) && mt == RMT - 1) { bh[nt] = *wslice(it + 1, nt, 0); bl[nt] = *wslice(it + 1, nt, 1); }
                 }
         }
         if constexpr ((EX & 4) != 0 && (EX & 2) != 0) __syncthreads();
@@ -240,53 +245,53 @@ __global__ __launch_bounds__((EX & 2) ? 512 : 256) void mfma_stream_probe_kernel
             // done with chunk c (its last fragment reads were issued for step it, which belong to the next chunk's slot in the real
             // kernel: the counter goes up once per chunk and wave); chunk c + 1 must be staged: four loader waves x (c + 1) chunks
             if (lane == 0) __hip_atomic_fetch_add(&flags[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            const int need = 4 * ((int)c + 1);
+            const int need = 4 * ((int)c + 1);                               // four loader waves staged chunk c + 1
             while (__hip_atomic_load(&flags[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need) __builtin_amdgcn_s_sleep(1);
         }
     }
     float total = 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < RMT; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) total += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
-    if (out) out[(size_t)blockIdx.x * 256 + threadIdx.x] = total;
+        for (int j = 0; j < RNT; ++j) total += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    if (out) out[(size_t)blockIdx.x * CTHR + threadIdx.x] = total;
 }
 
 }  // namespace
 
-template <int EX>
+template <int EX, bool WIDE>
 static int launch_stream_probe(int32_t blocks, int64_t iters, uint32_t seed, const void* wbuf, const void* abuf, int64_t arows,
                                float* out, void* stream) {
     const size_t LDS = 150 * 1024;
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute((const void*)mfma_stream_probe_kernel<EX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
+        (void)hipFuncSetAttribute((const void*)mfma_stream_probe_kernel<EX, WIDE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
         attr = true;
     }
-    hipLaunchKernelGGL((mfma_stream_probe_kernel<EX>), dim3(blocks), dim3((EX & 2) ? 512 : 256), LDS, (hipStream_t)stream, seed,
-                       (long)iters, reinterpret_cast<const f16x8*>(wbuf), reinterpret_cast<const f32x4*>(abuf), (long)arows, out);
+    hipLaunchKernelGGL((mfma_stream_probe_kernel<EX, WIDE>), dim3(blocks), dim3((WIDE ? 512 : 256) + ((EX & 2) ? 256 : 0)), LDS,
+                       (hipStream_t)stream, seed, (long)iters, reinterpret_cast<const f16x8*>(wbuf), reinterpret_cast<const f32x4*>(abuf),
+                       (long)arows, out);
     return sgd_check_launch();
 }
 
-// extras: bit 0 weight fragments from global (wbuf: >= 1 MiB), bit 1 loader waves (abuf: arows rows of 16 bytes), bit 2 a barrier per
-// 9 steps (only with bit 1).  iters is rounded down to a multiple of 9; flops = blocks * 4 * (iters / 9 * 9) * 48 * 16384.
+// extras: bit 0 weight fragments from global (wbuf: >= 2 MiB), bit 1 loader waves (abuf: arows rows of 16 bytes), bit 2 a barrier per
+// 9 steps (only with bit 1), bit 3 LDS counters instead of it, bit 4 the 8-wave variant (two MFMA waves of 64 x 64 per SIMD).  iters
+// is rounded down to a multiple of 9; flops = blocks * (4 or 8) * (iters / 9 * 9) * 48 * 16384.
 extern "C" int sgd_debug_mfma_stream_probe(int32_t blocks, int64_t iters, uint32_t seed, int32_t extras, const void* wbuf,
                                            const void* abuf, int64_t arows, float* out, void* stream) {
     SGD_CLEAR_ERR();
-    if (blocks <= 0 || blocks > 4096 || iters < 9 || extras < 0 || extras > 15 || (extras & 12) == 12 || ((extras & 1) && !wbuf) || ((extras & 2) && (!abuf || arows < 4096)))
+    const int wide = extras & 16;
+    extras &= 15;
+    if (blocks <= 0 || blocks > 4096 || iters < 9 || (extras & 12) == 12 || ((extras & 1) && !wbuf) || ((extras & 2) && (!abuf || arows < 4096)))
         return SGD_ERR_ARG;
     if ((extras & 12) && !(extras & 2)) return SGD_ERR_ARG;
+#define SGD_SP(E) case E: return wide ? launch_stream_probe<E, true>(blocks, iters, seed, wbuf, abuf, arows, out, stream) \
+                                      : launch_stream_probe<E, false>(blocks, iters, seed, wbuf, abuf, arows, out, stream)
     switch (extras) {
-        case 0: return launch_stream_probe<0>(blocks, iters, seed, wbuf, abuf, arows, out, stream);
-        case 1: return launch_stream_probe<1>(blocks, iters, seed, wbuf, abuf, arows, out, stream);
-        case 2: return launch_stream_probe<2>(blocks, iters, seed, wbuf, abuf, arows, out, stream);
-        case 3: return launch_stream_probe<3>(blocks, iters, seed, wbuf, abuf, arows, out, stream);
-        case 6: return launch_stream_probe<6>(blocks, iters, seed, wbuf, abuf, arows, out, stream);
-        case 7: return launch_stream_probe<7>(blocks, iters, seed, wbuf, abuf, arows, out, stream);
-        case 10: return launch_stream_probe<10>(blocks, iters, seed, wbuf, abuf, arows, out, stream);
-        case 11: return launch_stream_probe<11>(blocks, iters, seed, wbuf, abuf, arows, out, stream);
+        SGD_SP(0); SGD_SP(1); SGD_SP(2); SGD_SP(3); SGD_SP(6); SGD_SP(7); SGD_SP(10); SGD_SP(11);
         default: return SGD_ERR_ARG;
     }
+#undef SGD_SP
 }
 
 template <int MT, int NT, int WPS>

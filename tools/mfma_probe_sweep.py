@@ -49,6 +49,8 @@ if "--lds" in sys.argv:
              6: "+ loaders + barrier per chunk", 7: "+ weights + loaders + barrier", 10: "+ loaders + LDS counters",
              11: "+ weights + loaders + LDS counters"}
 
+    wbuf = torch.randn(1 << 20, device="cuda").half()                       # (2 MiB: the 8-wave variant's steps are twice as wide)
+
     def run_ex(ex, iters=36000):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -56,12 +58,14 @@ if "--lds" in sys.argv:
                                                 C.c_void_p(sink.data_ptr()), st), "stream probe")
         e1.record(); e1.synchronize()
         t = e0.elapsed_time(e1) * 1e-3
-        return cus * 4.0 * (iters // 9 * 9) * 48 * 16384 / t / 1e12, t
+        return cus * (8.0 if ex & 16 else 4.0) * (iters // 9 * 9) * 48 * 16384 / t / 1e12, t
+    for ex in (0, 1, 3, 7):
+        label[16 + ex] = "8 waves of 64x64: " + label[ex].replace("stream only (16 LDS reads)", "stream only (8 reads)")
     for ex in label:
         run_ex(ex, 1800)
     for rnd in range(3):
         for ex in label:
-            tf, t = run_ex(ex)
+            tf, t = run_ex(ex, 18000 if ex & 16 else 36000)
             print(f"round {rnd} {label[ex]:34s}: {t * 1e3:8.2f} ms  {tf:7.1f} TF raw = {tf / 3:6.1f} TF per fp32 product", flush=True)
     sys.exit(0)
 
