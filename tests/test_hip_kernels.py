@@ -765,3 +765,45 @@ def test_head_conv_narrow_out(n, h, w_, cin, cout, pro, silu):
     # argument validation: widths the kernel has no form for are refused
     assert lib.sgd_conv3_narrow_out(_p(xd), None, None, 0, _p(w9), None, _p(y), n, h, w_, cin, 5, y_ld, _stream()) == 1
     assert lib.sgd_conv3_narrow_out(_p(xd), None, None, 0, _p(w9), None, _p(y), n, h, w_, cin + 4, cout, y_ld, _stream()) == 1
+
+
+def test_device_probes_run_and_report_plausible_rates():
+    """csrc/probe.hip: the in-run device calibration of bench.py and the stream probes behind DESIGN section 9 -- every entry point
+    launches, fills its sink with finite values and lands in a plausible range (a broken probe would silently skew
+    roofline.frac_of_device_ceiling)"""
+    L, lib = _lib()
+    st = _stream()
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    sink = torch.full((4096 * 256,), float("nan"), device="cuda")
+
+    def timed(fn):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        e1.synchronize()
+        return e0.elapsed_time(e1) * 1e-3
+
+    iters = 20000
+    for variant in (0, 1, 2):
+        t = timed(lambda: L.check(lib.sgd_debug_mfma_probe(cus, iters, 7, variant, _p(sink), st), "mfma probe"))
+        tf = float(lib.sgd_debug_mfma_probe_flops(cus, iters, variant)) / t / 1e12
+        assert 500.0 < tf < 2600.0, (variant, tf)              # 2.5 PF is the dense 16-bit peak of the chip
+    assert torch.isfinite(sink[:cus * 256]).all()
+    for rb, wps in ((0, 1), (8, 1), (4, 2)):
+        t = timed(lambda: L.check(lib.sgd_debug_mfma_lds_probe(cus, 9000, 7, rb, wps, _p(sink), st), "lds probe"))
+        tf = cus * 4.0 * wps * 9000 * 48 * 16384 / t / 1e12
+        assert 500.0 < tf < 2600.0, (rb, wps, tf)
+    wbuf = torch.randn(1 << 20, device="cuda").half()
+    abuf = torch.randn(4 << 20, device="cuda")
+    for ex in (0, 1, 3, 7, 11, 16 + 7):
+        t = timed(lambda: L.check(lib.sgd_debug_mfma_stream_probe(cus, 9000, 7, ex, _p(wbuf), _p(abuf), 1 << 20, _p(sink), st), "stream probe"))
+        tf = cus * (8.0 if ex & 16 else 4.0) * 9000 * 48 * 16384 / t / 1e12
+        assert 300.0 < tf < 2600.0, (ex, tf)
+    assert lib.sgd_debug_mfma_stream_probe(cus, 9000, 7, 4, _p(wbuf), _p(abuf), 1 << 20, _p(sink), st) != 0      # barrier without loaders
+    src = torch.randn(1 << 24, device="cuda")
+    dst = torch.empty_like(src)
+    t = timed(lambda: L.check(lib.sgd_debug_copy_probe(_p(src), _p(dst), src.numel(), st), "copy probe"))
+    assert torch.equal(src, dst) and 1.0 < 2 * src.numel() * 4 / t / 1e12 < 8.0
