@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """What does the bare-MFMA probe (csrc/probe.hip) measure?  Sweeps variant (16x16x32 random / zeros, 32x32x16 random),
 launch duration and the number of active compute units, interleaved in one process.
-    python tools/mfma_probe_sweep.py [--lds]"""
+    python tools/mfma_probe_sweep.py [--lds [--quarter]]"""
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "self-guided-diffusion-models_amd"))
@@ -31,6 +31,8 @@ def run_lds(blocks, iters, row_blocks, wps):
     return blocks * 4.0 * wps * iters * 48 * 16384 / t / 1e12, t
 
 
+if "--quarter" in sys.argv:      # with --lds: a quarter of the CUs (no power limit: what each structure reaches at the full clock)
+    cus = cus // 4
 if "--lds" in sys.argv:
     # the conv kernel's compute-wave stream alone: 48 MFMAs per step, 16 / 8 / 0 LDS fragment reads per step, 1 or 2 waves per SIMD
     for rb, wps in ((0, 1), (8, 1), (4, 1), (0, 2), (8, 2), (4, 2)):
