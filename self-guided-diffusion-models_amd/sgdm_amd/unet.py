@@ -1014,8 +1014,11 @@ class _Engine:
         if m._cond_width:
             if is_i64 == 2 and getattr(self, "gather_cond", False) and not self._train_mode:
                 self.cond_ids = (cond, mask_u8, B)           # mlp_cond.0 runs as a column gather (see _build_cond_path)
-            elif is_i64 == 1 and getattr(self, "sparse_cond", False) and not self._train_mode:
+            elif is_i64 == 1 and getattr(self, "sparse_cond", False):
                 self.cond_rows = (cond, mask_u8, B)          # ... or over the non-zero entries of the int64 one-hot rows
+                if self._train_mode:                         # (the weight gradient of mlp_cond.0 still reads the expanded rows)
+                    L.check(lib.sgd_cond_select(_ptr(cond), int(is_i64), _ptr(mask_u8), _ptr(m.null_cond_emb), B, n,
+                                                m._cond_width, _ptr(self.cond_m), stream), "cond_select")
             else:
                 L.check(lib.sgd_cond_select(_ptr(cond), int(is_i64), _ptr(mask_u8), _ptr(m.null_cond_emb), B, n,
                                             m._cond_width, _ptr(self.cond_m), stream), "cond_select")
