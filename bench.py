@@ -193,23 +193,81 @@ def cpu_baseline(wl, sd, seconds_budget=25.0):
     return out
 
 
-def pmc_traffic(args, B):
+def pmc_traffic(workload, prec, B):
     """HBM bytes per igemm launch from the PMC passes committed under profiles/ (tools/pmc_hbm.sh: FETCH_SIZE and
     WRITE_SIZE in separate rocprofv3 --pmc runs of this same bench command, gfx950 FETCH_SIZE x2 correction).
     PMC collection needs the profiler around the process, so it cannot be taken live inside this run; null when no
-    committed pass matches the workload/precision/batch being benchmarked."""
-    for rnd in ("r5", "r4", "r3", "r2", "r1"):
-        path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_hbm_{args.workload}.json")
+    committed pass matches the workload / precision / batch being benchmarked (file: r<N>_pmc_hbm_<workload>.json at the
+    workload's own batch, r<N>_pmc_hbm_<workload>_bs<B>.json otherwise)."""
+    if prec != "f16x3":
+        return None, None
+    stem = workload if B == WORKLOADS[workload]["batch"] else f"{workload}_bs{B}"
+    for rnd in ("r6", "r5", "r4", "r3", "r2", "r1"):
+        path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_hbm_{stem}.json")
         if os.path.exists(path):
             break
     else:
-        return None, None
-    if args.prec != "f16x3" or B != WORKLOADS[args.workload]["batch"]:
         return None, None
     k = json.load(open(path))["kernels"].get("igemm_kernel")
     return (round(k["hbm_bytes_per_launch"]) if k else None,
             f"replayed from {os.path.relpath(path, ROOT)} (separate rocprofv3 --pmc passes of this command: FETCH_SIZE x2 + "
             "WRITE_SIZE; counters cannot be read from inside the process)")
+
+
+def with_probe(roof, probe, prec):
+    """the roofline figure against what this device delivers NOW (bare 16-bit MFMA loop / 3 products; exact mode: the fp32
+    MFMA peak has no such probe, the fields stay absent)"""
+    if not probe:
+        return roof
+    roof.update(probe)
+    if prec != "f32":
+        ceil = probe["device_mfma_tflops"] / 3.0
+        roof["device_ceiling_tflops"] = round(ceil, 1)
+        roof["frac_of_device_ceiling"] = round(roof["achieved"] / ceil, 4)
+        for v in roof["igemm_by_instance"].values():
+            v["frac_of_device_ceiling"] = round(v["tflops_per_s"] / ceil, 4)
+    return roof
+
+
+def sampling_roofline(eng, prec, workload, B, probe=None):
+    """the `roofline` block of one sampling workload: an instrumented pass over the engine's UNet program (HIP events around
+    every launch, on the launch stream), the conv / linear kernel's achieved TFLOP/s against the MFMA peak of the arithmetic
+    mode, per template instance, with the committed PMC traffic beside it and -- `probe` = device_probe()'s record -- against
+    what this device delivered on a bare MFMA loop in this process"""
+    stream = torch.cuda.current_stream().cuda_stream
+    agg, inst = {}, {}
+    reps = 3
+    conv3 = (".in_layers.2", ".out_layers.3", ".op", ".conv", "input_blocks.0.0", "out.2")
+    for _ in range(reps):
+        for tag, sym, ms, fl, nb in eng.prog.run_profiled(stream):
+            a = agg.setdefault(sym, [0.0, 0.0, 0.0, 0])
+            a[0] += ms; a[1] += fl; a[2] += nb; a[3] += 1
+            if sym == "sgd_igemm":        # the two template instantiations rocprofv3 lists separately
+                b = inst.setdefault("taps9_conv3x3" if tag.endswith(conv3) else "taps1_conv1x1_linear", [0.0, 0.0, 0])
+                b[0] += ms; b[1] += fl; b[2] += 1
+    tot_ms = sum(a[0] for a in agg.values()) / reps
+    ig = agg["sgd_igemm"]
+    ig_ms, ig_fl, ig_nb, ig_n = ig[0] / reps, ig[1] / reps, ig[2] / reps, ig[3] // reps
+    peak = PEAK_TFLOPS[prec]
+    ach = ig_fl / (ig_ms * 1e-3) / 1e12
+    traffic, traffic_src = pmc_traffic(workload, prec, B)
+    roof = dict(bound="mfma", kernel="igemm_kernel (fused implicit-GEMM conv/linear, all launches of one UNet eval)",
+                achieved=round(ach, 2), peak=round(peak, 1), unit="TFLOP/s", frac=round(ach / peak, 4),
+                traffic=traffic, traffic_source=traffic_src, launches_per_step=ig_n,
+                launches_per_step_all_kernels=sum(a[3] for a in agg.values()) // reps,
+                algorithmic_bytes_per_launch=round(ig_nb / ig_n), avg_launch_ms=round(ig_ms / ig_n, 4),
+                igemm_ms_per_step=round(ig_ms, 3), all_kernels_ms_per_step=round(tot_ms, 3),
+                algorithmic_gflop_per_step=round(ig_fl / 1e9, 1),
+                hbm_algorithmic_frac=round((ig_nb / (ig_ms * 1e-3)) / 8.0e12, 4),
+                peak_note=("exact fp32 MFMA peak" if prec == "f32" else
+                           "2.5 PF dense 16-bit MFMA / 3 products per fp32-equivalent product"),
+                per_kernel_ms={k: round(v[0] / reps, 3) for k, v in sorted(agg.items())},
+                igemm_by_instance={k: dict(launches=v[2] // reps, ms_per_step=round(v[0] / reps, 3),
+                                           tflops_per_s=round(v[1] / (v[0] * 1e-3) / 1e12, 1),
+                                           frac=round(v[1] / (v[0] * 1e-3) / 1e12 / peak, 4))
+                                   for k, v in sorted(inst.items())})
+    with_probe(roof, probe, prec)
+    return roof
 
 
 def train_step_bench(model, diff, data, cond, layout, B, world, barrier, wl, steps=4, warmup=2):
@@ -355,7 +413,7 @@ def device_probe(dev, seconds=0.15):
     measured in this process, seconds after the timed steps: a bare v_mfma_f32_16x16x32_f16 loop on random register operands
     (one wave per SIMD on every CU, csrc/probe.hip) and a 16-byte grid-stride copy of 256 MiB."""
     from sgdm_amd import _lib as L
-    lib = L.load()
+    lib = L.load_tools()                                  # diagnostics library (include/sgdm_hip_tools.h), not the product's
     st = torch.cuda.current_stream().cuda_stream
     cus = int(torch.cuda.get_device_properties(dev).multi_processor_count)
     sink = torch.empty(cus * 256, device=dev)
@@ -373,7 +431,7 @@ def device_probe(dev, seconds=0.15):
     mfma_tf = float(lib.sgd_debug_mfma_probe_flops(cus, iters, 0)) / t / 1e12
     n = 64 << 20                                                      # floats: 256 MiB read + 256 MiB written per pass
     src, dst = torch.randn(n, device=dev), torch.empty(n, device=dev)
-    cp = lambda: [L.check(lib.sgd_debug_copy_probe(C_void(src), C_void(dst), n, st), "copy_probe") for _ in range(10)]
+    cp = lambda: [L.check(lib.sgd_debug_copy_probe(C_void(src), C_void(dst), n, 0, 0, st), "copy_probe") for _ in range(10)]
     cp()
     tc = timed(cp)
     assert torch.equal(src[-4096:], dst[-4096:])
@@ -542,55 +600,18 @@ def main():
 
     # (right after the timed region, before the training / extra legs heat the device: the instrumented pass sees the
     # clocks the timed steps saw)
-    roof = None
-    if rank == 0:
-        # ---- instrumented pass: HIP events around every launch of the UNet program (same stream)
-        if not args.no_profile:
-            eng = model._engines[(2 * B, S, S, __import__("sgdm_amd._lib", fromlist=["x"]).PREC_BY_NAME[args.prec])]
-            stream = torch.cuda.current_stream().cuda_stream
-            agg, inst = {}, {}
-            reps = 3
-            conv3 = (".in_layers.2", ".out_layers.3", ".op", ".conv", "input_blocks.0.0", "out.2")
-            for _ in range(reps):
-                for tag, sym, ms, fl, nb in eng.prog.run_profiled(stream):
-                    a = agg.setdefault(sym, [0.0, 0.0, 0.0, 0])
-                    a[0] += ms; a[1] += fl; a[2] += nb; a[3] += 1
-                    if sym == "sgd_igemm":        # the two template instantiations rocprofv3 lists separately
-                        b = inst.setdefault("taps9_conv3x3" if tag.endswith(conv3) else "taps1_conv1x1_linear", [0.0, 0.0, 0])
-                        b[0] += ms; b[1] += fl; b[2] += 1
-            tot_ms = sum(a[0] for a in agg.values()) / reps
-            ig = agg["sgd_igemm"]
-            ig_ms, ig_fl, ig_nb, ig_n = ig[0] / reps, ig[1] / reps, ig[2] / reps, ig[3] // reps
-            peak = PEAK_TFLOPS[args.prec]
-            ach = ig_fl / (ig_ms * 1e-3) / 1e12
-            traffic, traffic_src = pmc_traffic(args, B)
-            roof = dict(bound="mfma", kernel="igemm_kernel (fused implicit-GEMM conv/linear, all launches of one UNet eval)",
-                        achieved=round(ach, 2), peak=round(peak, 1), unit="TFLOP/s", frac=round(ach / peak, 4),
-                        traffic=traffic, traffic_source=traffic_src, launches_per_step=ig_n,
-                        algorithmic_bytes_per_launch=round(ig_nb / ig_n), avg_launch_ms=round(ig_ms / ig_n, 4),
-                        igemm_ms_per_step=round(ig_ms, 3), all_kernels_ms_per_step=round(tot_ms, 3),
-                        algorithmic_gflop_per_step=round(ig_fl / 1e9, 1),
-                        hbm_algorithmic_frac=round((ig_nb / (ig_ms * 1e-3)) / 8.0e12, 4),
-                        peak_note=("exact fp32 MFMA peak" if args.prec == "f32" else
-                                   "2.5 PF dense 16-bit MFMA / 3 products per fp32-equivalent product"),
-                        per_kernel_ms={k: round(v[0] / reps, 3) for k, v in sorted(agg.items())},
-                        igemm_by_instance={k: dict(launches=v[2] // reps, ms_per_step=round(v[0] / reps, 3),
-                                                   tflops_per_s=round(v[1] / (v[0] * 1e-3) / 1e12, 1),
-                                                   frac=round(v[1] / (v[0] * 1e-3) / 1e12 / peak, 4))
-                                           for k, v in sorted(inst.items())})
-            # the same figure against what this device delivers NOW (bare 16-bit MFMA loop / 3 products; exact mode: the
-            # fp32 MFMA peak has no such probe, the field stays null)
-            try:
-                pr = device_probe(dev)
-                roof.update(pr)
-                if args.prec != "f32":
-                    ceil = pr["device_mfma_tflops"] / 3.0
-                    roof["device_ceiling_tflops"] = round(ceil, 1)
-                    roof["frac_of_device_ceiling"] = round(ach / ceil, 4)
-                    for v in roof["igemm_by_instance"].values():
-                        v["frac_of_device_ceiling"] = round(v["tflops_per_s"] / ceil, 4)
-            except Exception as exc:                          # a diagnostic must not cost the bench line
-                roof["device_probe_error"] = f"{type(exc).__name__}: {exc}"[:200]
+    roof, probe = None, None
+    PREC_ID = __import__("sgdm_amd._lib", fromlist=["x"]).PREC_BY_NAME[args.prec]
+    if rank == 0 and not args.no_profile:
+        # ---- instrumented pass: HIP events around every launch of the UNet program (same stream), and the device's own
+        # ceiling measured seconds later in this process
+        # (the pass first: the probe is a second of full-power MFMA, and what follows it reads a hotter device)
+        roof = sampling_roofline(model._engines[(2 * B, S, S, PREC_ID)], args.prec, args.workload, B)
+        try:
+            probe = device_probe(dev)
+            with_probe(roof, probe, args.prec)
+        except Exception as exc:                          # a diagnostic must not cost the bench line
+            roof["device_probe_error"] = f"{type(exc).__name__}: {exc}"[:200]
 
     # ---- second half of BASELINE.json's metric: DDPM train-step time (q_sample + UNet fwd/bwd + RCCL gradient
     # all-reduce overlapped with backward + AdamW + EMA), per-GPU batch of the config, dropout as configured
@@ -614,7 +635,10 @@ def main():
         # ---- one rank: the data-parallel step's own code on the hardware at hand -- a world-size-1 RCCL group with the
         # exchange forced (arena, bucketed all-reduce through librccl on the side stream, CU reserve): what the N > 1 legs
         # run, with its overlap record.  A record of the path, not a scaling number.
-        if world == 1 and not args.no_exchange_probe:
+        # (never from a traced process: the child would be started from a GPU-initialised parent with the profiler's
+        # preload in its environment -- ADVICE round 5)
+        traced = any("rocprof" in os.environ.get(k, "").lower() for k in ("LD_PRELOAD", "HSA_TOOLS_LIB", "ROCP_TOOL_LIBRARIES"))
+        if world == 1 and not args.no_exchange_probe and not traced:
             train["exchange_world1"] = exchange_probe(args, TB)
 
     def time_sampling(mdl, dif, bsz, size, kw, steps, warm, skw_):
@@ -683,6 +707,8 @@ def main():
         ms5 = time_sampling(m5, diff5, w5["batch"], S, k5, 5, 2, skw)
         extra["c5"] = dict(workload=w5["desc"], ms_per_step=round(ms5, 3), value=round(w5["batch"] / ms5, 4), unit="images/s",
                            tflops_per_s=round(2 * w5["batch"] * w5["gflop_per_eval_img"] / ms5, 1), steps=5, warmup=2)
+        if not args.no_profile:      # (the roofline at the batch north_star names, per workload)
+            extra["c5"]["roofline"] = sampling_roofline(m5._engines[(2 * w5["batch"], S, S, PREC_ID)], args.prec, "c5", w5["batch"], probe)
         if not args.no_train:
             extra["c5"]["train_step"] = train_step_bench(m5, diff5, d5, k5["cond"], k5["layout"], w5["batch"], world, barrier, w5)
         del m5, diff5
@@ -696,6 +722,8 @@ def main():
         ms4 = time_sampling(m4, diff4, w4["batch"], S, k4, 5, 2, skw)
         extra["c4"] = dict(workload=w4["desc"], ms_per_step=round(ms4, 3), value=round(w4["batch"] / ms4, 4), unit="images/s",
                            tflops_per_s=round(2 * w4["batch"] * w4["gflop_per_eval_img"] / ms4, 1), steps=5, warmup=2)
+        if not args.no_profile:
+            extra["c4"]["roofline"] = sampling_roofline(m4._engines[(2 * w4["batch"], S, S, PREC_ID)], args.prec, "c4", w4["batch"], probe)
         if not args.no_train:
             extra["c4"]["train_step"] = train_step_bench(m4, diff4, d4, k4["cond"], k4["layout"], w4["batch"], world, barrier, w4)
         del m4, diff4
@@ -710,6 +738,9 @@ def main():
             extra["c2_bs80"] = dict(workload=wl["desc"].replace("bs=40/GPU (UNet batch 80)", "bs=80/GPU (UNet batch 160)"),
                                     ms_per_step=round(ms2, 3), value=round(w5["batch"] / ms2, 4), unit="images/s",
                                     tflops_per_s=round(2 * w5["batch"] * wl["gflop_per_eval_img"] / ms2, 1), steps=5, warmup=2)
+            if not args.no_profile:
+                extra["c2_bs80"]["roofline"] = sampling_roofline(m2._engines[(2 * w5["batch"], S, S, PREC_ID)], args.prec,
+                                                                 args.workload, w5["batch"], probe)
             del m2, diff2
             gc.collect(); torch.cuda.empty_cache()
 

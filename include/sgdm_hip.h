@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define SGD_ABI_VERSION 17
+#define SGD_ABI_VERSION 18
 int sgd_abi_version(void);
 /* 16 hex digits identifying the sources and flags the library was compiled from (build.py: source_id()); static storage.
  * __graft_entry__.build() and tests/test_boundary_cpu.py compare it with the tree on disk. */
@@ -125,6 +125,8 @@ enum {
     SGD_TUNE_FLAT2 = 4,            /* sgd_igemm, 1x1 / linear: two 32-channel planes per barrier (never with PRO_LN_ROW) */
     SGD_TUNE_DEFER = 8,            /* sgd_igemm, 3x3 split modes: the epilogue on the loader waves */
     SGD_TUNE_PLAIN_SCHEDULE = 16,  /* sgd_igemm: no balanced tail even with a workspace */
+    SGD_TUNE_LN_PACKED = 32,       /* sgd_igemm, PRO_LN_ROW in a split mode: the regular instances (packed-f32 code generation on)
+                                      instead of the no-packed-f32 ones the launcher takes for that prologue (tools/ln_hazard.py) */
     SGD_TUNE_WGRAD_GENERIC_NARROW = 256,  /* sgd_wgrad: stem / head on the generic kernels instead of wgrad_narrow_kernel */
     SGD_TUNE_WGRAD_NO_POOLED_PLANES = 512,/* sgd_wgrad: fused-average-pool convs on the per-tap kernel (no pooled planes) */
     SGD_TUNE_WGRAD_F32 = 1024,            /* sgd_wgrad: the exact-f32 per-tap kernel in every mode */
@@ -139,33 +141,6 @@ int64_t sgd_igemm_work_bytes(void);
  * that share the workspace are ordered on one stream) sets it to 1 and multiplies its outputs by NaN instead of spinning
  * for ever: check it after a run that produced NaN, zero the whole workspace before using it again. */
 int64_t sgd_igemm_work_status_offset(void);
-/* Diagnostic (tests/test_hip_contention.py, tools/): occupy `blocks` compute units -- one 512-thread block with 150 KB of
- * LDS each, so nothing else fits beside it -- for `milliseconds` of wall-clock time.  Stands in for RCCL's kernels on a
- * side stream in the single-GPU contention tests. */
-int sgd_debug_occupy(int32_t blocks, float milliseconds, void* stream);
-/* Diagnostics (bench.py: the in-run device calibration beside every roofline figure; csrc/probe.hip).
- * sgd_debug_mfma_probe: `blocks` blocks of 4 waves (150 KB of LDS each: one block per compute unit, one wave per SIMD) run
- * `iters` x 8 independent v_mfma_f32_16x16x32_f16 on random register operands and nothing else;
- * sgd_debug_mfma_probe_flops gives the flop count of such a launch.  out: NULL or blocks * 256 floats (keeps the work live).
- * sgd_debug_copy_probe: dst[0..count) = src[0..count), 16 bytes per lane, four loads in flight (count % 4 == 0, both
- * pointers 16-byte aligned): the practical HBM rate of one read and one write stream. */
-int sgd_debug_mfma_probe(int32_t blocks, int64_t iters, uint32_t seed, int32_t variant /* 0: 16x16x32 on random operands,
-                         1: on zeros, 2: 32x32x16 on random operands */, float* out, void* stream);
-int64_t sgd_debug_mfma_probe_flops(int32_t blocks, int64_t iters, int32_t variant);
-int sgd_debug_copy_probe(const float* src, float* dst, int64_t count, void* stream);
-/* diagnostic: the conv kernel's compute-wave stream in isolation -- 48 split-precision 16x16x32 MFMAs per step into 64 accumulator
- * registers, the row-block operands re-read from LDS every step (row_blocks = 8: 16 reads per step, the shipped 128 x 32 wave tile;
- * 4: 8 reads, a 64 x 64 tile; 0: none), on one or two MFMA waves per SIMD.  out: blocks * 256 * waves_per_simd floats or NULL.
- * flops = blocks * 4 * waves_per_simd * iters * 48 * 16384 (tools/mfma_probe_sweep.py --lds) */
-int sgd_debug_mfma_lds_probe(int32_t blocks, int64_t iters, uint32_t seed, int32_t row_blocks, int32_t waves_per_simd, float* out,
-                             void* stream);
-/* diagnostic: that stream on the shipped wave tile with the rest of the conv kernel's per-step traffic added piece by piece --
- * extras bit 0: the weight fragments re-loaded from global memory every step (wbuf: >= 1 MiB, stays in L2); bit 1: four loader
- * waves per block moving six 16-byte rows per thread and chunk of 9 steps from abuf (arows rows, streamed) through affine + SiLU +
- * hi / lo split into LDS; bit 2 (with bit 1): one barrier per chunk; bit 3 (with bit 1, instead of bit 2): producer / consumer
- * counters in LDS; bit 4: eight MFMA waves of 64 x 64 (two per SIMD) instead of four of 128 x 32 (wbuf >= 2 MiB).  flops = blocks * (4 or 8) * (iters / 9 * 9) * 48 * 16384 */
-int sgd_debug_mfma_stream_probe(int32_t blocks, int64_t iters, uint32_t seed, int32_t extras, const void* wbuf, const void* abuf,
-                                int64_t arows, float* out, void* stream);
 /* Host-only test hook (no launch): the balanced-tail workspace layout of a launch of `total_tiles` tiles with `nchunks`
  * 32-channel chunks per tile and `taps` (9 / 1) K steps per chunk on `grid` persistent blocks.  out[4*b .. 4*b+3] =
  * {K split of block b's last tile (0: none), index of its arrival counter, first producer slab, producer slabs}.
@@ -562,7 +537,25 @@ typedef struct {
 int sgd_adamw_ema_step(const sgd_opt_tensor* table, const int32_t* chunk_start, int32_t count, int32_t total_chunks,
                        float lr, float one_minus_beta1, float beta2, float one_minus_beta2 /* host doubles, rounded
                        once: 1.0f - 0.999f is off by 1.3e-5 relative */, float eps, float weight_decay,
-                       float bias_correction1, float bias_correction2, float ema_one_minus_decay, void* stream);
+                       float bias_correction1, float bias_correction2, float ema_one_minus_decay,
+                       const float* skip_if_nonzero /* DEVICE float or NULL (ABI 18): when *skip_if_nonzero != 0 the launch
+                       writes NOTHING -- the health flag of the step's gradients (a balanced-tail time-out of the backward
+                       program, summed over the ranks of a data-parallel job: sgdm_amd/train.py) gates the optimizer, so a
+                       poisoned step never reaches parameters, moments or EMA shadows */, void* stream);
+
+/* --------------------------------------------------------------------------------------
+ * Gradient exchange (ABI 18; SURVEY 8(b), last row).  Replaces the per-bucket all-reduce torch DDP issues under
+ * pl.trainer.strategy=ddp (config/pl/default.yaml:2, README.md:84-94) for hosts that do not go through torch.distributed:
+ * bucket[0..count) = SUM over the ranks of `nccl_comm` (an ncclComm_t the caller created), in place, fp32, enqueued on
+ * `stream` (the caller's side stream: record an event behind the launches that fill the bucket, make the side stream wait
+ * for it, call this, record the completion event -- what sgdm_amd/ddp.py does through ProcessGroupNCCL).  The 1 / world of
+ * the average is folded into the backward program's un-scaling (sgd_wgrad_reduce*'s `scale`), so SUM is the whole collective.
+ * librccl is resolved at first use, not linked: sgd_exchange_bind(path) names the instance whose communicators will be
+ * passed (a PyTorch process must name torch/lib/librccl.so: communicators are only valid inside the copy that made them);
+ * NULL / never called: an instance already loaded in the process, else the system's librccl.so.1.
+ * Returns 0, 1 (invalid argument) or 2 (no RCCL library / the collective failed; the reason is written to stderr). */
+int sgd_exchange_bind(const char* librccl_path);
+int sgd_allreduce_bucket(void* nccl_comm, float* bucket, int64_t count, void* stream);
 
 #ifdef __cplusplus
 }

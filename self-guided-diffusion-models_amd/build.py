@@ -18,6 +18,10 @@ LIBDIR = os.path.join(HERE, "sgdm_amd", "lib")
 # tools: SGDM_BUILD_TAG=_x SGDM_EXTRA_FLAGS="-D..." builds libsgdm_hip_x.so from objects *_x.o next to the product library
 TAG = os.environ.get("SGDM_BUILD_TAG", "")
 LIB = os.path.join(LIBDIR, f"libsgdm_hip{TAG}.so")
+# diagnostics (csrc/tools/*.hip, include/sgdm_hip_tools.h): a library of their own -- bench.py's device calibration, the
+# contention tests and tools/ load it; the product path never does and the product library exports none of its symbols
+TOOLS_SRC = os.path.join(CSRC, "tools")
+TOOLS_LIB = os.path.join(LIBDIR, "libsgdm_hip_tools.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
          "-ffp-contract=fast"]
@@ -58,8 +62,12 @@ def source_id():
 
 # translation units compiled from ONE source with different defines (igemm.hip: the host unit + one unit per arithmetic
 # mode, see the end of that file) -- they build in parallel
+# (*_nopk: the 1x1 / linear instances of the split modes once more with packed-f32 code generation off -- the LayerNorm-row
+# prologue's launches run on these, csrc/igemm.hip: sgd_igemm_dispatch_*_nopk)
+NOPK = ["-DSGDM_IGEMM_NOPK", "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
 VARIANTS = {"igemm.hip": [("", []), ("_f32", ["-DSGDM_IGEMM_PREC=0"]), ("_f16x3", ["-DSGDM_IGEMM_PREC=1"]),
-                          ("_bf16x3", ["-DSGDM_IGEMM_PREC=2"])]}
+                          ("_bf16x3", ["-DSGDM_IGEMM_PREC=2"]), ("_f16x3_nopk", ["-DSGDM_IGEMM_PREC=1", *NOPK]),
+                          ("_bf16x3_nopk", ["-DSGDM_IGEMM_PREC=2", *NOPK])]}
 
 
 def _units():
@@ -133,9 +141,41 @@ def build_ablation(mask):
     return out
 
 
+def build_tools(force=False):
+    """libsgdm_hip_tools.so from csrc/tools/*.hip (content-digest reuse like the product objects)"""
+    os.makedirs(OBJ, exist_ok=True)
+    os.makedirs(LIBDIR, exist_ok=True)
+    root = os.path.dirname(HERE)
+    hdrs = [os.path.join(CSRC, "sgdm_common.h"), os.path.join(root, "include", "sgdm_hip_tools.h")]
+    objs = []
+    for f in sorted(x for x in os.listdir(TOOLS_SRC) if x.endswith(".hip")):
+        sp, obj = os.path.join(TOOLS_SRC, f), os.path.join(OBJ, "tools_" + f[:-4] + ".o")
+        cmd = [HIPCC, *FLAGS, "-c", sp, "-o", obj]
+        want = _digest([sp] + hdrs, [cmd])
+        stamp = obj + ".sha"
+        if force or not os.path.exists(obj) or not os.path.exists(stamp) or open(stamp).read().strip() != want:
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError(f"hipcc failed for tools/{f}:\n{r.stdout}\n{r.stderr}")
+            with open(stamp, "w") as fh:
+                fh.write(want)
+        objs.append(obj)
+    want = _digest([o + ".sha" for o in objs])
+    stamp = TOOLS_LIB + ".sha"
+    if force or not os.path.exists(TOOLS_LIB) or not os.path.exists(stamp) or open(stamp).read().strip() != want:
+        r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", TOOLS_LIB, *objs], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+        with open(stamp, "w") as fh:
+            fh.write(want)
+    return TOOLS_LIB
+
+
 def build_lib(force=False):
     os.makedirs(OBJ, exist_ok=True)
     os.makedirs(LIBDIR, exist_ok=True)
+    if not TAG:
+        build_tools(force)
     with ThreadPoolExecutor(max_workers=int(os.environ.get("SGDM_BUILD_JOBS", "6"))) as ex:
         objs = list(ex.map(lambda u: _compile(u, force), _units()))
     want = _digest([o + ".sha" for o in objs])

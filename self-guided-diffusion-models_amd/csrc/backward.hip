@@ -1987,7 +1987,9 @@ extern "C" int sgd_gn_bwd_coef_fold(const float* S, const float* sums, const flo
     if ((film || dfilm) && film_ld < 2 * c) return SGD_ERR_ARG;
     const int cpg = c / groups;
     const size_t lds = (size_t)(2 * n * cpg + 1) * sizeof(float) + (size_t)n * 4 * sizeof(double);
-    if (lds > 64 * 1024) return SGD_ERR_ARG;          // (callers fall back to sgd_gn_bwd_coef + sgd_colsum_pair)
+    // (+ the kernel's static red[2][8][32]: 2 KB of the same 64 KB default limit; callers fall back to sgd_gn_bwd_coef +
+    // sgd_colsum_pair -- train.Backward.gn_bwd applies the same bound)
+    if (lds + 2048 > 64 * 1024) return SGD_ERR_ARG;
     hipLaunchKernelGGL(gn_bwd_coef_fold_kernel, dim3(groups), dim3(256), lds, (hipStream_t)stream, S, sums, gamma, beta, film,
                        film_ld, n, c, groups, hw, eps, A, B, Cc, dfilm, dgamma, dbeta, accumulate, scale);
     return sgd_check_launch();

@@ -1845,6 +1845,19 @@ int launch1(const KArgs& ka, size_t smem, hipStream_t st) {
 template <int BN, int PREC>
 int launch(const KArgs& ka, int vec, int taps, size_t smem, hipStream_t st) {
     const bool conv = taps == 9;
+#ifdef SGDM_IGEMM_NOPK
+    // the unit compiled without packed-f32 code generation (see the end of this file) serves the 1x1 / linear launches with
+    // the LayerNorm-row prologue only: no 3x3 instance is instantiated here
+    if (conv) return SGD_ERR_ARG;
+    if constexpr (BN == 256) {
+        return taps == 2 ? launch1<BN, PREC, true, 2>(ka, smem, st) : launch1<BN, PREC, true, 1>(ka, smem, st);
+    } else {
+        if constexpr (BN == 128) {
+            if (taps == 2) return launch1<BN, PREC, true, 2>(ka, smem, st);
+        }
+        return vec ? launch1<BN, PREC, true, 1>(ka, smem, st) : launch1<BN, PREC, false, 1>(ka, smem, st);
+    }
+#else
     if constexpr (BN == 256) {                    // chosen for 16-byte launches only
         if (conv) return launch1<BN, PREC, true, 9>(ka, smem, st);
         return taps == 2 ? launch1<BN, PREC, true, 2>(ka, smem, st) : launch1<BN, PREC, true, 1>(ka, smem, st);
@@ -1858,6 +1871,7 @@ int launch(const KArgs& ka, int vec, int taps, size_t smem, hipStream_t st) {
         }
         return vec ? launch1<BN, PREC, true, 1>(ka, smem, st) : launch1<BN, PREC, false, 1>(ka, smem, st);
     }
+#endif
 }
 
 }  // namespace
@@ -1868,6 +1882,16 @@ int launch(const KArgs& ka, int vec, int taps, size_t smem, hipStream_t st) {
 int sgd_igemm_dispatch_f32(const void* ka, int bn, int vec, int taps, size_t smem, hipStream_t st);
 int sgd_igemm_dispatch_f16x3(const void* ka, int bn, int vec, int taps, size_t smem, hipStream_t st);
 int sgd_igemm_dispatch_bf16x3(const void* ka, int bn, int vec, int taps, size_t smem, hipStream_t st);
+// The LayerNorm-row prologue (Attention_LR's to_q / to_kv, crossattetion_lr.py:81-88) in a split mode runs on instances compiled
+// with packed-f32 code generation OFF (build.py: -DSGDM_IGEMM_NOPK -Xclang -target-feature -Xclang -packed-fp32-ops; 1x1 / linear
+// instances only).  Round 4 found the two-plane instance of that prologue returning exactly beta -- the LayerNorm value with a zero
+// product -- in the low lane of v_pk_{mul,fma}_f32 for lanes 48..63 of a loader wave, in specific unrolled copies, on every launch;
+// with packed-f32 code generation off the same source passes (profiles/r5_ln_hazard_isa.txt).  The one-plane
+// instance the product uses has never shown it (canary + bit-repeatability tests), but it issues the same instructions: since round 6
+// no LayerNorm launch executes a packed-f32 instruction at all.  The whole library built that way cost 7.6 % of a sampling step (76
+// spilled registers in the 3x3 instance); confined to these launches it costs C2 nothing and C4 / C5 the difference on ~20 launches.
+int sgd_igemm_dispatch_f16x3_nopk(const void* ka, int bn, int vec, int taps, size_t smem, hipStream_t st);
+int sgd_igemm_dispatch_bf16x3_nopk(const void* ka, int bn, int vec, int taps, size_t smem, hipStream_t st);
 
 #ifdef SGDM_IGEMM_PREC
 #ifdef SGDM_DEV_ONE      /* development: compile ONE kernel instance (register / asm inspection), never linked */
@@ -1882,8 +1906,12 @@ int sgd_igemm_dispatch_bf16x3(const void* ka, int bn, int vec, int taps, size_t 
 #endif
 #if SGDM_IGEMM_PREC == 0
 int sgd_igemm_dispatch_f32(const void* kap, int bn, int vec, int taps, size_t smem, hipStream_t st) { SGD_DISPATCH_BODY(SGD_PREC_F32) }
+#elif SGDM_IGEMM_PREC == 1 && defined(SGDM_IGEMM_NOPK)
+int sgd_igemm_dispatch_f16x3_nopk(const void* kap, int bn, int vec, int taps, size_t smem, hipStream_t st) { SGD_DISPATCH_BODY(SGD_PREC_F16X3) }
 #elif SGDM_IGEMM_PREC == 1
 int sgd_igemm_dispatch_f16x3(const void* kap, int bn, int vec, int taps, size_t smem, hipStream_t st) { SGD_DISPATCH_BODY(SGD_PREC_F16X3) }
+#elif defined(SGDM_IGEMM_NOPK)
+int sgd_igemm_dispatch_bf16x3_nopk(const void* kap, int bn, int vec, int taps, size_t smem, hipStream_t st) { SGD_DISPATCH_BODY(SGD_PREC_BF16X3) }
 #else
 int sgd_igemm_dispatch_bf16x3(const void* kap, int bn, int vec, int taps, size_t smem, hipStream_t st) { SGD_DISPATCH_BODY(SGD_PREC_BF16X3) }
 #endif
@@ -2139,8 +2167,12 @@ extern "C" int sgd_igemm(const sgd_igemm_args* args, void* stream) {
     // build of the combination).  A 0.3 % gain does not buy an unexplained failure mode: the instance is not a default,
     // and never serves that prologue.
     int taps = conv ? 9 : 1;
+    // LayerNorm-row prologue in a split mode: the unit without packed-f32 instructions (SGD_TUNE_LN_PACKED: the regular unit --
+    // tools/ln_hazard.py reproduces the round-4 fault with it); only there may the two-plane instance serve that prologue
+    const bool ln_nopk = !conv && a.pro == SGD_PRO_LN_ROW && a.prec != SGD_PREC_F32 && !(a.tune & SGD_TUNE_LN_PACKED);
+    const bool ln_any = !conv && a.pro == SGD_PRO_LN_ROW && (ln_nopk || (a.tune & SGD_TUNE_LN_PACKED));
     if (!conv && vec && bn >= 128 && a.drop_p == 0.f && cin % (2 * KC) == 0 && (a.c1 == 0 || a.c0 % KC == 0)
-        && (a.pro == SGD_PRO_NONE || (a.pro == SGD_PRO_AFFINE_NC && a.rows_per_n > 0 && a.rows_per_n % BM == 0))
+        && (a.pro == SGD_PRO_NONE || (a.pro == SGD_PRO_AFFINE_NC && a.rows_per_n > 0 && a.rows_per_n % BM == 0) || ln_any)
         && (a.tune & SGD_TUNE_FLAT2))
         taps = 2;
     {
@@ -2192,8 +2224,10 @@ extern "C" int sgd_igemm(const sgd_igemm_args* args, void* stream) {
     }
     switch (a.prec) {
         case SGD_PREC_F32: return sgd_igemm_dispatch_f32(&ka, bn, variant, taps, smem_launch, st);
-        case SGD_PREC_F16X3: return sgd_igemm_dispatch_f16x3(&ka, bn, variant, taps, smem_launch, st);
-        case SGD_PREC_BF16X3: return sgd_igemm_dispatch_bf16x3(&ka, bn, variant, taps, smem_launch, st);
+        case SGD_PREC_F16X3: return ln_nopk ? sgd_igemm_dispatch_f16x3_nopk(&ka, bn, variant, taps, smem_launch, st)
+                                            : sgd_igemm_dispatch_f16x3(&ka, bn, variant, taps, smem_launch, st);
+        case SGD_PREC_BF16X3: return ln_nopk ? sgd_igemm_dispatch_bf16x3_nopk(&ka, bn, variant, taps, smem_launch, st)
+                                             : sgd_igemm_dispatch_bf16x3(&ka, bn, variant, taps, smem_launch, st);
         default: return SGD_ERR_ARG;
     }
 }

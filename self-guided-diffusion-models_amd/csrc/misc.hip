@@ -578,7 +578,11 @@ constexpr int OPT_CHUNK = 4096;
 __global__ __launch_bounds__(256) void adamw_ema_kernel(const sgd_opt_tensor* __restrict__ table,
                                                         const int32_t* __restrict__ chunk_start, int count, float lr,
                                                         float omb1, float b2, float omb2, float eps, float wd,
-                                                        float bc1, float bc2, float omd) {
+                                                        float bc1, float bc2, float omd, const float* __restrict__ skip) {
+    // the step is void when the gradients are: a balanced-tail time-out of the backward program poisons its tiles with NaN
+    // and raises the health flag the caller hands in (all-reduced over the ranks of a data-parallel job) -- parameters,
+    // moments and EMA shadows stay as they are and the host raises at its next look at the flag (unet._Engine.poll_health)
+    if (skip && *skip != 0.f) return;
     // the tensor that owns this chunk: last t with chunk_start[t] <= blockIdx.x
     int lo = 0, hi = count - 1;
     const int b = blockIdx.x;
@@ -615,13 +619,14 @@ __global__ __launch_bounds__(256) void adamw_ema_kernel(const sgd_opt_tensor* __
 extern "C" int sgd_adamw_ema_step(const sgd_opt_tensor* table, const int32_t* chunk_start, int32_t count,
                                   int32_t total_chunks, float lr, float one_minus_beta1, float beta2,
                                   float one_minus_beta2, float eps, float weight_decay, float bias_correction1,
-                                  float bias_correction2, float ema_one_minus_decay, void* stream) {
+                                  float bias_correction2, float ema_one_minus_decay, const float* skip_if_nonzero,
+                                  void* stream) {
     SGD_CLEAR_ERR();
     if (!table || !chunk_start || count <= 0 || total_chunks <= 0 || bias_correction1 <= 0.f || bias_correction2 <= 0.f)
         return SGD_ERR_ARG;
     hipLaunchKernelGGL(adamw_ema_kernel, dim3(total_chunks), dim3(256), 0, (hipStream_t)stream, table, chunk_start,
                        count, lr, one_minus_beta1, beta2, one_minus_beta2, eps, weight_decay, bias_correction1, bias_correction2,
-                       ema_one_minus_decay);
+                       ema_one_minus_decay, skip_if_nonzero);
     return sgd_check_launch();
 }
 
@@ -752,35 +757,6 @@ extern "C" int sgd_linear_splitk(const float* x, int32_t x_ld, const float* w, c
     hipLaunchKernelGGL(linear_splitk_kernel, dim3((n + 63) / 64, ksplit), dim3(256), 0, st, x, x_ld, w, m, n, k, ksplit, work);
     hipLaunchKernelGGL(linear_splitk_fold_kernel, dim3((unsigned)(((long)m * n + 255) / 256)), dim3(256), 0, st, work, bias,
                        m, n, ksplit, y, y_ld);
-    return sgd_check_launch();
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// Diagnostic: hold `blocks` compute units for a wall-clock interval (sgd_debug_occupy).  512 threads + 150 KB of LDS per
-// block: nothing of the persistent conv kernel (one block per CU) fits beside it, which is what a collective's kernels on
-// a side stream do to the backward's launches (tests/test_hip_contention.py).
-// ---------------------------------------------------------------------------------------------------------------------
-namespace {
-__global__ __launch_bounds__(512) void occupy_kernel(unsigned long long ticks) {
-    extern __shared__ float occ_lds[];
-    const unsigned long long t0 = wall_clock64();                 // constant 100 MHz counter
-    occ_lds[threadIdx.x] = (float)threadIdx.x;                    // touch the allocation so it is real
-    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
-    if (occ_lds[threadIdx.x] < 0.f) __builtin_trap();
-}
-}  // namespace
-
-extern "C" int sgd_debug_occupy(int32_t blocks, float milliseconds, void* stream) {
-    SGD_CLEAR_ERR();
-    if (blocks <= 0 || blocks > 256 || !(milliseconds > 0.f) || milliseconds > 1000.f) return SGD_ERR_ARG;
-    static bool attr = false;
-    constexpr size_t LDS = 150 * 1024;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void*)occupy_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
-        attr = true;
-    }
-    hipLaunchKernelGGL(occupy_kernel, dim3(blocks), dim3(512), LDS, (hipStream_t)stream,
-                       (unsigned long long)(milliseconds * 1.0e5f));
     return sgd_check_launch();
 }
 

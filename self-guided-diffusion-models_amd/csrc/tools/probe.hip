@@ -8,9 +8,9 @@
 //     traffic inside the loop -- the matrix pipe's sustained rate under its own power draw;
 //   * sgd_debug_copy_probe: a 16-byte-per-lane grid-stride copy (four loads in flight per lane) -- the practical HBM rate
 //     for one read + one write stream.
-// Diagnostics like sgd_debug_occupy: never on the product path.
-#include "sgdm_common.h"
-#include "../../include/sgdm_hip.h"
+// Diagnostics (libsgdm_hip_tools.so, include/sgdm_hip_tools.h): never on the product path, not part of libsgdm_hip.so.
+#include "../sgdm_common.h"
+#include "../../../include/sgdm_hip_tools.h"
 
 namespace {
 
@@ -74,14 +74,57 @@ __global__ __launch_bounds__(256) void mfma_probe_kernel(uint32_t seed, long ite
     if (out) out[(size_t)blockIdx.x * 256 + threadIdx.x] = total;
 }
 
+// VARIANT 0: grid-stride, four 16-byte loads in flight per lane (the round-5 probe: 4.6-4.8 TB/s of read + written bytes);
+// 1: the same with eight in flight; 2: four in flight, non-temporal loads and stores; 3: every wave walks CONTIGUOUS 8 KiB pieces
+// (eight consecutive 1 KiB wave-instructions), pieces dealt round-robin over the waves of the grid; 4: as 3 with non-temporal
+// accesses; 5: read only (the sum lands in dst[wave]); 6: write only (fill).  tools/hbm_probe_sweep.py holds the sweep.
+template <int VARIANT>
 __global__ __launch_bounds__(256) void copy_probe_kernel(const f32x4* __restrict__ src, f32x4* __restrict__ dst, long n) {
     const long stride = (long)gridDim.x * 256;
     long i = (long)blockIdx.x * 256 + threadIdx.x;
-    for (; i + 3 * stride < n; i += 4 * stride) {
-        const f32x4 v0 = src[i], v1 = src[i + stride], v2 = src[i + 2 * stride], v3 = src[i + 3 * stride];
-        dst[i] = v0; dst[i + stride] = v1; dst[i + 2 * stride] = v2; dst[i + 3 * stride] = v3;
+    if constexpr (VARIANT <= 2) {
+        constexpr int U = VARIANT == 1 ? 8 : 4;
+        for (; i + (U - 1) * stride < n; i += U * stride) {
+            f32x4 v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) v[u] = VARIANT == 2 ? __builtin_nontemporal_load(src + i + u * stride) : src[i + u * stride];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if constexpr (VARIANT == 2) __builtin_nontemporal_store(v[u], dst + i + u * stride);
+                else dst[i + u * stride] = v[u];
+            }
+        }
+        for (; i < n; i += stride) dst[i] = src[i];
+    } else {
+        constexpr int U = 8;                                    // 8 KiB per wave and piece
+        const long wave = i >> 6, nwaves = stride >> 6;
+        const int lane = threadIdx.x & 63;
+        const long pieces = n / (64 * U);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (long p = wave; p < pieces; p += nwaves) {
+            const long b = p * (64 * U) + lane;
+            f32x4 v[U];
+            if constexpr (VARIANT != 6) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) v[u] = VARIANT == 4 ? __builtin_nontemporal_load(src + b + u * 64) : src[b + u * 64];
+            } else {
+#pragma unroll
+                for (int u = 0; u < U; ++u) v[u] = f32x4{(float)p, (float)u, 0.f, 1.f};
+            }
+            if constexpr (VARIANT == 5) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) acc += v[u];
+            } else {
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    if constexpr (VARIANT == 4) __builtin_nontemporal_store(v[u], dst + b + u * 64);
+                    else dst[b + u * 64] = v[u];
+                }
+            }
+        }
+        if constexpr (VARIANT == 5) dst[i] = acc;
+        else for (long t = pieces * (64 * U) + i; t < n; t += stride) dst[t] = VARIANT == 6 ? f32x4{0.f, 0.f, 0.f, 1.f} : src[t];
     }
-    for (; i < n; i += stride) dst[i] = src[i];
 }
 
 // What does the conv kernel's compute-wave stream cost the matrix pipe, and would a second MFMA wave per SIMD give it back?
@@ -346,10 +389,53 @@ extern "C" int64_t sgd_debug_mfma_probe_flops(int32_t blocks, int64_t iters, int
     return (int64_t)blocks * 4 * iters * (variant == 2 ? 4 * 32768 : 8 * 16384);
 }
 
-extern "C" int sgd_debug_copy_probe(const float* src, float* dst, int64_t count, void* stream) {
+extern "C" int sgd_debug_copy_probe(const float* src, float* dst, int64_t count, int32_t variant, int32_t blocks, void* stream) {
     SGD_CLEAR_ERR();
-    if (!src || !dst || count <= 0 || (count & 3) || (((uintptr_t)src | (uintptr_t)dst) & 15)) return SGD_ERR_ARG;
-    hipLaunchKernelGGL(copy_probe_kernel, dim3(256 * 8), dim3(256), 0, (hipStream_t)stream,
-                       reinterpret_cast<const f32x4*>(src), reinterpret_cast<f32x4*>(dst), (long)(count >> 2));
+    if (!src || !dst || count <= 0 || (count & 3) || (((uintptr_t)src | (uintptr_t)dst) & 15) || variant < 0 || variant > 6) return SGD_ERR_ARG;
+    if (blocks <= 0) blocks = 256 * 8;
+    if (variant == 5 && (long)blocks * 256 * 4 > count) return SGD_ERR_ARG;          // one result quad per thread
+    const f32x4* s = reinterpret_cast<const f32x4*>(src);
+    f32x4* d = reinterpret_cast<f32x4*>(dst);
+    const long n = (long)(count >> 2);
+    hipStream_t st = (hipStream_t)stream;
+    switch (variant) {
+        case 0: hipLaunchKernelGGL(copy_probe_kernel<0>, dim3(blocks), dim3(256), 0, st, s, d, n); break;
+        case 1: hipLaunchKernelGGL(copy_probe_kernel<1>, dim3(blocks), dim3(256), 0, st, s, d, n); break;
+        case 2: hipLaunchKernelGGL(copy_probe_kernel<2>, dim3(blocks), dim3(256), 0, st, s, d, n); break;
+        case 3: hipLaunchKernelGGL(copy_probe_kernel<3>, dim3(blocks), dim3(256), 0, st, s, d, n); break;
+        case 4: hipLaunchKernelGGL(copy_probe_kernel<4>, dim3(blocks), dim3(256), 0, st, s, d, n); break;
+        case 5: hipLaunchKernelGGL(copy_probe_kernel<5>, dim3(blocks), dim3(256), 0, st, s, d, n); break;
+        default: hipLaunchKernelGGL(copy_probe_kernel<6>, dim3(blocks), dim3(256), 0, st, s, d, n); break;
+    }
     return sgd_check_launch();
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Diagnostic: hold `blocks` compute units for a wall-clock interval (sgd_debug_occupy).  512 threads + 150 KB of LDS per
+// block: nothing of the persistent conv kernel (one block per CU) fits beside it, which is what a collective's kernels on
+// a side stream do to the backward's launches (tests/test_hip_contention.py).
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(512) void occupy_kernel(unsigned long long ticks) {
+    extern __shared__ float occ_lds[];
+    const unsigned long long t0 = wall_clock64();                 // constant 100 MHz counter
+    occ_lds[threadIdx.x] = (float)threadIdx.x;                    // touch the allocation so it is real
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+    if (occ_lds[threadIdx.x] < 0.f) __builtin_trap();
+}
+}  // namespace
+
+extern "C" int sgd_debug_occupy(int32_t blocks, float milliseconds, void* stream) {
+    SGD_CLEAR_ERR();
+    if (blocks <= 0 || blocks > 256 || !(milliseconds > 0.f) || milliseconds > 1000.f) return SGD_ERR_ARG;
+    static bool attr = false;
+    constexpr size_t LDS = 150 * 1024;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)occupy_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
+        attr = true;
+    }
+    hipLaunchKernelGGL(occupy_kernel, dim3(blocks), dim3(512), LDS, (hipStream_t)stream,
+                       (unsigned long long)(milliseconds * 1.0e5f));
+    return sgd_check_launch();
+}
+

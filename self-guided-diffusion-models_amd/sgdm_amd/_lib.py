@@ -20,10 +20,10 @@ RS_NONE, RS_AVGPOOL2, RS_UP2, RS_ZEROUP2 = 0, 1, 2, 3
 PRO_NONE, PRO_AFFINE_NC, PRO_LN_ROW = 0, 1, 2
 PREC_F32, PREC_F16X3, PREC_BF16X3 = 0, 1, 2
 PREC_BY_NAME = {"f32": PREC_F32, "f16x3": PREC_F16X3, "bf16x3": PREC_BF16X3}
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 # sgd_igemm_args.tune (include/sgdm_hip.h: SGD_TUNE_*): per-call schedule overrides for parity tests and A/B tools
-TUNE_BN128, TUNE_BN256, TUNE_FLAT2, TUNE_DEFER, TUNE_PLAIN_SCHEDULE = 1, 2, 4, 8, 16
+TUNE_BN128, TUNE_BN256, TUNE_FLAT2, TUNE_DEFER, TUNE_PLAIN_SCHEDULE, TUNE_LN_PACKED = 1, 2, 4, 8, 16, 32
 TUNE_WGRAD_GENERIC_NARROW, TUNE_WGRAD_NO_POOLED_PLANES, TUNE_WGRAD_F32 = 256, 512, 1024
 TUNE_WGRAD_NO_WS, TUNE_WGRAD_NO_PLANES, TUNE_WGRAD_NO_PIPE, TUNE_WGRAD_PLANES_ALWAYS = 2048, 4096, 8192, 16384
 
@@ -58,12 +58,6 @@ SIGNATURES = {
     "sgd_igemm_stats_parts": (i32, [C.POINTER(IgemmArgs)]),
     "sgd_igemm_work_bytes": (i64, []),
     "sgd_igemm_work_status_offset": (i64, []),
-    "sgd_debug_occupy": (i32, [i32, f32, vp]),
-    "sgd_debug_mfma_probe": (i32, [i32, i64, C.c_uint32, i32, vp, vp]),
-    "sgd_debug_mfma_probe_flops": (i64, [i32, i64, i32]),
-    "sgd_debug_copy_probe": (i32, [vp, vp, i64, vp]),
-    "sgd_debug_mfma_lds_probe": (i32, [i32, i64, C.c_uint32, i32, i32, vp, vp]),
-    "sgd_debug_mfma_stream_probe": (i32, [i32, i64, C.c_uint32, i32, vp, vp, i64, vp, vp]),
     "sgd_igemm_tail_layout": (i32, [i32, i32, i32, i32, C.POINTER(i32)]),
     "sgd_stats_reduce": (i32, [vp, i32, i32, i32, vp, i32, i32, vp]),
     "sgd_packed_weight_bytes": (i64, [i32, i32, i32, i32]),
@@ -110,7 +104,9 @@ SIGNATURES = {
     "sgd_resample_bwd": (i32, [vp, i32, i32, i32, i32, i32, vp, i32, vp]),
     "sgd_q_sample": (i32, [vp, vp, vp, vp, vp, i32, i64, vp, vp]),
     "sgd_mse_loss": (i32, [vp, vp, i32, i32, i32, vp, vp, vp]),
-    "sgd_adamw_ema_step": (i32, [vp, vp, i32, i32, f32, f32, f32, f32, f32, f32, f32, f32, f32, vp]),
+    "sgd_adamw_ema_step": (i32, [vp, vp, i32, i32, f32, f32, f32, f32, f32, f32, f32, f32, f32, vp, vp]),
+    "sgd_exchange_bind": (i32, [C.c_char_p]),
+    "sgd_allreduce_bucket": (i32, [vp, vp, i64, vp]),
     "sgd_timestep_embedding": (i32, [vp, vp, i32, i32, i32, vp, vp]),
     "sgd_cond_select": (i32, [vp, i32, vp, vp, i32, i32, i32, vp, vp]),
     "sgd_pack_input": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp]),
@@ -133,7 +129,20 @@ SIGNATURES = {
     "sgd_cfg_combine": (i32, [vp, i32, f32, i32, i32, i32, vp, vp]),
 }
 
+# include/sgdm_hip_tools.h: the diagnostics library (libsgdm_hip_tools.so) -- bench.py's device calibration, the contention
+# tests, tools/.  NOT part of the product library and never loaded by sgdm_amd/ itself.
+TOOLS_LIB_PATH = os.path.join(_HERE, "lib", "libsgdm_hip_tools.so")
+TOOLS_SIGNATURES = {
+    "sgd_debug_occupy": (i32, [i32, f32, vp]),
+    "sgd_debug_mfma_probe": (i32, [i32, i64, C.c_uint32, i32, vp, vp]),
+    "sgd_debug_mfma_probe_flops": (i64, [i32, i64, i32]),
+    "sgd_debug_copy_probe": (i32, [vp, vp, i64, i32, i32, vp]),
+    "sgd_debug_mfma_lds_probe": (i32, [i32, i64, C.c_uint32, i32, i32, vp, vp]),
+    "sgd_debug_mfma_stream_probe": (i32, [i32, i64, C.c_uint32, i32, vp, vp, i64, vp, vp]),
+}
+
 _lib = None
+_tools = None
 
 
 class HipLibraryError(RuntimeError):
@@ -160,6 +169,25 @@ def load():
     if lib.sgd_abi_version() != ABI_VERSION:
         raise HipLibraryError(f"ABI mismatch: library {lib.sgd_abi_version()} != binding {ABI_VERSION}")
     _lib = lib
+    return lib
+
+
+def load_tools():
+    """the diagnostics library (tests / bench / tools only)"""
+    global _tools
+    if _tools is not None:
+        return _tools
+    if not os.path.exists(TOOLS_LIB_PATH):
+        raise HipLibraryError(f"{TOOLS_LIB_PATH} not found (run `python self-guided-diffusion-models_amd/build.py`)")
+    lib = C.CDLL(TOOLS_LIB_PATH)
+    for name, (res, args) in TOOLS_SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise HipLibraryError(f"{TOOLS_LIB_PATH} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    _tools = lib
     return lib
 
 

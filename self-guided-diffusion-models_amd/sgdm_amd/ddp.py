@@ -61,8 +61,11 @@ def backend_runs_on_gpu(group=None):
 class GradArena:
     """flat gradient storage + bucket bookkeeping"""
 
-    def __init__(self, shapes, device, bucket_bytes=64 << 20, dtype=torch.float32):
-        """shapes: ordered [(name, shape)] in the order the backward produces the gradients"""
+    def __init__(self, shapes, device, bucket_bytes=64 << 20, dtype=torch.float32, tail_bytes=16 << 20):
+        """shapes: ordered [(name, shape)] in the order the backward produces the gradients.
+        tail_bytes: cap of the LAST bucket.  It is complete only with the backward's last launch, so its collective is the
+        part of the exchange no launch hides: whatever the bucket size, the last one is cut so that it holds at most this
+        much (as long as a parameter boundary allows)."""
         self.names = [n for n, _ in shapes]
         self.views, self.offsets = {}, {}
         total = 0
@@ -72,7 +75,12 @@ class GradArena:
                 numel *= int(s)
             self.offsets[name] = (total, numel)
             total += (numel + 3) // 4 * 4                    # keep every view 16-byte aligned
+        # one more quad behind the last gradient: [0] = health flag of the step (train.Backward.run writes 0 / 1 before the
+        # last bucket is sent; after the SUM every rank knows whether ANY rank's gradients are invalid)
+        self.health_off = total
+        total += 4
         self.flat = torch.zeros(max(total, 4), dtype=dtype, device=device)
+        self.health = self.flat[self.health_off:self.health_off + 1]
         for name, shape in shapes:
             off, numel = self.offsets[name]
             self.views[name] = self.flat[off:off + numel].view(*shape)
@@ -85,8 +93,20 @@ class GradArena:
             if end - start >= per:
                 self.buckets.append((start, end, name))
                 start = end
-        if start < total or not self.buckets:
+        if start < total or not self.buckets:          # (always: the health quad lies behind the last gradient)
             self.buckets.append((start, max(total, 4), self.names[-1] if self.names else None))
+        # cap the last bucket: split it at the first parameter boundary from which the rest fits into tail_bytes
+        cap = max(4, tail_bytes // self.flat.element_size())
+        ls, le, ln = self.buckets[-1]
+        if le - ls > cap:
+            prev = None
+            for name in self.names:
+                off, numel = self.offsets[name]
+                if off > ls and le - off <= cap:
+                    self.buckets[-1:] = [(ls, off, prev), (off, le, ln)]
+                    break
+                if off >= ls:
+                    prev = name
         self.bucket_of = {}
         for bi, (s, e, _) in enumerate(self.buckets):
             for name in self.names:
@@ -133,6 +153,26 @@ class BucketReducer:
         self.pending, self.done = [], set()
         self.marks, self.t_bwd_end = [], None
         self.t_start = self._mark() if self.active else None
+
+    def new_durations(self):
+        """True once per completed step: its per-bucket collective durations can be read without waiting"""
+        marks = self.marks
+        if not marks or marks is getattr(self, "_dur_from", None) or any(r[2] is None for r in marks):
+            return False
+        if self.cuda and not all(r[2].query() for r in marks):
+            return False
+        if self.cuda:
+            d = {r[0]: float(r[1].elapsed_time(r[2])) for r in marks}       # enqueue point -> completion, per bucket
+        else:
+            d = {r[0]: 1000.0 * (r[2] - r[1]) for r in marks}
+        # slowly forgetting maximum: one slow collective widens its window at once, a window shrinks over ~10 steps
+        old = getattr(self, "_durations", None) or {}
+        self._durations = {k: max(v, 0.9 * old.get(k, 0.0)) for k, v in d.items()}
+        self._dur_from = marks
+        return True
+
+    def bucket_durations_ms(self):
+        return getattr(self, "_durations", None)
 
     def backward_done(self):
         """call when the last launch of the backward program has been issued (before finish)"""
@@ -183,7 +223,7 @@ class BucketReducer:
         if self.cuda:
             torch.cuda.current_stream().wait_stream(self.stream)
         if self.average and self.world > 1:
-            self.arena.flat.mul_(1.0 / self.world)
+            self.arena.flat[:self.arena.health_off].mul_(1.0 / self.world)
         self.pending = []
 
     def overlap_stats(self):
@@ -202,7 +242,8 @@ class BucketReducer:
         enq = [el(self.t_start, r[1]) for r in self.marks]
         end = [el(self.t_start, r[2]) for r in self.marks]
         esz = self.arena.flat.element_size()
-        return dict(buckets=len(self.marks), backward_ms=round(bwd, 3),
+        late = sum((self.arena.buckets[r[0]][1] - self.arena.buckets[r[0]][0]) * esz for r, q in zip(self.marks, enq) if q > 0.9 * bwd)
+        return dict(buckets=len(self.marks), backward_ms=round(bwd, 3), mbytes_enqueued_after_0p9_of_backward=round(late / 2 ** 20, 1),
                     exchange_ms=round(max(end) - min(enq), 3),
                     exposed_exchange_ms=round(max(0.0, max(end) - bwd), 3),
                     first_bucket_at_frac_of_backward=round(min(enq) / bwd, 4) if bwd > 0 else None,
@@ -274,8 +315,14 @@ def sync_initial_state(module, group=None, src=0, late=False):
         return 0
     if getattr(module, "_hip_ddp_synced", False):
         return 0
-    if backend_runs_on_gpu(group):
-        cap_exchange_channels()                      # before what is normally the first collective of the job
+    if backend_runs_on_gpu(group) and exchange_group() is None:
+        # RCCL's half of the CU reserve.  Normally the buckets travel on a communicator of the exchange's own whose
+        # workgroup count is capped (exchange_group, created -- collectively, all ranks are here -- just above): nothing
+        # process-wide is touched and the user's other communicators (validation gathers, other models) keep RCCL's
+        # defaults.  Only a torch / RCCL build without the per-communicator option falls back to the
+        # environment variable, before what is then the first collective of the job.  The job owners that want the
+        # process-wide cap as well set it themselves: HipDDPStrategy.setup_environment, bench.py.
+        cap_exchange_channels()
     tensors = list(module.parameters()) + list(module.buffers())
     # one flat buffer per dtype: a few large broadcasts instead of ~400 small ones.  The copies back are in-place writes on
     # the parameters themselves (under no_grad): they bump the tensors' versions, which is what the packed-weight caches key on
@@ -386,10 +433,19 @@ def exchange_group(reserve=None):
     grp = None
     try:
         opts = dist.ProcessGroupNCCL.Options()
-        opts.config.max_ctas = reserve
-        opts.config.min_ctas = min(4, reserve)
+        # RCCL accepts 1 .. 64 workgroups per communicator (its MAXCHANNELS); a larger reserve still caps at 64
+        ctas = max(1, min(int(reserve), 64))
+        opts.config.max_ctas = ctas
+        opts.config.min_ctas = min(4, ctas)
         grp = dist.new_group(ranks=list(range(dist.get_world_size())), backend="nccl", pg_options=opts)
+        # ProcessGroupNCCL creates the communicator lazily: force it NOW, inside the try and outside any timed or overlapped
+        # region -- a configuration RCCL rejects then falls back to the default group here instead of failing at the first
+        # bucket in the middle of the first backward, and ncclCommInit does not land inside that backward either
+        probe = torch.zeros(1, device=torch.device("cuda", torch.cuda.current_device()))
+        dist.all_reduce(probe, group=grp)
+        torch.cuda.current_stream().synchronize()
     except Exception as exc:                          # pragma: no cover - depends on the torch / RCCL build
         warnings.warn(f"sgdm_amd: no per-communicator CTA cap available ({exc}); the exchange uses the default group")
+        grp = None
     _EXCHANGE_GROUPS[key] = grp
     return grp

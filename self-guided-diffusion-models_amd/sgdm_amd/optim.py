@@ -95,9 +95,13 @@ class FusedAdamWEma(torch.optim.Optimizer):
             table = torch.tensor(rows, dtype=torch.int64).to(dev, non_blocking=True)
             b1, b2 = group["betas"]
             t = step_t if step_t is not None else 1.0
+            # gate (ABI 18): the device's gradient-health flag -- the launch writes nothing while it is up, so gradients a
+            # balanced-tail time-out poisoned never reach parameters, moments or EMA shadows (train.Backward.run raises it,
+            # the engine's next poll_health() raises on the host and clears it)
+            from .unet import grad_health
             L.check(lib.sgd_adamw_ema_step(C.c_void_p(table.data_ptr()), C.c_void_p(cstart.data_ptr()), len(rows), total,
                                            float(group["lr"]), 1.0 - b1, b2, 1.0 - b2, group["eps"], group["weight_decay"],
-                                           1.0 - b1 ** t, 1.0 - b2 ** t, omd,
+                                           1.0 - b1 ** t, 1.0 - b2 ** t, omd, C.c_void_p(grad_health(dev).data_ptr()),
                                            torch.cuda.current_stream().cuda_stream), "sgd_adamw_ema_step")
             self._table_keep = (table, keep)
             # The kernel writes the parameters through raw pointers, which autograd's version counters do not see.

@@ -124,7 +124,7 @@ class Backward:
         self.e, self.lib, self.n, self.dev, self.prec = eng, eng.lib, eng.n, eng.dev, eng.prec
         self.m = eng.m
         self.prog = _Program()
-        self.packs, self.late = [], []
+        self.packs, self.late, self.late_at = [], [], []
         self.arena, self.reducer = arena, reducer
         self.world = reducer.world if reducer is not None else 1
         # Gradients run through the program multiplied by a power of two so that the split-f16 operands of the
@@ -178,7 +178,8 @@ class Backward:
         if self.reducer is None or not self.reducer.active:
             return
         bi = self.arena.bucket_of[name]
-        if self.arena.buckets[bi][2] == name:
+        # (the last bucket is flushed by reducer.finish(), after the step's health flag has been written into its tail slot)
+        if self.arena.buckets[bi][2] == name and bi != len(self.arena.buckets) - 1:
             red = self.reducer
 
             def bucket_ready(stream, bi=bi):
@@ -224,6 +225,7 @@ class Backward:
         if self.e.work_bytes:                # the forward engine's balanced-tail scratch (same stream: launches are ordered)
             a.work, a.work_bytes = self.e.work.data_ptr(), self.e.work_bytes
         a.grid_cap = getattr(self.e, "_grid_cap", 0)
+        self.late_at.append(len(self.prog.ops))          # program position of this launch (reserve windows)
         self.late.append((a, pk))
         self.keep.append(a)
         rows = (a.n * a.ho * a.wo) if conv is not None else m
@@ -315,7 +317,8 @@ class Backward:
             off += c
         A, B, Cc = (self.buf(n, ct) for _ in range(3))
         gamma, beta = self.m.P(gname + ".weight"), self.m.P(gname + ".bias")
-        fused = n <= 256 and 8 * n * (ct // GN_GROUPS) + 32 * n + 4 <= 64 * 1024 and os.environ.get("SGDM_GN_BWD_FOLD", "1") != "0"
+        # (the launcher's bound: dynamic table + the kernel's 2 KB of static reduction scratch inside the 64 KB default limit)
+        fused = n <= 256 and 8 * n * (ct // GN_GROUPS) + 32 * n + 4 + 2048 <= 64 * 1024 and os.environ.get("SGDM_GN_BWD_FOLD", "1") != "0"
         if fused:                # coefficients + dgamma / dbeta column sums in ONE launch (bit-identical to the two below)
             self.prog.add(tag + ".coef", lib.sgd_gn_bwd_coef_fold, _ptr(S), _ptr(sums), _ptr(gamma), _ptr(beta),
                           C.c_void_p(film_ptr), film_ld, n, ct, GN_GROUPS, h * w, GN_EPS, _ptr(A), _ptr(B), _ptr(Cc),
@@ -354,6 +357,7 @@ class Backward:
         self.geps = self.buf(*e.eps_nhwc.shape)           # filled by the autograd Function before the program runs
         film_rec = [r for r in e.tape if r["kind"] == "film"][0]
         self.gfilm = self.buf(n, film_rec["film_w"])
+        self._film_plan(film_rec)
         for rec in reversed(e.tape):
             kind = rec["kind"]
             if kind == "head":
@@ -419,6 +423,7 @@ class Backward:
         self.gn_bwd(p + ".out_layers.0", [(rec["h1"], cout)], (ho, wo), rec["a2"], rec["b2"], rec["sums2"],
                     p + ".out_layers.0", 1, gu2, cout, L.RS_NONE, None, 0, 0, film_ptr=film_ptr, film_ld=e.film_ld,
                     dfilm_ptr=dfilm_ptr, drop=(rec["drop_p"], rec["drop_seed"]))
+        self._film_group_done(p)
         gh1 = self.gread(rec["h1"])
         # conv1 (in_layers.2)
         w1 = P(p + ".in_layers.2.weight")
@@ -585,33 +590,10 @@ class Backward:
         ted = rec["emb_t"].shape[1]
         cc = rec["emb_c"].shape[1] if rec["emb_c"] is not None else 0
         ech = ted + cc
-        names, couts = rec["names"], rec["couts"]
+        names = rec["names"]
         wparams = [m.P(p + ".emb_layers.1.weight") for p in names]
-        dwcat, dbcat = self.buf(fw, ech), self.buf(fw)
-        self.wgrad("emb_layers", rec["a"], self.gfilm, fw, fw, ech, 1, n, None, None, dw_view=dwcat)
-        self.prog.add("emb_layers.bias", self.lib.sgd_colsum, _ptr(self.gfilm), n, fw, fw, _ptr(dbcat), 0, self.unscale,
-                      _ptr(self.cwork), self.CW)
-        views = []
-        off = 0
-        for p, co in zip(names, couts):
-            if self.arena is None:
-                # single process: the per-block gradients ARE row slices of the concatenated result (contiguous), no copies
-                self.pgrad[p + ".emb_layers.1.weight"] = dwcat[off:off + 2 * co]
-                self.pgrad[p + ".emb_layers.1.bias"] = dbcat[off:off + 2 * co]
-            else:
-                views.append((self.pg(p + ".emb_layers.1.weight"), dwcat[off:off + 2 * co]))
-                views.append((self.pg(p + ".emb_layers.1.bias"), dbcat[off:off + 2 * co]))
-            off += 2 * co
-
-        def film_split(stream):
-            # the concatenated emb_layers gradient back into the per-ResBlock parameters (device-side slice copies)
-            for dst, src in views:
-                dst.copy_(src)
-            return 0
-        self.prog.add("emb_layers.split", film_split)
-        for p in names:
-            self.wrote(p + ".emb_layers.1.weight")
-            self.wrote(p + ".emb_layers.1.bias")
+        # (the weight / bias gradients of the FiLM projections were produced stage by stage inside the walk: _film_group_done)
+        assert not self._film_open, self._film_open
         cat = lambda: torch.cat([w.detach() for w in wparams], 0)
         parts = [(rec["emb_t"], 0, ted)] + ([(rec["emb_c"], ted, cc)] if cc else [])
         # few rows (the batch), a very long reduction (all FiLM outputs, 13,824 at C2): split-K on the concatenated weight as
@@ -656,6 +638,73 @@ class Backward:
             g = self.buf(n, c)
             self.prog.add(f"emb.silu_bwd{o}", self.lib.sgd_silu_bwd, _ptr(t), _ptr(gact), n * c, _ptr(g))
             self.G[t.data_ptr()] = [g, True]
+
+    # FiLM projections (emb_layers of all ResBlocks: ONE GEMM in the forward, its 42 MB of weight gradients the largest single
+    # tensor group of the model).  As one launch at the end of the walk -- its gradient rows are complete only when the LAST
+    # ResBlock's GroupNorm backward has written its slice -- it was the last gradient of the backward: on 8 GPUs the part of the
+    # exchange nothing hides (round 5: bucket 4 + tail, ~80 MB, complete 0.4 ms before the end).  The walk visits the
+    # ResBlocks in reverse forward order and a block's slice of the FiLM gradient is final after its out_layers.0 backward,
+    # so the columns are cut into STAGES of consecutive blocks (>= FILM_STAGE_BYTES of weight gradient each) and every
+    # stage's weight / bias gradient is launched as soon as its first (in forward order) block is through.
+    FILM_STAGE_BYTES = 6 << 20
+
+    def _film_plan(self, rec):
+        names, couts = rec["names"], rec["couts"]
+        fw = rec["film_w"]
+        ech = rec["emb_t"].shape[1] + (rec["emb_c"].shape[1] if rec["emb_c"] is not None else 0)
+        offs, off = [], 0
+        for co in couts:
+            offs.append(off)
+            off += 2 * co
+        self._film = dict(rec=rec, ech=ech, fw=fw, dwcat=self.buf(fw, ech), dbcat=self.buf(fw))
+        # stages in WALK order (last ResBlock of the forward first); a stage closes at block i when it holds enough bytes
+        self._film_close = {}                       # block name -> (first block index, one past the last) of the stage it closes
+        hi = len(names)
+        acc = 0
+        for i in range(len(names) - 1, -1, -1):
+            acc += 2 * couts[i] * ech * 4
+            if acc >= self.FILM_STAGE_BYTES or i == 0:
+                self._film_close[names[i]] = (i, hi)
+                hi, acc = i, 0
+        self._film_offs = offs + [fw]
+        self._film_open = set(self._film_close)
+
+    def _film_group_done(self, p):
+        """called from the walk right after ResBlock `p`'s out_layers.0 backward has written its FiLM-gradient slice"""
+        grp = self._film_close.get(p)
+        if grp is None:
+            return
+        self._film_open.discard(p)
+        i0, i1 = grp
+        f, n = self._film, self.n
+        rec, ech, fw, dwcat, dbcat = f["rec"], f["ech"], f["fw"], f["dwcat"], f["dbcat"]
+        names, couts = rec["names"], rec["couts"]
+        c0, c1 = self._film_offs[i0], self._film_offs[i1]
+        tag = f"emb_layers.s{i0}"
+        gsl = self.gfilm[:, c0:c1]                  # columns of this stage (row stride fw)
+        self.wgrad(tag, rec["a"], gsl, fw, c1 - c0, ech, 1, n, None, None, dw_view=dwcat[c0:c1])
+        self.prog.add(tag + ".bias", self.lib.sgd_colsum, _ptr(gsl), n, c1 - c0, fw, _ptr(dbcat[c0:c1]), 0, self.unscale,
+                      _ptr(self.cwork), self.CW)
+        views = []
+        for i in range(i0, i1):
+            q, o, co = names[i], self._film_offs[i], couts[i]
+            if self.arena is None:
+                # single process: the per-block gradients ARE row slices of the concatenated result (contiguous), no copies
+                self.pgrad[q + ".emb_layers.1.weight"] = dwcat[o:o + 2 * co]
+                self.pgrad[q + ".emb_layers.1.bias"] = dbcat[o:o + 2 * co]
+            else:
+                views.append((self.pg(q + ".emb_layers.1.weight"), dwcat[o:o + 2 * co]))
+                views.append((self.pg(q + ".emb_layers.1.bias"), dbcat[o:o + 2 * co]))
+        if views:
+            def film_split(stream, views=views):
+                # the stage's rows of the concatenated gradient into the per-ResBlock parameters (device-side slice copies)
+                for dst, src in views:
+                    dst.copy_(src)
+                return 0
+            self.prog.add(tag + ".split", film_split)
+        for i in range(i1 - 1, i0 - 1, -1):
+            self.wrote(names[i] + ".emb_layers.1.weight")
+            self.wrote(names[i] + ".emb_layers.1.bias")
 
     def _mlp2(self, rec):
         """Linear -> SiLU -> Linear (time_embed / mlp_cond)"""
@@ -705,13 +754,66 @@ class Backward:
         g = (geps_nchw.float() * self.gscale).contiguous()
         L.check(lib.sgd_pack_input(_ptr(g), None, None, None, n, n, c, 0, h, w, _ptr(self.geps), stream), "geps")
         if self.reducer is not None:
+            if self.reducer.active and self.reducer.new_durations():
+                self.apply_grid_cap()        # windows from the step that has just completed
             self.reducer.start()
         self.prog.run(stream)
+        # Health of this step's gradients: 1.0 iff the engine's balanced-tail health word is up.  With an arena
+        # the flag is the arena's last slot and travels with the LAST bucket (SUM over the ranks: every rank sees > 0 when any
+        # rank failed); it is added to the device's sticky gate, which the fused optimizer takes as skip_if_nonzero -- a
+        # poisoned step is never applied -- and copied to pinned host memory for the next step's poll_health() to raise on.
+        word, flag = self.e.health_word(), None
+        if word is not None:
+            from .unet import grad_health
+            flag = self.arena.health if self.arena is not None else self._own_flag()
+            flag.copy_(word.ne(0))
         if self.reducer is not None:
             self.reducer.backward_done()     # (overlap record: everything the exchange could hide behind is issued)
-            self.reducer.finish()            # flush the tail bucket, join the side stream
-        self.e.note_health()                 # balanced-tail health word -> pinned host memory, read at the next step
+            self.reducer.finish()            # flush the tail bucket (it holds the flag), join the side stream
+        if flag is not None:
+            grad_health(self.dev).add_(flag)
+        self.e.note_health(flag)
         return self.pgrad
+
+    # ---- CU reserve only while a collective is in flight.  The persistent conv grid leaves
+    # `reserve` compute units to RCCL's kernels on the side stream (tests/test_hip_contention.py: a launch whose blocks do
+    # not all fit next to them takes up to 1.7x).  Taken from every launch of the backward the reserve cost ~1.1 ms of a
+    # 63 ms step; RCCL needs it only between a bucket's enqueue and its completion.  The host knows where in the PROGRAM each
+    # collective starts (the bucket hooks) and, from the completion events of the previous step, how long each one took: a
+    # launch keeps the whole device unless it falls into the window [hook, hook + 1.5 x measured duration + 0.3 ms) of
+    # estimated launch time (algorithmic flops at 300 TF/s, 40 us for the memory-bound launches in between).  Before any
+    # measurement exists the window is the whole rest of the program behind the first hook (the round-5 behaviour).
+    def apply_grid_cap(self):
+        cap = getattr(self.e, "_grid_cap", 0)
+        if cap <= 0 or self.reducer is None or not self.reducer.active or os.environ.get("SGDM_RESERVE_WINDOWS", "1") == "0":
+            for a, _ in self.late:
+                a.grid_cap = cap
+            self._windows = None
+            return
+        hooks = [(i, int(op[0][len("bucket"):].split(".")[0])) for i, op in enumerate(self.prog.ops)
+                 if op[0].startswith("bucket") and op[0].endswith(".allreduce")]
+        dur = self.reducer.bucket_durations_ms()         # {bucket: ms} of the last completed step, or None
+        est = [(mt[1] / 300e12 * 1e3 if mt[1] > 0 else 0.04) for mt in self.prog.meta]       # ms per program entry
+        inside = [False] * len(self.prog.ops)
+        for pos, bi in hooks:
+            if dur is None:
+                for j in range(pos, len(inside)):
+                    inside[j] = True
+                break
+            budget = 1.5 * dur.get(bi, 1.0) + 0.3
+            j = pos
+            while j < len(inside) and budget > 0:
+                inside[j] = True
+                budget -= est[j]
+                j += 1
+        for (a, _), at in zip(self.late, self.late_at):
+            a.grid_cap = cap if inside[at] else 0
+        self._windows = (sum(inside), len(inside), dur is not None)
+
+    def _own_flag(self):
+        if getattr(self, "_flag", None) is None:
+            self._flag = torch.zeros(1, dtype=torch.float32, device=self.dev)
+        return self._flag
 
 
 class _UNetTrainFn(torch.autograd.Function):

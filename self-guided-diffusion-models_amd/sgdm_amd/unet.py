@@ -556,6 +556,21 @@ def device_cus(dev):
 
 
 # ------------------------------------------------------------------------------------------------
+_GRAD_HEALTH = {}
+
+
+def grad_health(dev):
+    """device float[1], one per device and process: != 0 while a training backward on this device has produced invalid
+    gradients that the host has not yet acknowledged (balanced-tail time-out, summed over the ranks of a data-parallel
+    job).  train.Backward.run adds to it, sgd_adamw_ema_step takes it as its `skip_if_nonzero` (optim.FusedAdamWEma), the
+    engine's poll_health() raises and clears it."""
+    dev = torch.device(dev)
+    key = (dev.type, dev.index if dev.index is not None else (torch.cuda.current_device() if dev.type == "cuda" else 0))
+    if key not in _GRAD_HEALTH:
+        _GRAD_HEALTH[key] = torch.zeros(1, dtype=torch.float32, device=dev)
+    return _GRAD_HEALTH[key]
+
+
 class _Engine:
     """static launch program + workspace for one (UNet batch, H, W, precision)"""
 
@@ -888,11 +903,18 @@ class _Engine:
     # workspace is poisoned until the host zeroes it.  The paths that own a workspace honour that contract here: the
     # samplers at the end of a trajectory (check_health: one 4-byte read), the training step without a sync of its own
     # (note_health after the backward program, looked at when the next step is prepared).
-    def _health_fail(self):
+    def _health_fail(self, training=False):
         self.work.zero_()
-        raise RuntimeError("sgdm_amd: a conv launch's balanced tail timed out waiting for another block's partial sums "
-                           "(stale arrival counters: a faulted launch, or two streams on one engine); the affected outputs "
-                           "were poisoned with NaN.  The workspace has been re-zeroed: rerun the step.")
+        what = ("sgdm_amd: a conv launch's balanced tail timed out waiting for another block's partial sums (stale arrival "
+                "counters: a faulted launch, or two streams on one engine); the affected outputs were poisoned with NaN.  The "
+                "workspace has been re-zeroed")
+        if not training:
+            raise RuntimeError(what + ": rerun the step.")
+        grad_health(self.dev).zero_()
+        raise RuntimeError(what + ".  The gradients of that training iteration are invalid on every rank (the flag travels "
+                           "with the gradient exchange).  sgdm_amd.optim.FusedAdamWEma skipped its step for them -- parameters, "
+                           "moments and EMA shadows are untouched: repeat the iteration.  Any other optimizer has consumed "
+                           "non-finite gradients: restore the last checkpoint.")
 
     def check_health(self):
         """synchronising check (end of a sampling trajectory, tests)"""
@@ -901,24 +923,35 @@ class _Engine:
             if int(self.work.view(torch.int32)[off].item()) != 0:
                 self._health_fail()
 
-    def note_health(self):
-        """asynchronous: copy the word to pinned host memory behind the launches issued so far"""
+    def health_word(self):
+        """the workspace's health word as a 1-element int32 view (None without a workspace)"""
+        if not self.work_bytes:
+            return None
+        if getattr(self, "_health_off", None) is None:
+            self._health_off = int(self.lib.sgd_igemm_work_status_offset()) // 4
+        return self.work.view(torch.int32)[self._health_off:self._health_off + 1]
+
+    def note_health(self, flag=None):
+        """asynchronous: copy the word -- or `flag`, the float the training step derived from it and summed over the ranks
+        (train.Backward.run), so that every rank of a data-parallel job sees the same value -- to pinned host memory
+        behind the launches issued so far"""
         if not self.work_bytes:
             return
         if getattr(self, "_health_host", None) is None:
-            self._health_host = torch.zeros(1, dtype=torch.int32).pin_memory()
-            self._health_off = int(self.lib.sgd_igemm_work_status_offset()) // 4
-        self._health_host.copy_(self.work.view(torch.int32)[self._health_off:self._health_off + 1], non_blocking=True)
+            self._health_host = torch.zeros(1, dtype=torch.float32).pin_memory()
+        self._health_host.copy_(flag if flag is not None else self.health_word(), non_blocking=True)
+        self._health_training = flag is not None
         self._health_ev = torch.cuda.Event()
         self._health_ev.record()
 
     def poll_health(self):
-        """look at the last note_health() if its copy has landed (never waits)"""
+        """look at the last note_health() if its copy has landed (never waits: a training step that is found out one
+        iteration later has still not been applied -- the fused optimizer is gated by the same flag on the device)"""
         ev = getattr(self, "_health_ev", None)
         if ev is not None and ev.query():
             self._health_ev = None
-            if int(self._health_host[0]) != 0:
-                self._health_fail()
+            if float(self._health_host[0]) != 0:
+                self._health_fail(training=getattr(self, "_health_training", False))
 
     def set_grid_cap(self, reserve):
         """sgd_igemm_args.grid_cap of every conv / linear launch of the BACKWARD program: all CUs but `reserve` (0: the
@@ -932,8 +965,7 @@ class _Engine:
         self._grid_cap = cap
         bw = getattr(self, "backward", None)
         if bw is not None:
-            for a, _ in bw.late:
-                a.grid_cap = cap
+            bw.apply_grid_cap()
 
     def run(self, x, t, cond, layout, mask, train=False):
         stream = torch.cuda.current_stream().cuda_stream

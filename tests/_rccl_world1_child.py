@@ -105,6 +105,34 @@ def main():
         out["overlap_second_step"] = red.overlap_stats()
         bad2 = [k for k in ref if not torch.equal(model.get_parameter(k).grad, ref[k])]
         out["second_step_mismatched"] = bad2[:8]
+        # ---- C: the exchange entry of the C-ABI (include/sgdm_hip.h: sgd_allreduce_bucket, SURVEY 8(b) last row) on a communicator
+        # made with librccl's OWN API -- what a host that does not go through torch.distributed would do: event behind the
+        # producer, side stream waits, in-place SUM of the bucket, compute stream joins
+        import ctypes as C
+        from sgdm_amd import _lib as L
+        rccl_path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        rccl = C.CDLL(rccl_path)
+
+        class UID(C.Structure):
+            _fields_ = [("internal", C.c_char * 128)]
+        uid, comm = UID(), C.c_void_p()
+        rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UID, C.c_int]
+        rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+        out["cabi_comm_rc"] = [int(rccl.ncclGetUniqueId(C.byref(uid))), int(rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0))]
+        lib = L.load()
+        out["cabi_bind_rc"] = int(lib.sgd_exchange_bind(rccl_path.encode()))
+        buf = torch.randn(1 << 22, device="cuda")
+        want = buf.clone()
+        side, ev = torch.cuda.Stream(), torch.cuda.Event()
+        ev.record()
+        with torch.cuda.stream(side):
+            side.wait_event(ev)
+            out["cabi_allreduce_rc"] = int(lib.sgd_allreduce_bucket(comm, C.c_void_p(buf.data_ptr()), buf.numel(), side.cuda_stream))
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        out["cabi_allreduce_equal"] = bool(torch.equal(buf, want))           # SUM over one rank
+        out["cabi_bad_args_rc"] = int(lib.sgd_allreduce_bucket(None, C.c_void_p(buf.data_ptr()), 4, None))
+        rccl.ncclCommDestroy(comm)
         dist.barrier()
         dist.destroy_process_group()
     print("RESULT " + json.dumps(out), flush=True)

@@ -74,6 +74,77 @@ def test_bucketed_allreduce_world2_gloo():
     assert all(ok for _, ok, _ in res), res
 
 
+def _worker8(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    from sgdm_amd.ddp import BucketReducer, GradArena
+    # the production order of a small unetca_fast-like backward: head first, FiLM stages interleaved, embedding MLPs last;
+    # `to_cond_tokens_2d.*` (off the path, README.md:90-94) is NOT in the arena on any rank
+    shapes = [("out.2.weight", (3, 32, 3, 3)), ("out.2.bias", (3,)), ("output_blocks.2.0.out_layers.3.weight", (32, 32, 3, 3)),
+              ("output_blocks.2.0.emb_layers.1.weight", (64, 128)), ("output_blocks.2.0.emb_layers.1.bias", (64,)),
+              ("middle_block.0.in_layers.2.weight", (64, 64, 3, 3)), ("middle_block.0.emb_layers.1.weight", (128, 128)),
+              ("input_blocks.1.0.in_layers.2.weight", (32, 32, 3, 3)), ("input_blocks.1.0.emb_layers.1.weight", (64, 128)),
+              ("input_blocks.0.0.weight", (32, 3, 3, 3)), ("time_embed.2.weight", (128, 128)), ("time_embed.0.weight", (128, 32)),
+              ("time_embed.0.bias", (128,))]
+    arena = GradArena(shapes, "cpu", bucket_bytes=96 * 1024, tail_bytes=48 * 1024)
+    red = BucketReducer(arena, average=False)             # the product: SUM, 1 / world folded into the producers
+    unused = torch.full((5, 7), 3.25)                     # a parameter gradient outside the arena stays what it was
+    red.start()
+    g = torch.Generator().manual_seed(500 + rank)
+    last = len(arena.buckets) - 1
+    sent_from_hook = []
+    for name, shape in shapes:
+        arena.grad(name).copy_(torch.randn(shape, generator=g) / world)
+        bi = arena.bucket_of[name]
+        if name == arena.buckets[bi][2] and bi != last:  # (train.Backward.wrote: the last bucket waits for the health flag)
+            red.bucket_ready(bi)
+            sent_from_hook.append(bi)
+    arena.health.fill_(1.0 if rank == 3 else 0.0)         # rank 3's balanced tail timed out
+    red.finish()
+    exp = {name: torch.zeros(shape) for name, shape in shapes}
+    for r in range(world):
+        gr = torch.Generator().manual_seed(500 + r)
+        for name, shape in shapes:
+            exp[name] += torch.randn(shape, generator=gr) / world
+    ok = all(torch.allclose(arena.grad(n), exp[n], atol=1e-6) for n, _ in shapes)
+    import hashlib
+    digest = hashlib.sha256(arena.flat.numpy().tobytes()).hexdigest()
+    q.put((rank, ok, tuple(arena.buckets), tuple(sorted(arena.offsets.items())), float(arena.health[0]), digest,
+           float(unused.sum()), tuple(sent_from_hook), arena.flat.numel()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_arena_buckets_and_health_flag_world8_gloo():
+    """what an 8-GPU node would exercise, minus the wire -- eight ranks cut the SAME byte ranges out of
+    the same production order (bucket table and offsets identical on every rank), reduce them to bit-identical sums, leave a
+    gradient that is not on the path alone, cap the last bucket (the only one no launch hides) and carry the step's health flag in
+    its tail slot: one rank's time-out reaches every rank, so every rank's optimizer skips and every rank raises together."""
+    world = 8
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker8, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert all(r[1] for r in res), [r[:2] for r in res]
+    assert len({r[2] for r in res}) == 1 and len({r[3] for r in res}) == 1          # same buckets, same offsets
+    assert len({r[5] for r in res}) == 1                                            # bit-identical arenas after the exchange
+    assert all(r[4] == 1.0 for r in res)                                            # SUM of the flags: everyone knows
+    assert all(r[6] == 3.25 * 35 for r in res)
+    buckets, numel = res[0][2], res[0][8]
+    assert len(buckets) >= 3 and buckets[0][0] == 0 and buckets[-1][1] == numel
+    assert all(a[1] == b[0] for a, b in zip(buckets, buckets[1:]))                   # contiguous, no gaps, no overlap
+    assert (buckets[-1][1] - buckets[-1][0]) * 4 <= 48 * 1024                        # capped tail
+    assert res[0][7] == tuple(range(len(buckets) - 1))                              # every bucket but the last left from its hook
+
+
 def test_arena_views_are_aligned_and_ordered():
     from sgdm_amd.ddp import GradArena
     shapes = [("a", (3,)), ("b", (5, 5)), ("c", (2, 2, 2))]

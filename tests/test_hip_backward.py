@@ -151,7 +151,8 @@ def test_conv_wgrad_split_precision_at_production_shapes(shape, prec, tol):
     err = max_rel(dw.reshape(cout, cin, 3, 3), w.grad.float())
     assert err < tol, err
     if prec != "f32":    # the planes forms (what the training program launches): the same arithmetic, bit for bit
-        # default rule: both operands pre-split for cout > 128, only the gradient rows for a single 128-channel output tile
+        # default rule (csrc/backward.hip: wgrad_planes_ok): both operands pre-split into planes iff cin * cout > 100 * (cin + cout)
+        # (or the fused-average-pool form); narrow layers transform in the loaders
         dw2 = _wgrad(L, lib, fwd, gyd, cout, cin, 9, _train_ksplit(9, cout, cin, n * h * h), scratch=True)
         assert torch.equal(dw, dw2)
         fwd.tune = L.TUNE_WGRAD_PLANES_ALWAYS

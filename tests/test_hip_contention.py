@@ -66,9 +66,11 @@ def _timed(fn, reps):
 
 
 def _occupy(lib, side, blocks, ms):
-    """start the stand-in on the side stream and give it time to become resident"""
+    """start the stand-in on the side stream and give it time to become resident (the stand-in lives in the diagnostics
+    library, include/sgdm_hip_tools.h -- the product library `lib` does not export it)"""
+    from sgdm_amd import _lib as L
     with torch.cuda.stream(side):
-        assert lib.sgd_debug_occupy(blocks, float(ms), side.cuda_stream) == 0
+        assert L.load_tools().sgd_debug_occupy(blocks, float(ms), side.cuda_stream) == 0
     time.sleep(0.003)
 
 
@@ -306,6 +308,35 @@ def test_health_word_is_sticky_and_the_host_paths_raise():
     loss, _ = diff.forward_tao(x0, cond=kw["cond"], cond_drop_prob=0.1)
     loss.backward()
     assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
+    # ---- (3) ADVICE round 5 (medium): the poisoned step must not be APPLIED.  The backward derives a flag from the word, the
+    # fused optimizer takes it as skip_if_nonzero (device side, no host sync), the next step's prepare() raises and clears it.
+    from sgdm_amd.optim import FusedAdamWEma
+    from sgdm_amd.unet import grad_health
+    params = [p for p in model.parameters() if p.requires_grad]
+    opt = FusedAdamWEma(params, lr=1e-3)
+    opt.step()                                                      # healthy step: parameters move
+    torch.cuda.synchronize()
+    before = [p.detach().clone() for p in params]
+    moments = [opt.state[p]["exp_avg"].clone() for p in params if opt.state[p]]
+    opt.zero_grad(set_to_none=True)
+    teng.work.view(torch.int32)[status] = 1                         # a launch of this iteration timed out
+    loss, _ = diff.forward_tao(x0, cond=kw["cond"], cond_drop_prob=0.1)
+    loss.backward()
+    opt.step()
+    torch.cuda.synchronize()
+    assert float(grad_health("cuda")[0]) > 0
+    assert all(torch.equal(a, p.detach()) for a, p in zip(before, params))          # nothing was written
+    assert all(torch.equal(a, opt.state[p]["exp_avg"]) for a, p in zip(moments, [p for p in params if opt.state[p]]))
+    with pytest.raises(RuntimeError, match="repeat the iteration"):
+        diff.forward_tao(x0, cond=kw["cond"], cond_drop_prob=0.1)
+    assert float(grad_health("cuda")[0]) == 0 and int(teng.work.view(torch.int32).abs().sum()) == 0
+    opt.zero_grad(set_to_none=True)
+    loss, _ = diff.forward_tao(x0, cond=kw["cond"], cond_drop_prob=0.1)
+    loss.backward()
+    opt.step()
+    torch.cuda.synchronize()
+    assert all(torch.isfinite(p).all() for p in params)
+    assert any(not torch.equal(a, p.detach()) for a, p in zip(before, params))
 
 
 def test_bench_two_ranks_gloo_on_one_gpu():

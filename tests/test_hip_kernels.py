@@ -768,10 +768,11 @@ def test_head_conv_narrow_out(n, h, w_, cin, cout, pro, silu):
 
 
 def test_device_probes_run_and_report_plausible_rates():
-    """csrc/probe.hip: the in-run device calibration of bench.py and the stream probes behind DESIGN section 9 -- every entry point
-    launches, fills its sink with finite values and lands in a plausible range (a broken probe would silently skew
-    roofline.frac_of_device_ceiling)"""
-    L, lib = _lib()
+    """csrc/tools/probe.hip (libsgdm_hip_tools.so): the in-run device calibration of bench.py and the stream probes behind DESIGN
+    section 9 -- every entry point launches, fills its sink with finite values and lands in a plausible range (a broken probe
+    would silently skew roofline.frac_of_device_ceiling)"""
+    L, _ = _lib()
+    lib = L.load_tools()
     st = _stream()
     cus = torch.cuda.get_device_properties(0).multi_processor_count
     sink = torch.full((4096 * 256,), float("nan"), device="cuda")
@@ -805,5 +806,12 @@ def test_device_probes_run_and_report_plausible_rates():
     assert lib.sgd_debug_mfma_stream_probe(cus, 9000, 7, 4, _p(wbuf), _p(abuf), 1 << 20, _p(sink), st) != 0      # barrier without loaders
     src = torch.randn(1 << 24, device="cuda")
     dst = torch.empty_like(src)
-    t = timed(lambda: L.check(lib.sgd_debug_copy_probe(_p(src), _p(dst), src.numel(), st), "copy probe"))
-    assert torch.equal(src, dst) and 1.0 < 2 * src.numel() * 4 / t / 1e12 < 8.0
+    for variant in (0, 1, 2, 3, 4):
+        dst.zero_()
+        t = timed(lambda: L.check(lib.sgd_debug_copy_probe(_p(src), _p(dst), src.numel(), variant, 0, st), "copy probe"))
+        assert torch.equal(src, dst) and 1.0 < 2 * src.numel() * 4 / t / 1e12 < 8.0, variant
+    t = timed(lambda: L.check(lib.sgd_debug_copy_probe(_p(src), _p(dst), src.numel(), 5, 0, st), "read probe"))
+    assert 1.0 < src.numel() * 4 / t / 1e12 < 8.0
+    assert abs(float(dst[:2048 * 256 * 4].double().sum()) - float(src.double().sum())) < 1e-3 * src.numel() ** 0.5
+    t = timed(lambda: L.check(lib.sgd_debug_copy_probe(_p(src), _p(dst), src.numel(), 6, 0, st), "write probe"))
+    assert 1.0 < src.numel() * 4 / t / 1e12 < 8.0 and float(dst[3::4].min()) == 1.0

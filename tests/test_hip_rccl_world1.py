@@ -65,3 +65,12 @@ def test_training_step_through_world1_rccl_group(workload):
     ov = out["overlap_second_step"]
     assert all(b["complete_at_ms"] - b["enqueued_at_ms"] < 5.0 for b in ov["per_bucket"]), ov
     assert ov["exposed_exchange_ms"] < 2.0, ov
+    # round 6: the tail of the exchange is small BY CONSTRUCTION -- the FiLM projections' gradients leave stage by stage and the
+    # last bucket (complete only with the backward's last launch, sent by finish() with the health flag in its tail slot) is
+    # capped at 16 MB: what is enqueued in the last tenth of the backward is what an 8-GPU run cannot hide
+    assert ov["per_bucket"][-1]["mbytes"] <= 16.1, ov
+    assert ov["mbytes_enqueued_after_0p9_of_backward"] <= 40.0, ov
+    assert ov["per_bucket"][-2]["enqueued_at_ms"] <= 0.97 * ov["backward_ms"], ov
+    # the C-ABI's own exchange entry, on a communicator created with librccl's API (no torch.distributed in between)
+    assert out["cabi_comm_rc"] == [0, 0] and out["cabi_bind_rc"] == 0
+    assert out["cabi_allreduce_rc"] == 0 and out["cabi_allreduce_equal"] is True and out["cabi_bad_args_rc"] == 1

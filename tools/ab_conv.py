@@ -63,7 +63,8 @@ for shp in a.shapes:
             q.res = res.data_ptr()
         q.w, q.cin_p, q.cout_p, q.bias = buf.data_ptr(), cp.value, op.value, bias.data_ptr()
         q.y, q.cout, q.y_ld, q.prec = y.data_ptr(), cout, cout, prec
-        q.tune, q.grid_cap = int(env.pop("tune", 0)), int(env.pop("grid_cap", 0))
+        q.tune, q.grid_cap = int(env.get("tune", 0)), int(env.get("grid_cap", 0))
+        env = {k: v for k, v in env.items() if k not in ("tune", "grid_cap")}     # (a copy: the variant serves every shape)
         if hasattr(lib, "sgd_igemm_work_bytes"):            # balanced tail (tune=16 turns it off)
             wb = int(lib.sgd_igemm_work_bytes())
             if name not in WORK:

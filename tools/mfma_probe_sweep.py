@@ -7,7 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "self-guided-diffusion-models_amd"))
 import torch
 from sgdm_amd import _lib as L
-lib = L.load()
+lib = L.load_tools()
 st = torch.cuda.current_stream().cuda_stream
 cus = torch.cuda.get_device_properties(0).multi_processor_count
 sink = torch.empty(4096 * 256, device="cuda")

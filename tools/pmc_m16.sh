@@ -1,6 +1,6 @@
 #!/bin/bash
 # Effective clock and matrix-pipe duty of the 3x3 conv kernel in its two MFMA forms (run on the GPU box, repo root):
-#   tools/pmc_m16.sh gpurun_out/r3_pmc_m16.txt     (needs libsgdm_hip_nom16.so: apply profiles/r5_igemm_experiments.patch, then SGDM_BUILD_TAG=_nom16 SGDM_EXTRA_FLAGS=-DSGDM_NO_MFMA16 build.py;
+#   tools/pmc_m16.sh gpurun_out/r3_pmc_m16.txt     (needs libsgdm_hip_nom16.so: git show 4ce7de0:profiles/r5_igemm_experiments.patch | git apply, then SGDM_BUILD_TAG=_nom16 SGDM_EXTRA_FLAGS=-DSGDM_NO_MFMA16 build.py;
 #   the 128-column tile is the default for these shapes, no tile override needed)
 OUT="${GRAFT_REPO_ROOT:-/root/repo}/$1"
 L=self-guided-diffusion-models_amd/sgdm_amd/lib
