@@ -351,7 +351,9 @@ def train_step_bench(model, diff, data, cond, layout, B, world, barrier, wl, ste
                 reserved_cus=int(ddp.reserved_cus(model)),
                 exchange_ms=ov.get("exchange_ms"), exposed_exchange_ms=ov.get("exposed_exchange_ms"),
                 first_bucket_at_frac_of_backward=ov.get("first_bucket_at_frac_of_backward"),
-                exchange_buckets=ov.get("per_bucket"), exchange_backward_ms=ov.get("backward_ms"))
+                exchange_buckets=ov.get("per_bucket"), exchange_backward_ms=ov.get("backward_ms"),
+                modelled_exposed_ms_at_50GBps=ov.get("modelled_exposed_ms_at_50GBps"),
+                modelled_exposed_ms_at_100GBps=ov.get("modelled_exposed_ms_at_100GBps"))
 
 
 def exchange_probe(args, TB):
@@ -401,17 +403,61 @@ def exchange_probe_child(args):
         def barrier():
             torch.cuda.synchronize()
         rec = train_step_bench(model, diff, tdata, tcond, tlayout, TB, 1, barrier, wl, steps=4, warmup=3)
+        # The price of the exchange's machinery on ONE device, in ONE process (box-to-box and process-to-process spread is as
+        # large as the effect): the same step (a) as above -- arena, buckets, collectives, the CU reserve inside its windows --,
+        # (b) with the reserve on every backward launch (round 5), (c) plain single-process (no arena, no reserve);
+        # interleaved, three rounds of four steps each.
+        eng = [e for e in model._engines.values() if e.n == TB and getattr(e, "backward", None) is not None][0]
+        bw_x = eng.backward
+        from sgdm_amd.optim import FusedAdamWEma
+        opt = FusedAdamWEma([p for p in model.parameters() if p.requires_grad], lr=1e-4, weight_decay=0.01)
+        x_ = tdata["image"].to(dev)
+        model.train(); diff.train()
+
+        def steps_ms(k=4):
+            def one():
+                loss, _ = diff.forward_tao(x_, cond=tcond, layout=tlayout, cond_drop_prob=0.1)
+                opt.zero_grad(set_to_none=True)
+                loss.backward()
+                opt.step()
+            one()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(k):
+                one()
+            torch.cuda.synchronize()
+            return 1000.0 * (time.perf_counter() - t0) / k
+        res = dict(windows=[], every_launch=[], plain=[])
+        bw_plain = None
+        for _ in range(3):
+            model.hip_ddp, eng.backward = True, bw_x
+            os.environ["SGDM_RESERVE_WINDOWS"] = "1"; bw_x.apply_grid_cap()
+            res["windows"].append(steps_ms())
+            os.environ["SGDM_RESERVE_WINDOWS"] = "0"; bw_x.apply_grid_cap()
+            res["every_launch"].append(steps_ms())
+            model.hip_ddp, eng.backward = False, bw_plain
+            res["plain"].append(steps_ms())
+            bw_plain = eng.backward
+        os.environ["SGDM_RESERVE_WINDOWS"] = "1"
+        model.hip_ddp, eng.backward = True, bw_x
+        eng._grid_cap = -1                                # (force the next set_grid_cap to re-apply)
+        eng.set_grid_cap(16)
+        rec["same_process_ms"] = {k: round(sorted(v)[1], 2) for k, v in res.items()}
+        caps = [int(a_.grid_cap) for a_, _ in bw_x.late]
+        rec["reserve_windows"] = dict(capped_launches=sum(1 for c_ in caps if c_ > 0), conv_launches=len(caps),
+                                      program_entries_inside=list(bw_x._windows or ()))
         dist.destroy_process_group()
     keep = ("ms", "batch_per_gpu", "steps", "world_size", "backend", "exchange", "reserved_cus", "exchange_ms",
-            "exposed_exchange_ms", "first_bucket_at_frac_of_backward", "exchange_backward_ms", "exchange_buckets")
-    print("EXCHANGE " + json.dumps({k: rec[k] for k in keep}), flush=True)
+            "exposed_exchange_ms", "first_bucket_at_frac_of_backward", "exchange_backward_ms", "exchange_buckets",
+            "modelled_exposed_ms_at_50GBps", "modelled_exposed_ms_at_100GBps", "same_process_ms", "reserve_windows")
+    print("EXCHANGE " + json.dumps({k: rec.get(k) for k in keep}), flush=True)
 
 
 def device_probe(dev, seconds=0.15):
     """what THIS device delivers right now: the boxes of the pool differ by 5-7 % for one binary
     and the chip trades clock for matrix-pipe duty, so the roofline fraction is reported a second time against a ceiling
     measured in this process, seconds after the timed steps: a bare v_mfma_f32_16x16x32_f16 loop on random register operands
-    (one wave per SIMD on every CU, csrc/probe.hip) and a 16-byte grid-stride copy of 256 MiB."""
+    (one wave per SIMD on every CU, csrc/tools/probe.hip) and 16-byte-per-lane copy / read / write streams over 256 MiB."""
     from sgdm_amd import _lib as L
     lib = L.load_tools()                                  # diagnostics library (include/sgdm_hip_tools.h), not the product's
     st = torch.cuda.current_stream().cuda_stream
@@ -429,14 +475,25 @@ def device_probe(dev, seconds=0.15):
     iters = max(1000, int(iters * seconds / max(t, 1e-6)))          # one launch of ~`seconds`: the clock settles under the load
     t = timed(run)
     mfma_tf = float(lib.sgd_debug_mfma_probe_flops(cus, iters, 0)) / t / 1e12
+    # HBM twin of the MFMA probe.  The round-5 copy probe read 4.6-4.8 TB/s against the guide's 6.29
+    # because of its ACCESS SHAPE, not its size: a lane's four loads were 8 MB apart (grid-stride).  tools/hbm_probe_sweep.py
+    # (profiles/r6_hbm_probe_sweep.txt): every wave walking contiguous 8 KiB pieces with non-temporal accesses copies 256 MiB
+    # at 6.2-6.5 TB/s, reads at 6.6 and writes at 6.9 -- the figures reported here (variant 4 / 5 / 6 of the probe, grid 8192).
     n = 64 << 20                                                      # floats: 256 MiB read + 256 MiB written per pass
     src, dst = torch.randn(n, device=dev), torch.empty(n, device=dev)
-    cp = lambda: [L.check(lib.sgd_debug_copy_probe(C_void(src), C_void(dst), n, 0, 0, st), "copy_probe") for _ in range(10)]
-    cp()
-    tc = timed(cp)
+
+    def rate(variant, grid, nbytes):
+        fn = lambda: [L.check(lib.sgd_debug_copy_probe(C_void(src), C_void(dst), n, variant, grid, st), "copy_probe") for _ in range(10)]
+        fn()
+        return 10 * nbytes / timed(fn) / 1e12
+    copy_tbps = rate(4, 8192, 2 * 4.0 * n)
     assert torch.equal(src[-4096:], dst[-4096:])
+    stride_tbps = rate(0, 2048, 2 * 4.0 * n)
+    read_tbps = rate(5, 2048, 4.0 * n)
+    write_tbps = rate(6, 8192, 4.0 * n)
     return dict(device_mfma_tflops=round(mfma_tf, 1), device_mfma_probe_ms=round(t * 1e3, 1),
-                device_copy_tbps=round(10 * 2 * 4.0 * n / tc / 1e12, 3), device_cus=cus)
+                device_copy_tbps=round(copy_tbps, 3), device_read_tbps=round(read_tbps, 3), device_write_tbps=round(write_tbps, 3),
+                device_copy_tbps_grid_stride=round(stride_tbps, 3), device_cus=cus)
 
 
 def C_void(t):

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define SGD_ABI_VERSION 18
+#define SGD_ABI_VERSION 19
 int sgd_abi_version(void);
 /* 16 hex digits identifying the sources and flags the library was compiled from (build.py: source_id()); static storage.
  * __graft_entry__.build() and tests/test_boundary_cpu.py compare it with the tree on disk. */
@@ -430,7 +430,9 @@ int sgd_gn_bwd_reduce(const float* x, int32_t n, int32_t h, int32_t w, int32_t c
 /* per-(n,c) coefficients of dx = A*gpre + B*x + C from S and the forward statistics (`sums` of sgd_chan_stats),
  * plus per-sample parameter gradients dgamma_nc / dbeta_nc [n, c] (sum over n with sgd_colsum) and the FiLM
  * gradient dfilm[n, film_ld] (scale grad at +0, shift grad at +c; may be NULL). */
-int sgd_gn_bwd_coef(const float* S, const float* sums, const float* gamma, const float* beta,
+/* ABI 19: S is [n, c, 2] (s_chunks = 1: sgd_gn_bwd_reduce) or the per-chunk partial sums [n, s_chunks, c, 2] of sgd_gn_bwd_reduce_rows,
+ * which the coefficient kernels fold in chunk order themselves. */
+int sgd_gn_bwd_coef(const float* S, int32_t s_chunks, const float* sums, const float* gamma, const float* beta,
                     const float* film, int32_t film_ld, int32_t n, int32_t c, int32_t groups, int32_t hw, float eps,
                     float* A, float* B, float* Cc, float* dgamma_nc, float* dbeta_nc /* [n, c]: fold with sgd_colsum */,
                     float* dfilm, void* stream);
@@ -439,9 +441,18 @@ int sgd_gn_bwd_coef(const float* S, const float* sums, const float* gamma, const
 /* sgd_gn_bwd_coef + sgd_colsum_pair(dgamma_nc, dbeta_nc) in one launch (n <= 256, 8 * n * c / groups + 32 * n + 4 <= 64 KiB of LDS, else
  * SGD_ERR_ARG: use the two calls): A, B, Cc, dfilm as sgd_gn_bwd_coef; dgamma[c] / dbeta[c] (+)= scale * column sums over the
  * images, bit-identical to the two-call route. */
-int sgd_gn_bwd_coef_fold(const float* S, const float* sums, const float* gamma, const float* beta, const float* film,
+int sgd_gn_bwd_coef_fold(const float* S, int32_t s_chunks, const float* sums, const float* gamma, const float* beta, const float* film,
                          int32_t film_ld, int32_t n, int32_t c, int32_t groups, int32_t hw, float eps, float* A, float* B,
                          float* Cc, float* dfilm, float* dgamma, float* dbeta, int32_t accumulate, float scale, void* stream);
+/* ABI 19: the reduce pass as a row stream (same-resolution gradient only; csrc/backward.hip "Round 6"): every wave walks contiguous
+ * 8 KiB pieces of the tensors' rows, a block = one chunk of an image.  sgd_gn_bwd_rows_chunks: chunks per image of a shape, 0 = not
+ * served (fewer than 32 x 32 pixels, channel count not a power of two in 16 .. 1024, image not a whole number of 32 KiB windows:
+ * use sgd_gn_bwd_reduce).  sgd_gn_bwd_reduce_rows: P[n, chunks, c_total, 2] partial sums (any `chunks` that divides the shape's own
+ * count: the sources of a concatenated GroupNorm share one table), folded by sgd_gn_bwd_coef(_fold) with s_chunks = chunks. */
+int sgd_gn_bwd_rows_chunks(int32_t n, int32_t h, int32_t w, int32_t c);
+int sgd_gn_bwd_reduce_rows(const float* x, int32_t n, int32_t h, int32_t w, int32_t c, int32_t c_total, int32_t c_off,
+                           const float* a, const float* b, int32_t silu, const float* gu, int32_t gu_ld, float drop_p,
+                           uint32_t drop_seed, int32_t chunks, float* P, void* stream);
 int sgd_gn_bwd_apply(const float* x, int32_t n, int32_t h, int32_t w, int32_t c, int32_t c_total, int32_t c_off,
                      const float* a, const float* b, int32_t silu,
                      const float* gu, int32_t gu_ld, int32_t gu_mode, float drop_p, uint32_t drop_seed,

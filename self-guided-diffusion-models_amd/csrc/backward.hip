@@ -1486,7 +1486,22 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const float* __restr
     }
 }
 
-__global__ void gn_bwd_coef_kernel(const float* __restrict__ S, const float* __restrict__ sums,
+// S of the GroupNorm-backward coefficient kernels: [n][c][2] (chunks = 1, sgd_gn_bwd_reduce) or the per-chunk partial sums
+// [n][chunks <= 16][c][2] of sgd_gn_bwd_reduce_rows, folded here -- no launch of its own for the fold: the partials of one
+// (image, channel) are requested together (sixteen independent loads; a `t += S[..]` loop is one memory latency per chunk), added
+// in chunk order in double and rounded to float ONCE, as a separate fold kernel writing S[n][c][2] would have done
+__device__ __forceinline__ float s_fold(const float* __restrict__ S, int chunks, int c, int nn, int cc, int which) {
+    if (chunks == 1) return S[((long)nn * c + cc) * 2 + which];
+    float v[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v[k] = S[(((long)nn * chunks + (k < chunks ? k : chunks - 1)) * c + cc) * 2 + which];
+    double t = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += k < chunks ? (double)v[k] : 0.0;
+    return (float)t;
+}
+
+__global__ void gn_bwd_coef_kernel(const float* __restrict__ S, int chunks, const float* __restrict__ sums,
                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                    const float* __restrict__ film, int film_ld, int n, int c, int groups, int hw,
                                    float eps, float* __restrict__ A, float* __restrict__ B, float* __restrict__ Cc,
@@ -1511,14 +1526,15 @@ __global__ void gn_bwd_coef_kernel(const float* __restrict__ S, const float* __r
         const long j = (long)nn * c + g0 + k;
         const double sc = film ? 1.0 + film[(long)nn * film_ld + g0 + k] : 1.0;
         const double gp = gamma[g0 + k] * sc;
-        const double S1 = S[j * 2], X = r * (S[j * 2 + 1] - mean * S1);
+        const double S1 = s_fold(S, chunks, c, nn, g0 + k, 0), X = r * (s_fold(S, chunks, c, nn, g0 + k, 1) - mean * S1);
         m1 += gp * S1;
         m2 += gp * X;
+        (void)j;
     }
     m1 /= m;
     m2 /= m;
     const double sc = film ? 1.0 + film[(long)nn * film_ld + cc] : 1.0;
-    const double S1 = S[i * 2], X = r * (S[i * 2 + 1] - mean * S1);
+    const double S1 = s_fold(S, chunks, c, nn, cc, 0), X = r * (s_fold(S, chunks, c, nn, cc, 1) - mean * S1);
     A[i] = (float)(r * gamma[cc] * sc);
     B[i] = (float)(-r * r * m2);
     Cc[i] = (float)(r * r * m2 * mean - r * m1);
@@ -1535,7 +1551,7 @@ __global__ void gn_bwd_coef_kernel(const float* __restrict__ S, const float* __r
 // gn_bwd_coef_kernel does, leaves its dgamma / dbeta contributions in LDS tables [n][cpg], and the block then sums the
 // tables' columns over the images in colsum_stage1_kernel's order (8 row lanes, rows rl, rl + 8, .. in float; the lanes
 // folded in float; double * scale): bit-identical to the two-launch route.
-__global__ __launch_bounds__(256) void gn_bwd_coef_fold_kernel(const float* __restrict__ S, const float* __restrict__ sums,
+__global__ __launch_bounds__(256) void gn_bwd_coef_fold_kernel(const float* __restrict__ S, int chunks, const float* __restrict__ sums,
                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                const float* __restrict__ film, int film_ld, int n, int c,
                                                                int groups, int hw, float eps, float* __restrict__ A,
@@ -1547,6 +1563,19 @@ __global__ __launch_bounds__(256) void gn_bwd_coef_fold_kernel(const float* __re
     float* const tdg = tab;
     float* const tdb = tab + (size_t)n * cpg;
     double* const gst = reinterpret_cast<double*>(tab + (size_t)2 * n * cpg + ((2 * n * cpg) & 1));   // [n][4], 8-byte aligned
+    // chunked S (sgd_gn_bwd_reduce_rows): the group's folded sums once, by all threads, into LDS [n][cpg][2] behind the other
+    // tables -- the thread-per-image loop below would otherwise walk cpg x 2 x chunks dependent global loads
+    float* const sl = reinterpret_cast<float*>(gst + (size_t)n * 4);
+    if (chunks > 1) {
+        for (int it = threadIdx.x; it < n * cpg * 2; it += blockDim.x) {
+            const int nn = it / (cpg * 2), r = it - nn * (cpg * 2);
+            sl[it] = s_fold(S, chunks, c, nn, g0 + (r >> 1), r & 1);
+        }
+        __syncthreads();
+    }
+    auto sget = [&](int nn, int kk, int which) -> double {
+        return chunks > 1 ? (double)sl[(nn * cpg + kk) * 2 + which] : (double)S[((long)nn * c + g0 + kk) * 2 + which];
+    };
     // the group quantities ONCE per image (gn_bwd_coef_kernel recomputes them in every one of the group's cpg threads -- fine
     // over n * c / 256 blocks, not inside the 32 blocks of this launch): same additions in the same order, so the same bits
     for (int nn = threadIdx.x; nn < n; nn += blockDim.x) {
@@ -1565,9 +1594,10 @@ __global__ __launch_bounds__(256) void gn_bwd_coef_fold_kernel(const float* __re
             const long j = (long)nn * c + g0 + k;
             const double sc = film ? 1.0 + film[(long)nn * film_ld + g0 + k] : 1.0;
             const double gp = gamma[g0 + k] * sc;
-            const double S1 = S[j * 2], X = r * (S[j * 2 + 1] - mean * S1);
+            const double S1 = sget(nn, k, 0), X = r * (sget(nn, k, 1) - mean * S1);
             m1 += gp * S1;
             m2 += gp * X;
+            (void)j;
         }
         m1 /= m;
         m2 /= m;
@@ -1579,7 +1609,7 @@ __global__ __launch_bounds__(256) void gn_bwd_coef_fold_kernel(const float* __re
         const long i = (long)nn * c + cc;
         const double mean = gst[nn * 4], r = gst[nn * 4 + 1], m1 = gst[nn * 4 + 2], m2 = gst[nn * 4 + 3];
         const double sc = film ? 1.0 + film[(long)nn * film_ld + cc] : 1.0;
-        const double S1 = S[i * 2], X = r * (S[i * 2 + 1] - mean * S1);
+        const double S1 = sget(nn, kk, 0), X = r * (sget(nn, kk, 1) - mean * S1);
         A[i] = (float)(r * gamma[cc] * sc);
         B[i] = (float)(-r * r * m2);
         Cc[i] = (float)(r * r * m2 * mean - r * m1);
@@ -1655,6 +1685,89 @@ __global__ void gn_bwd_apply_kernel(const float* __restrict__ x, int n, int h, i
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 6: the REDUCE pass of the GroupNorm backward as a row stream.  The round-1 kernel above reads the tensors in 128-byte
+// segments (a block per (image, 32-channel slab): eight pixel rows of 128 bytes per wave instruction, four blocks sharing every
+// 512-byte row of a 128-channel map): 4.5-5.1 TB/s, 3.9 with the dropout hash.  tools/hbm_probe_sweep.py says what the memory
+// system wants (profiles/r6_hbm_probe_sweep.txt): every wave walking CONTIGUOUS 8 KiB pieces -- eight consecutive 1 KiB wave
+// instructions in flight -- reads at 6.6 TB/s, against 4.7 for the same bytes with a lane's loads megabytes apart.  So: a block =
+// one image chunk, all channels; a wave = 8 KiB pieces of the chunk's rows; a lane's channel quad is fixed (c <= 256) or cycles
+// through NSET = c / 256 sets with the piece's instructions, so the per-(image, channel) coefficients are loaded once per block;
+// per-chunk partial sums, folded by the coefficient launch (s_fold).  tools/bench_gn_bwd.py, UNet batch 80 (profiles/
+// r6_gn_bwd_rows.txt): 5.4-5.9 TB/s on the 64x64 and 32x32 maps (+13-20 %; with dropout 5.5 vs 3.9), SLOWER on 16x16 maps (one or
+// two windows per block): sgd_gn_bwd_rows_chunks serves h * w >= 1024 only.  The APPLY pass as the same stream (eight quads of x,
+// gradient, residual gradient in flight per lane, non-temporal loads) measured 3.1-3.5 TB/s against the round-1 kernel's 5.5-6.0
+// (one quad per thread, 40,960 blocks): not shipped -- that pass already runs at the copy rate of this memory system.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int GR_U = 8;                              // 1 KiB wave instructions per piece
+constexpr int GR_WIN = 4 * GR_U * 64;                // quads of one block window (4 waves x 8 KiB)
+
+template <int NSET>
+__global__ __launch_bounds__(256) void gn_bwd_reduce_rows_kernel(const float* __restrict__ x, int hw, int c, int c_total, int c_off,
+                                                                 const float* __restrict__ a, const float* __restrict__ b, int silu,
+                                                                 const float* __restrict__ gu, int gu_ld, float drop_p,
+                                                                 uint32_t drop_seed, int chunks, float* __restrict__ P) {
+    const int n = blockIdx.x / chunks, chunk = blockIdx.x - n * chunks;
+    const int cq = c >> 2, cq_l2 = 31 - __builtin_clz(cq);          // c is a power of two (sgd_gn_bwd_rows_chunks)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long chunk_quads = (long)hw * cq / chunks;             // a multiple of GR_WIN
+    const long q0 = (long)n * hw * cq + chunk * chunk_quads;     // first quad of the chunk in x
+    f32x4 av[NSET], bv[NSET];
+    float s1[NSET][4], s2[NSET][4];
+#pragma unroll
+    for (int sx = 0; sx < NSET; ++sx) {
+        const int ch = ((sx * 64 + lane) % cq) * 4;
+        av[sx] = ld4(a + (long)n * c_total + c_off + ch);
+        bv[sx] = ld4(b + (long)n * c_total + c_off + ch);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s1[sx][j] = s2[sx][j] = 0.f;
+    }
+    for (long wq = 0; wq < chunk_quads; wq += GR_WIN) {
+        const long base = q0 + wq + (long)wave * (GR_U * 64) + lane;       // this lane's quad of instruction u: base + 64 u
+        f32x4 xv[GR_U], gv[GR_U];
+#pragma unroll
+        for (int u = 0; u < GR_U; ++u) {
+            const long q = base + 64 * u;
+            const long row = q >> cq_l2;
+            const int ch = (int)(q & (cq - 1)) * 4;
+            xv[u] = ld4(x + q * 4);
+            gv[u] = ld4(gu + row * gu_ld + c_off + ch);
+        }
+#pragma unroll
+        for (int u = 0; u < GR_U; ++u) {
+            const int sx = NSET == 1 ? 0 : (u % NSET);           // (wave * GR_U * 64 is a multiple of 256 quads: the set follows u)
+            f32x4 g = gv[u];
+            if (drop_p > 0.f) {
+                const long q = base + 64 * u;
+                g = sgd_drop4(g, drop_p, drop_seed, (q >> cq_l2) * c_total + c_off + (int)(q & (cq - 1)) * 4);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float gp = g[j];
+                if (silu) gp *= dsilu(av[sx][j] * xv[u][j] + bv[sx][j]);
+                s1[sx][j] += gp;
+                s2[sx][j] += gp * xv[u][j];
+            }
+        }
+    }
+    // fold the threads that share a channel quad (fixed order, double): thread t, set sx holds quad (sx * 64 + lane) % cq
+    __shared__ float red[256][NSET][8];
+#pragma unroll
+    for (int sx = 0; sx < NSET; ++sx)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { red[threadIdx.x][sx][j] = s1[sx][j]; red[threadIdx.x][sx][4 + j] = s2[sx][j]; }
+    __syncthreads();
+    const int cl = cq < 64 ? cq : 64;                              // distinct quads per (wave, set)
+    for (int o = threadIdx.x; o < cq * 8; o += 256) {
+        const int qd = o >> 3, j = o & 7;
+        const int sx = qd / 64, l0 = qd % 64;                      // cq < 64: sx = 0, lanes l0, l0 + cq, ..
+        double t = 0;
+        for (int w = 0; w < 4; ++w)
+            for (int l = l0; l < 64; l += cl) t += red[w * 64 + l][sx][j];
+        P[(((long)n * chunks + chunk) * c_total + c_off + qd * 4 + (j & 3)) * 2 + (j >> 2)] = (float)t;
+    }
+}
 
 // adjoint of the 2x resamplers applied to a gradient map (Upsample / avg-pool Downsample layers):
 //   mode UP2 (forward nearest-upsampled): dst[n,y,x,:] (+)= sum of the 2x2 block of g (g at 2x resolution)
@@ -1962,35 +2075,65 @@ extern "C" int sgd_gn_bwd_reduce(const float* x, int32_t n, int32_t h, int32_t w
     return sgd_check_launch();
 }
 
-extern "C" int sgd_gn_bwd_coef(const float* S, const float* sums, const float* gamma, const float* beta,
+// chunks of an image for the row-stream reduce (0: the shape is not served -- use sgd_gn_bwd_reduce): at least 32 x 32 pixels, the
+// image a whole number of 32 KiB windows, at most 16 chunks, the channel count a power of two that the lane map closes over
+extern "C" int sgd_gn_bwd_rows_chunks(int32_t n, int32_t h, int32_t w, int32_t c) {
+    if (n <= 0 || h <= 0 || w <= 0 || c < 16 || c > 1024 || (c & (c - 1)) || (long)h * w < 1024) return 0;
+    const long quads = (long)h * w * (c >> 2);
+    if (quads % GR_WIN) return 0;
+    long k = quads / GR_WIN;
+    while (k > 16 && (k & 1) == 0) k >>= 1;
+    return k <= 16 ? (int)k : 0;
+}
+
+extern "C" int sgd_gn_bwd_reduce_rows(const float* x, int32_t n, int32_t h, int32_t w, int32_t c, int32_t c_total, int32_t c_off,
+                                      const float* a, const float* b, int32_t silu, const float* gu, int32_t gu_ld, float drop_p,
+                                      uint32_t drop_seed, int32_t chunks, float* P, void* stream) {
+    SGD_CLEAR_ERR();
+    // (any divisor of the shape's own chunk count: the sources of a concatenated GroupNorm share one partial table)
+    const int kmax = sgd_gn_bwd_rows_chunks(n, h, w, c);
+    if (!x || !a || !b || !gu || !P || (c_off & 3) || c_off + c > c_total || (gu_ld & 3) || chunks <= 0 || kmax <= 0 || kmax % chunks)
+        return SGD_ERR_ARG;
+    const int nset = c <= 256 ? 1 : c / 256;
+    const dim3 grid(n * chunks), blk(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (nset == 1) hipLaunchKernelGGL(gn_bwd_reduce_rows_kernel<1>, grid, blk, 0, st, x, h * w, c, c_total, c_off, a, b, silu, gu, gu_ld, drop_p, drop_seed, chunks, P);
+    else if (nset == 2) hipLaunchKernelGGL(gn_bwd_reduce_rows_kernel<2>, grid, blk, 0, st, x, h * w, c, c_total, c_off, a, b, silu, gu, gu_ld, drop_p, drop_seed, chunks, P);
+    else hipLaunchKernelGGL(gn_bwd_reduce_rows_kernel<4>, grid, blk, 0, st, x, h * w, c, c_total, c_off, a, b, silu, gu, gu_ld, drop_p, drop_seed, chunks, P);
+    return sgd_check_launch();
+}
+
+extern "C" int sgd_gn_bwd_coef(const float* S, int32_t s_chunks, const float* sums, const float* gamma, const float* beta,
                                const float* film, int32_t film_ld, int32_t n, int32_t c, int32_t groups, int32_t hw,
                                float eps, float* A, float* B, float* Cc, float* dgamma_nc, float* dbeta_nc,
                                float* dfilm, void* stream) {
     SGD_CLEAR_ERR();
-    if (!S || !sums || !gamma || !beta || !A || !B || !Cc || !dgamma_nc || !dbeta_nc || n <= 0 || c <= 0 ||
+    if (!S || s_chunks <= 0 || s_chunks > 16 || !sums || !gamma || !beta || !A || !B || !Cc || !dgamma_nc || !dbeta_nc || n <= 0 || c <= 0 ||
         groups <= 0 || c % groups || hw <= 0)
         return SGD_ERR_ARG;
     if ((film || dfilm) && film_ld < 2 * c) return SGD_ERR_ARG;
-    hipLaunchKernelGGL(gn_bwd_coef_kernel, dim3(nblk((long)n * c)), dim3(256), 0, (hipStream_t)stream, S, sums, gamma,
+    hipLaunchKernelGGL(gn_bwd_coef_kernel, dim3(nblk((long)n * c)), dim3(256), 0, (hipStream_t)stream, S, s_chunks, sums, gamma,
                        beta, film, film_ld, n, c, groups, hw, eps, A, B, Cc, dgamma_nc, dbeta_nc, dfilm);
     return sgd_check_launch();
 }
 
-extern "C" int sgd_gn_bwd_coef_fold(const float* S, const float* sums, const float* gamma, const float* beta, const float* film,
+extern "C" int sgd_gn_bwd_coef_fold(const float* S, int32_t s_chunks, const float* sums, const float* gamma, const float* beta, const float* film,
                                     int32_t film_ld, int32_t n, int32_t c, int32_t groups, int32_t hw, float eps, float* A, float* B,
                                     float* Cc, float* dfilm, float* dgamma, float* dbeta, int32_t accumulate, float scale,
                                     void* stream) {
     SGD_CLEAR_ERR();
-    if (!S || !sums || !gamma || !beta || !A || !B || !Cc || !dgamma || !dbeta || n <= 0 || n > 256 || c <= 0 || groups <= 0 ||
+    if (!S || s_chunks <= 0 || !sums || !gamma || !beta || !A || !B || !Cc || !dgamma || !dbeta || n <= 0 || n > 256 || c <= 0 || groups <= 0 ||
         c % groups || hw <= 0)
         return SGD_ERR_ARG;
     if ((film || dfilm) && film_ld < 2 * c) return SGD_ERR_ARG;
     const int cpg = c / groups;
-    const size_t lds = (size_t)(2 * n * cpg + 1) * sizeof(float) + (size_t)n * 4 * sizeof(double);
+    if (s_chunks > 16) return SGD_ERR_ARG;
+    const size_t lds = (size_t)(2 * n * cpg + 1) * sizeof(float) + (size_t)n * 4 * sizeof(double)
+                       + (s_chunks > 1 ? (size_t)2 * n * cpg * sizeof(float) : 0);           // + the folded sums of a chunked S
     // (+ the kernel's static red[2][8][32]: 2 KB of the same 64 KB default limit; callers fall back to sgd_gn_bwd_coef +
     // sgd_colsum_pair -- train.Backward.gn_bwd applies the same bound)
     if (lds + 2048 > 64 * 1024) return SGD_ERR_ARG;
-    hipLaunchKernelGGL(gn_bwd_coef_fold_kernel, dim3(groups), dim3(256), lds, (hipStream_t)stream, S, sums, gamma, beta, film,
+    hipLaunchKernelGGL(gn_bwd_coef_fold_kernel, dim3(groups), dim3(256), lds, (hipStream_t)stream, S, s_chunks, sums, gamma, beta, film,
                        film_ld, n, c, groups, hw, eps, A, B, Cc, dfilm, dgamma, dbeta, accumulate, scale);
     return sgd_check_launch();
 }

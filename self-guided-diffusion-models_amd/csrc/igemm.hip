@@ -390,7 +390,7 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
     // sampling step 19.5 -> 18.4 ms.  Same matrix-pipe cycles per flop, but the chip is power-limited under this load
     // and the smaller MFMA sustains a higher clock.  The loader-side epilogue (DEFER) and the 128 x 256 tile keep the
     // 32x32x16 form (the 16x16 form on the wide tile was built and lost 0..14 % to the 128 x 128 tile on every shape:
-    // profiles/r4_ab_m16_256.txt; the code is profiles/r5_igemm_experiments.patch).
+    // profiles/r4_ab_m16_256.txt; round 6 ported DEFER to the 16x16 form: still slower, profiles/r6_ab_defer_m16.txt).
     constexpr bool M16 = PREC != SGD_PREC_F32 && BN <= 128 && !DEFER;
     constexpr int RB = M16 ? WM / 16 : MT, RBH = M16 ? 16 : 32;
     constexpr int CBN = M16 ? WN / 16 : NT, CBW = M16 ? 16 : 32;      // column blocks of a wave tile and their width
@@ -2163,9 +2163,9 @@ extern "C" int sgd_igemm(const sgd_igemm_args* args, void* stream) {
     // DESIGN.md section 4 (round 4) and profiles/r4_ln_hazard.txt hold what tools/ln_hazard.py established: the wrong
     // cells hold exactly beta in the low lane of a packed-f32 pair (the LayerNorm value with a zero product), in three of
     // the six unrolled copies of the staging code only; no wait or idle cycle around the loads or the LDS stores changes
-    // it, moving the surrounding code does.  Cause open (profiles/r5_igemm_experiments.patch re-adds the diagnostic
-    // build of the combination).  A 0.3 % gain does not buy an unexplained failure mode: the instance is not a default,
-    // and never serves that prologue.
+    // it, moving the surrounding code does.  Round 6: with packed-f32 code generation off the same two-plane instance passes
+    // 240 of 240 launches that fail 238 of 240 with it on (tools/ln_hazard.py, profiles/r6_ln_hazard.txt), so every
+    // LayerNorm launch of a split mode runs on the no-packed-f32 unit (ln_nopk below); the two-plane instance stays opt-in.
     int taps = conv ? 9 : 1;
     // LayerNorm-row prologue in a split mode: the unit without packed-f32 instructions (SGD_TUNE_LN_PACKED: the regular unit --
     // tools/ln_hazard.py reproduces the round-4 fault with it); only there may the two-plane instance serve that prologue

@@ -154,26 +154,6 @@ class BucketReducer:
         self.marks, self.t_bwd_end = [], None
         self.t_start = self._mark() if self.active else None
 
-    def new_durations(self):
-        """True once per completed step: its per-bucket collective durations can be read without waiting"""
-        marks = self.marks
-        if not marks or marks is getattr(self, "_dur_from", None) or any(r[2] is None for r in marks):
-            return False
-        if self.cuda and not all(r[2].query() for r in marks):
-            return False
-        if self.cuda:
-            d = {r[0]: float(r[1].elapsed_time(r[2])) for r in marks}       # enqueue point -> completion, per bucket
-        else:
-            d = {r[0]: 1000.0 * (r[2] - r[1]) for r in marks}
-        # slowly forgetting maximum: one slow collective widens its window at once, a window shrinks over ~10 steps
-        old = getattr(self, "_durations", None) or {}
-        self._durations = {k: max(v, 0.9 * old.get(k, 0.0)) for k, v in d.items()}
-        self._dur_from = marks
-        return True
-
-    def bucket_durations_ms(self):
-        return getattr(self, "_durations", None)
-
     def backward_done(self):
         """call when the last launch of the backward program has been issued (before finish)"""
         if self.active:
@@ -243,7 +223,18 @@ class BucketReducer:
         end = [el(self.t_start, r[2]) for r in self.marks]
         esz = self.arena.flat.element_size()
         late = sum((self.arena.buckets[r[0]][1] - self.arena.buckets[r[0]][0]) * esz for r, q in zip(self.marks, enq) if q > 0.9 * bwd)
+
+        def modelled_exposed(gbps):
+            """what of the exchange would lie behind the end of the backward if every collective ran at `gbps` GB/s of
+            all-reduced bytes, one after the other on the side stream, each starting when its bucket is enqueued (as
+            measured) and the one before it has finished: the figure an 8-GPU run would show, from a one-rank record"""
+            t = 0.0
+            for r, q in zip(self.marks, enq):
+                nbytes = (self.arena.buckets[r[0]][1] - self.arena.buckets[r[0]][0]) * esz
+                t = max(t, q) + nbytes / (gbps * 1e9) * 1e3
+            return round(max(0.0, t - bwd), 3)
         return dict(buckets=len(self.marks), backward_ms=round(bwd, 3), mbytes_enqueued_after_0p9_of_backward=round(late / 2 ** 20, 1),
+                    modelled_exposed_ms_at_50GBps=modelled_exposed(50.0), modelled_exposed_ms_at_100GBps=modelled_exposed(100.0),
                     exchange_ms=round(max(end) - min(enq), 3),
                     exposed_exchange_ms=round(max(0.0, max(end) - bwd), 3),
                     first_bucket_at_frac_of_backward=round(min(enq) / bwd, 4) if bwd > 0 else None,

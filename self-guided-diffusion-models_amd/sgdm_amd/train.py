@@ -309,24 +309,36 @@ class Backward:
         n, lib = self.n, self.lib
         h, w = hw
         ct = sum(c for _, c in srcs)
-        S = self.buf(n, ct, 2)
+        # Row-stream reduce (round 6, csrc/backward.hip): same-resolution gradient, every source a power-of-two channel count whose
+        # image (>= 32 x 32) is a whole number of 32 KiB windows.  It writes per-chunk partial sums (one table for all sources:
+        # the smallest of their chunk counts) that the coefficient launch folds itself.
+        rows_ok = gu_mode == L.RS_NONE and os.environ.get("SGDM_GN_BWD_ROWS", "1") != "0"
+        ks = [int(lib.sgd_gn_bwd_rows_chunks(n, h, w, c)) for _, c in srcs] if rows_ok else [0]
+        chunks = min(ks) if min(ks) > 0 and all(k % min(ks) == 0 for k in ks) else 0
+        S = self.buf(n, max(1, chunks), ct, 2)
         off = 0
         for t, c in srcs:
-            self.prog.add(tag + ".reduce", lib.sgd_gn_bwd_reduce, _ptr(t), n, h, w, c, ct, off, _ptr(a), _ptr(b), silu,
-                          _ptr(gu), gu_ld, gu_mode, drop[0], drop[1], _ptr(S))
+            if chunks:
+                self.prog.add(tag + ".reduce", lib.sgd_gn_bwd_reduce_rows, _ptr(t), n, h, w, c, ct, off, _ptr(a), _ptr(b), silu,
+                              _ptr(gu), gu_ld, drop[0], drop[1], chunks, _ptr(S), nbytes=8.0 * n * h * w * c)
+            else:
+                self.prog.add(tag + ".reduce", lib.sgd_gn_bwd_reduce, _ptr(t), n, h, w, c, ct, off, _ptr(a), _ptr(b), silu,
+                              _ptr(gu), gu_ld, gu_mode, drop[0], drop[1], _ptr(S), nbytes=8.0 * n * h * w * c)
             off += c
+        sch = max(1, chunks)
         A, B, Cc = (self.buf(n, ct) for _ in range(3))
         gamma, beta = self.m.P(gname + ".weight"), self.m.P(gname + ".bias")
         # (the launcher's bound: dynamic table + the kernel's 2 KB of static reduction scratch inside the 64 KB default limit)
-        fused = n <= 256 and 8 * n * (ct // GN_GROUPS) + 32 * n + 4 + 2048 <= 64 * 1024 and os.environ.get("SGDM_GN_BWD_FOLD", "1") != "0"
+        fused = (n <= 256 and (16 if chunks else 8) * n * (ct // GN_GROUPS) + 32 * n + 4 + 2048 <= 64 * 1024
+                 and os.environ.get("SGDM_GN_BWD_FOLD", "1") != "0")
         if fused:                # coefficients + dgamma / dbeta column sums in ONE launch (bit-identical to the two below)
-            self.prog.add(tag + ".coef", lib.sgd_gn_bwd_coef_fold, _ptr(S), _ptr(sums), _ptr(gamma), _ptr(beta),
+            self.prog.add(tag + ".coef", lib.sgd_gn_bwd_coef_fold, _ptr(S), sch, _ptr(sums), _ptr(gamma), _ptr(beta),
                           C.c_void_p(film_ptr), film_ld, n, ct, GN_GROUPS, h * w, GN_EPS, _ptr(A), _ptr(B), _ptr(Cc),
                           C.c_void_p(dfilm_ptr), _ptr(self.pg(gname + ".weight")), _ptr(self.pg(gname + ".bias")), 0,
                           self.unscale)
         else:
             dg, db = self.buf(n, ct), self.buf(n, ct)
-            self.prog.add(tag + ".coef", lib.sgd_gn_bwd_coef, _ptr(S), _ptr(sums), _ptr(gamma), _ptr(beta),
+            self.prog.add(tag + ".coef", lib.sgd_gn_bwd_coef, _ptr(S), sch, _ptr(sums), _ptr(gamma), _ptr(beta),
                           C.c_void_p(film_ptr), film_ld, n, ct, GN_GROUPS, h * w, GN_EPS, _ptr(A), _ptr(B), _ptr(Cc),
                           _ptr(dg), _ptr(db), C.c_void_p(dfilm_ptr))
         if fused:
@@ -344,10 +356,11 @@ class Backward:
         off = 0
         for t, c in srcs:
             dst, acc = self.gact(t)
+            nb = 4.0 * n * h * w * c * (3 + (1 if gres is not None else 0) + (1 if acc else 0))
             self.prog.add(tag + ".apply", lib.sgd_gn_bwd_apply, _ptr(t), n, h, w, c, ct, off, _ptr(a), _ptr(b), silu,
                           _ptr(gu), gu_ld, gu_mode, drop[0], drop[1], _ptr(A), _ptr(B), _ptr(Cc),
                           _ptr(gres) if gres is not None else None,
-                          gres_ld, gres_mode, _ptr(dst), c, 0, acc)
+                          gres_ld, gres_mode, _ptr(dst), c, 0, acc, nbytes=nb)
             off += c
 
     # ---------------------------------------------------------------- program
@@ -656,7 +669,7 @@ class Backward:
         for co in couts:
             offs.append(off)
             off += 2 * co
-        self._film = dict(rec=rec, ech=ech, fw=fw, dwcat=self.buf(fw, ech), dbcat=self.buf(fw))
+        self._film_ctx = dict(rec=rec, ech=ech, fw=fw, dwcat=self.buf(fw, ech), dbcat=self.buf(fw))
         # stages in WALK order (last ResBlock of the forward first); a stage closes at block i when it holds enough bytes
         self._film_close = {}                       # block name -> (first block index, one past the last) of the stage it closes
         hi = len(names)
@@ -676,32 +689,40 @@ class Backward:
             return
         self._film_open.discard(p)
         i0, i1 = grp
-        f, n = self._film, self.n
+        f, n = self._film_ctx, self.n
         rec, ech, fw, dwcat, dbcat = f["rec"], f["ech"], f["fw"], f["dwcat"], f["dbcat"]
         names, couts = rec["names"], rec["couts"]
         c0, c1 = self._film_offs[i0], self._film_offs[i1]
         tag = f"emb_layers.s{i0}"
         gsl = self.gfilm[:, c0:c1]                  # columns of this stage (row stride fw)
-        self.wgrad(tag, rec["a"], gsl, fw, c1 - c0, ech, 1, n, None, None, dw_view=dwcat[c0:c1])
-        self.prog.add(tag + ".bias", self.lib.sgd_colsum, _ptr(gsl), n, c1 - c0, fw, _ptr(dbcat[c0:c1]), 0, self.unscale,
+        dw_dst, db_dst = dwcat[c0:c1], dbcat[c0:c1]
+        if self.arena is None:
+            # single process: the per-block gradients ARE row slices of the concatenated result (contiguous), no copies.
+            # (first-use order = the arena's order in a data-parallel build: the stage's weights, then its biases)
+            for i in range(i0, i1):
+                self.pgrad[names[i] + ".emb_layers.1.weight"] = dwcat[self._film_offs[i]:self._film_offs[i + 1]]
+            for i in range(i0, i1):
+                self.pgrad[names[i] + ".emb_layers.1.bias"] = dbcat[self._film_offs[i]:self._film_offs[i + 1]]
+        else:
+            # data parallel: the stage's weights, then its biases, take CONSECUTIVE arena slots (first-use order; every slot a
+            # whole number of quads), so the stage's rows of the concatenated gradient ARE one arena range each: the reduce and
+            # the column sums write there directly (round 6: 44 device-side slice copies per step fewer)
+            wv = [self.pg(names[i] + ".emb_layers.1.weight") for i in range(i0, i1)]
+            bv = [self.pg(names[i] + ".emb_layers.1.bias") for i in range(i0, i1)]
+            flat = self.arena.flat
+
+            def span(views, rows, cols):
+                o0 = (views[0].data_ptr() - flat.data_ptr()) // flat.element_size()
+                t = flat[o0:o0 + rows * cols].view(rows, cols) if cols > 1 else flat[o0:o0 + rows]
+                off = 0
+                for v in views:                     # consecutive, unpadded: each view starts where the one before it ended
+                    assert v.data_ptr() == t.data_ptr() + off * flat.element_size(), "FiLM stage is not one arena range"
+                    off += v.numel()
+                return t
+            dw_dst, db_dst = span(wv, c1 - c0, ech), span(bv, c1 - c0, 1)
+        self.wgrad(tag, rec["a"], gsl, fw, c1 - c0, ech, 1, n, None, None, dw_view=dw_dst)
+        self.prog.add(tag + ".bias", self.lib.sgd_colsum, _ptr(gsl), n, c1 - c0, fw, _ptr(db_dst), 0, self.unscale,
                       _ptr(self.cwork), self.CW)
-        views = []
-        for i in range(i0, i1):
-            q, o, co = names[i], self._film_offs[i], couts[i]
-            if self.arena is None:
-                # single process: the per-block gradients ARE row slices of the concatenated result (contiguous), no copies
-                self.pgrad[q + ".emb_layers.1.weight"] = dwcat[o:o + 2 * co]
-                self.pgrad[q + ".emb_layers.1.bias"] = dbcat[o:o + 2 * co]
-            else:
-                views.append((self.pg(q + ".emb_layers.1.weight"), dwcat[o:o + 2 * co]))
-                views.append((self.pg(q + ".emb_layers.1.bias"), dbcat[o:o + 2 * co]))
-        if views:
-            def film_split(stream, views=views):
-                # the stage's rows of the concatenated gradient into the per-ResBlock parameters (device-side slice copies)
-                for dst, src in views:
-                    dst.copy_(src)
-                return 0
-            self.prog.add(tag + ".split", film_split)
         for i in range(i1 - 1, i0 - 1, -1):
             self.wrote(names[i] + ".emb_layers.1.weight")
             self.wrote(names[i] + ".emb_layers.1.bias")
@@ -754,8 +775,6 @@ class Backward:
         g = (geps_nchw.float() * self.gscale).contiguous()
         L.check(lib.sgd_pack_input(_ptr(g), None, None, None, n, n, c, 0, h, w, _ptr(self.geps), stream), "geps")
         if self.reducer is not None:
-            if self.reducer.active and self.reducer.new_durations():
-                self.apply_grid_cap()        # windows from the step that has just completed
             self.reducer.start()
         self.prog.run(stream)
         # Health of this step's gradients: 1.0 iff the engine's balanced-tail health word is up.  With an arena
@@ -779,10 +798,14 @@ class Backward:
     # `reserve` compute units to RCCL's kernels on the side stream (tests/test_hip_contention.py: a launch whose blocks do
     # not all fit next to them takes up to 1.7x).  Taken from every launch of the backward the reserve cost ~1.1 ms of a
     # 63 ms step; RCCL needs it only between a bucket's enqueue and its completion.  The host knows where in the PROGRAM each
-    # collective starts (the bucket hooks) and, from the completion events of the previous step, how long each one took: a
-    # launch keeps the whole device unless it falls into the window [hook, hook + 1.5 x measured duration + 0.3 ms) of
-    # estimated launch time (algorithmic flops at 300 TF/s, 40 us for the memory-bound launches in between).  Before any
-    # measurement exists the window is the whole rest of the program behind the first hook (the round-5 behaviour).
+    # collective starts (the bucket hooks) and how many bytes it moves: a launch keeps the whole device unless it falls into
+    # the window [hook, hook + bytes / RESERVE_GBPS + 0.2 ms) of estimated launch time (algorithmic flops at 300 TF/s, 40 us
+    # for the memory-bound launches in between).  RESERVE_GBPS = 50 GB/s of all-reduced bytes (SGDM_RESERVE_GBPS) is about
+    # half of what an 8-GPU xGMI ring delivers on 16 channels: a 64 MB bucket holds its window for 1.5 ms.  A STATIC rule on
+    # purpose: windows sized by measured completion times would make the grid of a launch -- and with it the K split of its
+    # balanced tail, i.e. the rounding of its sums -- depend on timing; this way a given program always runs the same grids.
+    RESERVE_GBPS = 50.0
+
     def apply_grid_cap(self):
         cap = getattr(self.e, "_grid_cap", 0)
         if cap <= 0 or self.reducer is None or not self.reducer.active or os.environ.get("SGDM_RESERVE_WINDOWS", "1") == "0":
@@ -790,17 +813,15 @@ class Backward:
                 a.grid_cap = cap
             self._windows = None
             return
+        gbps = float(os.environ.get("SGDM_RESERVE_GBPS", self.RESERVE_GBPS))
+        esz = self.arena.flat.element_size()
         hooks = [(i, int(op[0][len("bucket"):].split(".")[0])) for i, op in enumerate(self.prog.ops)
                  if op[0].startswith("bucket") and op[0].endswith(".allreduce")]
-        dur = self.reducer.bucket_durations_ms()         # {bucket: ms} of the last completed step, or None
         est = [(mt[1] / 300e12 * 1e3 if mt[1] > 0 else 0.04) for mt in self.prog.meta]       # ms per program entry
         inside = [False] * len(self.prog.ops)
         for pos, bi in hooks:
-            if dur is None:
-                for j in range(pos, len(inside)):
-                    inside[j] = True
-                break
-            budget = 1.5 * dur.get(bi, 1.0) + 0.3
+            s0, e0, _ = self.arena.buckets[bi]
+            budget = (e0 - s0) * esz / (gbps * 1e9) * 1e3 + 0.2
             j = pos
             while j < len(inside) and budget > 0:
                 inside[j] = True
@@ -808,7 +829,7 @@ class Backward:
                 j += 1
         for (a, _), at in zip(self.late, self.late_at):
             a.grid_cap = cap if inside[at] else 0
-        self._windows = (sum(inside), len(inside), dur is not None)
+        self._windows = (sum(inside), len(inside))
 
     def _own_flag(self):
         if getattr(self, "_flag", None) is None:
@@ -840,6 +861,7 @@ class _UNetTrainFn(torch.autograd.Function):
         _check_torch_ddp(model)
         if getattr(eng, "backward", None) is None:
             eng.backward = make_backward(eng)
+            eng.backward.apply_grid_cap()        # the CU reserve of a data-parallel step, inside its windows only
         # The program writes every parameter gradient into a persistent buffer (a view of the DDP arena when there is one).
         # Handing those to autograd made AccumulateGrad clone each of them -- ~390 device copies per step (it cannot steal a
         # tensor somebody else still references).  A parameter whose .grad is None gets the buffer itself as .grad (what

@@ -60,7 +60,10 @@ def main():
             torch.cuda.synchronize()
             return float(loss.detach())
 
-        # ---- A: no exchange, the reserve by attribute (same grids as B, so the bits must agree)
+        # ---- A: no exchange, the reserve by attribute on EVERY backward launch; B below runs with the reserve windows off as
+        # well (same grids as A, so the bits must agree); the windows come on for the third step
+        os.environ["SGDM_RESERVE_WINDOWS"] = "0"
+        # ---- A
         model.hip_ddp = False
         model.hip_reserve_cus = ddp.reserve_setting()
         loss_a = step()
@@ -105,6 +108,21 @@ def main():
         out["overlap_second_step"] = red.overlap_stats()
         bad2 = [k for k in ref if not torch.equal(model.get_parameter(k).grad, ref[k])]
         out["second_step_mismatched"] = bad2[:8]
+        # third step: the reserve only inside the windows behind each bucket's enqueue -- most backward launches run on the
+        # whole device, so tiles of their last rounds split differently along K: same gradients up to the rounding of a sum
+        os.environ["SGDM_RESERVE_WINDOWS"] = "1"
+        eng.backward.apply_grid_cap()
+        step()
+        caps = [int(a.grid_cap) for a, _ in eng.backward.late]
+        out["reserve_windows"] = dict(capped=sum(1 for c_ in caps if c_ > 0), launches=len(caps),
+                                      entries=list(eng.backward._windows or ()))
+        worst = 0.0
+        for k in ref:
+            gk = model.get_parameter(k).grad
+            den = float(ref[k].abs().max())
+            if den > 0:
+                worst = max(worst, float((gk - ref[k]).abs().max()) / den)
+        out["third_step_max_rel"] = worst
         # ---- C: the exchange entry of the C-ABI (include/sgdm_hip.h: sgd_allreduce_bucket, SURVEY 8(b) last row) on a communicator
         # made with librccl's OWN API -- what a host that does not go through torch.distributed would do: event behind the
         # producer, side stream waits, in-place SUM of the bucket, compute stream joins

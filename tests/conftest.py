@@ -50,6 +50,17 @@ def max_rel(a, b):
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
 
 
+def elem_rel(a, b, floor=1e-2):
+    """element-wise relative error with a floor: max_i |a_i - b_i| / max(|b_i|, floor * max|b|).  max_rel (above) is an absolute
+    error in units of the tensor's largest element; this one also holds every element whose magnitude is at least `floor` of
+    the maximum to a RELATIVE bound (VERDICT round 5, weak #1a).  An fp32 reorder moves any element by ~1e-6 of the tensor's
+    scale, so for the smallest elements counted the bound reads 1 / floor times max_rel's."""
+    a = torch.as_tensor(a, dtype=torch.float64)
+    b = torch.as_tensor(b, dtype=torch.float64)
+    den = b.abs().clamp_min(floor * float(b.abs().max().clamp_min(1e-30)))
+    return float(((a - b).abs() / den).max())
+
+
 def cfg_from_index(entry):
     """unet_index.json entry (reference ctor kwargs) -> oracle cfg."""
     from oracle.unet_ref import make_cfg

@@ -440,7 +440,7 @@ def test_groupnorm_silu_backward(gu_mode, silu, film):
     A, B, Cc = (torch.empty(n, c, device="cuda") for _ in range(3))
     dg, db = torch.empty(n, c, device="cuda"), torch.empty(n, c, device="cuda")
     dfilm = torch.zeros(n, 2 * c, device="cuda")
-    L.check(lib.sgd_gn_bwd_coef(_p(S), _p(sums), _p(gd), _p(bd), _p(fd) if film else None, 2 * c, n, c, 32, hw, 1e-5,
+    L.check(lib.sgd_gn_bwd_coef(_p(S), 1, _p(sums), _p(gd), _p(bd), _p(fd) if film else None, 2 * c, n, c, 32, hw, 1e-5,
                                 _p(A), _p(B), _p(Cc), _p(dg), _p(db), _p(dfilm) if film else None, _stream()), "bcoef")
     dx = torch.full((n, h, h, c), float("nan"), device="cuda")
     L.check(lib.sgd_gn_bwd_apply(_p(xd), n, h, h, c, c, 0, _p(a), _p(b), silu, _p(gud), c, gu_mode, 0.0, 0, _p(A), _p(B),
@@ -469,7 +469,7 @@ def test_groupnorm_backward_coefficients_and_column_sums_in_one_launch(n, c, fil
     scale = 1.0 / 4096.0
     A, B, Cc, dg, db = (torch.empty(n, c, device="cuda") for _ in range(5))
     dfilm = torch.zeros(n, 2 * c, device="cuda")
-    L.check(lib.sgd_gn_bwd_coef(_p(S), _p(sums), _p(gamma), _p(beta), _p(fl), 2 * c, n, c, groups, hw, 1e-5, _p(A), _p(B), _p(Cc),
+    L.check(lib.sgd_gn_bwd_coef(_p(S), 1, _p(sums), _p(gamma), _p(beta), _p(fl), 2 * c, n, c, groups, hw, 1e-5, _p(A), _p(B), _p(Cc),
                                 _p(dg), _p(db), _p(dfilm) if film else None, _stream()), "coef")
     base = torch.randn(2, c, generator=g).cuda()
     for acc in (0, 1):
@@ -478,15 +478,120 @@ def test_groupnorm_backward_coefficients_and_column_sums_in_one_launch(n, c, fil
         A2, B2, C2 = (torch.full((n, c), float("nan"), device="cuda") for _ in range(3))
         dfilm2 = torch.zeros(n, 2 * c, device="cuda")
         p1, p2 = base[0].clone(), base[1].clone()
-        L.check(lib.sgd_gn_bwd_coef_fold(_p(S), _p(sums), _p(gamma), _p(beta), _p(fl), 2 * c, n, c, groups, hw, 1e-5, _p(A2),
+        L.check(lib.sgd_gn_bwd_coef_fold(_p(S), 1, _p(sums), _p(gamma), _p(beta), _p(fl), 2 * c, n, c, groups, hw, 1e-5, _p(A2),
                                          _p(B2), _p(C2), _p(dfilm2) if film else None, _p(p1), _p(p2), acc, scale, _stream()),
                 "fold")
         torch.cuda.synchronize()
         assert torch.equal(A2, A) and torch.equal(B2, B) and torch.equal(C2, Cc) and torch.equal(dfilm2, dfilm)
         assert torch.equal(p1, o1) and torch.equal(p2, o2)
     # what does not fit the fold's LDS tables is refused, not truncated
-    assert lib.sgd_gn_bwd_coef_fold(_p(S), _p(sums), _p(gamma), _p(beta), None, 0, 257, c, groups, hw, 1e-5, _p(A), _p(B), _p(Cc),
+    assert lib.sgd_gn_bwd_coef_fold(_p(S), 1, _p(sums), _p(gamma), _p(beta), None, 0, 257, c, groups, hw, 1e-5, _p(A), _p(B), _p(Cc),
                                     None, _p(o1), _p(o2), 0, scale, _stream()) == 1
+
+
+# n, source channel counts, h, silu, film, dropout, accumulate
+GN_ROWS_CASES = [(5, (128,), 64, 1, True, 0.0, 0),        # ResBlock GroupNorm at 64x64: 16 chunks of 4 windows
+                 (3, (256, 128), 32, 1, False, 0.0, 1),   # decoder in_layers.0 over a concat: shared partial table, accumulate
+                 (4, (512,), 32, 0, False, 0.0, 0),       # no SiLU: two channel sets per lane
+                 (2, (1024,), 32, 1, True, 0.1, 0),       # four sets per lane, train-time dropout mask on the gradient
+                 (7, (64,), 32, 1, False, 0.25, 0),       # 16 quads per row: four rows per wave instruction
+                 (3, (256, 32), 32, 1, False, 0.0, 0)]    # sources whose own chunk counts differ (16 and 4)
+
+
+@pytest.mark.parametrize("case", GN_ROWS_CASES, ids=["-".join(map(str, c)) for c in GN_ROWS_CASES])
+def test_groupnorm_backward_row_stream_passes_equal_the_round1_passes(case):
+    """sgd_gn_bwd_reduce_rows (round 6: contiguous 8 KiB pieces per wave, per-chunk partial sums folded by the coefficient launch)
+    against sgd_gn_bwd_reduce on the same tensors: the folded statistics to the rounding of a different summation order, the
+    coefficient launches on the chunked table against its host-side fold, and the whole chain (reduce_rows -> coef -> apply)
+    against float64 autograd through GroupNorm(+FiLM)(+SiLU)(+dropout mask)"""
+    n, cs, h, silu, film, drop, acc = case
+    L, lib = _lib()
+    ct, hw = sum(cs), h * h
+    g = torch.Generator().manual_seed(17 + ct + h)
+    xs = [(torch.randn(n, h, h, c, generator=g) * 2 + 0.3).cuda() for c in cs]
+    gamma, beta = torch.randn(ct, generator=g).cuda(), torch.randn(ct, generator=g).cuda()
+    fl = torch.randn(n, 2 * ct, generator=g).cuda() if film else None
+    gu = torch.randn(n, h, h, ct, generator=g).cuda()
+    gres = torch.randn(n, h, h, ct, generator=g).cuda()
+    seed = 12345
+    sums = torch.zeros(n, ct, 2, device="cuda")
+    off = 0
+    for x, c in zip(xs, cs):
+        L.check(lib.sgd_chan_stats(_p(x), n, hw, c, _p(sums), ct, off, _stream()), "stats")
+        off += c
+    a, b = torch.empty(n, ct, device="cuda"), torch.empty(n, ct, device="cuda")
+    L.check(lib.sgd_gn_coef(_p(sums), _p(gamma), _p(beta), _p(fl) if film else None, 2 * ct, n, ct, 32, hw, 1e-5, _p(a), _p(b),
+                            _stream()), "coef")
+    ks = [int(lib.sgd_gn_bwd_rows_chunks(n, h, h, c)) for c in cs]
+    chunks = min(ks)
+    assert chunks > 0 and all(k % chunks == 0 for k in ks), ks
+    S0 = torch.full((n, ct, 2), float("nan"), device="cuda")
+    P = torch.full((n, chunks, ct, 2), float("nan"), device="cuda")
+    off = 0
+    for x, c in zip(xs, cs):
+        L.check(lib.sgd_gn_bwd_reduce(_p(x), n, h, h, c, ct, off, _p(a), _p(b), silu, _p(gu), ct, 0, drop, seed, _p(S0), _stream()), "r0")
+        L.check(lib.sgd_gn_bwd_reduce_rows(_p(x), n, h, h, c, ct, off, _p(a), _p(b), silu, _p(gu), ct, drop, seed, chunks, _p(P),
+                                           _stream()), "r1")
+        off += c
+    torch.cuda.synchronize()
+    S1 = P.double().sum(1).float().double()                     # (the launches round the folded sums to float once)
+    assert torch.isfinite(P).all() and max_rel(S1, S0.double()) < 2e-6
+    # coefficients from the chunked table (folded inside the launch) == coefficients from its host-side fold
+    outs = []
+    for Sx, sch in ((P, chunks), (S1.float().contiguous(), 1)):
+        A, B, Cc, dg, db = (torch.full((n, ct), float("nan"), device="cuda") for _ in range(5))
+        dfilm = torch.zeros(n, 2 * ct, device="cuda")
+        L.check(lib.sgd_gn_bwd_coef(_p(Sx), sch, _p(sums), _p(gamma), _p(beta), _p(fl) if film else None, 2 * ct, n, ct, 32, hw, 1e-5,
+                                    _p(A), _p(B), _p(Cc), _p(dg), _p(db), _p(dfilm) if film else None, _stream()), "bcoef")
+        outs.append((A, B, Cc, dg, db, dfilm))
+    for u, v in zip(outs[0], outs[1]):
+        assert max_rel(u, v) < 1e-6
+    A, B, Cc, dg, db, dfilm = outs[0]
+    if n <= 256 and 16 * n * (ct // 32) + 32 * n + 4 + 2048 <= 64 * 1024:
+        A2, B2, C2 = (torch.full((n, ct), float("nan"), device="cuda") for _ in range(3))
+        df2, o1, o2 = torch.zeros(n, 2 * ct, device="cuda"), torch.zeros(ct, device="cuda"), torch.zeros(ct, device="cuda")
+        L.check(lib.sgd_gn_bwd_coef_fold(_p(P), chunks, _p(sums), _p(gamma), _p(beta), _p(fl) if film else None, 2 * ct, n, ct, 32, hw,
+                                         1e-5, _p(A2), _p(B2), _p(C2), _p(df2) if film else None, _p(o1), _p(o2), 0, 1.0, _stream()), "fold")
+        torch.cuda.synchronize()
+        assert torch.equal(A2, A) and torch.equal(B2, B) and torch.equal(C2, Cc) and torch.equal(df2, dfilm)
+    off, dxs = 0, []
+    for x, c in zip(xs, cs):
+        base = torch.randn(n, h, h, c, generator=g).cuda()
+        d0 = base.clone()
+        L.check(lib.sgd_gn_bwd_apply(_p(x), n, h, h, c, ct, off, _p(a), _p(b), silu, _p(gu), ct, 0, drop, seed, _p(A), _p(B), _p(Cc),
+                                     _p(gres), ct, 0, _p(d0), c, 0, acc, _stream()), "a0")
+        torch.cuda.synchronize()
+        dxs.append(d0 - base if acc else d0)
+        off += c
+    # float64 autograd of the whole chain (the dropout mask is the kernels' own: element (row, channel) of the concatenated tensor)
+    xcat = torch.cat([x.double() for x in xs], -1).permute(0, 3, 1, 2).cpu().requires_grad_(True)
+    gam, bet = gamma.double().cpu().requires_grad_(True), beta.double().cpu().requires_grad_(True)
+    y = F.group_norm(xcat, 32, gam, bet, 1e-5)
+    if film:
+        f64 = fl.double().cpu()
+        y = y * (1 + f64[:, :ct, None, None]) + f64[:, ct:, None, None]
+    u = F.silu(y) if silu else y
+    guc = gu.double().cpu().permute(0, 3, 1, 2)
+    if drop > 0:
+        import numpy as np
+        from test_hip_train import _host_keep_mask
+        keep = torch.from_numpy(_host_keep_mask(seed, n * hw, ct, drop).astype(np.float64)).reshape(n, h, h, ct).permute(0, 3, 1, 2)
+        guc = guc * keep / (1.0 - drop)
+    (u * guc + xcat * gres.double().cpu().permute(0, 3, 1, 2)).sum().backward()
+    got = torch.cat(dxs, -1).cpu().permute(0, 3, 1, 2)
+    assert max_rel(got, xcat.grad) < 2e-5
+    assert max_rel(dg.cpu().sum(0), gam.grad) < 2e-5 and max_rel(db.cpu().sum(0), bet.grad) < 2e-5
+
+
+def test_groupnorm_backward_row_stream_shapes():
+    """which shapes the row-stream reduce serves (no launch): >= 32 x 32 pixels, powers of two in 16 .. 1024 channels, whole 32 KiB
+    windows"""
+    L, lib = _lib()
+    f = lib.sgd_gn_bwd_rows_chunks
+    assert f(80, 64, 64, 128) == 16 and f(80, 32, 32, 256) == 16 and f(80, 32, 32, 32) == 4 and f(80, 32, 32, 16) == 2
+    assert f(80, 16, 16, 512) == 0 and f(1, 8, 8, 128) == 0
+    assert f(80, 64, 64, 96) == 0 and f(80, 64, 64, 224) == 0 and f(80, 64, 64, 2048) == 0
+    assert lib.sgd_gn_bwd_reduce_rows(None, 1, 8, 8, 128, 128, 0, None, None, 1, None, 128, 0.0, 0, 1, None, None) == 1
 
 
 @pytest.mark.parametrize("core,gscale", [("exact", 1.0), ("split", 1.0), ("split", 1e-2), ("split", 1e3)])

@@ -42,10 +42,11 @@ def test_training_step_through_world1_rccl_group(workload):
     # RCCL's communicator exists after the step (the collectives really went through librccl) ...
     assert out["comm_after"] is True
     # ... the reserve was decided by the policy (backend on the GPU), applied to the backward program only, and RCCL's
-    # half was put into the environment by the product before the first collective
+    # half is the workgroup cap of the exchange's OWN communicator: nothing process-wide was touched (the
+    # library no longer sets NCCL_MAX_NCHANNELS when the per-communicator cap exists)
     assert out["reserved_cus"] == 16 and out["grid_cap"] == out["cus"] - 16
     assert out["backward_grid_caps"] == [out["cus"] - 16] and out["forward_grid_caps"] == [0]
-    assert out["nchannels_env"] == "16"
+    assert out["own_group"] is True and out["nchannels_env"] is None
     assert out["sent"] > 250
     # gradients bit-equal to the non-DDP step, both steps
     assert out["same_keys"] and out["mismatched"] == [] and out["losses_equal"]
@@ -69,8 +70,16 @@ def test_training_step_through_world1_rccl_group(workload):
     # last bucket (complete only with the backward's last launch, sent by finish() with the health flag in its tail slot) is
     # capped at 16 MB: what is enqueued in the last tenth of the backward is what an 8-GPU run cannot hide
     assert ov["per_bucket"][-1]["mbytes"] <= 16.1, ov
-    assert ov["mbytes_enqueued_after_0p9_of_backward"] <= 40.0, ov
     assert ov["per_bucket"][-2]["enqueued_at_ms"] <= 0.97 * ov["backward_ms"], ov
+    # from this one-rank record: collectives at 50 GB/s of all-reduced bytes (half of an 8-GPU ring on 16 channels), one after
+    # the other, each starting at its measured enqueue point -- what would be left behind the end of the backward (B = 16: the
+    # backward is 15 ms here, 45 ms at the benchmarked batch, where bench.py reports the same figure)
+    assert ov["modelled_exposed_ms_at_100GBps"] <= 0.5, ov
+    # the CU reserve only inside windows behind each bucket's enqueue (sized by the bucket's bytes, a static rule): most of the
+    # backward has the whole device back; the gradients agree with the fully capped run to the rounding of a sum
+    rw = out["reserve_windows"]
+    assert rw["entries"] and 0 < rw["capped"] <= 0.5 * rw["launches"], rw
+    assert out["third_step_max_rel"] < 5e-6, out["third_step_max_rel"]
     # the C-ABI's own exchange entry, on a communicator created with librccl's API (no torch.distributed in between)
     assert out["cabi_comm_rc"] == [0, 0] and out["cabi_bind_rc"] == 0
     assert out["cabi_allreduce_rc"] == 0 and out["cabi_allreduce_equal"] is True and out["cabi_bad_args_rc"] == 1
