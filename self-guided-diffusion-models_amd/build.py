@@ -27,7 +27,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-u
          "-ffp-contract=fast"]
 # per-file extras.  igemm: no SLP vectorisation -- packed f32 VALU (v_pk_fma_f32 ...) next to a saturated matrix pipe costs
 # more issue time than the two scalar ops it replaces (measured +2..3 % on the conv launches with it off)
-FILE_FLAGS = {"igemm.hip": ["-fno-slp-vectorize"]}
+FILE_FLAGS = {"igemm.hip": ["-fno-slp-vectorize"], "pack.hip": ["-fno-slp-vectorize"]}      # (pack.hip: part of igemm.hip up to round 5)
 
 
 def _sources():
@@ -60,12 +60,12 @@ def source_id():
     return _digest(srcs + _headers(), [FLAGS, sorted(FILE_FLAGS.items()), sorted(VARIANTS.items())])[:16]
 
 
-# translation units compiled from ONE source with different defines (igemm.hip: the host unit + one unit per arithmetic
-# mode, see the end of that file) -- they build in parallel
+# translation units compiled from ONE source with different defines (igemm.hip, the conv kernel: one unit per arithmetic mode,
+# see the end of that file; its geometry / entry points are igemm_host.hip, the weight packing pack.hip) -- they build in parallel
 # (*_nopk: the 1x1 / linear instances of the split modes once more with packed-f32 code generation off -- the LayerNorm-row
 # prologue's launches run on these, csrc/igemm.hip: sgd_igemm_dispatch_*_nopk)
 NOPK = ["-DSGDM_IGEMM_NOPK", "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
-VARIANTS = {"igemm.hip": [("", []), ("_f32", ["-DSGDM_IGEMM_PREC=0"]), ("_f16x3", ["-DSGDM_IGEMM_PREC=1"]),
+VARIANTS = {"igemm.hip": [("_f32", ["-DSGDM_IGEMM_PREC=0"]), ("_f16x3", ["-DSGDM_IGEMM_PREC=1"]),
                           ("_bf16x3", ["-DSGDM_IGEMM_PREC=2"]), ("_f16x3_nopk", ["-DSGDM_IGEMM_PREC=1", *NOPK]),
                           ("_bf16x3_nopk", ["-DSGDM_IGEMM_PREC=2", *NOPK])]}
 

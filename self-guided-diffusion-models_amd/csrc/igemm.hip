@@ -25,78 +25,13 @@
 //             (BASELINE.md section 2 "precision headroom": 4.3e-6 / 2.6e-5 rel. error per UNet eval).
 //
 // Replaces (reference): nn.Conv2d/Conv1d/Linear call sites listed in include/sgdm_hip.h.
-#include <stdlib.h>
 #include <type_traits>
 #include <utility>
 
-#include "sgdm_common.h"
-#include "../../include/sgdm_hip.h"
+#include "igemm_shared.h"
 #include "prologue.h"
 
 namespace {
-
-constexpr int KC = 32;        // input channels per K chunk
-constexpr int LDA = KC + 4;   // LDS row stride in floats (144 B): conflict-free b128 fragment reads
-constexpr int BM = 128;
-constexpr int NB_RING = 3;    // register ring depth of the 1x1 loaders (input rows requested 3 steps ahead)
-constexpr int BIAS_LDS_MAX = 4096;   // layers up to this many (padded) output channels keep their bias in LDS (16 KB)
-constexpr int A_THREADS = 256;  // 4 input-tile loader waves
-constexpr int NCOMP = 256;      // 4 compute (MFMA) waves, one per SIMD
-constexpr int NTHREADS = NCOMP + A_THREADS;
-constexpr int WUNIT = 4096;   // bytes of one packed weight unit: 32 output x 32 input channels of one tap, fragment order
-constexpr int MIN_PART_STEPS = 27;   // K steps (tap x 32 channels) of the smallest K part worth splitting off
-constexpr int SPLIT_MAX = 4;   // K parts of a tile of the balanced tail (sgd_igemm_args.work)
-constexpr int WORK_TILES = 256;                        // split tiles of one launch: < blocks
-constexpr int WORK_HEAD = WORK_TILES * 8;              // bytes: per split tile {arrived, consumed} wave counters
-// Health word of the workspace (sgd_igemm_work_status_offset): the last int of the head.  Counter pairs use indices
-// < 8 * (nloc / 2) <= 128 of the 256 pairs, so the word is never a counter.
-constexpr int WORK_STATUS_INT = WORK_HEAD / 4 - 1;
-// Finisher poll bound: s_sleep 16 = 1024 cycles + one L2 round trip per poll, 2^20 polls ~ 1-2 s (measured 2.1 s at 2^22 sleeps
-// only; a legitimate wait is a producer's K part: a few hundred microseconds).  Producers never wait and the launches that share a
-// workspace are ordered on one stream, so a finisher that is still waiting then is waiting for a block that will never
-// store (stale counters after a faulted launch, a second stream on the same workspace): it flags the workspace and
-// poisons its outputs with NaN instead of hanging the device.
-constexpr int FINISH_POLL_MAX = 1 << 20;
-
-// Balanced-tail arithmetic shared by the kernel and sgd_igemm_tail_layout (the CPU test of the workspace layout).
-// K parts of the `xrem` tiles an XCD has left after its whole rounds (0: no split): a part must be worth its hand-off
-// (publish + poll + acquire + the slab reads of the finisher, ~10 us): at least MIN_PART_STEPS K steps.  Measured
-// (tools/ab_conv.py, UNet batch 80): 3x3 convs of >= 256 input channels gain 4..7 %, 128-channel ones (2 chunks per
-// part) and every 1x1 launch lose 5..15 %.
-__host__ __device__ inline int tail_split(int xrem, int nloc, int nchunks, int taps) {
-    if (xrem <= 0 || nchunks < 2) return 0;
-    int split = nloc / xrem;
-    if (split > SPLIT_MAX) split = SPLIT_MAX;
-    while (split >= 2 && (nchunks / split) * taps < MIN_PART_STEPS) --split;
-    return split < 2 ? 0 : split;
-}
-// Every XCD owns a FIXED range of counters and slabs: its split depends on ITS remainder (the last XCD of a launch usually
-// has fewer tiles), and ranges sized by the XCD's own split overlapped between XCDs of different splits -- two split tiles
-// on one counter: sums of the wrong tile, then a finisher polling forever (round 3: 1 evaluation in ~20 of the ch=224
-// model at batch 1).  An XCD has at most nloc / 2 split tiles and (nloc / split) * (split - 1) <= 3 nloc / 4 producer
-// slabs: 8 * 24 = 192 at 256 blocks (sgd_igemm_work_bytes).
-__host__ __device__ inline int tail_counter(int xcd, int loc, int nloc, int split) { return xcd * (nloc >> 1) + loc / split; }
-__host__ __device__ inline int tail_slab(int xcd, int loc, int nloc, int split) {
-    return xcd * ((nloc * 3) >> 2) + (loc / split) * (split - 1);
-}
-constexpr int FAST_PIX = 192;  // halo tiles up to this many pixels (16x8 outputs + halo = 180) use the split-phase A loader
-
-struct Geo {
-    int tw_l2, th_l2;         // log2 of the spatial tile (CONV3)
-    int hh, hw;               // halo tile dims (rows, cols) in conv-input pixels
-    int nb;                   // images per M tile
-    int tiles_x, tiles_y;     // spatial tiles per image
-    int pix;                  // nb*hh*hw (CONV3) or 128 (FLAT)
-    int mt, nt;               // number of M / N tiles
-    int hc, wc;               // conv-input dims (after resample)
-    int sparts;               // statistics slots per image (args.stats), 0: unsupported geometry
-    int fast_a;               // 1: split-phase A loader (stride 1, no avg-pool, pix*8 <= JMAX*256)
-#ifdef SGDM_PROBE
-    int dbg;                  // SGDM_DBG bits: 1 skip A staging, 2 skip B staging, 4 skip MFMA, 8 skip stores, 16 skip the epilogue, 256 skip its statistics
-    unsigned long long* stamp;   // [block][wave][4]: total cycles, cycles inside barriers, barriers, epilogue cycles
-    unsigned long long* trace;   // [16 blocks][wave][512 barriers][2]: arrival / release time of every barrier
-#endif
-};
 
 // Diagnostic build only (build.py --probe -> libsgdm_hip_probe.so, never loaded by the product path): ablation knobs
 // and per-wave cycle accounting.  In the shipped library the knobs fold to constants and no stamp executes.
@@ -138,11 +73,6 @@ struct Geo {
 #else
 #define KEEP_LIVE(x) (void)(x)
 #endif
-
-struct KArgs {
-    sgd_igemm_args a;
-    Geo g;
-};
 
 // ---------------------------------------------------------------------------------------------
 // LDS element packing per precision
@@ -1657,164 +1587,6 @@ __global__ __launch_bounds__(NTHREADS) void igemm_kernel(const KArgs ka) {
     PROBE_END(0);
 }
 
-// ---------------------------------------------------------------------------------------------
-// weight packing:  OIHW [cout, cin, k, k]  ->  MFMA fragment order, so that the compute waves load their operands
-// straight from global memory with fully coalesced 16-byte-per-lane loads (no LDS staging of weights).
-//
-//   unit(chunk, tap, nb) = 4 KiB holding the 32 output channels nb*32.. x 32 input channels chunk*32.. of one tap,
-//   units ordered [chunk][tap][nb] (nb over ALL cout_p / 32 blocks: a K step of the stream is contiguous).
-//   split modes: unit = [ks 0..1][hi | lo][lane 0..63][8 x 16-bit]   lane = lh*32 + li holds W[nb*32+li][chunk*32+ks*16+lh*8 .. +7]
-//   f32        : unit = [ks 0..3][lane 0..63][4 x f32]               lane = lh*32 + li holds W[nb*32+li][chunk*32+ks*8+lh*4 .. +3]
-//   (exactly the A-operand lane map of v_mfma_f32_32x32x16_f16 / four v_mfma_f32_32x32x2_f32 k-pairs).
-// One thread produces one lane's 16 bytes (f32) or its hi AND lo 16 bytes (split) of one sub-step.
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ float pow2_scale_of(uint32_t amax_bits) {
-    // 2^k with max|w| * 2^k in [1, 2): k = -(exponent of amax); all-zero / non-finite tensors: 1
-    const float amax = __uint_as_float(amax_bits);
-    // subnormal maxima count as zero: 2^(1-e) would overflow to +inf for e <= -127 (1/inf = 0 -> NaN weights)
-    if (!(amax >= 1.17549435e-38f) || !(amax < 3.0e38f)) return 1.f;
-    int e;
-    frexpf(amax, &e);                                          // amax = m * 2^e, m in [0.5, 1)
-    return ldexpf(1.f, 1 - e);                                 // e >= -125: at most 2^126
-}
-
-// max |w| of a tensor: every thread takes 16 elements as four independent 16-byte loads (the one-element grid-stride loop
-// this replaces was a chain of dependent-latency iterations: 20 us per conv weight, 142 tensors per training step)
-__device__ __forceinline__ void weight_amax_body(const float* __restrict__ w, long count, uint32_t* __restrict__ amax_bits, int vec,
-                                                 int blk, int nblk) {
-    float m = 0.f;
-    if (vec) {
-        const long nq = count >> 2;                                        // float4 quads
-        const long q0 = (blk * (long)blockDim.x + threadIdx.x) * 4;
-        const long step = (long)nblk * blockDim.x * 4;
-        for (long q = q0; q < nq; q += step) {
-            f32x4 v[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const long qq = q + j < nq ? q + j : nq - 1;               // clamped: a duplicate does not change a maximum
-                v[j] = *reinterpret_cast<const f32x4*>(w + qq * 4);
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) m = fmaxf(m, fabsf(v[j][e]));
-        }
-        for (long i = (nq << 2) + blk * (long)blockDim.x + threadIdx.x; i < count; i += (long)nblk * blockDim.x)
-            m = fmaxf(m, fabsf(w[i]));
-    } else {
-        for (long i = blk * (long)blockDim.x + threadIdx.x; i < count; i += (long)nblk * blockDim.x) m = fmaxf(m, fabsf(w[i]));
-    }
-    // one atomic per BLOCK: 2,300 same-address atomics (one per wave) took longer than reading the tensor
-    m = wave_max(m);
-    __shared__ float wm[4];
-    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
-    __syncthreads();
-    if (threadIdx.x == 0) atomicMax(amax_bits, __float_as_uint(fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]))));
-}
-__global__ void weight_amax_kernel(const float* __restrict__ w, long count, uint32_t* __restrict__ amax_bits, int vec) {
-    weight_amax_body(w, count, amax_bits, vec, blockIdx.x, gridDim.x);
-}
-
-template <int PREC>
-__device__ __forceinline__ void pack_weight_body(const float* __restrict__ src, float* __restrict__ dst, int cout, int cin,
-                                                 int ks, int cout_p, int cin_p, int transpose, const uint32_t* __restrict__ amax_bits,
-                                                 float* __restrict__ scale_inv_out, int blk, int grid_blocks) {
-    const float wscale = amax_bits ? pow2_scale_of(*amax_bits) : 1.f;
-    if (scale_inv_out && blk == 0 && threadIdx.x == 0) *scale_inv_out = 1.f / wscale;     // exact: power of two
-    constexpr int NKS = PREC == SGD_PREC_F32 ? 4 : 2;         // sub-steps per unit
-    constexpr int CPL = PREC == SGD_PREC_F32 ? 4 : 8;         // input channels per lane per sub-step
-    const int kk = ks * ks, nblk = cout_p >> 5;
-    const long total = (long)(cin_p >> 5) * kk * nblk * NKS * 64;
-    for (long i = blk * (long)blockDim.x + threadIdx.x; i < total; i += (long)grid_blocks * blockDim.x) {
-        const int lane = i & 63;
-        long t = i >> 6;
-        const int sub = t % NKS; t /= NKS;
-        const long unit = t;
-        const int nb = t % nblk; t /= nblk;
-        const int tap = t % kk;
-        const int chunk = t / kk;
-        const int co = nb * 32 + (lane & 31);
-        const int ci0 = chunk * 32 + sub * (2 * CPL) + (lane >> 5) * CPL;
-        float v[CPL];
-#pragma unroll
-        for (int j = 0; j < CPL; ++j) {
-            const int ci = ci0 + j;
-            float x = 0.f;
-            if (ci < cin && co < cout) {
-                // forward: W[co][ci][tap].  dgrad (adjoint conv): the packed "output" index co walks W's input channels,
-                // "input" index ci walks W's output channels, taps are flipped.
-                if (!transpose) x = src[((long)co * cin + ci) * kk + tap];
-                else x = src[((long)ci * cout + co) * kk + (kk - 1 - tap)];
-            }
-            v[j] = x * wscale;
-        }
-        if constexpr (PREC == SGD_PREC_F32) {
-            *reinterpret_cast<f32x4*>(dst + unit * 1024 + sub * 256 + lane * 4) = f32x4{v[0], v[1], v[2], v[3]};
-        } else {
-            typedef typename Split<PREC>::T T;
-            typedef T T8 __attribute__((ext_vector_type(8)));
-            T8 h, l;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                T hj, lj;
-                Split<PREC>::split(v[j], hj, lj);
-                h[j] = hj;
-                l[j] = lj;
-            }
-            T* up = reinterpret_cast<T*>(dst + unit * 1024) + sub * 1024 + lane * 8;
-            *reinterpret_cast<T8*>(up) = h;
-            *reinterpret_cast<T8*>(up + 512) = l;
-        }
-    }
-}
-template <int PREC>
-__global__ void pack_weight_kernel(const float* __restrict__ src, float* __restrict__ dst, int cout, int cin,
-                                   int ks, int cout_p, int cin_p, int transpose, const uint32_t* __restrict__ amax_bits,
-                                   float* __restrict__ scale_inv_out) {
-    pack_weight_body<PREC>(src, dst, cout, cin, ks, cout_p, cin_p, transpose, amax_bits, scale_inv_out, blockIdx.x, gridDim.x);
-}
-
-// ---- every weight of a training step in three launches (sgd_pack_weights_batched): the per-step re-pack was 142 pack +
-// 74 amax launches of ~6 us each for 1.2 GB of traffic that takes 0.25 ms at HBM speed
-__global__ void pack_zero_amax_kernel(const sgd_pack_job* __restrict__ jobs, int n) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n && jobs[i].own_amax && jobs[i].amax_bits) *jobs[i].amax_bits = 0u;
-}
-__global__ void weight_amax_batched_kernel(const sgd_pack_job* __restrict__ jobs, const int32_t* __restrict__ block_job,
-                                           const int32_t* __restrict__ first) {
-    const int j = block_job[blockIdx.x];
-    const sgd_pack_job jb = jobs[j];
-    const long count = (long)jb.cout * jb.cin * jb.ksize * jb.ksize;
-    weight_amax_body(jb.src, count, jb.amax_bits, (((uintptr_t)jb.src) & 15) == 0 && count >= 4, blockIdx.x - first[j], first[j + 1] - first[j]);
-}
-template <int PREC>
-__global__ void pack_weight_batched_kernel(const sgd_pack_job* __restrict__ jobs, const int32_t* __restrict__ block_job,
-                                           const int32_t* __restrict__ first) {
-    const int j = block_job[blockIdx.x];
-    const sgd_pack_job jb = jobs[j];
-    // (the adjoint operator's dims are the transposed ones, as in sgd_pack_weight_scaled)
-    const int co = jb.transpose ? jb.cin : jb.cout, ci = jb.transpose ? jb.cout : jb.cin;
-    const int bn = (co % 128 == 0) ? 128 : 32;
-    const int cout_p = ((co + bn - 1) / bn) * bn, cin_p = ((ci + KC - 1) / KC) * KC;
-    pack_weight_body<PREC>(jb.src, reinterpret_cast<float*>(jb.dst), co, ci, jb.ksize, cout_p, cin_p, jb.transpose, jb.amax_bits,
-                           jb.scale_inv, blockIdx.x - first[j], first[j + 1] - first[j]);
-}
-
-inline int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
-// compute units of the current device in whole groups of 8, at most 256 (the balanced tail's workspace layout is sized for
-// 32 blocks per XCD); read once per process and translation unit
-inline int device_cus() {
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256;
-        n &= ~7;
-        cus = n < 8 ? 8 : (n > 256 ? 256 : n);
-    }
-    return cus;
-}
-inline bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
-
 template <int BN, int PREC, bool VEC, int TAPS, bool DEFER = false>
 int launch1(const KArgs& ka, size_t smem, hipStream_t st) {
     static bool attr = false;
@@ -1876,24 +1648,9 @@ int launch(const KArgs& ka, int vec, int taps, size_t smem, hipStream_t st) {
 
 }  // namespace
 
-// One translation unit per arithmetic mode (build.py compiles this file with -DSGDM_IGEMM_PREC=0 / 1 / 2, in parallel: the
-// kernel template has 12 instances per mode and eight epilogue variants each): the mode's launch dispatcher has external
-// linkage, everything else lives in the host unit (no -DSGDM_IGEMM_PREC).  The argument block crosses as bytes.
-int sgd_igemm_dispatch_f32(const void* ka, int bn, int vec, int taps, size_t smem, hipStream_t st);
-int sgd_igemm_dispatch_f16x3(const void* ka, int bn, int vec, int taps, size_t smem, hipStream_t st);
-int sgd_igemm_dispatch_bf16x3(const void* ka, int bn, int vec, int taps, size_t smem, hipStream_t st);
-// The LayerNorm-row prologue (Attention_LR's to_q / to_kv, crossattetion_lr.py:81-88) in a split mode runs on instances compiled
-// with packed-f32 code generation OFF (build.py: -DSGDM_IGEMM_NOPK -Xclang -target-feature -Xclang -packed-fp32-ops; 1x1 / linear
-// instances only).  Round 4 found the two-plane instance of that prologue returning exactly beta -- the LayerNorm value with a zero
-// product -- in the low lane of v_pk_{mul,fma}_f32 for lanes 48..63 of a loader wave, in specific unrolled copies, on every launch;
-// with packed-f32 code generation off the same source passes (profiles/r5_ln_hazard_isa.txt).  The one-plane
-// instance the product uses has never shown it (canary + bit-repeatability tests), but it issues the same instructions: since round 6
-// no LayerNorm launch executes a packed-f32 instruction at all.  The whole library built that way cost 7.6 % of a sampling step (76
-// spilled registers in the 3x3 instance); confined to these launches it costs C2 nothing and C4 / C5 the difference on ~20 launches.
-int sgd_igemm_dispatch_f16x3_nopk(const void* ka, int bn, int vec, int taps, size_t smem, hipStream_t st);
-int sgd_igemm_dispatch_bf16x3_nopk(const void* ka, int bn, int vec, int taps, size_t smem, hipStream_t st);
-
-#ifdef SGDM_IGEMM_PREC
+#ifndef SGDM_IGEMM_PREC
+#error "igemm.hip is compiled once per arithmetic mode: -DSGDM_IGEMM_PREC=0|1|2 (build.py); geometry and entry points: igemm_host.hip"
+#endif
 #ifdef SGDM_DEV_ONE      /* development: compile ONE kernel instance (register / asm inspection), never linked */
 #define SGD_DISPATCH_BODY(P)                                                                                        \
     const KArgs& ka = *reinterpret_cast<const KArgs*>(kap); (void)bn; (void)vec; (void)taps;                         \
@@ -1915,320 +1672,3 @@ int sgd_igemm_dispatch_bf16x3_nopk(const void* kap, int bn, int vec, int taps, s
 #else
 int sgd_igemm_dispatch_bf16x3(const void* kap, int bn, int vec, int taps, size_t smem, hipStream_t st) { SGD_DISPATCH_BODY(SGD_PREC_BF16X3) }
 #endif
-#else   // ---------------------------------------------------------------------------------- host unit
-
-extern "C" int sgd_abi_version(void) { return SGD_ABI_VERSION; }
-
-static inline int pick_bn(int cout) { return (cout % 128 == 0) ? 128 : 32; }
-
-extern "C" int64_t sgd_packed_weight_bytes(int32_t cout, int32_t cin, int32_t ksize, int32_t prec) {
-    (void)prec;
-    const int bn = pick_bn(cout);
-    const int64_t cout_p = (int64_t)((cout + bn - 1) / bn) * bn;
-    const int64_t cin_p = (int64_t)((cin + KC - 1) / KC) * KC;
-    return (int64_t)ksize * ksize * cout_p * cin_p * 4;
-}
-
-static int pack_weight_impl(const float* w_src, void* w_dst, int32_t cout, int32_t cin, int32_t ksize, int32_t prec,
-                            int32_t* cin_p_out, int32_t* cout_p_out, int transpose, void* stream,
-                            const uint32_t* amax_bits = nullptr, float* scale_inv_out = nullptr) {
-    SGD_CLEAR_ERR();
-    if (!w_src || !w_dst || cout <= 0 || cin <= 0 || (ksize != 1 && ksize != 3)) return SGD_ERR_ARG;
-    const int bn = pick_bn(cout);
-    const int cout_p = ((cout + bn - 1) / bn) * bn;
-    const int cin_p = ((cin + KC - 1) / KC) * KC;
-    if (cin_p_out) *cin_p_out = cin_p;
-    if (cout_p_out) *cout_p_out = cout_p;
-    const long total = (long)ksize * ksize * cout_p * cin_p / (prec == SGD_PREC_F32 ? 4 : 8);     // 16-byte vectors
-    int grid = (int)((total + 255) / 256);
-    if (grid > 4096) grid = 4096;
-    hipStream_t st = (hipStream_t)stream;
-    float* dst = reinterpret_cast<float*>(w_dst);
-    if (prec == SGD_PREC_F32) hipLaunchKernelGGL((pack_weight_kernel<SGD_PREC_F32>), dim3(grid), dim3(256), 0, st, w_src, dst, cout, cin, ksize, cout_p, cin_p, transpose, amax_bits, scale_inv_out);
-    else if (prec == SGD_PREC_F16X3) hipLaunchKernelGGL((pack_weight_kernel<SGD_PREC_F16X3>), dim3(grid), dim3(256), 0, st, w_src, dst, cout, cin, ksize, cout_p, cin_p, transpose, amax_bits, scale_inv_out);
-    else if (prec == SGD_PREC_BF16X3) hipLaunchKernelGGL((pack_weight_kernel<SGD_PREC_BF16X3>), dim3(grid), dim3(256), 0, st, w_src, dst, cout, cin, ksize, cout_p, cin_p, transpose, amax_bits, scale_inv_out);
-    else return SGD_ERR_ARG;
-    return sgd_check_launch();
-}
-
-extern "C" int sgd_pack_weight(const float* w_src, void* w_dst, int32_t cout, int32_t cin, int32_t ksize,
-                               int32_t prec, int32_t* cin_p_out, int32_t* cout_p_out, void* stream) {
-    return pack_weight_impl(w_src, w_dst, cout, cin, ksize, prec, cin_p_out, cout_p_out, 0, stream);
-}
-
-// weights of the adjoint convolution (dgrad): w_src is the FORWARD weight [cout_fwd, cin_fwd, k, k]; the packed
-// operator maps cout_fwd input channels to cin_fwd output channels with flipped taps.
-extern "C" int sgd_pack_weight_dgrad(const float* w_src, void* w_dst, int32_t cout_fwd, int32_t cin_fwd, int32_t ksize,
-                                     int32_t prec, int32_t* cin_p_out, int32_t* cout_p_out, void* stream) {
-    return pack_weight_impl(w_src, w_dst, cin_fwd, cout_fwd, ksize, prec, cin_p_out, cout_p_out, 1, stream);
-}
-
-extern "C" int sgd_weight_amax(const float* w, int64_t count, uint32_t* amax_bits, void* stream) {
-    SGD_CLEAR_ERR();
-    if (!w || !amax_bits || count <= 0) return SGD_ERR_ARG;
-    const int vec = (((uintptr_t)w) & 15) == 0 && count >= 4;
-    long grid = vec ? (count + 4095) / 4096 : (count + 1023) / 1024;       // 16 elements per thread on the vector path
-    if (grid > 256) grid = 256;
-    hipLaunchKernelGGL(weight_amax_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, w, (long)count, amax_bits, vec);
-    return sgd_check_launch();
-}
-
-extern "C" int sgd_pack_weight_scaled(const float* w_src, void* w_dst, int32_t cout, int32_t cin, int32_t ksize, int32_t prec,
-                                      int32_t transpose, const uint32_t* amax_bits, float* scale_inv_out, int32_t* cin_p_out,
-                                      int32_t* cout_p_out, void* stream) {
-    if (!amax_bits || !scale_inv_out) return SGD_ERR_ARG;
-    if (transpose) return pack_weight_impl(w_src, w_dst, cin, cout, ksize, prec, cin_p_out, cout_p_out, 1, stream, amax_bits, scale_inv_out);
-    return pack_weight_impl(w_src, w_dst, cout, cin, ksize, prec, cin_p_out, cout_p_out, 0, stream, amax_bits, scale_inv_out);
-}
-
-extern "C" int sgd_pack_job_blocks(int32_t cout, int32_t cin, int32_t ksize, int32_t prec, int32_t transpose, int32_t* amax_blocks,
-                                   int32_t* pack_blocks, int32_t* cin_p_out, int32_t* cout_p_out) {
-    if (cout <= 0 || cin <= 0 || (ksize != 1 && ksize != 3)) return SGD_ERR_ARG;
-    const int co = transpose ? cin : cout, ci = transpose ? cout : cin;
-    const int bn = pick_bn(co);
-    const int cout_p = ((co + bn - 1) / bn) * bn, cin_p = ((ci + KC - 1) / KC) * KC;
-    const long count = (long)cout * cin * ksize * ksize;
-    long ab = (count + 4095) / 4096;
-    if (ab > 256) ab = 256;
-    const long total = (long)ksize * ksize * cout_p * cin_p / (prec == SGD_PREC_F32 ? 4 : 8);
-    long pb = (total + 255) / 256;
-    if (pb > 4096) pb = 4096;
-    if (amax_blocks) *amax_blocks = (int32_t)ab;
-    if (pack_blocks) *pack_blocks = (int32_t)pb;
-    if (cin_p_out) *cin_p_out = cin_p;
-    if (cout_p_out) *cout_p_out = cout_p;
-    return SGD_OK;
-}
-
-extern "C" int sgd_pack_weights_batched(const sgd_pack_job* jobs, int32_t n_jobs, const int32_t* amax_block_job,
-                                        const int32_t* amax_first, int32_t n_amax_blocks, const int32_t* pack_block_job,
-                                        const int32_t* pack_first, int32_t n_pack_blocks, int32_t prec, void* stream) {
-    SGD_CLEAR_ERR();
-    if (!jobs || n_jobs <= 0 || !pack_block_job || !pack_first || n_pack_blocks <= 0) return SGD_ERR_ARG;
-    hipStream_t st = (hipStream_t)stream;
-    if (prec != SGD_PREC_F32 && n_amax_blocks > 0) {
-        if (!amax_block_job || !amax_first) return SGD_ERR_ARG;
-        hipLaunchKernelGGL(pack_zero_amax_kernel, dim3((n_jobs + 255) / 256), dim3(256), 0, st, jobs, n_jobs);
-        hipLaunchKernelGGL(weight_amax_batched_kernel, dim3(n_amax_blocks), dim3(256), 0, st, jobs, amax_block_job, amax_first);
-    }
-    if (prec == SGD_PREC_F32) hipLaunchKernelGGL((pack_weight_batched_kernel<SGD_PREC_F32>), dim3(n_pack_blocks), dim3(256), 0, st, jobs, pack_block_job, pack_first);
-    else if (prec == SGD_PREC_F16X3) hipLaunchKernelGGL((pack_weight_batched_kernel<SGD_PREC_F16X3>), dim3(n_pack_blocks), dim3(256), 0, st, jobs, pack_block_job, pack_first);
-    else if (prec == SGD_PREC_BF16X3) hipLaunchKernelGGL((pack_weight_batched_kernel<SGD_PREC_BF16X3>), dim3(n_pack_blocks), dim3(256), 0, st, jobs, pack_block_job, pack_first);
-    else return SGD_ERR_ARG;
-    return sgd_check_launch();
-}
-
-// tile geometry of a launch (everything that does not depend on the packed-weight dims)
-static int make_geo(const sgd_igemm_args& a, Geo& g, int bn, int& na, int fg = 1) {
-    if (a.c0 <= 0 || a.c1 < 0 || a.cout <= 0 || a.y_ld < a.cout) return SGD_ERR_ARG;
-    if (a.mode == SGD_MODE_CONV3) {
-        if (a.n <= 0 || a.hi <= 0 || a.wi <= 0 || (a.stride != 1 && a.stride != 2)) return SGD_ERR_ARG;
-        if (a.stride == 2 && a.resample != SGD_RS_NONE) return SGD_ERR_ARG;
-        const bool up = a.resample == SGD_RS_UP2 || a.resample == SGD_RS_ZEROUP2;
-        g.hc = a.resample == SGD_RS_AVGPOOL2 ? a.hi / 2 : (up ? a.hi * 2 : a.hi);
-        g.wc = a.resample == SGD_RS_AVGPOOL2 ? a.wi / 2 : (up ? a.wi * 2 : a.wi);
-        if (a.resample == SGD_RS_AVGPOOL2 && ((a.hi | a.wi) & 1)) return SGD_ERR_ARG;
-        const int ho = a.stride == 2 ? (g.hc + 1) / 2 : g.hc, wo = a.stride == 2 ? (g.wc + 1) / 2 : g.wc;
-        if (a.ho != ho || a.wo != wo) return SGD_ERR_ARG;
-        if (!is_pow2(a.ho) || !is_pow2(a.wo) || a.ho < 2 || a.wo < 2) return SGD_ERR_ARG;
-        if (a.res && a.res_mode == SGD_RS_UP2 && ((a.ho | a.wo) & 1)) return SGD_ERR_ARG;
-        if ((long)a.n * a.hi * a.wi >= (1L << 31)) return SGD_ERR_ARG;      // source rows are 32-bit in the tile table
-        int tw = a.wo < 16 ? a.wo : 16;
-        int th = BM / tw; if (th > a.ho) th = a.ho;
-        while (th * tw > BM) th >>= 1;
-        if (a.stride == 2) { if (tw > 8) tw = 8; if (th > 8) th = 8; }   // big input halos: smaller spatial tile
-        int nb = BM / (th * tw);
-        g.hh = a.stride == 2 ? 2 * th + 1 : th + 2;
-        g.hw = a.stride == 2 ? 2 * tw + 1 : tw + 2;
-        // the double-buffered halo tile must fit LDS; rows of images beyond nb are computed on don't-care data and
-        // masked in the epilogue
-        while (nb > 1 && 3 * (size_t)nb * g.hh * g.hw * LDA * 4 + (size_t)nb * g.hh * g.hw * 32 > 150 * 1024)
-            nb >>= 1;
-        g.tw_l2 = ilog2(tw); g.th_l2 = ilog2(th); g.nb = nb;
-        g.tiles_x = a.wo / tw; g.tiles_y = a.ho / th;
-        g.pix = nb * g.hh * g.hw;
-        g.mt = ((a.n + nb - 1) / nb) * g.tiles_x * g.tiles_y;
-        g.fast_a = g.pix <= FAST_PIX ? 1 : 0;
-        na = 3;
-    } else if (a.mode == SGD_MODE_FLAT) {
-        if (a.m <= 0) return SGD_ERR_ARG;
-        if (a.pro == SGD_PRO_AFFINE_NC && a.rows_per_n <= 0) return SGD_ERR_ARG;
-        if (a.res && a.res_mode != SGD_RS_NONE) return SGD_ERR_ARG;
-        g.tw_l2 = g.th_l2 = 0; g.nb = 1; g.tiles_x = g.tiles_y = 1; g.hh = g.hw = 1; g.hc = g.wc = 1;
-        g.pix = BM * fg;          // fg 32-channel planes of the 128 rows side by side in one ring slot
-        g.mt = (a.m + BM - 1) / BM;
-        g.fast_a = 1;
-        na = 3;
-    } else {
-        return SGD_ERR_ARG;
-    }
-    // epilogue statistics (args.stats): whole 128-row tiles of ONE image, 16-byte stores
-    g.sparts = 0;
-    const int ppt = bn >= 128 ? 1 : 4;                        // M slices per tile = compute-wave rows
-    if (((a.cout | a.y_ld) & 3) == 0 && a.orows_in == 0) {
-        if (a.mode == SGD_MODE_CONV3) {
-            if (g.nb == 1 && (1 << (g.tw_l2 + g.th_l2)) == BM) g.sparts = g.tiles_x * g.tiles_y * ppt;
-        } else if (a.rows_per_n > 0 && a.rows_per_n % BM == 0 && a.m % a.rows_per_n == 0) {
-            g.sparts = a.rows_per_n / BM * ppt;
-        }
-    }
-    return SGD_OK;
-}
-
-// args.tune: SGD_TUNE_BN128 never, SGD_TUNE_BN256 whenever the shape allows; default: the rule below
-static bool want_bn256(const sgd_igemm_args& a) {
-    if (a.tune & SGD_TUNE_BN128) return false;
-    if (a.tune & SGD_TUNE_BN256) return true;
-    // whole rounds of 256 persistent blocks: a 128 x 256 tile costs 2 / 1.07 of a 128 x 128 one (measured, tools/ab_conv.py:
-    // +5..9 % where both shapes fill the chip evenly), so it wins unless the coarser tiles quantise worse
-    const long rows = a.mode == SGD_MODE_CONV3 ? (long)a.n * a.ho * a.wo : (long)a.m;
-    const long mt = (rows + BM - 1) / BM;
-    const long t256 = mt * (a.cout_p / 256), t128 = mt * (a.cout_p / 128);
-    if (t256 <= 256 && t128 > 256) return true;    // one round of bigger tiles instead of a second, partly empty one
-    // 3x3 launches in a split mode: the 128-column tile runs the 16x16x32 MFMA form, which the 64-column wave tile has no
-    // registers for, and wins wherever it fills the chip (measured, round 3: +4..14 % on every layer of more than one
-    // round); below one round (8x8 maps at UNet batch 80: 160 tiles) the bigger tile still does (+6..21 %)
-    if (a.mode == SGD_MODE_CONV3 && a.prec != SGD_PREC_F32) return t128 <= 256;
-    const long r256 = (t256 + 255) / 256, r128 = (t128 + 255) / 256;
-    return r256 * 2.0 < r128 * 1.07;
-}
-
-// Test hook (tests/test_boundary_cpu.py, no GPU): the balanced-tail workspace layout of a launch of `total_tiles` tiles with
-// `nchunks` channel chunks per tile on `grid` blocks -- per block {split, counter index, first slab, slabs} (split 0: the
-// block has no split tile) -- from the same functions the kernel uses.
-extern "C" int sgd_igemm_tail_layout(int32_t total_tiles, int32_t nchunks, int32_t taps, int32_t grid, int32_t* out) {
-    if (!out || grid < 8 || (grid & 7) || total_tiles < 0) return SGD_ERR_ARG;
-    const int xchunk = (total_tiles + 7) >> 3, nloc = grid >> 3;
-    for (int b = 0; b < grid; ++b) {
-        const int xcd = b & 7, loc = b >> 3;
-        const int xbeg = xcd * xchunk, xend = (xbeg + xchunk < total_tiles) ? xbeg + xchunk : total_tiles;
-        const int xtiles = xend > xbeg ? xend - xbeg : 0;
-        const int nfull = xtiles / nloc, xrem = xtiles - nfull * nloc;
-        const int split = tail_split(xrem, nloc, nchunks, taps);
-        int32_t* o = out + 4 * b;
-        o[0] = o[1] = o[2] = o[3] = 0;
-        if (split && loc < xrem * split) {
-            o[0] = split;
-            o[1] = tail_counter(xcd, loc, nloc, split);
-            o[2] = tail_slab(xcd, loc, nloc, split);
-            o[3] = split - 1;
-        }
-    }
-    return SGD_OK;
-}
-
-extern "C" int64_t sgd_igemm_work_bytes(void) {
-    // counters + the most slabs one launch can need: 8 XCDs x floor(32 / split) split tiles x (split - 1) producers, at the
-    // 128 x 256 tile (128 KiB of partial accumulators per slab): split = 4 -> 192 slabs
-    return (int64_t)WORK_HEAD + 192 * (int64_t)(BM * 256 * 4);
-}
-
-extern "C" int64_t sgd_igemm_work_status_offset(void) { return (int64_t)WORK_STATUS_INT * 4; }
-
-extern "C" int sgd_igemm_stats_parts(const sgd_igemm_args* args) {
-    if (!args) return 0;
-    Geo g;
-    int na;
-    if (make_geo(*args, g, pick_bn(args->cout), na) != SGD_OK) return 0;
-    return g.sparts;
-}
-
-extern "C" int sgd_igemm(const sgd_igemm_args* args, void* stream) {
-    SGD_CLEAR_ERR();
-    if (!args) return SGD_ERR_ARG;
-    KArgs ka;
-    ka.a = *args;
-    sgd_igemm_args& a = ka.a;
-    Geo& g = ka.g;
-    if (!a.x0 || !a.w || !a.y || a.c0 <= 0 || a.c1 < 0 || a.cout <= 0) return SGD_ERR_ARG;
-    if (a.c1 > 0 && (!a.x1 || a.c0 % KC != 0)) return SGD_ERR_ARG;
-    if (a.y_ld < a.cout) return SGD_ERR_ARG;
-    if (a.pro != SGD_PRO_NONE && (!a.pa || !a.pb)) return SGD_ERR_ARG;
-    const int cin = a.c0 + a.c1;
-    int bn = pick_bn(a.cout);
-    if (a.cout_p % bn != 0 || a.cout_p < a.cout || a.cin_p % KC != 0 || a.cin_p < cin) return SGD_ERR_ARG;
-    const bool vec = (a.c0 % 4 == 0) && (a.c1 % 4 == 0);
-    // 128 x 256 tile (64 columns per compute wave): launches whose output channels allow it.  The packed-weight layout does
-    // not depend on the tile (units of 32 output channels), so this is a launch-time choice.
-    if (bn == 128 && a.cout_p % 256 == 0 && vec && (!a.res || a.res_mode == SGD_RS_NONE) && want_bn256(a)) bn = 256;
-    int na;
-    const bool conv = a.mode == SGD_MODE_CONV3;
-    // Two planes per chunk (igemm_kernel<.., TAPS = 2>): OPT-IN, args.tune & SGD_TUNE_FLAT2.  Flat launches the lean loaders serve
-    // (16-byte rows, no / per-image GroupNorm prologue, no dropout, whole 32-channel planes per source) with an even
-    // number of planes.  Measured (round 4, tools/ab_conv.py, UNet batch 80): bit-identical to the one-plane instance,
-    // +3..6 % on proj_out / decoder skips with a prologue, 0..3 % on plain ones, 0 on qkv and the HBM-bound 64x64 skips
-    // -- the barrier per K step was never these launches' cost.  With the LayerNorm-row prologue (Attention_LR's to_q /
-    // to_kv) in a split mode the same instance returns wrong rows -- always tile rows 6, 7 mod 8, i.e. lanes 48..63 of a
-    // loader wave, a different subset on every launch -- while exact f32 and every other prologue stay bit-identical.
-    // DESIGN.md section 4 (round 4) and profiles/r4_ln_hazard.txt hold what tools/ln_hazard.py established: the wrong
-    // cells hold exactly beta in the low lane of a packed-f32 pair (the LayerNorm value with a zero product), in three of
-    // the six unrolled copies of the staging code only; no wait or idle cycle around the loads or the LDS stores changes
-    // it, moving the surrounding code does.  Round 6: with packed-f32 code generation off the same two-plane instance passes
-    // 240 of 240 launches that fail 238 of 240 with it on (tools/ln_hazard.py, profiles/r6_ln_hazard.txt), so every
-    // LayerNorm launch of a split mode runs on the no-packed-f32 unit (ln_nopk below); the two-plane instance stays opt-in.
-    int taps = conv ? 9 : 1;
-    // LayerNorm-row prologue in a split mode: the unit without packed-f32 instructions (SGD_TUNE_LN_PACKED: the regular unit --
-    // tools/ln_hazard.py reproduces the round-4 fault with it); only there may the two-plane instance serve that prologue
-    const bool ln_nopk = !conv && a.pro == SGD_PRO_LN_ROW && a.prec != SGD_PREC_F32 && !(a.tune & SGD_TUNE_LN_PACKED);
-    const bool ln_any = !conv && a.pro == SGD_PRO_LN_ROW && (ln_nopk || (a.tune & SGD_TUNE_LN_PACKED));
-    if (!conv && vec && bn >= 128 && a.drop_p == 0.f && cin % (2 * KC) == 0 && (a.c1 == 0 || a.c0 % KC == 0)
-        && (a.pro == SGD_PRO_NONE || (a.pro == SGD_PRO_AFFINE_NC && a.rows_per_n > 0 && a.rows_per_n % BM == 0) || ln_any)
-        && (a.tune & SGD_TUNE_FLAT2))
-        taps = 2;
-    {
-        const int rc = make_geo(a, g, bn, na, conv ? 1 : taps);
-        if (rc != SGD_OK) return rc;
-    }
-    if (a.stats && g.sparts == 0) return SGD_ERR_ARG;
-    g.nt = a.cout_p / bn;
-    if ((a.work && a.work_bytes < sgd_igemm_work_bytes()) || (a.tune & SGD_TUNE_PLAIN_SCHEDULE)) a.work = nullptr;
-    {
-        // epilogue uses 32-bit row indices
-        const long rows_out = a.mode == SGD_MODE_CONV3 ? (long)a.n * a.ho * a.wo : (long)a.m;
-        const long rows_res = a.res_mode == SGD_RS_AVGPOOL2 ? rows_out * 4 : rows_out;
-        if (rows_out >= (1L << 31) || rows_res >= (1L << 31)) return SGD_ERR_ARG;
-    }
-#ifdef SGDM_PROBE
-    {
-        const char* e = getenv("SGDM_DBG");
-        g.dbg = e ? atoi(e) : 0;
-        const char* sp = getenv("SGDM_STAMP_PTR");       // device buffer of gridDim * 12 * 4 u64 (tools/probe_conv.py)
-        g.stamp = sp ? reinterpret_cast<unsigned long long*>(strtoull(sp, nullptr, 0)) : nullptr;
-        const char* tp = getenv("SGDM_TRACE_PTR");
-        g.trace = tp ? reinterpret_cast<unsigned long long*>(strtoull(tp, nullptr, 0)) : nullptr;
-    }
-#endif
-    const size_t smem = (size_t)na * g.pix * LDA * sizeof(float) + (size_t)g.pix * 32
-                        + (a.cout_p <= BIAS_LDS_MAX ? (size_t)a.cout_p * sizeof(float) : 0);
-    if (smem > 160 * 1024) return SGD_ERR_ARG;
-    hipStream_t st = (hipStream_t)stream;
-    // Loader-side epilogue (igemm_kernel<.., DEFER>): 3x3 launches with 128-column tiles in a split mode, 16-byte inputs
-    // and outputs, no or same-row residual, bias in LDS, at least 3 chunks per tile (the slices of a tile's epilogue ride
-    // on the periods of the next one), buffers addressable with 32-bit byte offsets, and room for the staging tile
-    int variant = vec ? 1 : 0;
-    size_t smem_launch = smem;
-    {
-        // Opt-in (args.tune & SGD_TUNE_DEFER).  Measured (round 3, UNet batch 80): correct, the compute waves' epilogue time drops from
-        // 8..10 us per tile to 0.3 us -- and the launches are 3..7 % SLOWER: the chip is power-limited, the idle wait cost
-        // little energy, and the staging copy plus the loaders' extra instructions cost more than the wait saved.
-        const int nchunks = (cin + KC - 1) / KC;
-        const long rows_out = (long)a.n * a.ho * a.wo;
-        const size_t smem_defer = smem + (size_t)BM * (128 + 4) * sizeof(float);
-        if (conv && vec && bn == 128 && a.prec != SGD_PREC_F32 && ((a.cout | a.y_ld) & 3) == 0
-            && (!a.res || a.res_mode == SGD_RS_NONE) && a.resample != SGD_RS_AVGPOOL2 && a.cout_p <= BIAS_LDS_MAX && nchunks >= 3
-            && rows_out * a.y_ld * 4 < (1L << 32) && (!a.stats || (long)a.n * g.sparts * 2 * a.cout * 4 < (1L << 32))
-            && smem_defer <= 160 * 1024 && (a.tune & SGD_TUNE_DEFER)) {
-            variant = 2;
-            smem_launch = smem_defer;
-        }
-    }
-    switch (a.prec) {
-        case SGD_PREC_F32: return sgd_igemm_dispatch_f32(&ka, bn, variant, taps, smem_launch, st);
-        case SGD_PREC_F16X3: return ln_nopk ? sgd_igemm_dispatch_f16x3_nopk(&ka, bn, variant, taps, smem_launch, st)
-                                            : sgd_igemm_dispatch_f16x3(&ka, bn, variant, taps, smem_launch, st);
-        case SGD_PREC_BF16X3: return ln_nopk ? sgd_igemm_dispatch_bf16x3_nopk(&ka, bn, variant, taps, smem_launch, st)
-                                             : sgd_igemm_dispatch_bf16x3(&ka, bn, variant, taps, smem_launch, st);
-        default: return SGD_ERR_ARG;
-    }
-}
-#endif   // host unit

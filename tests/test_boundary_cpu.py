@@ -67,7 +67,8 @@ def test_release_library_reads_no_environment():
     data = open(L.LIB_PATH, "rb").read()
     assert b"getenv" not in data
     assert b"SGDM_" not in data
-    for src in ("igemm.hip", "backward.hip", "attention.hip", "misc.hip", "norm.hip", "narrow.hip"):
+    for src in ("igemm.hip", "igemm_host.hip", "igemm_shared.h", "pack.hip", "exchange.hip", "backward.hip", "attention.hip", "misc.hip",
+                "norm.hip", "narrow.hip"):
         text = open(os.path.join(ROOT, "self-guided-diffusion-models_amd", "csrc", src)).read()
         outside_probe = re.sub(r"#ifdef SGDM_PROBE\n.*?#endif", "", text, flags=re.S)
         assert "getenv(" not in outside_probe, src
