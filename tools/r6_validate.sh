@@ -8,6 +8,7 @@ if [ "$2" = "probes" ]; then
   timeout 600 python tools/ln_hazard.py --reps 30 --prec bf16x3 > $OUT/ln_hazard_bf16x3.txt 2>&1
   timeout 600 python tools/hbm_probe_sweep.py --rounds 3 > $OUT/hbm_probe.txt 2>&1
 fi
+timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.txt 2>&1; tail -3 $OUT/smoke.txt
 timeout 1800 python bench.py --steps 20 --warmup 5 > $OUT/bench.log 2>&1; grep '^{"metric"' $OUT/bench.log | tail -1 > $OUT/bench.json
 python - "$OUT/bench.json" <<'PY'
 import json, sys
