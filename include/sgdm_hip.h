@@ -125,6 +125,7 @@ enum {
     SGD_TUNE_FLAT2 = 4,            /* sgd_igemm, 1x1 / linear: two 32-channel planes per barrier (never with PRO_LN_ROW) */
     SGD_TUNE_DEFER = 8,            /* sgd_igemm, 3x3 split modes: the epilogue on the loader waves */
     SGD_TUNE_PLAIN_SCHEDULE = 16,  /* sgd_igemm: no balanced tail even with a workspace */
+    SGD_TUNE_NO_SMALL = 64,        /* sgd_igemm: the 128-column tile even for launches of fewer such tiles than an eighth of the device */
     SGD_TUNE_LN_PACKED = 32,       /* sgd_igemm, PRO_LN_ROW in a split mode: the regular instances (packed-f32 code generation on)
                                       instead of the no-packed-f32 ones the launcher takes for that prologue (tools/ln_hazard.py) */
     SGD_TUNE_WGRAD_GENERIC_NARROW = 256,  /* sgd_wgrad: stem / head on the generic kernels instead of wgrad_narrow_kernel */

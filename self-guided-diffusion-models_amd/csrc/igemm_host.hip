@@ -10,6 +10,22 @@ extern "C" int sgd_abi_version(void) { return SGD_ABI_VERSION; }
 
 static inline int pick_bn(int cout) { return (cout % 128 == 0) ? 128 : 32; }
 
+// Column tile of a launch.  Layers of a multiple of 128 output channels take the 128-column tile -- unless the launch is SMALL
+// (round 6): a persistent grid is one block per compute unit, and at small batch the low-resolution
+// layers have a handful of 128-column tiles (C1: 256 -> 256 at 8 x 8, UNet batch 16: 8 tiles of 128 x 256 on 256 compute
+// units, 65 us per launch under rocprofv3).  With at most a quarter of the device's compute units in 128-column tiles the launch
+// runs the 32-column instance instead (four times the tiles, four waves of 32 x 32 per block; the input tile is staged once per
+// 32 columns, which an idle device does not notice): measured 1.2 .. 2.2 x on 3x3 launches of 8 .. 64 such tiles and 1.1 .. 1.5 x on
+// 1x1 launches, slower from 96 .. 128 tiles on (profiles/r6_ab_small_launches.txt).  The packed weights do not depend on the tile;
+// the statistics slots do (sgd_igemm_stats_parts applies the same rule).  SGD_TUNE_NO_SMALL: off.
+static inline int column_tile(const sgd_igemm_args& a) {
+    const int bn = pick_bn(a.cout);
+    if (bn != 128 || (a.tune & (SGD_TUNE_NO_SMALL | SGD_TUNE_BN128 | SGD_TUNE_BN256))) return bn;
+    const long rows = a.mode == SGD_MODE_CONV3 ? (long)a.n * a.ho * a.wo : (long)a.m;
+    const long t128 = ((rows + BM - 1) / BM) * ((a.cout + 127) / 128);
+    return t128 * 4 <= device_cus() ? 32 : 128;
+}
+
 static int make_geo(const sgd_igemm_args& a, Geo& g, int bn, int& na, int fg = 1) {
     if (a.c0 <= 0 || a.c1 < 0 || a.cout <= 0 || a.y_ld < a.cout) return SGD_ERR_ARG;
     if (a.mode == SGD_MODE_CONV3) {
@@ -70,16 +86,20 @@ static int make_geo(const sgd_igemm_args& a, Geo& g, int bn, int& na, int fg = 1
 static bool want_bn256(const sgd_igemm_args& a) {
     if (a.tune & SGD_TUNE_BN128) return false;
     if (a.tune & SGD_TUNE_BN256) return true;
-    // whole rounds of 256 persistent blocks: a 128 x 256 tile costs 2 / 1.07 of a 128 x 128 one (measured, tools/ab_conv.py:
-    // +5..9 % where both shapes fill the chip evenly), so it wins unless the coarser tiles quantise worse
     const long rows = a.mode == SGD_MODE_CONV3 ? (long)a.n * a.ho * a.wo : (long)a.m;
     const long mt = (rows + BM - 1) / BM;
     const long t256 = mt * (a.cout_p / 256), t128 = mt * (a.cout_p / 128);
-    if (t256 <= 256 && t128 > 256) return true;    // one round of bigger tiles instead of a second, partly empty one
     // 3x3 launches in a split mode: the 128-column tile runs the 16x16x32 MFMA form, which the 64-column wave tile has no
-    // registers for, and wins wherever it fills the chip (measured, round 3: +4..14 % on every layer of more than one
-    // round); below one round (8x8 maps at UNet batch 80: 160 tiles) the bigger tile still does (+6..21 %)
-    if (a.mode == SGD_MODE_CONV3 && a.prec != SGD_PREC_F32) return t128 <= 256;
+    // registers for, and wins wherever it fills the chip (measured, round 3: +4..14 % on every layer of more than one round).
+    // Up to one round of 128-column tiles the bigger tile was the rule since round 3 (8x8 maps at UNet batch 80: 160 tiles,
+    // +6..21 %); round 6 re-measured the zone (profiles/r6_ab_small_launches.txt): the bigger tile wins only where the
+    // balanced tail can cut it along K and two images share a tile -- 8x8 maps of >= 512 input channels (+7..21 %) -- and loses
+    // 10..37 % elsewhere (16 x 256 -> 256 @32^2: 0.075 vs 0.055 ms; 32 x 512 -> 512 @16^2: 0.114 vs 0.092), as does "one round of
+    // bigger tiles instead of a second, partly empty one" (80 x 1024 -> 1024 @8^2: 0.321 vs 0.277; 40 x 512 -> 512 @16^2: 0.141 vs 0.135)
+    if (a.mode == SGD_MODE_CONV3 && a.prec != SGD_PREC_F32) return t128 <= 256 && a.ho * a.wo <= 64 && a.c0 + a.c1 >= 512;
+    // whole rounds of 256 persistent blocks: a 128 x 256 tile costs 2 / 1.07 of a 128 x 128 one (measured, tools/ab_conv.py:
+    // +5..9 % where both shapes fill the chip evenly), so it wins unless the coarser tiles quantise worse
+    if (t256 <= 256 && t128 > 256) return true;    // one round of bigger tiles instead of a second, partly empty one
     const long r256 = (t256 + 255) / 256, r128 = (t128 + 255) / 256;
     return r256 * 2.0 < r128 * 1.07;
 }
@@ -120,7 +140,7 @@ extern "C" int sgd_igemm_stats_parts(const sgd_igemm_args* args) {
     if (!args) return 0;
     Geo g;
     int na;
-    if (make_geo(*args, g, pick_bn(args->cout), na) != SGD_OK) return 0;
+    if (make_geo(*args, g, column_tile(*args), na) != SGD_OK) return 0;
     return g.sparts;
 }
 
@@ -136,8 +156,8 @@ extern "C" int sgd_igemm(const sgd_igemm_args* args, void* stream) {
     if (a.y_ld < a.cout) return SGD_ERR_ARG;
     if (a.pro != SGD_PRO_NONE && (!a.pa || !a.pb)) return SGD_ERR_ARG;
     const int cin = a.c0 + a.c1;
-    int bn = pick_bn(a.cout);
-    if (a.cout_p % bn != 0 || a.cout_p < a.cout || a.cin_p % KC != 0 || a.cin_p < cin) return SGD_ERR_ARG;
+    int bn = column_tile(a);
+    if (a.cout_p % pick_bn(a.cout) != 0 || a.cout_p < a.cout || a.cin_p % KC != 0 || a.cin_p < cin) return SGD_ERR_ARG;
     const bool vec = (a.c0 % 4 == 0) && (a.c1 % 4 == 0);
     // 128 x 256 tile (64 columns per compute wave): launches whose output channels allow it.  The packed-weight layout does
     // not depend on the tile (units of 32 output channels), so this is a launch-time choice.

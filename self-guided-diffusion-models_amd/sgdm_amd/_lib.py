@@ -23,7 +23,7 @@ PREC_BY_NAME = {"f32": PREC_F32, "f16x3": PREC_F16X3, "bf16x3": PREC_BF16X3}
 ABI_VERSION = 19
 
 # sgd_igemm_args.tune (include/sgdm_hip.h: SGD_TUNE_*): per-call schedule overrides for parity tests and A/B tools
-TUNE_BN128, TUNE_BN256, TUNE_FLAT2, TUNE_DEFER, TUNE_PLAIN_SCHEDULE, TUNE_LN_PACKED = 1, 2, 4, 8, 16, 32
+TUNE_BN128, TUNE_BN256, TUNE_FLAT2, TUNE_DEFER, TUNE_PLAIN_SCHEDULE, TUNE_LN_PACKED, TUNE_NO_SMALL = 1, 2, 4, 8, 16, 32, 64
 TUNE_WGRAD_GENERIC_NARROW, TUNE_WGRAD_NO_POOLED_PLANES, TUNE_WGRAD_F32 = 256, 512, 1024
 TUNE_WGRAD_NO_WS, TUNE_WGRAD_NO_PLANES, TUNE_WGRAD_NO_PIPE, TUNE_WGRAD_PLANES_ALWAYS = 2048, 4096, 8192, 16384
 
