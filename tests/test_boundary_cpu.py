@@ -59,6 +59,31 @@ def test_diagnostics_live_in_their_own_library():
                 assert "load_tools" not in open(os.path.join(base, f)).read(), f
 
 
+def test_host_side_launch_rules_need_no_gpu():
+    """round 6: rules that live on the host side of the C-ABI answer without a device -- the column tile of small launches (through
+    the statistics-slot count it implies), the shapes the row-stream GroupNorm-backward reduce serves, and the argument checks of the
+    exchange entry (no RCCL library is touched for an invalid call)"""
+    from sgdm_amd import _lib as L
+    lib = L.load()
+    a = L.IgemmArgs()
+    a.mode, a.c0, a.stride, a.prec = L.MODE_CONV3, 128, 1, L.PREC_F16X3
+
+    def parts(n, hw, cout, tune=0):
+        a.n, a.hi, a.wi, a.ho, a.wo, a.cout, a.y_ld, a.tune = n, hw, hw, hw, hw, cout, cout, tune
+        return lib.sgd_igemm_stats_parts(ctypes.byref(a))
+    # 128-row tiles of one image: hw^2 / 128 slots per wave row; one wave row on the 128-column tile, four on the 32-column instance
+    assert parts(80, 64, 128) == 32 and parts(80, 16, 512) == 2          # the benchmark batch: 128-column tiles
+    assert parts(2, 16, 128) == 8 and parts(2, 16, 128, L.TUNE_NO_SMALL) == 2     # 4 tiles of 128 columns: the 32-column instance
+    assert parts(16, 16, 256) == 8 and parts(32, 16, 256) == 2          # 64 such tiles: still small; 128: not any more
+    assert parts(80, 8, 256) == 0                                       # two images per tile: no fused statistics
+    assert parts(80, 64, 96) == 128                                     # not a multiple of 128 channels: always the 32-column instance
+    f = lib.sgd_gn_bwd_rows_chunks
+    assert f(80, 64, 64, 128) == 16 and f(80, 32, 32, 256) == 16 and f(80, 32, 32, 32) == 4 and f(80, 16, 16, 512) == 0
+    assert f(80, 64, 64, 96) == 0 and f(80, 64, 64, 2048) == 0
+    assert lib.sgd_allreduce_bucket(None, None, 0, None) == 1
+    assert lib.sgd_adamw_ema_step(None, None, 0, 0, 1e-3, 0.1, 0.999, 1e-3, 1e-8, 0.0, 1.0, 1.0, -1.0, None, None) == 1
+
+
 def test_release_library_reads_no_environment():
     """"no global state, re-entrant per stream" (VERDICT round 4, weak #7).  The shipped library neither
     imports getenv nor carries the name of a tuning variable: schedule overrides are fields of the call
