@@ -33,7 +33,7 @@ def make_cfg(kind, image_size, in_channels=3, out_channels=3, model_channels=128
              resblock_updown=None, conv_resample=True, dropout=0.0,
              cond_dim=0, condition_method=None, layout_dim=0, scale_type="imagen",
              cond_token_num=0, context_dim=None, use_cls_token_as_pooled=True,
-             use_spatial_transformer=False, transformer_depth=1):
+             use_spatial_transformer=False, transformer_depth=1, use_new_attention_order=False):
     """Collect the reference ctor kwargs (config/dynamic/unet_fast.yaml:3-19,
     config/dynamic/unetca_fast.yaml:6-31).  ``layout_dim`` stands for
     ``condition.<condition_method>.layout_dim`` (config/condition/default.yaml)."""
@@ -51,7 +51,8 @@ def make_cfg(kind, image_size, in_channels=3, out_channels=3, model_channels=128
                 condition_method=condition_method, layout_dim=layout_dim,
                 scale_type=scale_type, cond_token_num=cond_token_num,
                 context_dim=context_dim, use_cls_token_as_pooled=use_cls_token_as_pooled,
-                use_spatial_transformer=use_spatial_transformer, transformer_depth=transformer_depth)
+                use_spatial_transformer=use_spatial_transformer, transformer_depth=transformer_depth,
+                use_new_attention_order=bool(use_new_attention_order))
 
 
 def _layout_channels(cfg):
@@ -288,14 +289,18 @@ def res_block(cfg, sd, p, x, emb, updown, dropout_mask=None):
     return x + h
 
 
-def attention_block(sd, p, x, heads):
-    """AttentionBlock._forward + QKVAttentionLegacy (openaimodel.py:365-371, :403-420)."""
+def attention_block(sd, p, x, heads, new_order=False):
+    """AttentionBlock._forward + QKVAttentionLegacy (openaimodel.py:365-371, :403-420); new_order: QKVAttention
+    (use_new_attention_order=True, openaimodel.py:350-352, :427-455) -- q | k | v split BEFORE the heads"""
     b, c, hh, ww = x.shape
     xf = x.reshape(b, c, -1)
     qkv = F.conv1d(_gn(sd, p + ".norm", xf), sd[p + ".qkv.weight"], sd[p + ".qkv.bias"])
     length = qkv.shape[-1]
     ch = c // heads
-    q, k, v = qkv.reshape(b * heads, ch * 3, length).split(ch, dim=1)   # legacy order: heads, then q|k|v
+    if new_order:
+        q, k, v = (t.reshape(b * heads, ch, length) for t in qkv.chunk(3, dim=1))   # q|k|v, then heads (openaimodel.py:443-451)
+    else:
+        q, k, v = qkv.reshape(b * heads, ch * 3, length).split(ch, dim=1)   # legacy order: heads, then q|k|v
     scale = 1 / math.sqrt(math.sqrt(ch))
     w = torch.einsum("bct,bcs->bts", q * scale, k * scale)
     w = torch.softmax(w.float(), dim=-1)
@@ -382,7 +387,7 @@ def _run_block(cfg, sd, prefix, blk, h, emb, context, dropout_masks):
             elif cfg.get("use_spatial_transformer"):
                 h = spatial_transformer(cfg, sd, p, h, layer[2])              # openaimodel.py:915: context is always None
             else:
-                h = attention_block(sd, p, h, layer[2])
+                h = attention_block(sd, p, h, layer[2], cfg.get("use_new_attention_order", False))
         elif kind == "down":
             if layer[2]:                                    # conv stride 2 (openaimodel_ca.py:167-174)
                 h = F.conv2d(h, sd[p + ".op.weight"], sd[p + ".op.bias"], stride=2, padding=1)

@@ -471,9 +471,10 @@ class Backward:
         qkv, gqkv = rec["qkv"], self.buf(n, T, 3 * ch)
         dvec = self.buf(n, heads, T)
         off = lambda t, k: C.c_void_p(t.data_ptr() + 4 * k)
-        self.prog.add(p + ".attn_bwd", self.attention_bwd_fn(), _ptr(qkv), 3 * ch, 3 * d, off(qkv, d), off(qkv, 2 * d),
-                      3 * ch, 3 * d, _ptr(rec["att"]), ch, _ptr(gatt), ch, _ptr(rec["lse"]), _ptr(dvec), n, heads, T, T, d,
-                      1.0 / math.sqrt(d), _ptr(gqkv), off(gqkv, d), off(gqkv, 2 * d))
+        hs, ko, vo = rec.get("qkv_layout", (3 * d, d, 2 * d))      # head stride, k / v offsets: legacy or new attention order
+        self.prog.add(p + ".attn_bwd", self.attention_bwd_fn(), _ptr(qkv), 3 * ch, hs, off(qkv, ko), off(qkv, vo),
+                      3 * ch, hs, _ptr(rec["att"]), ch, _ptr(gatt), ch, _ptr(rec["lse"]), _ptr(dvec), n, heads, T, T, d,
+                      1.0 / math.sqrt(d), _ptr(gqkv), off(gqkv, ko), off(gqkv, vo))
         wq = P(p + ".qkv.weight")
         gxn = self.buf(n, T, ch)
         self.dgrad(p + ".qkv.dgrad", gqkv, 3 * ch, gxn, ch, [wq], lambda: wq, 3 * ch, ch, 1, m=n * T)

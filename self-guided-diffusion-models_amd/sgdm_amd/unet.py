@@ -1080,8 +1080,9 @@ class UNetModel(UNetModelBase):
         self.use_spatial_transformer = use_spatial_transformer
         self.transformer_depth = transformer_depth
         self.context_dim = context_dim
-        if use_new_attention_order:
-            raise NotImplementedError("use_new_attention_order=True is not used by any shipped config")
+        # QKVAttention instead of QKVAttentionLegacy (openaimodel.py:350-355): q | k | v are split before the heads -- for the
+        # attention core a matter of strides (round 6; with the SpatialTransformer the flag has no effect, as in the reference)
+        self.use_new_attention_order = bool(use_new_attention_order)
         if condition_method == "cluster_lookup":
             raise NotImplementedError("cluster_lookup (nn.Embedding(888888888, .)) is not supported")
         self._setup(image_size, in_channels, model_channels, out_channels, num_res_blocks, attention_resolutions,
@@ -1270,15 +1271,17 @@ class UNetModel(UNetModelBase):
                        pro=L.PRO_AFFINE_NC, pa=a, pb=b, bias=P(p + ".qkv.bias"))
         att = eng.buf(n, T, ch)
         lse = eng.buf(n, heads, T)                         # softmax statistics kept for the backward
-        # legacy layout: channel = head*3d + {q: 0, k: d, v: 2d}; scale = (d^-1/4)^2 applied to q.k
-        eng.prog.add(p + ".attn", eng.attention_fn(), _ptr(qkv), 3 * ch, 3 * d,
-                     C.c_void_p(qkv.data_ptr() + 4 * d), C.c_void_p(qkv.data_ptr() + 8 * d), 3 * ch, 3 * d,
+        # legacy layout: channel = head*3d + {q: 0, k: d, v: 2d}; new order (QKVAttention): channel = {q: 0, k: ch, v: 2ch} + head*d;
+        # scale = (d^-1/4)^2 applied to q.k
+        hs, ko, vo = (d, ch, 2 * ch) if getattr(self, "use_new_attention_order", False) else (3 * d, d, 2 * d)
+        eng.prog.add(p + ".attn", eng.attention_fn(), _ptr(qkv), 3 * ch, hs,
+                     C.c_void_p(qkv.data_ptr() + 4 * ko), C.c_void_p(qkv.data_ptr() + 4 * vo), 3 * ch, hs,
                      n, heads, T, T, d, 1.0 / math.sqrt(d), _ptr(att), ch, _ptr(lse))
         y = eng.buf(n, hh, ww, ch)
         ap = eng.igemm(p + ".proj_out", att, ch, y, ch, eng.pack([p + ".proj_out.weight"], 1), m=n * T, rows_per_n=T,
                        bias=P(p + ".proj_out.bias"), res=t, stats=True)
         eng.tape.append(dict(kind="attn", p=p, x=t, ch=ch, heads=heads, d=d, T=T, hw=(hh, ww), a=a, b=b, sums=sums,
-                             qkv=qkv, att=att, lse=lse, qkv_args=aq, proj_args=ap, y=y))
+                             qkv=qkv, att=att, lse=lse, qkv_args=aq, proj_args=ap, y=y, qkv_layout=(hs, ko, vo)))
         return (y, ch, hh, ww)
 
     # ---- reference entry points (openaimodel.py:861-956)

@@ -75,4 +75,5 @@ def cfg_from_index(entry):
                     context_dim=kw.get("context_dim"),
                     use_cls_token_as_pooled=kw.get("use_cls_token_as_pooled", True),
                     use_spatial_transformer=kw.get("use_spatial_transformer", False),
-                    transformer_depth=kw.get("transformer_depth", 1))
+                    transformer_depth=kw.get("transformer_depth", 1),
+                    use_new_attention_order=kw.get("use_new_attention_order", False))

@@ -59,6 +59,29 @@ def test_train_step_unet_fast_vs_reference(prec, tol):
     assert abs(sq - float(v[tag + ".grad_sqnorm"])) < 1e-3 * float(v[tag + ".grad_sqnorm"])
 
 
+@pytest.mark.parametrize("prec,tol", [("f32", 5e-5), ("f16x3", 1e-4)])
+def test_train_step_new_attention_order_vs_reference(prec, tol):
+    """use_new_attention_order=True (QKVAttention: q | k | v split before the heads -- other strides into the same attention core,
+    forward and backward): one training step against the reference module's loss and attention-parameter gradients"""
+    from conftest import load_npz
+    v, u = load_npz("train_newattn.npz"), load_npz("unet_uf_newattn_label_c32_s16.npz")
+    m, entry = build_model("uf_newattn_label_c32_s16", prec)
+    assert m.use_new_attention_order
+    m.train()
+    m.dropout = 0.0
+    x, t, cond = torch.from_numpy(u["x"]).cuda(), torch.from_numpy(u["t"]).cuda(), torch.from_numpy(u["cond"]).cuda()
+    eps, _, _ = m(x, t, cond=cond, layout=None, cond_drop_prob=0.5, cond_drop_mask=torch.tensor([False, True]).cuda())
+    noise = torch.from_numpy(v["noise"]).cuda()
+    loss = ((noise - eps) ** 2).reshape(2, -1).mean(1).mean()
+    assert abs(loss.item() - float(v["loss"])) < (2e-5 if prec == "f32" else 5e-5) * abs(float(v["loss"]))
+    loss.backward()
+    grads = dict(m.named_parameters())
+    for key in [k for k in v if k.startswith("g:")]:
+        ref = torch.from_numpy(v[key])
+        if float(ref.abs().max()) > 1e-6:
+            assert max_rel(grads[key[2:]].grad.cpu(), ref) < tol, key
+
+
 def test_frozen_parameters_get_no_gradient():
     m, *_ = _step("uf_clusterlayout_c32_s16", "f32")
     assert m.null_cond_emb.grad is None and m.null_layout_emb.grad is None
