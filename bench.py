@@ -352,6 +352,7 @@ def train_step_bench(model, diff, data, cond, layout, B, world, barrier, wl, ste
                 exchange_ms=ov.get("exchange_ms"), exposed_exchange_ms=ov.get("exposed_exchange_ms"),
                 first_bucket_at_frac_of_backward=ov.get("first_bucket_at_frac_of_backward"),
                 exchange_buckets=ov.get("per_bucket"), exchange_backward_ms=ov.get("backward_ms"),
+                mbytes_enqueued_after_0p9_of_backward=ov.get("mbytes_enqueued_after_0p9_of_backward"),
                 modelled_exposed_ms_at_50GBps=ov.get("modelled_exposed_ms_at_50GBps"),
                 modelled_exposed_ms_at_100GBps=ov.get("modelled_exposed_ms_at_100GBps"))
 
@@ -449,7 +450,8 @@ def exchange_probe_child(args):
         dist.destroy_process_group()
     keep = ("ms", "batch_per_gpu", "steps", "world_size", "backend", "exchange", "reserved_cus", "exchange_ms",
             "exposed_exchange_ms", "first_bucket_at_frac_of_backward", "exchange_backward_ms", "exchange_buckets",
-            "modelled_exposed_ms_at_50GBps", "modelled_exposed_ms_at_100GBps", "same_process_ms", "reserve_windows")
+            "mbytes_enqueued_after_0p9_of_backward", "modelled_exposed_ms_at_50GBps", "modelled_exposed_ms_at_100GBps",
+            "same_process_ms", "reserve_windows")
     print("EXCHANGE " + json.dumps({k: rec.get(k) for k in keep}), flush=True)
 
 
