@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define SGD_ABI_VERSION 19
+#define SGD_ABI_VERSION 20
 int sgd_abi_version(void);
 /* 16 hex digits identifying the sources and flags the library was compiled from (build.py: source_id()); static storage.
  * __graft_entry__.build() and tests/test_boundary_cpu.py compare it with the tree on disk. */
@@ -503,6 +503,23 @@ int sgd_attention_bwd_split(const float* q, int32_t q_ld, int32_t q_hs, const fl
                       float* dvec /* workspace [batch, heads, tq] */,
                       int32_t batch, int32_t heads, int32_t tq, int32_t tk, int32_t d, float scale,
                       float* dq, float* dk, float* dv, void* stream);
+
+/* Backward of the two attention_ldm cores above (autograd of dynamic/attention_ldm.py:239-254 / :283-296; the reference trains these
+ * classes through torch.autograd).  sgd_attention_masked_bwd: sgd_attention_bwd's exact-fp32 kernels with the forward's key mask --
+ * a masked key had weight exactly 0, so dk / dv of its rows are 0 and nothing flows through it into dq; lse from
+ * sgd_attention_masked; head dims 16 / 32 / 64; kv_hs == 0 only with heads == 1.
+ * sgd_linear_attention_bwd: dq / dk / dv of sgd_linear_attention for dout [b, tq, *] (row stride dout_ld, head h at +h*q_hs like
+ * out), written with q's / k's / v's own strides; masked keys receive 0; d <= 128; fixed summation order (no atomics). */
+int sgd_attention_masked_bwd(const float* q, int32_t q_ld, int32_t q_hs, const float* k, const float* v, int32_t kv_ld,
+                             int32_t kv_hs, const uint8_t* kmask, const float* o /* forward output */, int32_t o_ld,
+                             const float* dout, int32_t dout_ld, const float* lse /* from sgd_attention_masked */,
+                             float* dvec /* workspace [batch, heads, tq] */,
+                             int32_t batch, int32_t heads, int32_t tq, int32_t tk, int32_t d, float scale,
+                             float* dq, float* dk, float* dv, void* stream);
+int sgd_linear_attention_bwd(const float* q, int32_t q_ld, int32_t q_hs, const float* k, const float* v, int32_t kv_ld,
+                             int32_t kv_hs, const uint8_t* kmask, const float* dout, int32_t dout_ld,
+                             int32_t batch, int32_t heads, int32_t tq, int32_t tk, int32_t d, float scale,
+                             float* dq, float* dk, float* dv, void* stream);
 
 /* q_sample + loss (diffusion/ddpm.py:54-86, ddpm_sampler.py:116-119):
  *   x_noisy = sa[t]*x0 + s1ma[t]*noise      (NCHW in, NCHW out; tables are the float32 schedule buffers) */

@@ -419,18 +419,21 @@ __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const float* __restr
     dvec[((long)b * heads + head) * tq + qi] = s;
 }
 
-template <int D, int SWEEP>
+// MASKED (sgd_attention_masked_bwd): kmask [batch, tk] bytes, 1 = attend -- a masked key had weight exactly 0 in the forward
+// (and is absent from its log-sum-exp), so its P and dS are 0: no gradient into its key / value rows, none through it into q.
+template <int D, int SWEEP, bool MASKED = false>
 __global__ __launch_bounds__(256) void attention_bwd_kernel(
     const float* __restrict__ q, int q_ld, int q_hs, const float* __restrict__ k, const float* __restrict__ v,
     int kv_ld, int kv_hs, const float* __restrict__ dout, int dout_ld, const float* __restrict__ lse,
     const float* __restrict__ dvec, int tq, int tk, float scale, float* __restrict__ dq, float* __restrict__ dk,
-    float* __restrict__ dv, int heads, int mq) {
+    float* __restrict__ dv, int heads, int mq, const uint8_t* __restrict__ kmask = nullptr) {
     constexpr int LD = D + 4;
     constexpr int DT = (D + 31) / 32;
     constexpr int TT = 64;                               // streamed rows per LDS tile
     __shared__ __attribute__((aligned(16))) float Us[TT * LD];     // kv sweep: Q rows   | q sweep: K rows
     __shared__ __attribute__((aligned(16))) float Ws[TT * LD];     // kv sweep: dO rows  | q sweep: V rows
     __shared__ float Ls[TT], Ds[TT];                                // kv sweep: LSE / D of the streamed queries
+    __shared__ float Ms[MASKED ? TT : 1];                           // q sweep, masked: 1.0 / 0.0 per streamed key
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
@@ -442,6 +445,8 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(
     const int str_n = SWEEP == 0 ? tq : tk;              // rows on the streamed side
     const int oi = blockIdx.x * 128 + wave * 32 + li;    // this lane's owned row (key or query)
     const int oc = oi < own_n ? oi : own_n - 1;
+    float own_keep = 1.f;             // kv sweep, masked: validity of this lane's key
+    if (MASKED && SWEEP == 0) own_keep = kmask[(long)b * tk + oc] ? 1.f : 0.f;
 
     f32x16 accA[DT], accB[DT];        // kv: dK^T, dV^T   q: dQ^T (accB unused)
 #pragma unroll
@@ -506,6 +511,10 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(
             Ls[tid] = r < str_n ? lseb[r] : 0.f;
             Ds[tid] = r < str_n ? dvb[r] : 0.f;
         }
+        if (MASKED && SWEEP == 1 && tid < TT) {
+            const int r = t0 + tid;
+            Ms[tid] = (r < str_n && kmask[(long)b * tk + r]) ? 1.f : 0.f;
+        }
         __syncthreads();
 #pragma unroll
         for (int st = 0; st < TT / 32; ++st) {
@@ -531,7 +540,16 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(
                 const bool ok = (t0 + srow < str_n) && (oi < own_n);
                 const float l = SWEEP == 0 ? Ls[srow] : own_lse;
                 const float dd = SWEEP == 0 ? Ds[srow] : own_d;
-                const float p = ok ? __expf(sacc[r] * scale - l) : 0.f;
+                float p;
+                if (MASKED) {
+                    // a masked key is absent from the row's log-sum-exp, so its exponent has no bound: clamp it (valid keys
+                    // have exponents <= 0 up to rounding) and multiply by 0 / 1 -- not a second condition on `ok`, see the
+                    // note on masked lanes in attention_kernel
+                    p = ok ? __expf(fminf(sacc[r] * scale - l, 0.f)) : 0.f;
+                    p *= SWEEP == 0 ? own_keep : Ms[srow];
+                } else {
+                    p = ok ? __expf(sacc[r] * scale - l) : 0.f;
+                }
                 sacc[r] = p;
                 pacc[r] = p * (pacc[r] - dd);
             }
@@ -886,6 +904,127 @@ __global__ __launch_bounds__(256) void linear_attention_kernel(const float* __re
     }
 }
 
+// Backward of linear_attention_kernel (autograd of attention_ldm.py:283-296).  With s = softmax_d(q), K~ = the key softmax of k (0 at
+// masked keys), v' = v (0 at masked keys), ctx = K~^T v' and out = scale s ctx:
+//   dctx[c][e] = scale sum_i s[i][c] g[i][e]                                  t[i][c] = scale sum_e g[i][e] ctx[c][e]
+//   dq[i][c]   = s[i][c] (t[i][c] - sum_c' s[i][c'] t[i][c'])                 dv[j][e] = sum_c K~[j][c] dctx[c][e]
+//   dk[j][c]   = K~[j][c] (sum_e dctx[c][e] v'[j][e] - sum_e dctx[c][e] ctx[c][e])
+// (the column term is sum_j K~[j][c] dK~[j][c] with ctx = K~^T v' substituted); masked keys receive no gradient, as
+// masked_fill gives them.  One block per (batch, head), the query rows in tiles of `tr`; ctx and dctx (d x d) stay in LDS.
+// Fixed summation order, no atomics.
+__global__ __launch_bounds__(256) void linear_attention_bwd_kernel(const float* __restrict__ q, int q_ld, int q_hs,
+                                                                   const float* __restrict__ k, const float* __restrict__ v,
+                                                                   int kv_ld, int kv_hs, int tq, int tk, int d, float scale,
+                                                                   const uint8_t* __restrict__ kmask,
+                                                                   const float* __restrict__ dout, int dout_ld,
+                                                                   float* __restrict__ dq, float* __restrict__ dk,
+                                                                   float* __restrict__ dv, int tr) {
+    extern __shared__ float sh[];
+    const int P = d + 1;
+    float* ctx = sh;                   // [d][d + 1]
+    float* dctx = ctx + d * P;         // [d][d + 1]
+    float* cmax = dctx + d * P;        // [d] key-softmax statistics of the columns of k
+    float* csum = cmax + d;
+    float* colt = csum + d;            // [d] sum_e dctx[c][e] ctx[c][e]
+    float* S = colt + d;               // [tr][d] softmax_d(q) of the tile's rows
+    float* G = S + tr * d;             // [tr][d] their output gradients
+    float* T = G + tr * d;             // [tr][d] scale g ctx^T
+    float* rmax = T + tr * d;          // [tr]
+    float* rinv = rmax + tr;           // [tr]
+    float* rdot = rinv + tr;           // [tr]
+    const int head = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const float* kb = k + (long)b * tk * kv_ld + head * kv_hs;
+    const float* vb = v + (long)b * tk * kv_ld + head * kv_hs;
+    const uint8_t* mb = kmask ? kmask + (long)b * tk : nullptr;
+    for (int c = tid; c < d; c += 256) {
+        float m = -INFINITY;
+        for (int j = 0; j < tk; ++j) m = fmaxf(m, (mb && !mb[j]) ? -3.402823466e38f : kb[(long)j * kv_ld + c]);
+        float sum = 0.f;
+        for (int j = 0; j < tk; ++j) sum += __expf(((mb && !mb[j]) ? -3.402823466e38f : kb[(long)j * kv_ld + c]) - m);
+        cmax[c] = m;
+        csum[c] = sum;
+    }
+    __syncthreads();
+    for (int i = tid; i < d * d; i += 256) {
+        const int c = i / d, e = i % d;
+        float acc = 0.f;
+        for (int j = 0; j < tk; ++j) {
+            const bool ok = !mb || mb[j];
+            const float kk = ok ? kb[(long)j * kv_ld + c] : -3.402823466e38f;
+            const float vv = ok ? vb[(long)j * kv_ld + e] : 0.f;
+            acc += __expf(kk - cmax[c]) / csum[c] * vv;
+        }
+        ctx[c * P + e] = acc;
+        dctx[c * P + e] = 0.f;
+    }
+    __syncthreads();
+    for (int i0 = 0; i0 < tq; i0 += tr) {
+        const int rows = tq - i0 < tr ? tq - i0 : tr;
+        if (tid < rows) {
+            const float* qp = q + ((long)b * tq + i0 + tid) * q_ld + head * q_hs;
+            float m = -INFINITY;
+            for (int c = 0; c < d; ++c) m = fmaxf(m, qp[c]);
+            float sum = 0.f;
+            for (int c = 0; c < d; ++c) sum += __expf(qp[c] - m);
+            rmax[tid] = m;
+            rinv[tid] = 1.f / sum;
+        }
+        __syncthreads();
+        for (int idx = tid; idx < rows * d; idx += 256) {
+            const int r = idx / d, c = idx % d;
+            const long row = (long)b * tq + i0 + r;
+            S[idx] = __expf(q[row * q_ld + head * q_hs + c] - rmax[r]) * rinv[r];
+            G[idx] = dout[row * dout_ld + head * q_hs + c];
+        }
+        __syncthreads();
+        for (int i = tid; i < d * d; i += 256) {
+            const int c = i / d, e = i % d;
+            float acc = 0.f;
+            for (int r = 0; r < rows; ++r) acc += S[r * d + c] * G[r * d + e];
+            dctx[c * P + e] += scale * acc;
+        }
+        for (int idx = tid; idx < rows * d; idx += 256) {
+            const int r = idx / d, c = idx % d;
+            float acc = 0.f;
+            for (int e = 0; e < d; ++e) acc += G[r * d + e] * ctx[c * P + e];
+            T[idx] = scale * acc;
+        }
+        __syncthreads();
+        if (tid < rows) {
+            float acc = 0.f;
+            for (int c = 0; c < d; ++c) acc += S[tid * d + c] * T[tid * d + c];
+            rdot[tid] = acc;
+        }
+        __syncthreads();
+        for (int idx = tid; idx < rows * d; idx += 256) {
+            const int r = idx / d, c = idx % d;
+            dq[((long)b * tq + i0 + r) * q_ld + head * q_hs + c] = S[idx] * (T[idx] - rdot[r]);
+        }
+        __syncthreads();
+    }
+    for (int c = tid; c < d; c += 256) {
+        float acc = 0.f;
+        for (int e = 0; e < d; ++e) acc += dctx[c * P + e] * ctx[c * P + e];
+        colt[c] = acc;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < tk * d; idx += 256) {
+        const int j = idx / d, c = idx % d;
+        const bool ok = !mb || mb[j];
+        float gk = 0.f, gv = 0.f;
+        if (ok) {
+            const float kt = __expf(kb[(long)j * kv_ld + c] - cmax[c]) / csum[c];
+            float acc = 0.f;
+            for (int e = 0; e < d; ++e) acc += dctx[c * P + e] * vb[(long)j * kv_ld + e];
+            gk = kt * (acc - colt[c]);
+            for (int c2 = 0; c2 < d; ++c2) gv += __expf(kb[(long)j * kv_ld + c2] - cmax[c2]) / csum[c2] * dctx[c2 * P + c];
+        }
+        dk[((long)b * tk + j) * kv_ld + head * kv_hs + c] = gk;
+        dv[((long)b * tk + j) * kv_ld + head * kv_hs + c] = gv;
+    }
+}
+
+
 }  // namespace
 
 extern "C" int sgd_attention(const float* q, int32_t q_ld, int32_t q_hs, const float* k, const float* v,
@@ -1021,5 +1160,57 @@ extern "C" int sgd_linear_attention(const float* q, int32_t q_ld, int32_t q_hs, 
     }
     hipLaunchKernelGGL(linear_attention_kernel, dim3(heads, batch), dim3(256), smem, (hipStream_t)stream, q, q_ld, q_hs, k,
                        v, kv_ld, kv_hs, tq, tk, d, scale, kmask, out, out_ld);
+    return sgd_check_launch();
+}
+
+// sgd_attention_bwd's exact-fp32 kernels with the forward's key mask (sgd_attention_masked): head dims 16 / 32 / 64, one head per
+// block (kv_hs may be 0 only with heads == 1)
+extern "C" int sgd_attention_masked_bwd(const float* q, int32_t q_ld, int32_t q_hs, const float* k, const float* v,
+                                        int32_t kv_ld, int32_t kv_hs, const uint8_t* kmask, const float* o, int32_t o_ld,
+                                        const float* dout, int32_t dout_ld, const float* lse, float* dvec, int32_t batch,
+                                        int32_t heads, int32_t tq, int32_t tk, int32_t d, float scale, float* dq, float* dk,
+                                        float* dv, void* stream) {
+    SGD_CLEAR_ERR();
+    if (!q || !k || !v || !kmask || !o || !dout || !lse || !dvec || !dq || !dk || !dv || batch <= 0 || heads <= 0 || tq <= 0 ||
+        tk <= 0)
+        return SGD_ERR_ARG;
+    if ((q_ld & 3) || (q_hs & 3) || (kv_ld & 3) || (kv_hs & 3) || (o_ld & 3) || (dout_ld & 3)) return SGD_ERR_ARG;
+    if (kv_hs == 0 && heads > 1) return SGD_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 gp((heads * tq + 255) / 256, batch), gkv((tk + 127) / 128, heads, batch), gq((tq + 127) / 128, heads, batch);
+#define SGD_ATTN_BWD_M(DD)                                                                                            \
+    hipLaunchKernelGGL((attn_bwd_prep_kernel<DD>), gp, dim3(256), 0, st, o, o_ld, dout, dout_ld, heads, tq, dvec);      \
+    hipLaunchKernelGGL((attention_bwd_kernel<DD, 0, true>), gkv, dim3(256), 0, st, q, q_ld, q_hs, k, v, kv_ld, kv_hs,   \
+                       dout, dout_ld, lse, dvec, tq, tk, scale, dq, dk, dv, heads, 0, kmask);                          \
+    hipLaunchKernelGGL((attention_bwd_kernel<DD, 1, true>), gq, dim3(256), 0, st, q, q_ld, q_hs, k, v, kv_ld, kv_hs,    \
+                       dout, dout_ld, lse, dvec, tq, tk, scale, dq, dk, dv, heads, 0, kmask);
+    switch (d) {
+        case 16: SGD_ATTN_BWD_M(16) break;
+        case 32: SGD_ATTN_BWD_M(32) break;
+        case 64: SGD_ATTN_BWD_M(64) break;
+        default: return SGD_ERR_ARG;
+    }
+#undef SGD_ATTN_BWD_M
+    return sgd_check_launch();
+}
+
+extern "C" int sgd_linear_attention_bwd(const float* q, int32_t q_ld, int32_t q_hs, const float* k, const float* v,
+                                        int32_t kv_ld, int32_t kv_hs, const uint8_t* kmask, const float* dout,
+                                        int32_t dout_ld, int32_t batch, int32_t heads, int32_t tq, int32_t tk, int32_t d,
+                                        float scale, float* dq, float* dk, float* dv, void* stream) {
+    SGD_CLEAR_ERR();
+    if (!q || !k || !v || !dout || !dq || !dk || !dv || batch <= 0 || heads <= 0 || tq <= 0 || tk <= 0 || d <= 0 || d > 128)
+        return SGD_ERR_ARG;
+    // query rows per tile: ctx + dctx take 2 d (d + 1) floats (129 KB at d = 128) of the 160 KB
+    const int tr = d > 64 ? 8 : 32;
+    const size_t smem = ((size_t)2 * d * (d + 1) + 3 * d + (size_t)3 * tr * d + 3 * tr) * sizeof(float);
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)linear_attention_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  152 * 1024);
+        attr = true;
+    }
+    hipLaunchKernelGGL(linear_attention_bwd_kernel, dim3(heads, batch), dim3(256), smem, (hipStream_t)stream, q, q_ld, q_hs,
+                       k, v, kv_ld, kv_hs, tq, tk, d, scale, kmask, dout, dout_ld, dq, dk, dv, tr);
     return sgd_check_launch();
 }

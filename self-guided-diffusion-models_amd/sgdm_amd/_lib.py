@@ -20,7 +20,7 @@ RS_NONE, RS_AVGPOOL2, RS_UP2, RS_ZEROUP2 = 0, 1, 2, 3
 PRO_NONE, PRO_AFFINE_NC, PRO_LN_ROW = 0, 1, 2
 PREC_F32, PREC_F16X3, PREC_BF16X3 = 0, 1, 2
 PREC_BY_NAME = {"f32": PREC_F32, "f16x3": PREC_F16X3, "bf16x3": PREC_BF16X3}
-ABI_VERSION = 19
+ABI_VERSION = 20
 
 # sgd_igemm_args.tune (include/sgdm_hip.h: SGD_TUNE_*): per-call schedule overrides for parity tests and A/B tools
 TUNE_BN128, TUNE_BN256, TUNE_FLAT2, TUNE_DEFER, TUNE_PLAIN_SCHEDULE, TUNE_LN_PACKED, TUNE_NO_SMALL = 1, 2, 4, 8, 16, 32, 64
@@ -84,6 +84,10 @@ SIGNATURES = {
                               vp, vp, vp, vp]),
     "sgd_attention_bwd_split": (i32, [vp, i32, i32, vp, vp, i32, i32, vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, i32, f32,
                                     vp, vp, vp, vp]),
+    "sgd_attention_masked_bwd": (i32, [vp, i32, i32, vp, vp, i32, i32, vp, vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, i32,
+                                     f32, vp, vp, vp, vp]),
+    "sgd_linear_attention_bwd": (i32, [vp, i32, i32, vp, vp, i32, i32, vp, vp, i32, i32, i32, i32, i32, i32, f32, vp, vp, vp,
+                                     vp]),
     "sgd_pack_weight_dgrad": (i32, [vp, vp, i32, i32, i32, i32, C.POINTER(i32), C.POINTER(i32), vp]),
     "sgd_wgrad": (i32, [C.POINTER(IgemmArgs), vp, i32, i32, vp, i32, vp, vp]),
     "sgd_wgrad_scratch_bytes": (i64, [C.POINTER(IgemmArgs), i32]),
