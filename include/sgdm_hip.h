@@ -487,7 +487,8 @@ int sgd_linear_attention(const float* q, int32_t q_ld, int32_t q_hs, const float
                          float scale, float* out, int32_t out_ld, void* stream);
 /* legacy QKV attention backward (autograd of openaimodel.py:403-420), same addressing as sgd_attention:
  * dq/dk/dv are written with the same row strides / head strides as q/k/v (i.e. into a gqkv tensor).
- * Multi-query (kv_hs == 0, crossattetion_lr.py:115-137): dk/dv are summed over the heads inside the kernel. */
+ * Multi-query (kv_hs == 0, crossattetion_lr.py:115-137): dk/dv are summed over the heads inside the kernel.
+ * Head dims 16 / 32 / 64 / 128 (config/dynamic/unet_fast_s64.yaml: 1024 channels / 8 heads). */
 int sgd_attention_bwd(const float* q, int32_t q_ld, int32_t q_hs, const float* k, const float* v, int32_t kv_ld,
                       int32_t kv_hs, const float* o /* forward output */, int32_t o_ld,
                       const float* dout, int32_t dout_ld, const float* lse /* from sgd_attention */,
@@ -507,7 +508,7 @@ int sgd_attention_bwd_split(const float* q, int32_t q_ld, int32_t q_hs, const fl
 /* Backward of the two attention_ldm cores above (autograd of dynamic/attention_ldm.py:239-254 / :283-296; the reference trains these
  * classes through torch.autograd).  sgd_attention_masked_bwd: sgd_attention_bwd's exact-fp32 kernels with the forward's key mask --
  * a masked key had weight exactly 0, so dk / dv of its rows are 0 and nothing flows through it into dq; lse from
- * sgd_attention_masked; head dims 16 / 32 / 64; kv_hs == 0 only with heads == 1.
+ * sgd_attention_masked; head dims 16 / 32 / 64 / 128; kv_hs == 0 only with heads == 1.
  * sgd_linear_attention_bwd: dq / dk / dv of sgd_linear_attention for dout [b, tq, *] (row stride dout_ld, head h at +h*q_hs like
  * out), written with q's / k's / v's own strides; masked keys receive 0; d <= 128; fixed summation order (no atomics). */
 int sgd_attention_masked_bwd(const float* q, int32_t q_ld, int32_t q_hs, const float* k, const float* v, int32_t kv_ld,

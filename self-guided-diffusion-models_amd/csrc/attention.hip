@@ -429,7 +429,7 @@ __global__ __launch_bounds__(256) void attention_bwd_kernel(
     float* __restrict__ dv, int heads, int mq, const uint8_t* __restrict__ kmask = nullptr) {
     constexpr int LD = D + 4;
     constexpr int DT = (D + 31) / 32;
-    constexpr int TT = 64;                               // streamed rows per LDS tile
+    constexpr int TT = D > 64 ? 32 : 64;                 // streamed rows per LDS tile (head dim 128: 2 x 32 x 132 floats)
     __shared__ __attribute__((aligned(16))) float Us[TT * LD];     // kv sweep: Q rows   | q sweep: K rows
     __shared__ __attribute__((aligned(16))) float Ws[TT * LD];     // kv sweep: dO rows  | q sweep: V rows
     __shared__ float Ls[TT], Ds[TT];                                // kv sweep: LSE / D of the streamed queries
@@ -1088,6 +1088,7 @@ extern "C" int sgd_attention_bwd(const float* q, int32_t q_ld, int32_t q_hs, con
         case 16: SGD_ATTN_BWD(16) break;
         case 32: SGD_ATTN_BWD(32) break;
         case 64: SGD_ATTN_BWD(64) break;
+        case 128: SGD_ATTN_BWD(128) break;
         default: return SGD_ERR_ARG;
     }
 #undef SGD_ATTN_BWD
@@ -1188,6 +1189,7 @@ extern "C" int sgd_attention_masked_bwd(const float* q, int32_t q_ld, int32_t q_
         case 16: SGD_ATTN_BWD_M(16) break;
         case 32: SGD_ATTN_BWD_M(32) break;
         case 64: SGD_ATTN_BWD_M(64) break;
+        case 128: SGD_ATTN_BWD_M(128) break;
         default: return SGD_ERR_ARG;
     }
 #undef SGD_ATTN_BWD_M

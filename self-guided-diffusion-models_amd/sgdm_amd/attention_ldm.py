@@ -16,8 +16,7 @@ LayerNorms, the forward implicit-GEMM kernel on adjoint-packed weights for the i
 ``sgd_wgrad`` + ``sgd_wgrad_reduce`` for their weight gradients (the LayerNorm-row prologue recomputed from the raw input),
 ``sgd_attention_bwd`` / ``sgd_attention_masked_bwd`` / ``sgd_linear_attention_bwd`` for the core, column sums over batch and
 heads for ``null_kv``.  The backward runs in exact fp32 whatever ``hip_precision`` the forward used (gradients of arbitrary
-magnitude would need the power-of-two scaling the UNet's backward program carries, train.Backward.gscale); the softmax core's
-backward exists for (padded) head widths up to 64."""
+magnitude would need the power-of-two scaling the UNet's backward program carries, train.Backward.gscale)."""
 import ctypes as C
 
 import torch
@@ -109,9 +108,6 @@ class CrossAttention(nn.Module):
             raise RuntimeError("sgdm_amd attention_ldm modules run on the MI355X HIP path only; there is no CPU fallback")
         if torch.is_grad_enabled() and (x.requires_grad or context.requires_grad
                                         or any(p.requires_grad for p in self.parameters())):
-            if not self.LINEAR and padded_head_dim(self.dim_head) > 64:
-                raise NotImplementedError("attention_ldm.CrossAttention: the attention core's backward exists for head widths "
-                                          "up to 64; call wider heads under torch.no_grad()")
             return _CrossAttnFn.apply(self, mask, x, context, *self.parameters())
         return self._run(x, context, mask, None)
 

@@ -141,10 +141,11 @@ class Backward:
         self._build()
 
     # ---------------------------------------------------------------- helpers
-    def attention_bwd_fn(self):
-        """the attention backward in the engine's arithmetic: split-precision MFMA for f16x3 (head dims up to 64; the
-        forward's choice, unet._Engine.attention_fn), exact fp32 otherwise"""
-        if self.prec == L.PREC_F16X3 and os.environ.get("SGDM_ATTN_BWD_SPLIT", "1") != "0":
+    def attention_bwd_fn(self, d):
+        """the attention backward in the engine's arithmetic: split-precision MFMA for f16x3 at head widths up to 64 (the
+        forward's choice, unet._Engine.attention_fn), exact fp32 otherwise -- 128-wide heads (config/dynamic/unet_fast_s64.yaml:
+        1024 channels / 8 heads) included"""
+        if self.prec == L.PREC_F16X3 and d <= 64 and os.environ.get("SGDM_ATTN_BWD_SPLIT", "1") != "0":
             return self.lib.sgd_attention_bwd_split
         return self.lib.sgd_attention_bwd
 
@@ -472,7 +473,7 @@ class Backward:
         dvec = self.buf(n, heads, T)
         off = lambda t, k: C.c_void_p(t.data_ptr() + 4 * k)
         hs, ko, vo = rec.get("qkv_layout", (3 * d, d, 2 * d))      # head stride, k / v offsets: legacy or new attention order
-        self.prog.add(p + ".attn_bwd", self.attention_bwd_fn(), _ptr(qkv), 3 * ch, hs, off(qkv, ko), off(qkv, vo),
+        self.prog.add(p + ".attn_bwd", self.attention_bwd_fn(d), _ptr(qkv), 3 * ch, hs, off(qkv, ko), off(qkv, vo),
                       3 * ch, hs, _ptr(rec["att"]), ch, _ptr(gatt), ch, _ptr(rec["lse"]), _ptr(dvec), n, heads, T, T, d,
                       1.0 / math.sqrt(d), _ptr(gqkv), off(gqkv, ko), off(gqkv, vo))
         wq = P(p + ".qkv.weight")
@@ -544,7 +545,7 @@ class Backward:
         q, kv = rec["q"], rec["kv"]
         gq, gkv = self.buf(n, T, inner), self.buf(n, J, 2 * dp)
         dvec = self.buf(n, heads, T)
-        self.prog.add(p + ".attn_bwd", self.attention_bwd_fn(), _ptr(q), inner, dp, _ptr(kv),
+        self.prog.add(p + ".attn_bwd", self.attention_bwd_fn(dp), _ptr(q), inner, dp, _ptr(kv),
                       C.c_void_p(kv.data_ptr() + 4 * dp), 2 * dp, 0, _ptr(rec["att"]), inner, _ptr(gatt), inner,
                       _ptr(rec["lse"]), _ptr(dvec), n, heads, T, J, dp, d ** -0.5, _ptr(gq), _ptr(gkv),
                       C.c_void_p(gkv.data_ptr() + 4 * dp))

@@ -111,15 +111,43 @@ def test_attention_ldm_frozen_parameters_and_inputs_only():
         assert not m(x, ctx, mask=mask).requires_grad
 
 
-def test_attention_ldm_wide_heads_raise_in_grad_mode():
-    """the softmax core's backward has no instance above 64 channels per head: loud, not a silent detach"""
+def test_attention_ldm_wide_heads_train():
+    """dim_head 96 (zero-padded to the 128-wide core) and 128 in grad mode: input and parameter gradients against fp32 torch
+    autograd of the reference's forward restated on the module's own parameters (attention_ldm.py:220-254)"""
     from sgdm_amd import attention_ldm as A
-    m = A.CrossAttention(64, context_dim=32, dim_head=96, heads=2).cuda()
-    x, ctx = torch.randn(1, 8, 64, device="cuda"), torch.randn(1, 3, 32, device="cuda")
-    with torch.no_grad():
-        m(x, ctx)
-    with pytest.raises(NotImplementedError):
-        m(x, ctx)
+    for dh in (96, 128):
+        torch.manual_seed(dh)
+        heads, dim, cdim, b, n, mm = 2, 64, 32, 2, 40, 6
+        m = A.CrossAttention(dim, context_dim=cdim, dim_head=dh, heads=heads, norm_context=True).cuda()
+        m.hip_precision = "f32"
+        x = torch.randn(b, n, dim, device="cuda", requires_grad=True)
+        ctx = torch.randn(b, mm, cdim, device="cuda", requires_grad=True)
+        mask = torch.rand(b, mm, device="cuda") > 0.3
+        mask[:, 0] = True
+        gy = torch.randn(b, n, dim, device="cuda")
+        (m(x, ctx, mask=mask) * gy).sum().backward()
+        got = {"x": x.grad.cpu(), "context": ctx.grad.cpu(), **{k: p.grad.cpu() for k, p in m.named_parameters()}}
+        # the reference's forward in plain torch on CPU copies
+        P = {k: p.detach().cpu().clone().requires_grad_(True) for k, p in m.named_parameters()}
+        xc, cc = x.detach().cpu().requires_grad_(True), ctx.detach().cpu().requires_grad_(True)
+        F = torch.nn.functional
+        xn = F.layer_norm(xc, (dim,), P["norm.gamma"], torch.zeros(dim))
+        cn = F.layer_norm(cc, (cdim,), P["norm_context.gamma"], torch.zeros(cdim))
+        q = xn @ P["to_q.weight"].t()
+        k, v = (cn @ P["to_kv.weight"].t()).chunk(2, dim=-1)
+        sp = lambda t_: t_.reshape(b, -1, heads, dh).permute(0, 2, 1, 3)
+        q, k, v = sp(q), sp(k), sp(v)
+        nk, nv = P["null_kv"][0].expand(b, heads, 1, dh), P["null_kv"][1].expand(b, heads, 1, dh)
+        k, v = torch.cat((nk, k), -2), torch.cat((nv, v), -2)
+        sim = torch.einsum("bhid,bhjd->bhij", q * dh ** -0.5, k)
+        mk = F.pad(mask.cpu(), (1, 0), value=True)[:, None, None, :]
+        sim = sim.masked_fill(~mk, -torch.finfo(torch.float32).max)
+        out = torch.einsum("bhij,bhjd->bhid", sim.softmax(-1), v).permute(0, 2, 1, 3).reshape(b, n, heads * dh)
+        y = F.layer_norm(out @ P["to_out.0.weight"].t(), (dim,), P["to_out.1.gamma"], torch.zeros(dim))
+        (y * gy.cpu()).sum().backward()
+        want = {"x": xc.grad, "context": cc.grad, **{k_: p.grad for k_, p in P.items()}}
+        errs = {k_: max_rel(got[k_], want[k_]) for k_ in want}
+        assert max(errs.values()) < 5e-6, (dh, errs)
 
 
 def _heads(t, heads, d):
@@ -127,7 +155,7 @@ def _heads(t, heads, d):
     return t.reshape(b, n, heads, d).permute(0, 2, 1, 3)
 
 
-@pytest.mark.parametrize("d", [16, 32, 64])
+@pytest.mark.parametrize("d", [16, 32, 64, 128])
 def test_masked_attention_backward_vs_autograd(d):
     """sgd_attention_masked_bwd against fp32 torch autograd of softmax(masked_fill(q k^T scale)) v (attention_ldm.py:239-254):
     masked keys get exactly zero gradient"""

@@ -633,6 +633,16 @@ def test_attention_backward(b, heads, t, d, core, gscale):
         assert max_rel(x3[:, :, :, i], r3[:, :, :, i]) < 1e-5, (core, nm)
 
 
+def test_attention_backward_128_wide_heads():
+    """config/dynamic/unet_fast_s64.yaml: 1024 channels / 8 heads at 16 x 16 -- the exact kernels' D = 128 instances (32-row LDS
+    tiles); the split-precision backward has none and refuses"""
+    test_attention_backward(2, 8, 256, 128, "exact", 1.0)
+    test_attention_backward(1, 2, 70, 128, "exact", 1.0)
+    L, lib = _lib()
+    assert lib.sgd_attention_bwd_split(None, 0, 0, None, None, 0, 0, None, 0, None, 0, None, None, 1, 1, 1, 1, 128, 1.0, None, None,
+                                       None, None) != 0
+
+
 def test_q_sample_and_mse_loss():
     L, lib = _lib()
     from oracle import diffusion_ref as D

@@ -705,6 +705,51 @@ def test_train_step_with_zero_padded_attention_heads_vs_oracle(prec, tol):
     assert checked > 50 and any(".to_q." in k for k in trainable)
 
 
+@pytest.mark.parametrize("prec,tol", [("f32", 5e-5), ("f16x3", 1e-4)])
+def test_train_step_at_the_shipped_unet_fast_s64_plan_vs_oracle(prec, tol):
+    """config/dynamic/unet_fast_s64.yaml at full width (ch 256, channel_mult [1, 2, 4], 64 x 64, attention at ds 4 on 1024 channels /
+    8 heads = 128 channels per head): one training step, loss and every parameter gradient against the oracle's autograd.  The
+    attention backward of 128-wide heads runs on the exact-fp32 kernels in both modes (the split-precision backward has instances
+    up to 64) -- until round 6 it had none and this step raised.  Dropout off (the masks have their own test)."""
+    import bench
+    from conftest import cfg_from_index
+    from oracle import diffusion_ref as D
+    from oracle import unet_ref as U
+    from sgdm_amd.diffusion import LatentDiffusion
+    from sgdm_amd.synth import synth_batch, weights_from_seed
+    m, entry = build_model("uf_s64_c256", prec)
+    m.dropout = 0.0
+    m.train()
+    d = LatentDiffusion(device="cuda", **bench.MODEL_PARAMS).train()
+    d.set_denoise_fn(m.forward, m.forward_with_cond_scale)
+    kw = entry["ctor"]
+    B, S = 2, int(kw["image_size"])
+    batch = synth_batch(kw["condition_method"], B, S, kw["cond_dim"], entry["layout_dim"], seed=41)
+    g = torch.Generator().manual_seed(41)
+    t = torch.randint(0, 1000, (B,), generator=g)
+    noise = torch.randn(B, 3, S, S, generator=g)
+    mask = torch.tensor([False, True])
+    loss, _ = d.p_losses(batch["image"].cuda(), t.cuda(), noise.cuda(), cond=batch["cond"].float().cuda(), layout=None,
+                         cond_drop_prob=0.5, cond_drop_mask=mask.cuda())
+    loss.backward()
+    assert any(rec["kind"] == "attn" and rec["d"] == 128 for rec in m._engines[next(iter(m._engines))].tape)
+    cfg = cfg_from_index(entry)                      # (the oracle applies dropout only through explicit masks)
+    sd = {k: tt.clone().requires_grad_(kind == "param")
+          for (k, _, kind), tt in zip(entry["manifest"], weights_from_seed(entry["manifest"], entry["seed"]).values())}
+    fn = lambda xn, tt: U.unet_forward(cfg, sd, xn, tt, batch["cond"].float(), None, mask)
+    l, _, _, _ = D.p_losses(D.make_schedule(), fn, batch["image"], t, noise)
+    l.backward()
+    assert abs(loss.item() - l.item()) < 2e-5 * abs(l.item())
+    bad, checked = [], 0
+    for k, p in m.named_parameters():
+        if p.requires_grad and sd[k].grad is not None and float(sd[k].grad.abs().max()) > 1e-6:
+            e = max_rel(p.grad.cpu(), sd[k].grad)
+            checked += 1
+            if e > tol:
+                bad.append((k, e))
+    assert not bad and checked > 200, (checked, bad[:5])
+
+
 @pytest.mark.parametrize("prec", ["f32", "f16x3"])
 def test_batched_weight_repack_equals_single_packs(prec, monkeypatch):
     """round 4: the per-step re-pack of every conv / linear weight (forward operators and their adjoints) as ONE
