@@ -459,27 +459,52 @@ class Backward:
         self.gn_bwd(p + ".in_layers.0", rec["srcs"], (hh, ww), rec["a1"], rec["b1"], rec["sums1"], p + ".in_layers.0",
                     1, gu1, cin, rs, gres, gres_ld, gres_mode)
 
+    def wgrad_padded(self, tag, fwd, g, cout, cin, nrows, wname, wpad, bias_name=None, bpad=None):
+        """weight (and bias) gradient of a 1x1 / linear layer whose packed operator is a zero-padded re-layout of the parameter
+        (unet._Pad; cout / cin are the PADDED widths): the padded gradient is gathered back into the parameter's own shape -- the
+        padding rows / columns receive gradients that belong to no parameter.  bpad None with a bias: the bias is not padded."""
+        if wpad is None:
+            return self.wgrad(tag, fwd, g, cout, cout, cin, 1, nrows, wname, bias_name)
+        tmp = self.buf(cout, cin)
+        self.wgrad(tag, fwd, g, cout, cout, cin, 1, nrows, wname, None, dw_view=tmp)
+        self.gather_op(tag + ".unpad", wname, tmp, wpad)
+        if bias_name is None:
+            return
+        if bpad is None:
+            return self.colsum(tag + ".bias", _ptr(g), nrows, cout, cout, bias_name)
+        tb = self.buf(1, cout)             # bias gradient = column sums of g, gathered like the weight's rows
+        self.prog.add(tag + ".bias", self.lib.sgd_colsum, _ptr(g), nrows, cout, cout, _ptr(tb), 0, self.unscale,
+                      _ptr(self.cwork), self.CW)
+        self.gather_op(tag + ".bias.unpad", bias_name, tb, bpad)
+
     def _attn(self, rec):
+        """AttentionBlock backward (autograd of openaimodel.py:365-371, 403-420 / 427-451); zero-padded heads (rec["pads"]) as in
+        _attn_lr: every tensor between qkv and proj_out is dp wide per head"""
         n, p, ch, heads, d, T = self.n, rec["p"], rec["ch"], rec["heads"], rec["d"], rec["T"]
+        dp, pads = rec.get("dp", d), rec.get("pads")
+        inner = heads * dp
         P = self.m.P
         hh, ww = rec["hw"]
         gy = self.gread(rec["y"])
+        adj = lambda w, key: (lambda: w) if pads is None else (lambda: pads[key].apply(w.detach().float()))
+        pad = lambda key: None if pads is None else pads[key]
         wp = P(p + ".proj_out.weight")
-        gatt = self.buf(n, T, ch)
-        self.dgrad(p + ".proj_out.dgrad", gy, ch, gatt, ch, [wp], lambda: wp, ch, ch, 1, m=n * T)
-        self.wgrad(p + ".proj_out", rec["proj_args"], gy, ch, ch, ch, 1, n * T, p + ".proj_out.weight",
-                   p + ".proj_out.bias")
-        qkv, gqkv = rec["qkv"], self.buf(n, T, 3 * ch)
+        gatt = self.buf(n, T, inner)
+        self.dgrad(p + ".proj_out.dgrad", gy, ch, gatt, inner, [wp], adj(wp, "out"), ch, inner, 1, m=n * T)
+        self.wgrad_padded(p + ".proj_out", rec["proj_args"], gy, ch, inner, n * T, p + ".proj_out.weight", pad("out"),
+                          p + ".proj_out.bias")
+        qkv, gqkv = rec["qkv"], self.buf(n, T, 3 * inner)
         dvec = self.buf(n, heads, T)
         off = lambda t, k: C.c_void_p(t.data_ptr() + 4 * k)
         hs, ko, vo = rec.get("qkv_layout", (3 * d, d, 2 * d))      # head stride, k / v offsets: legacy or new attention order
-        self.prog.add(p + ".attn_bwd", self.attention_bwd_fn(d), _ptr(qkv), 3 * ch, hs, off(qkv, ko), off(qkv, vo),
-                      3 * ch, hs, _ptr(rec["att"]), ch, _ptr(gatt), ch, _ptr(rec["lse"]), _ptr(dvec), n, heads, T, T, d,
-                      1.0 / math.sqrt(d), _ptr(gqkv), off(gqkv, ko), off(gqkv, vo))
+        self.prog.add(p + ".attn_bwd", self.attention_bwd_fn(dp), _ptr(qkv), 3 * inner, hs, off(qkv, ko), off(qkv, vo),
+                      3 * inner, hs, _ptr(rec["att"]), inner, _ptr(gatt), inner, _ptr(rec["lse"]), _ptr(dvec), n, heads, T, T,
+                      dp, 1.0 / math.sqrt(d), _ptr(gqkv), off(gqkv, ko), off(gqkv, vo))
         wq = P(p + ".qkv.weight")
         gxn = self.buf(n, T, ch)
-        self.dgrad(p + ".qkv.dgrad", gqkv, 3 * ch, gxn, ch, [wq], lambda: wq, 3 * ch, ch, 1, m=n * T)
-        self.wgrad(p + ".qkv", rec["qkv_args"], gqkv, 3 * ch, 3 * ch, ch, 1, n * T, p + ".qkv.weight", p + ".qkv.bias")
+        self.dgrad(p + ".qkv.dgrad", gqkv, 3 * inner, gxn, ch, [wq], adj(wq, "qkv"), 3 * inner, ch, 1, m=n * T)
+        self.wgrad_padded(p + ".qkv", rec["qkv_args"], gqkv, 3 * inner, ch, n * T, p + ".qkv.weight", pad("qkv"),
+                          p + ".qkv.bias", pad("qkv_bias"))
         self.gn_bwd(p + ".norm", [(rec["x"], ch)], (hh, ww), rec["a"], rec["b"], rec["sums"], p + ".norm", 0, gxn, ch,
                     L.RS_NONE, gy, ch, L.RS_NONE)                       # residual: x + proj(...)
 
@@ -523,16 +548,8 @@ class Backward:
             return (lambda: w) if pads is None else (lambda: pads[key].apply(w.detach().float()))
 
         def wgrad(tag, fwd, g, cout, cin, nrows, wname, key, bias_name=None):
-            if pads is None:
-                return self.wgrad(tag, fwd, g, cout, cout, cin, 1, nrows, wname, bias_name)
-            tmp = self.buf(cout, cin)
-            self.wgrad(tag, fwd, g, cout, cout, cin, 1, nrows, wname, None, dw_view=tmp)
-            self.gather_op(tag + ".unpad", wname, tmp, pads[key])
-            if bias_name is not None:          # bias gradient = column sums of g, gathered like the weight's rows
-                tb = self.buf(1, cout)
-                self.prog.add(tag + ".bias", lib.sgd_colsum, _ptr(g), nrows, cout, cout, _ptr(tb), 0, self.unscale,
-                              _ptr(self.cwork), self.CW)
-                self.gather_op(tag + ".bias.unpad", bias_name, tb, pads["vec"])
+            self.wgrad_padded(tag, fwd, g, cout, cin, nrows, wname, None if pads is None else pads[key], bias_name,
+                              None if pads is None else pads["vec"])
 
         # y = x + LN_out(o):  LN_out backward (gamma trainable, beta is a buffer)
         go = self.buf(n, T, ch)

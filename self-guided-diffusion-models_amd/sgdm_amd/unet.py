@@ -1263,25 +1263,41 @@ class UNetModel(UNetModelBase):
         t, c, hh, ww = src
         n, T, P = eng.n, hh * ww, self.P
         d = ch // heads
-        _check_head_dim(d, ch, heads)
+        # head widths the attention core has no instance for (config/dynamic/unet.yaml: 256 / 32 = 8 channels per head at ds 2) run
+        # zero-padded to dp, like Attention_LR's: qkv's packed weight / bias and proj_out's packed weight are padded re-layouts of
+        # the parameters (_Pad), qkv and att are dp wide per head, the softmax scale stays that of the TRUE width
+        dp = padded_head_dim(d)
+        inner = heads * dp
+        new_order = getattr(self, "use_new_attention_order", False)
+        pads = None
+        if dp != d:
+            # legacy layout: channel = head*3d + {q: 0, k: d, v: 2d}; new order (QKVAttention): channel = {q: 0, k: ch, v: 2ch} + head*d
+            if new_order:
+                qkvmap = [s * inner + h * dp + i for s in range(3) for h in range(heads) for i in range(d)]
+            else:
+                qkvmap = [h * 3 * dp + s * dp + i for h in range(heads) for s in range(3) for i in range(d)]
+            omap = [h * dp + i for h in range(heads) for i in range(d)]
+            pads = dict(qkv=_Pad(rows=qkvmap, n_rows=3 * inner), qkv_bias=_Pad(cols=qkvmap, n_cols=3 * inner),
+                        out=_Pad(cols=omap, n_cols=inner))
+        pad = (lambda k: pads[k]) if pads else (lambda k: None)
         a, b = eng.gn(p + ".norm", [(t, c)], T, p + ".norm")
         sums = eng._last_sums
-        qkv = eng.buf(n, T, 3 * ch)
-        aq = eng.igemm(p + ".qkv", t, c, qkv, 3 * ch, eng.pack([p + ".qkv.weight"], 1), m=n * T, rows_per_n=T,
-                       pro=L.PRO_AFFINE_NC, pa=a, pb=b, bias=P(p + ".qkv.bias"))
-        att = eng.buf(n, T, ch)
+        qkv = eng.buf(n, T, 3 * inner)
+        qbias = eng.padded(p + ".qkv.bias", pads["qkv_bias"]) if pads else P(p + ".qkv.bias")
+        aq = eng.igemm(p + ".qkv", t, c, qkv, 3 * inner, eng.pack([p + ".qkv.weight"], 1, pad("qkv")), m=n * T, rows_per_n=T,
+                       pro=L.PRO_AFFINE_NC, pa=a, pb=b, bias=qbias)
+        att = eng.buf(n, T, inner)
         lse = eng.buf(n, heads, T)                         # softmax statistics kept for the backward
-        # legacy layout: channel = head*3d + {q: 0, k: d, v: 2d}; new order (QKVAttention): channel = {q: 0, k: ch, v: 2ch} + head*d;
-        # scale = (d^-1/4)^2 applied to q.k
-        hs, ko, vo = (d, ch, 2 * ch) if getattr(self, "use_new_attention_order", False) else (3 * d, d, 2 * d)
-        eng.prog.add(p + ".attn", eng.attention_fn(), _ptr(qkv), 3 * ch, hs,
-                     C.c_void_p(qkv.data_ptr() + 4 * ko), C.c_void_p(qkv.data_ptr() + 4 * vo), 3 * ch, hs,
-                     n, heads, T, T, d, 1.0 / math.sqrt(d), _ptr(att), ch, _ptr(lse))
+        # head stride, k / v offsets of the (padded) layout; scale = (d^-1/4)^2 applied to q.k
+        hs, ko, vo = (dp, inner, 2 * inner) if new_order else (3 * dp, dp, 2 * dp)
+        eng.prog.add(p + ".attn", eng.attention_fn(), _ptr(qkv), 3 * inner, hs,
+                     C.c_void_p(qkv.data_ptr() + 4 * ko), C.c_void_p(qkv.data_ptr() + 4 * vo), 3 * inner, hs,
+                     n, heads, T, T, dp, 1.0 / math.sqrt(d), _ptr(att), inner, _ptr(lse))
         y = eng.buf(n, hh, ww, ch)
-        ap = eng.igemm(p + ".proj_out", att, ch, y, ch, eng.pack([p + ".proj_out.weight"], 1), m=n * T, rows_per_n=T,
-                       bias=P(p + ".proj_out.bias"), res=t, stats=True)
-        eng.tape.append(dict(kind="attn", p=p, x=t, ch=ch, heads=heads, d=d, T=T, hw=(hh, ww), a=a, b=b, sums=sums,
-                             qkv=qkv, att=att, lse=lse, qkv_args=aq, proj_args=ap, y=y, qkv_layout=(hs, ko, vo)))
+        ap = eng.igemm(p + ".proj_out", att, inner, y, ch, eng.pack([p + ".proj_out.weight"], 1, pad("out")), m=n * T,
+                       rows_per_n=T, bias=P(p + ".proj_out.bias"), res=t, stats=True)
+        eng.tape.append(dict(kind="attn", p=p, x=t, ch=ch, heads=heads, d=d, dp=dp, pads=pads, T=T, hw=(hh, ww), a=a, b=b,
+                             sums=sums, qkv=qkv, att=att, lse=lse, qkv_args=aq, proj_args=ap, y=y, qkv_layout=(hs, ko, vo)))
         return (y, ch, hh, ww)
 
     # ---- reference entry points (openaimodel.py:861-956)
@@ -1561,12 +1577,6 @@ def _cfg_eval(model, x, t, cond_scale, cond, layout, probs):
     if not isinstance(cond_scale, (int, float)):
         raise TypeError(f"cond_scale must be a number or a tensor, got {type(cond_scale)}")
     return model._cfg_combine(eng, cond_scale, B)
-
-
-def _check_head_dim(d, ch, heads):
-    if d not in (16, 32, 64, 128):
-        raise ValueError(f"the MFMA attention core takes head dims 16 / 32 / 64 / 128, got {ch} channels / {heads} heads = {d} "
-                         "(set num_head_channels to one of them)")
 
 
 def _layout_dim(condition, method):

@@ -82,6 +82,34 @@ def test_train_step_new_attention_order_vs_reference(prec, tol):
             assert max_rel(grads[key[2:]].grad.cpu(), ref) < tol, key
 
 
+@pytest.mark.parametrize("prec,tol", [("f32", 5e-5), ("f16x3", 1e-4)])
+def test_train_step_narrow_attention_heads_vs_reference(prec, tol):
+    """the attention layout of config/dynamic/unet.yaml (attention at ds 2 and 4, heads narrower than any attention-core instance:
+    64 / 8 = 8 channels per head run zero-padded to 16, next to native 16-wide ones): one training step against the reference
+    module's loss and the gradients of every attention parameter, the head and the stem (make_golden_narrow_heads.py)"""
+    from conftest import load_npz
+    v, u = load_npz("train_heads8.npz"), load_npz("unet_uf_heads8_label_c32_s16.npz")
+    m, entry = build_model("uf_heads8_label_c32_s16", prec)
+    m.train()
+    m.dropout = 0.0
+    x, t, cond = torch.from_numpy(u["x"]).cuda(), torch.from_numpy(u["t"]).cuda(), torch.from_numpy(u["cond"]).cuda()
+    eps, _, _ = m(x, t, cond=cond, layout=None, cond_drop_prob=0.5, cond_drop_mask=torch.tensor([False, True]).cuda())
+    tape = m._engines[next(iter(m._engines))].tape
+    assert sorted({(r["d"], r["dp"]) for r in tape if r["kind"] == "attn"}) == [(8, 16), (16, 16)]
+    noise = torch.from_numpy(v["noise"]).cuda()
+    loss = ((noise - eps) ** 2).reshape(2, -1).mean(1).mean()
+    assert abs(loss.item() - float(v["loss"])) < (2e-5 if prec == "f32" else 5e-5) * abs(float(v["loss"]))
+    loss.backward()
+    grads = dict(m.named_parameters())
+    keys = [k for k in v if k.startswith("g:")]
+    assert len(keys) == 59
+    for key in keys:
+        ref = torch.from_numpy(v[key])
+        assert grads[key[2:]].grad.shape == ref.shape, key
+        if float(ref.abs().max()) > 1e-6:
+            assert max_rel(grads[key[2:]].grad.cpu(), ref) < tol, key
+
+
 def test_frozen_parameters_get_no_gradient():
     m, *_ = _step("uf_clusterlayout_c32_s16", "f32")
     assert m.null_cond_emb.grad is None and m.null_layout_emb.grad is None
