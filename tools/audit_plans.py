@@ -34,9 +34,38 @@ def plans():
     c = copy.deepcopy(idx["ca_stego_c128_s64"])
     c["ctor"].update(attention_resolutions=[4, 2])                               # config/dynamic/unetca.yaml:10
     out["unetca"] = c
+    # the data configs' other image sizes (config/data/: 32 x 32 -- cifar, in32 --, 128 x 128 -- ffhq128) on the two benchmark plans
+    for base in ("unet_fast", "unetca_fast"):
+        for size in (32, 128):
+            e = copy.deepcopy(out[base])
+            e["ctor"]["image_size"] = size
+            out[f"{base}@{size}"] = e
     for e in out.values():
         e.pop("manifest", None)
     return out
+
+
+def sample_audit(m, kw, e, batch, B, S):
+    """a short trajectory of every sampler of LatentDiffusion.sampler_list on this plan: finite uint8 images, healthy engines"""
+    import bench
+    from sgdm_amd.diffusion import LatentDiffusion
+    m.eval()
+    d = LatentDiffusion(device="cuda", **bench.MODEL_PARAMS).eval()
+    d.set_denoise_fn(m.forward, m.forward_with_cond_scale)
+    cnd = batch["cond"].float().cuda() if batch.get("cond") is not None else None
+    lay = batch["layout"].cuda() if batch.get("layout") is not None else None
+    done = []
+    for method, steps in (("ddim", 10), ("plms", 10), ("native", 1000)):
+        sk = dict(sampling_method=method, num_timesteps=steps, ddim_eta=0.0, log_num_per_prog=10, clip_denoised=True, dtp=1,
+                  temperature=1.0, noise_dropout=0, random_sample_condition=False, return_inter_dict=True)
+        img, inter = d.p_sample_loop(method, (B, 3, S, S), sk,
+                                     denoise_sample_fn_kwargs=dict(cond=cnd if e["kind"] != "unet_fast" else batch.get("cond").cuda(),
+                                                                   layout=lay, cond_scale=2.0))
+        assert img.dtype == torch.uint8 and tuple(img.shape) == (B, 3, S, S), (method, img.dtype, img.shape)
+        sd = float(img.float().std())
+        assert sd > 1.0, (method, sd)
+        done.append(f"{method}{steps}")
+    return " ".join(done)
 
 
 def main():
@@ -44,6 +73,7 @@ def main():
     ap.add_argument("--prec", default="f16x3")
     ap.add_argument("--plans", default="")
     ap.add_argument("--batch", type=int, default=2)
+    ap.add_argument("--sample", action="store_true", help="also run a short trajectory of every sampler on each plan")
     a = ap.parse_args()
     import bench
     from conftest import cfg_from_index, max_rel
@@ -106,8 +136,9 @@ def main():
                     n += 1
                     if err > worst[1]:
                         worst = (k, err)
+            smp = ("  samplers: " + sample_audit(m, kw, e, batch, B, S)) if a.sample else ""
             print(f"{name:16s} OK  forward {ferr:.2e} | loss rel {abs(loss.item() - l.item()) / abs(l.item()):.1e}  worst of {n} gradients "
-                  f"{worst[1]:.2e} ({worst[0]})  [{time.time() - t0:.0f} s]", flush=True)
+                  f"{worst[1]:.2e} ({worst[0]}){smp}  [{time.time() - t0:.0f} s]", flush=True)
         except Exception as ex:                                           # the audit's purpose: report, go on
             tb = traceback.format_exc().strip().splitlines()
             print(f"{name:16s} FAILED  {type(ex).__name__}: {str(ex)[:300]}   at {tb[-3].strip() if len(tb) >= 3 else ''}", flush=True)
