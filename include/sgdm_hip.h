@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define SGD_ABI_VERSION 20
+#define SGD_ABI_VERSION 21
 int sgd_abi_version(void);
 /* 16 hex digits identifying the sources and flags the library was compiled from (build.py: source_id()); static storage.
  * __graft_entry__.build() and tests/test_boundary_cpu.py compare it with the tree on disk. */
@@ -214,6 +214,9 @@ int sgd_linear_splitk_t(const float* x, int32_t x_ld, const float* w, int32_t w_
  * -------------------------------------------------------------------------------------- */
 int sgd_chan_stats(const float* x, int32_t n, int32_t hw, int32_t c,
                    float* sums /* [n, c_total, 2] */, int32_t c_total, int32_t c_off, void* stream);
+/* ResBlock without scale-shift norm (use_scale_shift_norm=False, openaimodel.py:317-319): x[n, hw, c] += e[n, c] in place
+ * (e row stride e_ld; c, e_ld multiples of 4; 16-byte aligned).  The statistics of the sum are taken by sgd_chan_stats. */
+int sgd_add_rows_nc(float* x, const float* e, int32_t e_ld, int32_t n, int64_t hw, int32_t c, void* stream);
 /* sums[n, c_off + c, 2] = sum over parts of partial[n, parts, 2, c] (partials written by sgd_igemm's epilogue) */
 int sgd_stats_reduce(const float* partial, int32_t n, int32_t parts, int32_t c,
                      float* sums /* [n, c_total, 2] */, int32_t c_total, int32_t c_off, void* stream);

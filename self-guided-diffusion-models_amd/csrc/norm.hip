@@ -287,6 +287,20 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
     }
 }
 
+// ResBlock WITHOUT scale-shift norm (openaimodel.py:317-319: h = h + emb_out[..., None, None] in front of out_layers' GroupNorm):
+// x[n, px, c] += e[n, c], in place, 16-byte accesses (c, e_ld multiples of 4).  The shipped plans all use the FiLM form, which
+// folds the embedding into the GroupNorm coefficients instead (sgd_gn_coef); this form keeps the statistics pass of its own.
+__global__ __launch_bounds__(256) void add_rows_nc_kernel(float* __restrict__ x, const float* __restrict__ e, int e_ld, long hw,
+                                                          int c4, long total) {
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int q = (int)(i % c4);
+        const long img = (i / c4) / hw;
+        f32x4 v = reinterpret_cast<f32x4*>(x)[i];
+        v += *reinterpret_cast<const f32x4*>(e + img * e_ld + q * 4);
+        reinterpret_cast<f32x4*>(x)[i] = v;
+    }
+}
+
 }  // namespace
 
 extern "C" int sgd_chan_stats(const float* x, int32_t n, int32_t hw, int32_t c, float* sums, int32_t c_total,
@@ -296,6 +310,18 @@ extern "C" int sgd_chan_stats(const float* x, int32_t n, int32_t hw, int32_t c, 
     const int slabs = (c + 31) / 32;
     hipLaunchKernelGGL(chan_stats_kernel, dim3(n * slabs), dim3(256), 0, (hipStream_t)stream, x, hw, c, sums,
                        c_total, c_off);
+    return sgd_check_launch();
+}
+
+extern "C" int sgd_add_rows_nc(float* x, const float* e, int32_t e_ld, int32_t n, int64_t hw, int32_t c, void* stream) {
+    SGD_CLEAR_ERR();
+    if (!x || !e || n <= 0 || hw <= 0 || c <= 0 || (c & 3) || (e_ld & 3) || e_ld < c) return SGD_ERR_ARG;
+    if ((((uintptr_t)x) | ((uintptr_t)e)) & 15) return SGD_ERR_ARG;
+    const long total = (long)n * hw * (c / 4);
+    long blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(add_rows_nc_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, e, e_ld, (long)hw, c / 4,
+                       total);
     return sgd_check_launch();
 }
 

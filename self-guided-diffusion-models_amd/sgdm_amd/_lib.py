@@ -20,7 +20,7 @@ RS_NONE, RS_AVGPOOL2, RS_UP2, RS_ZEROUP2 = 0, 1, 2, 3
 PRO_NONE, PRO_AFFINE_NC, PRO_LN_ROW = 0, 1, 2
 PREC_F32, PREC_F16X3, PREC_BF16X3 = 0, 1, 2
 PREC_BY_NAME = {"f32": PREC_F32, "f16x3": PREC_F16X3, "bf16x3": PREC_BF16X3}
-ABI_VERSION = 20
+ABI_VERSION = 21
 
 # sgd_igemm_args.tune (include/sgdm_hip.h: SGD_TUNE_*): per-call schedule overrides for parity tests and A/B tools
 TUNE_BN128, TUNE_BN256, TUNE_FLAT2, TUNE_DEFER, TUNE_PLAIN_SCHEDULE, TUNE_LN_PACKED, TUNE_NO_SMALL = 1, 2, 4, 8, 16, 32, 64
@@ -74,6 +74,7 @@ SIGNATURES = {
     "sgd_chan_stats": (i32, [vp, i32, i32, i32, vp, i32, i32, vp]),
     "sgd_gn_coef_parts": (i32, [vp, i32, i32, vp, i32, i32, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp, vp, vp]),
     "sgd_gn_coef": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, vp, vp, vp]),
+    "sgd_add_rows_nc": (i32, [vp, vp, i32, i32, i64, i32, vp]),
     "sgd_ln_stats": (i32, [vp, i32, i32, f32, vp, vp]),
     "sgd_ln_apply": (i32, [vp, vp, vp, vp, i32, i32, f32, vp, vp]),
     "sgd_attention": (i32, [vp, i32, i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, vp, i32, vp, vp]),

@@ -434,11 +434,22 @@ class Backward:
         film_ptr = e.film.data_ptr() + 4 * rec["film_off"]
         dfilm_ptr = self.gfilm.data_ptr() + 4 * rec["film_off"]
         self.G[rec["h1"].data_ptr()] = [self.buf(*rec["h1"].shape), False]
-        self.gn_bwd(p + ".out_layers.0", [(rec["h1"], cout)], (ho, wo), rec["a2"], rec["b2"], rec["sums2"],
-                    p + ".out_layers.0", 1, gu2, cout, L.RS_NONE, None, 0, 0, film_ptr=film_ptr, film_ld=e.film_ld,
-                    dfilm_ptr=dfilm_ptr, drop=(rec["drop_p"], rec["drop_seed"]))
+        if rec.get("ss", True):
+            self.gn_bwd(p + ".out_layers.0", [(rec["h1"], cout)], (ho, wo), rec["a2"], rec["b2"], rec["sums2"],
+                        p + ".out_layers.0", 1, gu2, cout, L.RS_NONE, None, 0, 0, film_ptr=film_ptr, film_ld=e.film_ld,
+                        dfilm_ptr=dfilm_ptr, drop=(rec["drop_p"], rec["drop_seed"]))
+            gh1 = self.gread(rec["h1"])
+        else:
+            # additive embedding (openaimodel.py:317-319): h1 holds h + emb_out; the gradient of emb_out[n, c] is the pixel sum of
+            # the gradient of h1 -- the (sum, .) column of a statistics pass over it -- and lands in this block's slice of the
+            # embedding-projection gradient like the FiLM form's (dscale, dshift)
+            self.gn_bwd(p + ".out_layers.0", [(rec["h1"], cout)], (ho, wo), rec["a2"], rec["b2"], rec["sums2"],
+                        p + ".out_layers.0", 1, gu2, cout, L.RS_NONE, None, 0, 0, drop=(rec["drop_p"], rec["drop_seed"]))
+            gh1 = self.gread(rec["h1"])
+            st = self.buf(n, cout, 2)
+            self.prog.add(p + ".emb_add.bwd", self.lib.sgd_chan_stats, _ptr(gh1), n, ho * wo, cout, _ptr(st), cout, 0)
+            self.copy_op(p + ".emb_add.gfilm", self.gfilm[:, rec["film_off"]:rec["film_off"] + cout], st[:, :, 0])
         self._film_group_done(p)
-        gh1 = self.gread(rec["h1"])
         # conv1 (in_layers.2)
         w1 = P(p + ".in_layers.2.weight")
         gu1 = self.buf(n, ho, wo, cin)
@@ -685,16 +696,17 @@ class Backward:
         fw = rec["film_w"]
         ech = rec["emb_t"].shape[1] + (rec["emb_c"].shape[1] if rec["emb_c"] is not None else 0)
         offs, off = [], 0
+        fm = self.m._film_mult                     # 2: FiLM (scale, shift); 1: additive embedding (use_scale_shift_norm=False)
         for co in couts:
             offs.append(off)
-            off += 2 * co
+            off += fm * co
         self._film_ctx = dict(rec=rec, ech=ech, fw=fw, dwcat=self.buf(fw, ech), dbcat=self.buf(fw))
         # stages in WALK order (last ResBlock of the forward first); a stage closes at block i when it holds enough bytes
         self._film_close = {}                       # block name -> (first block index, one past the last) of the stage it closes
         hi = len(names)
         acc = 0
         for i in range(len(names) - 1, -1, -1):
-            acc += 2 * couts[i] * ech * 4
+            acc += fm * couts[i] * ech * 4
             if acc >= self.FILM_STAGE_BYTES or i == 0:
                 self._film_close[names[i]] = (i, hi)
                 hi, acc = i, 0

@@ -359,8 +359,6 @@ class UNetModelBase(nn.Module):
             raise NotImplementedError("use_fp16=True is not supported (reference configs use fp32)")
         if num_heads == -1 and num_head_channels == -1:
             raise AssertionError("Either num_heads or num_head_channels has to be set")
-        if not use_scale_shift_norm:
-            raise NotImplementedError("HIP path implements use_scale_shift_norm=True (all shipped configs)")
         if not conv_resample:
             raise NotImplementedError("HIP path implements conv_resample=True (ctor default)")
         self.image_size = image_size
@@ -378,6 +376,7 @@ class UNetModelBase(nn.Module):
         self.num_head_channels = num_head_channels
         self.num_heads_upsample = num_heads if num_heads_upsample == -1 else num_heads_upsample
         self.use_scale_shift_norm = use_scale_shift_norm
+        self._film_mult = 2 if use_scale_shift_norm else 1        # emb_layers' width per ResBlock channel (openaimodel.py:259-264)
         self.resblock_updown = resblock_updown
         self.cond_dim = 0 if cond_dim is None else cond_dim
         self.condition = condition
@@ -432,7 +431,7 @@ class UNetModelBase(nn.Module):
             _, cin, cout, _ud = layer
             sp.norm(p + ".in_layers.0", cin)
             sp.conv(p + ".in_layers.2", cin, cout, 3)
-            sp.linear(p + ".emb_layers.1", self._emb_ch, 2 * cout)
+            sp.linear(p + ".emb_layers.1", self._emb_ch, self._film_mult * cout)      # openaimodel.py:259-264
             sp.norm(p + ".out_layers.0", cout)
             sp.conv(p + ".out_layers.3", cout, cout, 3, zero=True)        # zero_module, openaimodel.py:273-276
             if cin != cout:
@@ -771,7 +770,8 @@ class _Engine:
         m._build_cond_path(self, emb)
         # all ResBlocks' emb_layers in one GEMM (they share SiLU(emb))
         res_names = m._res_prefixes()
-        film_w = sum(2 * co for _, co in res_names)
+        fm = m._film_mult                     # 2: (scale, shift) of the FiLM form; 1: the additive form (use_scale_shift_norm=False)
+        film_w = sum(fm * co for _, co in res_names)
         film = self.buf(n, film_w)
         fbias = self.buf(film_w)
         self._film_bias_src = [P(p + ".emb_layers.1.bias") for p, _ in res_names]
@@ -787,7 +787,7 @@ class _Engine:
         off = 0
         for p, co in res_names:
             self.film_off[p] = off
-            off += 2 * co
+            off += fm * co
         # ---------------- trunk
         inp, mid, out = m._plan
         hs = []
@@ -841,7 +841,9 @@ class _Engine:
         return srcs[0]
 
     def _res(self, p, layer, srcs):
-        """ResBlock._forward (openaimodel.py:300-320), use_scale_shift_norm=True"""
+        """ResBlock._forward (openaimodel.py:300-320).  use_scale_shift_norm=True (every shipped plan): the embedding's (scale, shift)
+        folded into out_layers' GroupNorm coefficients.  False (:317-319, h = h + emb_out): the embedding row added to conv1's output
+        in place, the GroupNorm statistics by a pass of their own (conv1's epilogue statistics are those of h without it)."""
         _, cin, cout, ud = layer
         n, P = self.n, self.m.P
         t0, c0, hh, ww = srcs[0]
@@ -849,16 +851,21 @@ class _Engine:
         assert c0 + c1 == cin
         rs = {None: L.RS_NONE, "down": L.RS_AVGPOOL2, "up": L.RS_UP2}[ud]
         ho, wo = (hh // 2, ww // 2) if ud == "down" else ((hh * 2, ww * 2) if ud == "up" else (hh, ww))
+        ss = self.m.use_scale_shift_norm
         a1, b1 = self.gn(p + ".in_layers.0", [(t0, c0)] + ([(t1, c1)] if t1 is not None else []), hh * ww,
                          p + ".in_layers.0")
         sums1 = self._last_sums
         h1 = self.buf(n, ho, wo, cout)
         ac1 = self.igemm(p + ".in_layers.2", t0, c0, h1, cout, self.pack([p + ".in_layers.2.weight"], 3), x1=t1,
                          c1=c1, conv=(n, hh, ww, ho, wo, 1, rs), pro=L.PRO_AFFINE_NC, silu=1, pa=a1, pb=b1,
-                         bias=P(p + ".in_layers.2.bias"), stats=True)
+                         bias=P(p + ".in_layers.2.bias"), stats=ss)
         film_ptr = self.film.data_ptr() + 4 * self.film_off[p]
-        a2, b2 = self.gn(p + ".out_layers.0", [(h1, cout)], ho * wo, p + ".out_layers.0", film=film_ptr,
-                         film_ld=self.film_ld)
+        if ss:
+            a2, b2 = self.gn(p + ".out_layers.0", [(h1, cout)], ho * wo, p + ".out_layers.0", film=film_ptr,
+                             film_ld=self.film_ld)
+        else:
+            self.prog.add(p + ".emb_add", self.lib.sgd_add_rows_nc, _ptr(h1), C.c_void_p(film_ptr), self.film_ld, n, ho * wo, cout)
+            a2, b2 = self.gn(p + ".out_layers.0", [(h1, cout)], ho * wo, p + ".out_layers.0")
         sums2 = self._last_sums
         ask = None
         if cin != cout:
@@ -881,7 +888,7 @@ class _Engine:
                               srcs=[(t0, c0)] + ([(t1, c1)] if t1 is not None else []), cin=cin,
                               cout=cout, hw_in=(hh, ww), hw_out=(ho, wo), rs=rs, a1=a1, b1=b1, sums1=sums1, h1=h1,
                               a2=a2, b2=b2, sums2=sums2, film_off=self.film_off[p], conv1=ac1, conv2=ac2, skip=ask,
-                              y=y))
+                              y=y, ss=ss))
         return (y, cout, ho, wo)
 
     # ---- execution

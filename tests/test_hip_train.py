@@ -1,5 +1,7 @@
 """One DDPM training step of the HIP drop-in (LatentDiffusion.p_losses -> UNet -> loss.backward()) against the
 loss / per-sample loss / parameter gradients recorded from the reference (tests/golden/diffusion.npz).  GPU only."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -108,6 +110,131 @@ def test_train_step_narrow_attention_heads_vs_reference(prec, tol):
         assert grads[key[2:]].grad.shape == ref.shape, key
         if float(ref.abs().max()) > 1e-6:
             assert max_rel(grads[key[2:]].grad.cpu(), ref) < tol, key
+
+
+@pytest.mark.parametrize("prec,tol", [("f32", 5e-5), ("f16x3", 1e-4)])
+def test_train_step_without_scale_shift_norm_vs_reference(prec, tol):
+    """use_scale_shift_norm=False (openaimodel.py:317-319: h = h + emb_out in front of out_layers' GroupNorm; emb_layers is
+    out_channels wide): one training step against the reference module's loss and the gradients of every embedding projection,
+    out_layers GroupNorm, conv1 bias, the time MLP, the head and the stem (make_golden_no_scale_shift.py)"""
+    from conftest import load_npz
+    v, u = load_npz("train_noss.npz"), load_npz("unet_uf_noss_label_c32_s16.npz")
+    m, entry = build_model("uf_noss_label_c32_s16", prec)
+    assert m.use_scale_shift_norm is False
+    m.train()
+    m.dropout = 0.0
+    x, t, cond = torch.from_numpy(u["x"]).cuda(), torch.from_numpy(u["t"]).cuda(), torch.from_numpy(u["cond"]).cuda()
+    eps, _, _ = m(x, t, cond=cond, layout=None, cond_drop_prob=0.5, cond_drop_mask=torch.tensor([False, True]).cuda())
+    noise = torch.from_numpy(v["noise"]).cuda()
+    loss = ((noise - eps) ** 2).reshape(2, -1).mean(1).mean()
+    assert abs(loss.item() - float(v["loss"])) < (2e-5 if prec == "f32" else 5e-5) * abs(float(v["loss"]))
+    loss.backward()
+    grads = dict(m.named_parameters())
+    keys = [k for k in v if k.startswith("g:")]
+    assert len(keys) == 113
+    for key in keys:
+        ref = torch.from_numpy(v[key])
+        assert grads[key[2:]].grad.shape == ref.shape, key
+        if float(ref.abs().max()) > 1e-6:
+            assert max_rel(grads[key[2:]].grad.cpu(), ref) < tol, key
+
+
+def test_data_parallel_backward_without_scale_shift_norm_equals_the_plain_one():
+    """the gradient arena, the staged embedding-projection gradients (half as wide in this form) and the bucketed exchange, forced
+    through a one-rank gloo group: every gradient bit-equal to the single-process backward"""
+    import tempfile
+    import torch.distributed as dist
+    from conftest import load_npz
+    u = load_npz("unet_uf_noss_label_c32_s16.npz")
+    m, entry = build_model("uf_noss_label_c32_s16", "f32")
+    m.train()
+    m.dropout = 0.0
+    x, t, cond = torch.from_numpy(u["x"]).cuda(), torch.from_numpy(u["t"]).cuda(), torch.from_numpy(u["cond"]).cuda()
+
+    def step():
+        for p in m.parameters():
+            p.grad = None
+        eps, _, _ = m(x, t, cond=cond, layout=None, cond_drop_prob=0.5, cond_drop_mask=torch.tensor([False, True]).cuda())
+        (eps ** 2).mean().backward()
+        torch.cuda.synchronize()
+        return {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}
+
+    m.hip_ddp = False
+    ref = step()
+    eng = next(iter(m._engines.values()))
+    assert eng.backward.arena is None
+    with tempfile.TemporaryDirectory() as td:
+        dist.init_process_group("gloo", init_method=f"file://{os.path.join(td, 'store')}", rank=0, world_size=1)
+        try:
+            for e in m._engines.values():
+                e.backward = None
+            m.hip_ddp = True
+            m.hip_force_exchange = True
+            got = step()
+            assert eng.backward.arena is not None and eng.backward.reducer.active
+            assert sorted(got) == sorted(ref)
+            bad = [k for k in ref if not torch.equal(got[k], ref[k])]
+            assert not bad, bad[:5]
+        finally:
+            dist.destroy_process_group()
+            m.hip_ddp = False
+
+
+@pytest.mark.parametrize("prec,tol", [("f32", 5e-5), ("f16x3", 1e-4)])
+def test_train_step_unetca_without_scale_shift_norm_vs_oracle(prec, tol):
+    """the same ResBlock form in the `unetca_fast` class (openaimodel_ca.py's copy of the block): loss and every parameter
+    gradient of one step against the oracle's autograd, data-parallel bookkeeping included (the embedding-projection gradient's
+    stages are half as wide)"""
+    import bench
+    from oracle import diffusion_ref as D
+    from oracle import unet_ref as U
+    from sgdm_amd.diffusion import LatentDiffusion
+    from sgdm_amd.synth import synth_batch, weights_from_seed
+    from sgdm_amd.unet import UNetModelCA
+    from test_hip_unet import AttrDict
+    kw = dict(image_size=16, in_channels=3, out_channels=3, model_channels=32, num_res_blocks=1, channel_mult=[1, 2, 4],
+              attention_resolutions=[4], num_heads=4, use_scale_shift_norm=False, use_ca_block=True, legacy=False, dropout=0.0,
+              cond_token_num=1, cond_dim=27, context_dim=32, use_cls_token_as_pooled=True, condition_method="stegoclusterlayout")
+    m = UNetModelCA(condition=AttrDict(scale_type="imagen", stegoclusterlayout=AttrDict(layout_dim=27)), **kw)
+    cfg = U.make_cfg("unetca_fast", 16, model_channels=32, num_res_blocks=1, channel_mult=(1, 2, 4), attention_resolutions=(4,),
+                     num_heads=4, cond_dim=27, condition_method="stegoclusterlayout", layout_dim=27, cond_token_num=1,
+                     context_dim=32, use_scale_shift_norm=False)
+    manifest = [(k, tuple(v.shape)) for k, v in m.state_dict().items()]
+    assert [(k, s) for k, s in manifest] == [(k, tuple(s)) for k, s, _ in U.param_manifest(cfg)]
+    sd = weights_from_seed(manifest, 37)
+    m.load_state_dict(sd)
+    m = m.cuda().train()
+    m.hip_precision = prec
+    d = LatentDiffusion(device="cuda", **bench.MODEL_PARAMS).train()
+    d.set_denoise_fn(m.forward, m.forward_with_cond_scale)
+    B = 3
+    batch = synth_batch("stegoclusterlayout", B, 16, 27, 27, seed=9)
+    g = torch.Generator().manual_seed(10)
+    t = torch.randint(0, 1000, (B,), generator=g)
+    noise = torch.randn(B, 3, 16, 16, generator=g)
+    mask = torch.tensor([False, True, False])
+    loss, _ = d.p_losses(batch["image"].cuda(), t.cuda(), noise.cuda(), cond=batch["cond"].float().cuda(),
+                         layout=batch["layout"].cuda(), cond_drop_prob=0.5, cond_drop_mask=mask.cuda())
+    loss.backward()
+    trainable = [k for k, p in m.named_parameters() if p.requires_grad]
+    w = {k: v.clone().requires_grad_(k in trainable) for k, v in sd.items()}
+    ref_loss, _, _, _ = D.p_losses(D.make_schedule(), lambda xx, tt: U.unet_forward(cfg, w, xx, tt, batch["cond"].float(),
+                                                                                      batch["layout"], drop_mask=mask),
+                                   batch["image"], t, noise)
+    ref_loss.backward()
+    assert abs(loss.item() - float(ref_loss.detach())) < 2e-5 * abs(float(ref_loss.detach()))
+    checked = 0
+    for name, p in m.named_parameters():
+        if w[name].grad is None:
+            continue
+        assert p.grad is not None, name
+        if float(w[name].grad.abs().max()) < 1e-6:
+            assert float(p.grad.abs().max()) < 1e-5, name
+            continue
+        err = max_rel(p.grad.cpu(), w[name].grad)
+        assert err < tol, (name, err)
+        checked += 1
+    assert checked > 50
 
 
 def test_frozen_parameters_get_no_gradient():

@@ -330,6 +330,30 @@ def test_train_step_narrow_attention_heads_matches_reference():
             assert max_rel(sd[key[2:]].grad, ref) < 5e-5, key
 
 
+def test_train_step_without_scale_shift_norm_matches_reference():
+    """use_scale_shift_norm=False (openaimodel.py:317-319): the oracle's loss and gradients against one training step of the
+    reference module (tests/golden/make_golden_no_scale_shift.py)"""
+    v = load_npz("train_noss.npz")
+    u = load_npz("unet_uf_noss_label_c32_s16.npz")
+    entry = INDEX["uf_noss_label_c32_s16"]
+    cfg = cfg_from_index(entry)
+    assert cfg["use_scale_shift_norm"] is False
+    sd = {k: t.clone().requires_grad_(kind == "param")
+          for (k, _, kind), t in zip(entry["manifest"], _weights(entry).values())}
+    x, t, cond = torch.from_numpy(u["x"]), torch.from_numpy(u["t"]), torch.from_numpy(u["cond"])
+    eps = U.unet_forward(cfg, sd, x, t, cond.float(), None, torch.tensor([False, True]))
+    noise = torch.from_numpy(v["noise"])
+    loss = ((noise - eps) ** 2).reshape(2, -1).mean(1).mean()
+    assert abs(loss.item() - float(v["loss"])) < 1e-5 * abs(float(v["loss"]))
+    loss.backward()
+    keys = [k for k in v if k.startswith("g:")]
+    assert len(keys) == 113
+    for key in keys:
+        ref = torch.from_numpy(v[key])
+        if float(ref.abs().max()) > 1e-6:
+            assert max_rel(sd[key[2:]].grad, ref) < 5e-5, key
+
+
 def test_plms10_trajectory():
     """PLMS (ddim_plms_sampler.py:394-525): double UNet evaluation on the first step, Adams-Bashforth history"""
     v = load_npz("plms.npz")
