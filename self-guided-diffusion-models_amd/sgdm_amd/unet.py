@@ -356,6 +356,9 @@ class UNetModelBase(nn.Module):
         if dims != 2:
             raise NotImplementedError("HIP path implements dims=2 only")
         if use_fp16:
+            # (the reference's own forward raises with the flag set -- `h = x.type(torch.float16)` meets fp32 weights,
+            # openaimodel.py:564,926: "Input type (c10::Half) and bias type (float) should be the same" -- unless a caller has run
+            # convert_to_fp16() (:837), and nothing in the reference calls it)
             raise NotImplementedError("use_fp16=True is not supported (reference configs use fp32)")
         if num_heads == -1 and num_head_channels == -1:
             raise AssertionError("Either num_heads or num_head_channels has to be set")
